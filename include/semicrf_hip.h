@@ -1,0 +1,136 @@
+/*
+ * semicrf_hip.h -- C ABI of the MI355X (gfx950) Neural Semi-CRF interval layer.
+ *
+ * This is the drop-in boundary: plain pointers, sizes and a HIP stream handle; no torch
+ * types.  The reference (Yujia-Yan/Transkun) has no FFI of its own -- its boundary is the
+ * pure-Python class transkun/CRF/NeuralSemiCRFInterval.py:553-588 -- so each entry point
+ * below cites the reference *function* it replaces; transkun_amd/CRF (ctypes) is the
+ * host-side mirror of that class, and INTEGRATION.md shows the binding a Transkun
+ * maintainer would add.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers (HBM) unless named h_*.  fp32 everywhere.
+ *   - score  [T][T][B]  C-contiguous, indexed [end][begin][chain]; only end >= begin is read.
+ *   - noise  [T-1][B]   score of "no event between frames t and t+1".
+ *   - stream is a hipStream_t passed as void*; every call only ENQUEUES work on it
+ *     (no host synchronisation), so calls compose with torch's current stream.
+ *   - ws / ws_bytes: caller-owned scratch of at least semicrf_workspace_bytes(op,T,B) bytes,
+ *     256-byte aligned; contents are undefined afterwards.
+ *   - Return value: SEMICRF_OK or an error code; semicrf_last_error() gives the message of the
+ *     last failing call on this thread.  Nothing is written on SEMICRF_EINVAL.
+ */
+#ifndef SEMICRF_HIP_H
+#define SEMICRF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEMICRF_ABI_VERSION 1
+
+#define SEMICRF_OK 0
+#define SEMICRF_EINVAL 1      /* bad shape / null pointer / unsupported size */
+#define SEMICRF_EWORKSPACE 2  /* ws_bytes too small */
+#define SEMICRF_ELAUNCH 3     /* HIP reported an error at enqueue time */
+
+/* op ids for semicrf_workspace_bytes */
+#define SEMICRF_OP_LOGZ_FWD 0
+#define SEMICRF_OP_LOGZ_BWD 1
+#define SEMICRF_OP_VITERBI 2
+#define SEMICRF_OP_EVAL_PATH 3
+#define SEMICRF_OP_INTERVAL_SCORE 4
+
+/* length scaling of the interval scorer (LayersTransformer.py:416-427) */
+#define SEMICRF_LEN_LINEAR 0
+#define SEMICRF_LEN_SQRT 1
+#define SEMICRF_LEN_NONE 2
+
+typedef void* semicrf_stream_t;
+
+int semicrf_abi_version(void);
+const char* semicrf_last_error(void);
+size_t semicrf_workspace_bytes(int op, int T, int B);
+
+/* Select kernel implementation: 0 = auto (fastest valid), 1 = row-sequential reference kernels.
+ * Process-wide; meant for tests and A/B benchmarking. */
+void semicrf_set_impl(int impl);
+int semicrf_get_impl(void);
+
+/*
+ * Log-partition, forward (alpha) sweep.
+ * Replaces: computeLogZ (NeuralSemiCRFInterval.py:207-246) and the un-flipped half of
+ * forward_backward (:394-410,:417).
+ *   v[0] = softplus(s[0,0]);  v[i] = logaddexp(v[i-1]+n[i-1], logsumexp_{j<i}(v[j]+s[i,j])) + softplus(s[i,i])
+ * Outputs: logZ [B] (= v[T-1]);  v [T][B] (may be NULL when no backward will follow).
+ */
+int semicrf_logz_fwd(const float* score, const float* noise, int T, int B,
+                     float* logZ, float* v, void* ws, size_t ws_bytes, semicrf_stream_t stream);
+
+/*
+ * Gradient of sum_c gout[c]*logZ[c] w.r.t. score and noise: the backward (beta) sweep fused with
+ * the marginals.  Replaces: the flipped half of forward_backward (:386-414), the marginals
+ * (:424-447) and ComputeLogZFasterGrad.backward (:469-472).
+ *   dScore[e,b,c] = gout[c] * exp(v[b] + q[e] - logZ + s[e,b])                     e > b
+ *   dScore[t,t,c] = gout[c] * exp(v[t] + q[t] - logZ + s[t,t] - 2 softplus(s[t,t]))
+ *   dScore[e,b,c] = 0 exactly                                                       e < b
+ *   dNoise[t,c]   = gout[c] * exp(v[t] + q[t+1] + n[t] - logZ)
+ * Inputs v, logZ come from semicrf_logz_fwd on the same score/noise.  dScore [T][T][B] is fully
+ * written (including the zeros).  q_out [T][B] may be NULL.
+ */
+int semicrf_logz_bwd(const float* score, const float* noise, const float* v, const float* logZ,
+                     const float* gout, int T, int B, float* dScore, float* dNoise, float* q_out,
+                     void* ws, size_t ws_bytes, semicrf_stream_t stream);
+
+/*
+ * Viterbi decode.  Replaces: viterbiBackward (:13-104, forward=0, the default of .decode) and
+ * viterbi (:107-202, forward=1), including the backtrack that the reference runs on the host.
+ *   start: NULL or B ints (forcedStartPos; for forward=1 it is the END position, :161-165).
+ *   pairs: int32 [cap][2] (begin,end), chain-major, ascending within a chain (packed).
+ *   offsets: int32 [B+1] prefix counts; offsets[B] = total.  If total > cap the pairs content is
+ *   truncated but offsets are still exact (callers allocate cap = B*(2T) to be safe, or retry).
+ * Decoded indices are bit-identical to the reference's CPU path (first-maximum tie-break in the
+ * candidate order [skip, nearest, ..., farthest], single fp32 add per candidate).
+ */
+int semicrf_viterbi(const float* score, const float* noise, int T, int B, const int32_t* start,
+                    int forward, int32_t* pairs, int64_t cap, int32_t* offsets,
+                    void* ws, size_t ws_bytes, semicrf_stream_t stream);
+
+/*
+ * Unnormalised path score.  Replaces: evalPath (:508-550).
+ *   pairs int32 [K][2] (begin,end), offsets int32 [B+1] (chain c owns pairs[offsets[c]:offsets[c+1]]).
+ *   out[c] = sum_path ( s[end,begin,c] - (cum[end]-cum[begin]) ) + cum[T-1],  cum = prefix sums of noise.
+ */
+int semicrf_eval_path(const float* score, const float* noise, int T, int B,
+                      const int32_t* pairs, const int32_t* offsets, float* out,
+                      void* ws, size_t ws_bytes, semicrf_stream_t stream);
+
+/*
+ * Gradient of sum_c gout[c]*evalPath[c], ACCUMULATED (+=) into dScore / dNoise (autograd of the
+ * gathers at :540-548).  dScore[end,begin,c] += gout[c] per path interval;
+ * dNoise[t,c] += gout[c] * [gap t not covered by an interval of the path].
+ * Either output may be NULL.  Callers that want a fresh gradient zero the buffers first.
+ */
+int semicrf_eval_path_bwd(const float* gout, int T, int B, const int32_t* pairs, const int32_t* offsets,
+                          float* dScore, float* dNoise, semicrf_stream_t stream);
+
+/*
+ * Interval-score construction.  Replaces: ScaledInnerProductIntervalScorer.forward after the
+ * Linear map (LayersTransformer.py:406-441).
+ *   q,k: [C][T][D] with row strides ldq/ldk (in floats; >= D); diag: [C][T] with stride ldd between
+ *   consecutive t (so the packed Linear output [C][T][2D+1] can be passed without a split copy).
+ *   S[e,b,c] = (sum_d (q[c,e,d]*qscale) * k[c,b,d]) * len(|e-b|)  (+ diag[c,t] on e==b)
+ *   S is [T][T][C] (chain axis contiguous, the CRF's layout).  Only e >= b is written unless
+ *   full_square != 0 (the reference materialises the full square; the CRF never reads e < b).
+ *   noise_out [T-1][C] is zero-filled when non-NULL (:436-437).
+ */
+int interval_score_fwd(const float* q, const float* k, const float* diag, int C, int T, int D,
+                       int64_t ldq, int64_t ldk, int64_t ldd, float qscale, int length_scaling,
+                       int full_square, float* S, float* noise_out, semicrf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEMICRF_HIP_H */

@@ -1,0 +1,140 @@
+"""Pins the C oracle (oracle/semicrf_oracle.c) against golden vectors produced by the
+reference itself (tools/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import EDGE_CASES, edge_inputs, grad_weights, load_golden, rel_err, unpack_lists
+
+FP_TOL = 2e-6      # fp32 logsumexp-order differences between torch's vectorised sums and the scalar C loops
+GRAD_TOL = 1e-4    # marginals = exp(sum of O(1e2..1e3) terms): one fp32 ulp at 370 is 3e-5 (SURVEY hard part 5)
+
+
+def scorer_close(S, ref):
+    """fp32 dot-product round-off (~1e-6 of sum|q.k|) is multiplied by the length scale |e-b|."""
+    T = ref.shape[0]
+    ln = np.abs(np.arange(T)[:, None] - np.arange(T)[None, :]).astype(np.float64) + 1.0
+    tol = 5e-6 * ln[:, :, None] + 1e-5 * np.abs(ref)
+    return bool(np.all(np.abs(S.astype(np.float64) - ref) <= tol))
+
+
+def grad_tol(logz):
+    return max(1e-4, 2e-6 * float(np.max(np.abs(logz))))
+
+
+def _starts(g, key):
+    k = key + "_start"
+    return None if k not in g else [int(x) for x in g[k]]
+
+
+def _check_decodes(oracle, g, score, noise):
+    keys = [k[:-6] for k in g if k.startswith("decode_") and k.endswith("_pairs")]
+    assert keys
+    for key in keys:
+        fwd = key.endswith("_fwd")
+        want = unpack_lists(g[key + "_pairs"], g[key + "_offsets"])
+        got = oracle.viterbi(score, noise, _starts(g, key), forward=fwd)
+        assert got == want, key
+
+
+def _check_fp(oracle, g, score, noise, full_grad=True):
+    T, B = score.shape[0], score.shape[2]
+    logz, grad, gn, v, q = oracle.forward_backward(score, noise)
+    # marginals are exp() of sums of O(|logZ|) fp32 numbers: their noise floor scales with ulp(|logZ|)
+    GRAD_TOL = grad_tol(g["fb_logZ"])
+    # the f64 instantiation of the same restatement must agree with the reference's fp32 results too
+    lz64, grad64, gn64, _, _ = oracle.forward_backward_f64(score, noise)
+    assert rel_err(lz64, g["fb_logZ"]) < FP_TOL
+    assert rel_err(gn64, g["fb_gradNoise"]) < GRAD_TOL
+    assert rel_err(logz, g["fb_logZ"]) < FP_TOL
+    assert rel_err(logz, g["logZ_noBackward"]) < 1e-5
+    assert rel_err(gn, g["fb_gradNoise"]) < GRAD_TOL
+    if full_grad and "fb_grad" in g:
+        assert rel_err(grad, g["fb_grad"]) < GRAD_TOL
+        assert np.all(np.triu(grad.transpose(2, 0, 1), 1) == 0.0)
+    w = grad_weights(T)
+    assert rel_err(grad.astype(np.float64).sum(axis=(0, 1)), g["fb_grad_sum"]) < GRAD_TOL
+    assert rel_err((grad.astype(np.float64) * w[:, :, None]).sum(axis=(0, 1)), g["fb_grad_wsum"]) < GRAD_TOL
+    # v[T-1] == q[0] (reference comment :332-334)
+    assert rel_err(v[-1], q[0]) < 1e-5
+    if "evalPath" in g:
+        iv = unpack_lists(g["intervals_pairs"], g["intervals_offsets"])
+        path = oracle.eval_path(iv, score, noise)
+        assert rel_err(path, g["evalPath"]) < FP_TOL
+        assert rel_err(path - logz, g["logProb"]) < 1e-5
+
+
+def test_minimal_example(oracle):
+    g = load_golden("minimal_T200_B4")
+    score, noise = g["score"], g["noise"]
+    _check_decodes(oracle, g, score, noise)
+    _check_fp(oracle, g, score, noise)
+    logz, grad, gn, v, q = oracle.forward_backward(score, noise)
+    rows = g["rows"]
+    assert rel_err(grad[rows], g["fb_grad_rows"]) < GRAD_TOL
+    # d logProb / d score = onehot(path) - marginals
+    iv = unpack_lists(g["intervals_pairs"], g["intervals_offsets"])
+    d = -grad.copy()
+    for c, lst in enumerate(iv):
+        for b, e in lst:
+            d[e, b, c] += 1.0
+    # golden holds d(-sum logProb): sign flip
+    assert rel_err(-d[rows], g["dScore_logProb_rows"]) < GRAD_TOL
+
+
+@pytest.mark.parametrize("case", EDGE_CASES, ids=[c[0] for c in EDGE_CASES])
+def test_edge_cases(oracle, case):
+    name, T, B, kind, seed, tr = case
+    g = load_golden("edge_" + name)
+    score, noise = edge_inputs(T, B, kind, seed, tr)
+    score, noise = score.numpy(), noise.numpy()
+    _check_decodes(oracle, g, score, noise)
+    _check_fp(oracle, g, score, noise)
+
+
+@pytest.mark.parametrize("kind", ["randn", "model"])
+def test_medium(oracle, kind):
+    from transkun_amd import synth
+    g = load_golden(f"medium_T256_B90_{kind}")
+    T, B, seed = (int(x) for x in g["meta"])
+    score, noise = synth.crf_inputs_numpy(T, B, seed, kind)
+    _check_decodes(oracle, g, score, noise)
+    _check_fp(oracle, g, score, noise, full_grad=False)
+
+
+@pytest.mark.parametrize("name", ["small", "sqrt", "none", "medium"])
+def test_scorer(oracle, name):
+    import torch
+    from transkun_amd import synth
+    g = load_golden("scorer_" + name)
+    N, P, T, D = (int(x) for x in g["meta"])
+    ls = str(g["ls"])
+    W = synth.hash_normal((2 * D + 1) * D, 41, "cpu").view(2 * D + 1, D) * (1.0 / D ** 0.5)
+    bvec = synth.hash_normal(2 * D + 1, 42, "cpu") * 0.1
+    ctx = synth.hash_normal(N * P * T * D, 43, "cpu").view(N, P, T, D)
+    y = torch.nn.functional.linear(ctx, W, bvec)
+    q, k, diag = y.split([D, D, 1], dim=-1)
+    S = oracle.interval_score(q.reshape(N * P, T, D).numpy(), k.reshape(N * P, T, D).numpy(),
+                              diag.reshape(N * P, T).numpy(), ls)
+    if "S" in g:
+        ref = g["S"].reshape(T, T, N * P)
+        assert scorer_close(S, ref)
+    w = grad_weights(T)
+    Sd = S.astype(np.float64)
+    assert rel_err((Sd * np.tril(np.ones((T, T)))[:, :, None]).sum(axis=(0, 1)), g["S_tril_sum"]) < 1e-4
+    assert rel_err((Sd * w[:, :, None]).sum(axis=(0, 1)), g["S_wsum"]) < 1e-4
+    assert float(g["noise_absmax"]) == 0.0
+
+
+def test_oploop_port_matches_oracle(oracle):
+    """The torch op-loop port (timed as cpu_baseline) computes the same thing as the C oracle."""
+    import torch
+    from transkun_amd import synth
+    score, noise = synth.crf_inputs(48, 5, 3, "cpu", "randn")
+    logz, grad, gn = oracle.oploop_forward_backward(score, noise)
+    lz, g2, gn2, _, _ = oracle.forward_backward(score.numpy(), noise.numpy())
+    assert rel_err(logz.numpy(), lz) < FP_TOL
+    assert rel_err(grad.numpy(), g2) < GRAD_TOL
+    assert rel_err(gn.numpy(), gn2) < GRAD_TOL
+    st = [(c * 5) % 48 for c in range(5)]
+    assert oracle.oploop_viterbi_backward(score, noise, st) == oracle.viterbi(score.numpy(), noise.numpy(), st)
+    assert oracle.oploop_viterbi_backward(score, noise) == oracle.viterbi(score.numpy(), noise.numpy())

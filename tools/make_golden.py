@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE ITSELF (torch CPU) in the build container.
+
+Run here only (needs /root/reference): `PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py [--large]`.
+The fixtures hold data only: inputs (when small and not regenerable) and the reference's
+outputs.  Inputs of all but the crfMinimalExample case come from transkun_amd.synth (exact
+integer hash, same bits everywhere) and are NOT stored.
+
+Decoded interval lists are stored packed: pairs int32 [K,2] + offsets int64 [B+1].
+Large cases store digests/checksums only.
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/transkun")
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+import CRF as REF  # noqa: E402  (the reference package, /root/reference/transkun/CRF)
+from CRF import NeuralSemiCRFInterval as RM  # noqa: E402,F401
+import importlib  # noqa: E402
+
+REFMOD = importlib.import_module("CRF.NeuralSemiCRFInterval")
+
+from transkun_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def pack(lists):
+    counts = [len(x) for x in lists]
+    off = np.zeros(len(lists) + 1, np.int64)
+    np.cumsum(counts, out=off[1:])
+    pairs = np.asarray([p for l in lists for p in l], dtype=np.int32).reshape(-1, 2)
+    return pairs, off
+
+
+def digest(lists):
+    pairs, off = pack(lists)
+    h = hashlib.sha256()
+    h.update(off.astype("<i8").tobytes())
+    h.update(pairs.astype("<i4").tobytes())
+    return h.hexdigest()
+
+
+def grad_weights(T):
+    e = np.arange(T)[:, None]
+    b = np.arange(T)[None, :]
+    return (((e * 31 + b * 17) % 64).astype(np.float32) / 64.0)
+
+
+def run_case(score, noise, intervals, starts, want_grad="full"):
+    """Run the reference on one (score, noise) and collect everything."""
+    out = {}
+    s = score.clone().requires_grad_()
+    n = noise.clone().requires_grad_()
+    crf = REF.NeuralSemiCRFInterval(s, n)
+    T, _, B = score.shape
+    if intervals is not None:
+        path = crf.evalPath(intervals)
+        logz = crf.computeLogZ()
+        lp = path - logz
+        out["evalPath"] = path.detach().numpy()
+        out["logZ"] = logz.detach().numpy()
+        out["logProb"] = lp.detach().numpy()
+        (-lp.sum()).backward()
+        out["dNoise_logProb"] = n.grad.numpy().copy()
+        g = s.grad.numpy()
+        if want_grad == "full":
+            out["dScore_logProb"] = g.copy()
+        w = grad_weights(T)
+        out["dScore_logProb_sum"] = g.sum(axis=(0, 1)).astype(np.float64)
+        out["dScore_logProb_wsum"] = (g.astype(np.float64) * w[:, :, None]).sum(axis=(0, 1))
+        out["dScore_upper_absmax"] = np.float64(np.abs(np.triu(g.transpose(2, 0, 1), 1)).max()) if T > 1 else np.float64(0)
+    with torch.no_grad():
+        logz, grad, gn = REFMOD.forward_backward(score, noise)
+        out["fb_logZ"] = logz.numpy()
+        out["fb_gradNoise"] = gn.numpy()
+        g = grad.numpy()
+        if want_grad == "full":
+            out["fb_grad"] = g.copy()
+        w = grad_weights(T)
+        out["fb_grad_sum"] = g.astype(np.float64).sum(axis=(0, 1))
+        out["fb_grad_wsum"] = (g.astype(np.float64) * w[:, :, None]).sum(axis=(0, 1))
+        out["logZ_noBackward"] = REFMOD.computeLogZ(score, noise).numpy()
+        if T > 1:
+            for name, st in starts.items():
+                for fwd in (False, True):
+                    key = f"decode_{name}_{'fwd' if fwd else 'bwd'}"
+                    if fwd and st is not None:
+                        stf = [T - 1 - x for x in st]      # forward variant: start = END position
+                    else:
+                        stf = st
+                    res = crf.decode(forcedStartPos=stf, forward=fwd)
+                    p, o = pack(res)
+                    out[key + "_pairs"] = p
+                    out[key + "_offsets"] = o
+                    if st is not None:
+                        out[key + "_start"] = np.asarray(stf, np.int32)
+    return out
+
+
+def save(name, d):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"  wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def case_minimal():
+    """crfMinimalExample.py on CPU: T=200, NBatch=4 (BASELINE.json configs[0])."""
+    torch.manual_seed(1234)
+    T, B = 200, 4
+    score = torch.randn(T, T, B)
+    noise = torch.randn(T - 1, B)
+    intervals = [[(0, 2), (4, 6), (6, 6), (7, 8)], [(1, 2), (3, 5), (19, 19)], [(0, 0), (4, 7)], []]
+    d = run_case(score, noise, intervals, {"none": None, "four": [4] * B})
+    # keep the file small: inputs fp32 (640 KB), full grads dropped in favour of a few rows
+    g = d.pop("dScore_logProb"); fb = d.pop("fb_grad")
+    rows = np.asarray([0, 1, 2, 7, 19, 100, 198, 199])
+    d["rows"] = rows
+    d["dScore_logProb_rows"] = g[rows]
+    d["fb_grad_rows"] = fb[rows]
+    d["score"] = score.numpy(); d["noise"] = noise.numpy()
+    ip, io = pack(intervals)
+    d["intervals_pairs"] = ip; d["intervals_offsets"] = io
+    save("minimal_T200_B4", d)
+
+
+EDGE = [
+    # name, T, B, kind, seed, transform
+    ("T2_B3", 2, 3, "randn", 11, None),
+    ("T3_B5", 3, 5, "randn", 12, None),
+    ("T24_B1", 24, 1, "randn", 13, None),
+    ("T24_B63", 24, 63, "randn", 14, None),
+    ("T24_B65", 24, 65, "randn", 15, None),
+    ("T40_B90", 40, 90, "randn", 16, None),
+    ("T33_B7_negdiag", 33, 7, "randn", 17, "negdiag"),
+    ("T33_B7_posdiag", 33, 7, "randn", 18, "posdiag"),
+    ("T33_B7_noise0", 33, 7, "randn", 19, "noise0"),
+    ("T48_B9_ties", 48, 9, "ties", 20, None),
+    ("T48_B6_huge", 48, 6, "model", 21, "huge"),
+    ("T70_B20_model", 70, 20, "model", 22, None),
+]
+
+
+def edge_inputs(T, B, kind, seed, tr):
+    score, noise = synth.crf_inputs(T, B, seed, "cpu", kind)
+    score = score.clone(); noise = noise.clone()
+    d = torch.diagonal(score, dim1=0, dim2=1)
+    if tr == "negdiag":
+        d.copy_(-d.abs() - 0.125)
+    elif tr == "posdiag":
+        d.copy_(d.abs() + 0.125)
+    elif tr == "noise0":
+        noise.zero_()
+    elif tr == "huge":
+        dd = d.clone()
+        score.mul_(4000.0)          # off-diagonal up to ~ +-1e3*|e-b| (SURVEY hard part 6)
+        d.copy_(dd)
+    return score.contiguous(), noise.contiguous()
+
+
+def edge_starts(T, B):
+    mixed = [(c * 7) % T for c in range(B)]
+    return {"none": None, "zero": [0] * B, "Tm2": [max(T - 2, 0)] * B, "Tm1": [T - 1] * B, "mixed": mixed}
+
+
+def case_edges():
+    for name, T, B, kind, seed, tr in EDGE:
+        score, noise = edge_inputs(T, B, kind, seed, tr)
+        intervals = synth.synthetic_intervals(T, B, seed=seed, every=5, active_every=2)
+        d = run_case(score, noise, intervals, edge_starts(T, B))
+        ip, io = pack(intervals)
+        d["intervals_pairs"] = ip; d["intervals_offsets"] = io
+        d["meta"] = np.asarray([T, B, seed])
+        save("edge_" + name, d)
+
+
+def case_medium():
+    for kind in ("randn", "model"):
+        T, B, seed = 256, 90, 31
+        score, noise = synth.crf_inputs(T, B, seed, "cpu", kind)
+        intervals = synth.synthetic_intervals(T, B, seed=seed)
+        d = run_case(score, noise, intervals, {"none": None, "four": [4] * B, "mixed": [(c * 13) % T for c in range(B)]},
+                     want_grad="sums")
+        ip, io = pack(intervals)
+        d["intervals_pairs"] = ip; d["intervals_offsets"] = io
+        d["meta"] = np.asarray([T, B, seed])
+        save(f"medium_T{T}_B{B}_{kind}", d)
+
+
+def case_scorer():
+    from transkun.LayersTransformer import ScaledInnerProductIntervalScorer
+    for name, N, P, T, D, ls in (("small", 1, 3, 40, 16, "linear"), ("sqrt", 2, 2, 24, 32, "sqrt"),
+                                 ("none", 1, 4, 24, 8, "none"), ("medium", 2, 5, 96, 256, "linear")):
+        torch.manual_seed(5)
+        m = ScaledInnerProductIntervalScorer(D, 1, lengthScaling=ls)
+        W = synth.hash_normal((2 * D + 1) * D, 41, "cpu").view(2 * D + 1, D) * (1.0 / D ** 0.5)
+        bvec = synth.hash_normal(2 * D + 1, 42, "cpu") * 0.1
+        with torch.no_grad():
+            m.map[0].weight.copy_(W); m.map[0].bias.copy_(bvec)
+        ctx = synth.hash_normal(N * P * T * D, 43, "cpu").view(N, P, T, D).requires_grad_()
+        S, b = m(ctx)
+        d = {"meta": np.asarray([N, P, T, D]), "ls": np.asarray(ls)}
+        # a fixed cotangent to pin the backward (row f1 of SURVEY 8f comes later; data is cheap now)
+        cot = synth.hash_normal(S.numel(), 44, "cpu").view_as(S)
+        cot = cot * torch.ones(T, T).tril()[:, :, None, None]
+        (S * cot).sum().backward()
+        if S.numel() <= 200_000:
+            d["S"] = S.detach().numpy()
+        w = grad_weights(T)
+        Sd = S.detach().numpy().astype(np.float64).reshape(T, T, -1)
+        d["S_sum"] = Sd.sum(axis=(0, 1)); d["S_wsum"] = (Sd * w[:, :, None]).sum(axis=(0, 1))
+        d["S_tril_sum"] = (Sd * np.tril(np.ones((T, T)))[:, :, None]).sum(axis=(0, 1))
+        d["noise_absmax"] = np.float64(b.abs().max())
+        d["dctx_sum"] = ctx.grad.numpy().astype(np.float64).sum(axis=(2, 3))
+        d["dW_rows"] = m.map[0].weight.grad.numpy()[[0, 1, D - 1, D, 2 * D - 1, 2 * D]]
+        d["dbias"] = m.map[0].bias.grad.numpy()
+        save("scorer_" + name, d)
+
+
+def case_large():
+    """BASELINE.json configs[1] and [2] plus the headline size.  Outputs only."""
+    torch.set_num_threads(8)
+    # configs[1]: T=1024, NBatch=88, logProb fwd+bwd
+    for T, B in ((1024, 88), (1024, 352)):
+        seed = 1234
+        t0 = time.time()
+        score, noise = synth.crf_inputs(T, B, seed, "cpu", "randn")
+        intervals = synth.synthetic_intervals(T, B, seed=seed)
+        s = score.requires_grad_(); n = noise.requires_grad_()
+        crf = REF.NeuralSemiCRFInterval(s, n)
+        path = crf.evalPath(intervals); logz = crf.computeLogZ()
+        lp = path - logz
+        (-lp.sum()).backward()
+        g = s.grad.numpy(); w = grad_weights(T)
+        d = {"meta": np.asarray([T, B, seed]), "evalPath": path.detach().numpy(), "logZ": logz.detach().numpy(),
+             "logProb": lp.detach().numpy(), "dNoise_logProb": n.grad.numpy(),
+             "dScore_logProb_sum": g.astype(np.float64).sum(axis=(0, 1)),
+             "dScore_logProb_wsum": np.einsum("ebc,eb->c", g.astype(np.float64), w.astype(np.float64)),
+             "dScore_rows": np.asarray([1, 500, T - 1]), "dScore_logProb_rows": g[[1, 500, T - 1]][:, :, :8].copy()}
+        print(f"  T={T} B={B} reference logProb fwd+bwd took {time.time() - t0:.1f}s")
+        save(f"large_T{T}_B{B}_randn", d)
+        del g, s, n, crf, score, noise
+    # configs[2]: Viterbi decode T=2048, NBatch=352, forcedStartPos set
+    T, B, seed = 2048, 352, 1234
+    score, noise = synth.crf_inputs(T, B, seed, "cpu", "randn")
+    crf = REF.NeuralSemiCRFInterval(score, noise)
+    d = {"meta": np.asarray([T, B, seed])}
+    with torch.no_grad():
+        for name, st in (("four", [4] * B), ("mixed", [(c * 37) % T for c in range(B)])):
+            t0 = time.time()
+            res = crf.decode(forcedStartPos=st)
+            print(f"  T={T} B={B} reference decode({name}) took {time.time() - t0:.1f}s")
+            p, o = pack(res)
+            d[f"decode_{name}_offsets"] = o
+            d[f"decode_{name}_sha256"] = np.asarray(digest(res))
+            d[f"decode_{name}_head"] = p[:64]
+            d[f"decode_{name}_start"] = np.asarray(st, np.int32)
+    save(f"large_T{T}_B{B}_decode", d)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--large", action="store_true")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    todo = a.only.split(",") if a.only else ["minimal", "edges", "medium", "scorer"] + (["large"] if a.large else [])
+    for t in todo:
+        print("case", t)
+        {"minimal": case_minimal, "edges": case_edges, "medium": case_medium, "scorer": case_scorer,
+         "large": case_large}[t]()

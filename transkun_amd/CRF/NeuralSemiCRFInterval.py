@@ -1,0 +1,301 @@
+"""MI355X-native Neural Semi-CRF interval layer -- host-side mirror of the reference class.
+
+Drop-in for /root/reference/transkun/CRF/NeuralSemiCRFInterval.py (class at :553-588): same
+constructor, method names, defaults, argument meaning and result types.  All arithmetic runs
+in hand-written gfx950 HIP kernels behind the C ABI of include/semicrf_hip.h; this file only
+validates shapes, marshals the Python interval lists to/from packed int32 buffers and wires the
+kernels into autograd.  There is no CPU path: CPU tensors raise RuntimeError.
+
+What differs from the reference, invisibly at the API:
+  * computeLogZ saves alpha (v [T,B]) and logZ instead of the dense marginals [T,T,B]
+    (reference :463-464) and recomputes them in backward, fused with the beta sweep.
+  * logProb() is ONE autograd node: its backward writes gout*(onehot(path) - marginal) in a single
+    pass instead of summing two dense [T,T,B] gradients.
+  * decode() backtracks on the device; only the packed (begin,end) pairs cross PCIe.
+"""
+from __future__ import annotations
+
+from itertools import chain
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+Intervals = List[List[Tuple[int, int]]]
+
+
+# --------------------------------------------------------------------------------------
+# marshalling
+# --------------------------------------------------------------------------------------
+
+def _check_inputs(score: torch.Tensor, noiseScore: torch.Tensor):
+    # same asserts as the reference (:209-215, :377-382, :510-511) -> AssertionError
+    assert len(score.shape) == 3
+    assert score.shape[0] == score.shape[1]
+    assert len(noiseScore.shape) == 2
+    T, B = score.shape[0], score.shape[2]
+    assert noiseScore.shape[0] == T - 1
+    assert noiseScore.shape[1] == B
+    _lib.require_gpu(score, "score")
+    _lib.require_gpu(noiseScore, "noiseScore")
+    return T, B
+
+
+def _prep(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def pack_intervals(intervals: Sequence[Sequence[Tuple[int, int]]], T: int, B: int, device):
+    """List[List[(begin,end)]] (len B) -> (pairs int32 [K,2], offsets int32 [B+1]) on `device`."""
+    assert len(intervals) == B, f"expected {B} interval lists, got {len(intervals)}"
+    counts = np.fromiter((len(x) for x in intervals), dtype=np.int64, count=B)
+    offsets = np.zeros(B + 1, dtype=np.int32)
+    np.cumsum(counts, out=offsets[1:])
+    K = int(offsets[-1])
+    flat = np.fromiter(chain.from_iterable(chain.from_iterable(intervals)), dtype=np.int64, count=2 * K)
+    if K:
+        pr = flat.reshape(K, 2)
+        if (pr < 0).any() or (pr >= T).any():
+            raise IndexError(f"interval index out of range for T={T}")   # reference: gather index error
+    pairs_t = torch.from_numpy(flat.astype(np.int32).reshape(K, 2) if K else np.zeros((1, 2), np.int32))
+    offsets_t = torch.from_numpy(offsets)
+    return pairs_t.to(device, non_blocking=True), offsets_t.to(device, non_blocking=True)
+
+
+def unpack_intervals(pairs_host: torch.Tensor, offsets_host: torch.Tensor) -> Intervals:
+    flat = pairs_host.reshape(-1).tolist()
+    it = iter(flat)
+    tuples = list(zip(it, it))
+    off = offsets_host.tolist()
+    return [tuples[off[c]:off[c + 1]] for c in range(len(off) - 1)]
+
+
+# --------------------------------------------------------------------------------------
+# raw kernel calls (no autograd)
+# --------------------------------------------------------------------------------------
+
+def _logz_fwd_raw(score, noise, want_v: bool):
+    T, B = score.shape[0], score.shape[2]
+    lib = _lib.load()
+    logz = torch.empty(B, dtype=torch.float32, device=score.device)
+    v = torch.empty(T, B, dtype=torch.float32, device=score.device) if want_v else None
+    ws = _lib.workspace(_lib.OP_LOGZ_FWD, T, B, score.device)
+    rc = lib.semicrf_logz_fwd(_lib.ptr(score), _lib.ptr(noise), T, B, _lib.ptr(logz), _lib.ptr(v),
+                              _lib.ptr(ws), ws.numel(), _lib.stream_of(score))
+    _lib.check(rc, "semicrf_logz_fwd")
+    return logz, v
+
+
+def _logz_bwd_raw(score, noise, v, logz, gout, want_q: bool = False):
+    T, B = score.shape[0], score.shape[2]
+    lib = _lib.load()
+    dscore = torch.empty_like(score)
+    dnoise = torch.empty_like(noise)
+    q = torch.empty(T, B, dtype=torch.float32, device=score.device) if want_q else None
+    ws = _lib.workspace(_lib.OP_LOGZ_BWD, T, B, score.device)
+    rc = lib.semicrf_logz_bwd(_lib.ptr(score), _lib.ptr(noise), _lib.ptr(v), _lib.ptr(logz), _lib.ptr(gout),
+                              T, B, _lib.ptr(dscore), _lib.ptr(dnoise), _lib.ptr(q), _lib.ptr(ws), ws.numel(),
+                              _lib.stream_of(score))
+    _lib.check(rc, "semicrf_logz_bwd")
+    return dscore, dnoise, q
+
+
+def _eval_path_raw(score, noise, pairs, offsets):
+    T, B = score.shape[0], score.shape[2]
+    lib = _lib.load()
+    out = torch.empty(B, dtype=torch.float32, device=score.device)
+    ws = _lib.workspace(_lib.OP_EVAL_PATH, T, B, score.device)
+    rc = lib.semicrf_eval_path(_lib.ptr(score), _lib.ptr(noise), T, B, _lib.ptr(pairs), _lib.ptr(offsets),
+                               _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_of(score))
+    _lib.check(rc, "semicrf_eval_path")
+    return out
+
+
+def _eval_path_bwd_raw(gout, T, B, pairs, offsets, dscore, dnoise):
+    lib = _lib.load()
+    rc = lib.semicrf_eval_path_bwd(_lib.ptr(gout), T, B, _lib.ptr(pairs), _lib.ptr(offsets), _lib.ptr(dscore),
+                                   _lib.ptr(dnoise), _lib.stream_of(gout))
+    _lib.check(rc, "semicrf_eval_path_bwd")
+
+
+def _gout(grad_output: torch.Tensor, B: int) -> torch.Tensor:
+    assert grad_output.shape[-1] == B      # reference :471
+    g = grad_output.reshape(B)
+    if g.dtype != torch.float32:
+        g = g.float()
+    return g.contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# autograd nodes
+# --------------------------------------------------------------------------------------
+
+class ComputeLogZFasterGrad(torch.autograd.Function):
+    """logZ with a hand-written gradient (reference :459-475), recompute-in-backward flavour."""
+
+    @staticmethod
+    def forward(ctx, score, noiseScore):
+        score_c, noise_c = _prep(score), _prep(noiseScore)
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        logz, v = _logz_fwd_raw(score_c, noise_c, want_v=need)
+        if need:
+            ctx.save_for_backward(score_c, noise_c, v, logz)
+        return logz
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        score, noise, v, logz = ctx.saved_tensors
+        B = score.shape[2]
+        dscore, dnoise, _ = _logz_bwd_raw(score, noise, v, logz, _gout(grad_output, B))
+        return dscore, dnoise
+
+
+computeLogZFasterGrad = ComputeLogZFasterGrad.apply
+
+
+class _EvalPath(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, score, noiseScore, pairs, offsets):
+        score_c, noise_c = _prep(score), _prep(noiseScore)
+        ctx.save_for_backward(pairs, offsets)
+        ctx.shape = (score_c.shape[0], score_c.shape[2])
+        return _eval_path_raw(score_c, noise_c, pairs, offsets)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        pairs, offsets = ctx.saved_tensors
+        T, B = ctx.shape
+        g = _gout(grad_output, B)
+        dscore = torch.zeros(T, T, B, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
+        dnoise = torch.zeros(max(T - 1, 0), B, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1] else None
+        _eval_path_bwd_raw(g, T, B, pairs, offsets, dscore, dnoise)
+        return dscore, dnoise, None, None
+
+
+class _LogProb(torch.autograd.Function):
+    """evalPath - logZ as one node; backward = gout * (onehot(path) - marginals) in one dense pass."""
+
+    @staticmethod
+    def forward(ctx, score, noiseScore, pairs, offsets):
+        score_c, noise_c = _prep(score), _prep(noiseScore)
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        logz, v = _logz_fwd_raw(score_c, noise_c, want_v=need)
+        path = _eval_path_raw(score_c, noise_c, pairs, offsets)
+        if need:
+            ctx.save_for_backward(score_c, noise_c, v, logz, pairs, offsets)
+        return path - logz
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        score, noise, v, logz, pairs, offsets = ctx.saved_tensors
+        T, B = score.shape[0], score.shape[2]
+        g = _gout(grad_output, B)
+        dscore, dnoise, _ = _logz_bwd_raw(score, noise, v, logz, -g)
+        _eval_path_bwd_raw(g, T, B, pairs, offsets, dscore, dnoise)
+        return dscore, dnoise, None, None
+
+
+# --------------------------------------------------------------------------------------
+# module-level functions with the reference's names
+# --------------------------------------------------------------------------------------
+
+def _decode(score, noiseScore, forcedStartPos: Optional[Sequence[int]], forward: bool) -> Intervals:
+    assert len(score.shape) == 3
+    assert score.shape[0] == score.shape[1]
+    T, B = _check_inputs(score, noiseScore)
+    with torch.no_grad():
+        score_c, noise_c = _prep(score.detach()), _prep(noiseScore.detach())
+        dev = score_c.device
+        start = None
+        if forcedStartPos is not None:
+            assert len(forcedStartPos) == B
+            st = np.asarray(forcedStartPos, dtype=np.int64)
+            if (st < 0).any() or (st > T - 1).any():
+                raise IndexError(f"forcedStartPos out of range for T={T}")
+            start = torch.from_numpy(st.astype(np.int32)).to(dev, non_blocking=True)
+        cap = B * 2 * T
+        pairs = torch.empty(cap, 2, dtype=torch.int32, device=dev)
+        offsets = torch.empty(B + 1, dtype=torch.int32, device=dev)
+        ws = _lib.workspace(_lib.OP_VITERBI, T, B, dev)
+        lib = _lib.load()
+        rc = lib.semicrf_viterbi(_lib.ptr(score_c), _lib.ptr(noise_c), T, B, _lib.ptr(start), 1 if forward else 0,
+                                 _lib.ptr(pairs), cap, _lib.ptr(offsets), _lib.ptr(ws), ws.numel(),
+                                 _lib.stream_of(score_c))
+        _lib.check(rc, "semicrf_viterbi")
+        off_h = offsets.cpu()                      # the one host sync of decode
+        total = int(off_h[-1])
+        pairs_h = pairs[:total].cpu()
+    return unpack_intervals(pairs_h, off_h)
+
+
+def viterbiBackward(score, noiseScore, forcedStartPos: Optional[List[int]] = None) -> Intervals:
+    """Right-to-left Viterbi, the default decode (reference :13-104)."""
+    return _decode(score, noiseScore, forcedStartPos, forward=False)
+
+
+def viterbi(score, noiseScore, forcedStartPos: Optional[List[int]] = None) -> Intervals:
+    """Left-to-right Viterbi (reference :107-202); forcedStartPos is the END position here."""
+    return _decode(score, noiseScore, forcedStartPos, forward=True)
+
+
+def computeLogZ(score, noiseScore):
+    """Reference :207-246 (the autograd-traceable variant).  Same kernel as computeLogZFasterGrad."""
+    _check_inputs(score, noiseScore)
+    return ComputeLogZFasterGrad.apply(score, noiseScore)
+
+
+def forward_backward(score, noiseScore):
+    """Reference :375-456: returns (logZ [B], grad [T,T,B], gradNoise [T-1,B])."""
+    T, B = _check_inputs(score, noiseScore)
+    with torch.no_grad():
+        s, n = _prep(score.detach()), _prep(noiseScore.detach())
+        logz, v = _logz_fwd_raw(s, n, want_v=True)
+        ones = torch.ones(B, dtype=torch.float32, device=s.device)
+        grad, grad_noise, _ = _logz_bwd_raw(s, n, v, logz, ones)
+    return logz, grad, grad_noise
+
+
+def evalPath(intervals: Intervals, score, noiseScore):
+    """Unnormalised path score (reference :508-550)."""
+    T, B = _check_inputs(score, noiseScore)
+    pairs, offsets = pack_intervals(intervals, T, B, score.device)
+    return _EvalPath.apply(score, noiseScore, pairs, offsets)
+
+
+class NeuralSemiCRFInterval:
+    def __init__(self, score, noiseScore):
+        """The output layer for multiple tracks of non-overlapping intervals (reference :553-564).
+
+        score      -- [T, T, nBatch]: score of every closed interval [begin, end], indexed
+                      [end, begin, track]; only end >= begin is read.
+        noiseScore -- [T-1, nBatch]: score of "no event" between frames t and t+1.
+        """
+        self.score = score
+        self.noiseScore = noiseScore
+
+    def decode(self, forcedStartPos=None, forward=False):
+        if forward:
+            return viterbi(self.score, self.noiseScore, forcedStartPos)
+        else:
+            return viterbiBackward(self.score, self.noiseScore, forcedStartPos)
+
+    def evalPath(self, intervals):
+        """compute the unnormalized score"""
+        return evalPath(intervals, self.score, self.noiseScore)
+
+    def computeLogZ(self, noBackward=False):
+        """compute the log normalization factor"""
+        if noBackward:
+            return computeLogZ(self.score, self.noiseScore)
+        else:
+            _check_inputs(self.score, self.noiseScore)
+            return computeLogZFasterGrad(self.score, self.noiseScore)
+
+    def logProb(self, intervals, noBackward=False):
+        T, B = _check_inputs(self.score, self.noiseScore)
+        pairs, offsets = pack_intervals(intervals, T, B, self.score.device)
+        return _LogProb.apply(self.score, self.noiseScore, pairs, offsets)

@@ -1,0 +1,96 @@
+"""ctypes binding to libsemicrf_hip.so (the C ABI of include/semicrf_hip.h).
+
+torch is imported first on purpose: the library needs libamdhip64.so.7 and must bind to the
+HIP runtime torch has already loaded (one runtime per process), not to a second copy.
+There is NO fallback: a missing library or a non-GPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsemicrf_hip.so")
+
+OP_LOGZ_FWD, OP_LOGZ_BWD, OP_VITERBI, OP_EVAL_PATH, OP_INTERVAL_SCORE = range(5)
+LEN_MODES = {"linear": 0, "sqrt": 1, "none": 2}
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_sz = ctypes.c_size_t
+
+_SIGS = {
+    "semicrf_abi_version": (ctypes.c_int, []),
+    "semicrf_last_error": (ctypes.c_char_p, []),
+    "semicrf_workspace_bytes": (_sz, [_i, _i, _i]),
+    "semicrf_set_impl": (None, [_i]),
+    "semicrf_get_impl": (ctypes.c_int, []),
+    "semicrf_logz_fwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "semicrf_logz_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "semicrf_viterbi": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "semicrf_eval_path": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "semicrf_eval_path_bwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "interval_score_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, ctypes.c_float, _i, _i, _vp, _vp, _vp]),
+}
+
+EXPORTED = tuple(_SIGS)
+_lib = None
+
+
+class SemiCRFLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SemiCRFLibraryError(
+                f"{LIB_PATH} not found: build it with `python -m transkun_amd._build` "
+                "(hipcc --offload-arch=gfx950).  transkun_amd has no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().semicrf_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_gpu(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"transkun_amd: `{name}` is on {t.device}; this layer only runs on an AMD GPU through its "
+            "HIP kernels (there is deliberately no CPU fallback)")
+
+
+def workspace(op: int, T: int, B: int, device) -> torch.Tensor:
+    n = load().semicrf_workspace_bytes(op, T, B)
+    return torch.empty(max(int(n), 256), dtype=torch.uint8, device=device)
+
+
+def set_impl(impl: int) -> None:
+    load().semicrf_set_impl(int(impl))
+
+
+def get_impl() -> int:
+    return int(load().semicrf_get_impl())

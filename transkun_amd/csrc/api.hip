@@ -1,0 +1,186 @@
+// api.hip -- extern "C" entry points declared in include/semicrf_hip.h: argument checks,
+// workspace carving and dispatch to the kernels.  Nothing here synchronises the host.
+#include <stdarg.h>
+#include <string.h>
+#include <atomic>
+#include "common.h"
+
+namespace semicrf {
+
+static thread_local char g_err[512] = "";
+static std::atomic<int> g_impl{0};
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// kernels (defined in the other translation units)
+void launch_rowseq_sweep(int mode, int dir, const float* score, const float* noise, int T, int B, float* u,
+                         int* code, float* out_last, hipStream_t stream);
+void launch_marginals(const float* score, const float* noise, const float* v, const float* q,
+                      const float* logZ, const float* gout, int T, int B, float* dScore, float* dNoise,
+                      hipStream_t stream);
+void launch_backtrack(const int* code, int T, int B, const int* start, int forward, int* region, int* counts,
+                      int* pairs, long long cap, int* offsets, hipStream_t stream);
+void launch_eval_path(const float* score, const float* noise, int T, int B, const int* pairs,
+                      const int* offsets, float* cum, float* out, hipStream_t stream);
+void launch_eval_path_bwd(const float* gout, int T, int B, const int* pairs, const int* offsets,
+                          float* dScore, float* dNoise, hipStream_t stream);
+void launch_interval_score_naive(const float* q, const float* k, const float* diag, int C, int T, int D,
+                                 long long ldq, long long ldk, long long ldd, float qscale, int mode, int full,
+                                 float* S, hipStream_t stream);
+
+struct Carver {
+    char* p;
+    size_t left;
+    bool ok = true;
+    Carver(void* ws, size_t n) : p((char*)ws), left(n) {}
+    template <typename U>
+    U* take(size_t count)
+    {
+        size_t bytes = align_up(count * sizeof(U));
+        if (bytes > left) { ok = false; return nullptr; }
+        U* r = (U*)p;
+        p += bytes;
+        left -= bytes;
+        return r;
+    }
+};
+
+static size_t tb(int T, int B) { return align_up((size_t)T * (size_t)B * 4); }
+
+}  // namespace semicrf
+
+using namespace semicrf;
+
+extern "C" {
+
+int semicrf_abi_version(void) { return SEMICRF_ABI_VERSION; }
+const char* semicrf_last_error(void) { return g_err; }
+void semicrf_set_impl(int impl) { g_impl.store(impl); }
+int semicrf_get_impl(void) { return g_impl.load(); }
+
+size_t semicrf_workspace_bytes(int op, int T, int B)
+{
+    if (T <= 0 || B <= 0) return 0;
+    switch (op) {
+        case SEMICRF_OP_LOGZ_FWD: return tb(T, B) + 4096;
+        case SEMICRF_OP_LOGZ_BWD: return tb(T, B) + 4096;
+        case SEMICRF_OP_VITERBI:
+            // u [T][B] f32, code [B][T] i32, region [B][2T][2] i32, counts [B] i32
+            return tb(T, B) * 2 + align_up((size_t)B * 2 * T * 2 * 4) + align_up((size_t)B * 4) + 4096;
+        case SEMICRF_OP_EVAL_PATH: return tb(T, B) + 4096;
+        case SEMICRF_OP_INTERVAL_SCORE: return 4096;
+        default: return 0;
+    }
+}
+
+static int check_common(const float* score, const float* noise, int T, int B)
+{
+    SEMICRF_CHECK_ARG(T >= 1 && B >= 1, "T=%d, B=%d must be >= 1", T, B);
+    SEMICRF_CHECK_ARG((long long)T * T * B < (1ll << 40), "T*T*B too large");
+    SEMICRF_CHECK_ARG(T < (1 << 29), "T too large");
+    SEMICRF_CHECK_ARG(score != nullptr, "score is NULL");
+    SEMICRF_CHECK_ARG(noise != nullptr || T == 1, "noise is NULL");
+    return SEMICRF_OK;
+}
+
+int semicrf_logz_fwd(const float* score, const float* noise, int T, int B, float* logZ, float* v, void* ws,
+                     size_t ws_bytes, semicrf_stream_t stream)
+{
+    if (int rc = check_common(score, noise, T, B)) return rc;
+    SEMICRF_CHECK_ARG(logZ != nullptr, "logZ is NULL");
+    Carver cv(ws, ws_bytes);
+    float* vv = v ? v : cv.take<float>((size_t)T * B);
+    if (!cv.ok || (!v && !ws)) { set_error("workspace too small for logz_fwd"); return SEMICRF_EWORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    launch_rowseq_sweep(0, 0, score, noise, T, B, vv, nullptr, logZ, st);
+    SEMICRF_CHECK_LAUNCH("semicrf_logz_fwd");
+    return SEMICRF_OK;
+}
+
+int semicrf_logz_bwd(const float* score, const float* noise, const float* v, const float* logZ,
+                     const float* gout, int T, int B, float* dScore, float* dNoise, float* q_out, void* ws,
+                     size_t ws_bytes, semicrf_stream_t stream)
+{
+    if (int rc = check_common(score, noise, T, B)) return rc;
+    SEMICRF_CHECK_ARG(v && logZ && gout && dScore, "v/logZ/gout/dScore must be non-NULL");
+    SEMICRF_CHECK_ARG(dNoise != nullptr || T == 1, "dNoise is NULL");
+    Carver cv(ws, ws_bytes);
+    float* q = q_out ? q_out : cv.take<float>((size_t)T * B);
+    if (!cv.ok || (!q_out && !ws)) { set_error("workspace too small for logz_bwd"); return SEMICRF_EWORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    launch_rowseq_sweep(0, 1, score, noise, T, B, q, nullptr, nullptr, st);
+    launch_marginals(score, noise, v, q, logZ, gout, T, B, dScore, dNoise, st);
+    SEMICRF_CHECK_LAUNCH("semicrf_logz_bwd");
+    return SEMICRF_OK;
+}
+
+int semicrf_viterbi(const float* score, const float* noise, int T, int B, const int32_t* start, int forward,
+                    int32_t* pairs, int64_t cap, int32_t* offsets, void* ws, size_t ws_bytes,
+                    semicrf_stream_t stream)
+{
+    if (int rc = check_common(score, noise, T, B)) return rc;
+    SEMICRF_CHECK_ARG(pairs && offsets && cap >= 0, "pairs/offsets must be non-NULL");
+    SEMICRF_CHECK_ARG((long long)B * 2 * T < (1ll << 31), "B*2T exceeds int32 offsets");
+    Carver cv(ws, ws_bytes);
+    float* u = cv.take<float>((size_t)T * B);
+    int* code = cv.take<int>((size_t)T * B);
+    int* region = cv.take<int>((size_t)B * 2 * T * 2);
+    int* counts = cv.take<int>((size_t)B);
+    if (!cv.ok || !ws) { set_error("workspace too small for viterbi"); return SEMICRF_EWORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    launch_rowseq_sweep(1, forward ? 0 : 1, score, noise, T, B, u, code, nullptr, st);
+    launch_backtrack(code, T, B, start, forward ? 1 : 0, region, counts, pairs, (long long)cap, offsets, st);
+    SEMICRF_CHECK_LAUNCH("semicrf_viterbi");
+    return SEMICRF_OK;
+}
+
+int semicrf_eval_path(const float* score, const float* noise, int T, int B, const int32_t* pairs,
+                      const int32_t* offsets, float* out, void* ws, size_t ws_bytes, semicrf_stream_t stream)
+{
+    if (int rc = check_common(score, noise, T, B)) return rc;
+    SEMICRF_CHECK_ARG(offsets && out, "offsets/out must be non-NULL");
+    Carver cv(ws, ws_bytes);
+    float* cum = cv.take<float>((size_t)T * B);
+    if (!cv.ok || !ws) { set_error("workspace too small for eval_path"); return SEMICRF_EWORKSPACE; }
+    launch_eval_path(score, noise, T, B, pairs, offsets, cum, out, (hipStream_t)stream);
+    SEMICRF_CHECK_LAUNCH("semicrf_eval_path");
+    return SEMICRF_OK;
+}
+
+int semicrf_eval_path_bwd(const float* gout, int T, int B, const int32_t* pairs, const int32_t* offsets,
+                          float* dScore, float* dNoise, semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(T >= 1 && B >= 1, "T=%d, B=%d must be >= 1", T, B);
+    SEMICRF_CHECK_ARG(gout && offsets, "gout/offsets must be non-NULL");
+    launch_eval_path_bwd(gout, T, B, pairs, offsets, dScore, dNoise, (hipStream_t)stream);
+    SEMICRF_CHECK_LAUNCH("semicrf_eval_path_bwd");
+    return SEMICRF_OK;
+}
+
+int interval_score_fwd(const float* q, const float* k, const float* diag, int C, int T, int D, int64_t ldq,
+                       int64_t ldk, int64_t ldd, float qscale, int length_scaling, int full_square, float* S,
+                       float* noise_out, semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(C >= 1 && T >= 1 && D >= 1, "C=%d T=%d D=%d must be >= 1", C, T, D);
+    SEMICRF_CHECK_ARG(q && k && diag && S, "q/k/diag/S must be non-NULL");
+    SEMICRF_CHECK_ARG(ldq >= D && ldk >= D && ldd >= 1, "bad leading dimensions");
+    SEMICRF_CHECK_ARG(length_scaling >= 0 && length_scaling <= 2, "bad length_scaling %d", length_scaling);
+    hipStream_t st = (hipStream_t)stream;
+    launch_interval_score_naive(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, length_scaling, full_square, S, st);
+    if (noise_out && T > 1) {
+        if (hipMemsetAsync(noise_out, 0, (size_t)(T - 1) * C * sizeof(float), st) != hipSuccess) {
+            set_error("hipMemsetAsync failed");
+            return SEMICRF_ELAUNCH;
+        }
+    }
+    SEMICRF_CHECK_LAUNCH("interval_score_fwd");
+    return SEMICRF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+// common.h -- shared helpers for the gfx950 semi-CRF kernels (internal; the public ABI is include/semicrf_hip.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+#include "../../include/semicrf_hip.h"
+
+namespace semicrf {
+
+constexpr int WAVE = 64;
+#define SEMICRF_NEG_INF (-__builtin_huge_valf())
+
+void set_error(const char* fmt, ...);
+
+#define SEMICRF_CHECK_ARG(cond, ...)                      \
+    do {                                                  \
+        if (!(cond)) {                                    \
+            ::semicrf::set_error(__VA_ARGS__);            \
+            return SEMICRF_EINVAL;                        \
+        }                                                 \
+    } while (0)
+
+#define SEMICRF_CHECK_LAUNCH(what)                                                            \
+    do {                                                                                      \
+        hipError_t e__ = hipGetLastError();                                                   \
+        if (e__ != hipSuccess) {                                                              \
+            ::semicrf::set_error("%s: %s", what, hipGetErrorString(e__));                     \
+            return SEMICRF_ELAUNCH;                                                           \
+        }                                                                                     \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// ---- device math ---------------------------------------------------------------------------
+// F.softplus(beta=1, threshold=20): NeuralSemiCRFInterval.py:218,232,395,427
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+// online log-sum-exp accumulator update in natural-log domain: (M,S) <- (M,S) (+) t
+__device__ __forceinline__ void lse_push(float& M, float& S, float t)
+{
+    float nm = fmaxf(M, t);
+    S = S * expf(M - nm) + expf(t - nm);
+    M = nm;
+}
+// merge two accumulators
+__device__ __forceinline__ void lse_merge(float& M, float& S, float M2, float S2)
+{
+    float nm = fmaxf(M, M2);
+    // (-inf) - (-inf) would be NaN: an empty accumulator has S == 0, guard it
+    float a = (S == 0.0f) ? 0.0f : S * expf(M - nm);
+    float b = (S2 == 0.0f) ? 0.0f : S2 * expf(M2 - nm);
+    S = a + b;
+    M = nm;
+}
+
+// Viterbi candidate merge: larger value wins; on ties the smaller key (candidate order) wins.
+__device__ __forceinline__ void max_push(float& best, int& key, float t, int k)
+{
+    if (t > best || (t == best && k < key)) { best = t; key = k; }
+}
+
+}  // namespace semicrf
