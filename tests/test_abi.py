@@ -1,0 +1,117 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports every
+symbol include/semicrf_hip.h declares; the Python mirror keeps the reference's surface and
+refuses to run without a GPU (no CPU fallback)."""
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "semicrf_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b([a-z_0-9]+)\s*\([^;{]*\)\s*;", src)
+    return sorted(set(n for n in names if n.startswith(("semicrf_", "interval_score"))))
+
+
+def test_library_builds_and_exports_header_symbols():
+    from transkun_amd import _build, _lib
+    path = _build.build()
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    declared = _declared_functions()
+    assert len(declared) >= 10
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in semicrf_hip.h but not exported"
+    assert set(_lib.EXPORTED) == set(declared)
+    loaded = _lib.load()
+    assert loaded.semicrf_abi_version() == 1
+    assert loaded.semicrf_workspace_bytes(_lib.OP_VITERBI, 1024, 352) > 0
+
+
+def test_invalid_arguments_are_rejected_without_gpu():
+    from transkun_amd import _lib
+    lib = _lib.load()
+    rc = lib.semicrf_logz_fwd(None, None, 0, 4, None, None, None, 0, None)
+    assert rc == 1
+    assert b"must be >= 1" in lib.semicrf_last_error()
+    rc = lib.semicrf_logz_fwd(None, None, 8, 4, None, None, None, 0, None)
+    assert rc == 1 and b"NULL" in lib.semicrf_last_error()
+
+
+def test_python_surface_matches_reference():
+    from transkun_amd import CRF
+    cls = CRF.NeuralSemiCRFInterval
+    assert list(inspect.signature(cls.__init__).parameters) == ["self", "score", "noiseScore"]
+    sig = inspect.signature(cls.decode)
+    assert list(sig.parameters) == ["self", "forcedStartPos", "forward"]
+    assert sig.parameters["forcedStartPos"].default is None and sig.parameters["forward"].default is False
+    assert list(inspect.signature(cls.evalPath).parameters) == ["self", "intervals"]
+    assert inspect.signature(cls.computeLogZ).parameters["noBackward"].default is False
+    assert list(inspect.signature(cls.logProb).parameters) == ["self", "intervals", "noBackward"]
+    for fn in ("viterbi", "viterbiBackward", "computeLogZ", "forward_backward", "evalPath", "computeLogZFasterGrad"):
+        assert hasattr(CRF, fn)
+    crf = cls(torch.zeros(3, 3, 2), torch.zeros(2, 2))
+    assert crf.score.shape == (3, 3, 2) and crf.noiseScore.shape == (2, 2)
+
+
+def test_no_cpu_fallback():
+    from transkun_amd import CRF
+    crf = CRF.NeuralSemiCRFInterval(torch.zeros(4, 4, 2), torch.zeros(3, 2))
+    for call in (lambda: crf.decode(), lambda: crf.computeLogZ(), lambda: crf.logProb([[], []]),
+                 lambda: crf.evalPath([[], []])):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            call()
+
+
+def test_shape_asserts_like_reference():
+    from transkun_amd import CRF
+    with pytest.raises(AssertionError):
+        CRF.NeuralSemiCRFInterval(torch.zeros(4, 5, 2), torch.zeros(3, 2)).computeLogZ()
+    with pytest.raises(AssertionError):
+        CRF.NeuralSemiCRFInterval(torch.zeros(4, 4, 2), torch.zeros(4, 2)).computeLogZ()
+    with pytest.raises(AssertionError):
+        CRF.NeuralSemiCRFInterval(torch.zeros(4, 4), torch.zeros(3, 2)).decode()
+
+
+def test_product_never_imports_oracle():
+    """The product package must not reference oracle/ (it is test infrastructure)."""
+    pkg = os.path.join(ROOT, "transkun_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "oracle/" not in txt, f
+
+
+def test_pack_unpack_roundtrip():
+    from transkun_amd.CRF.NeuralSemiCRFInterval import pack_intervals, unpack_intervals
+    iv = [[(0, 2), (4, 6), (6, 6), (7, 8)], [(1, 2), (3, 5), (19, 19)], [(0, 0), (4, 7)], []]
+    pairs, offsets = pack_intervals(iv, 200, 4, "cpu")
+    assert offsets.tolist() == [0, 4, 7, 9, 9]
+    assert unpack_intervals(pairs, offsets) == iv
+    with pytest.raises(IndexError):
+        pack_intervals([[(0, 200)], [], [], []], 200, 4, "cpu")
+    p2, o2 = pack_intervals([[], []], 5, 2, "cpu")
+    assert o2.tolist() == [0, 0, 0]
+    assert unpack_intervals(p2[:0], o2) == [[], []]
+
+
+def test_synth_numpy_torch_identical():
+    import numpy as np
+    from transkun_amd import synth
+    a = synth.hash_normal(10007, 99, "cpu").numpy()
+    b = synth.hash_normal_numpy(10007, 99)
+    assert np.array_equal(a, b)
+    assert abs(float(a.mean())) < 0.05 and 1.0 < float(a.std()) < 1.3
+    iv = synth.synthetic_intervals(256, 12, seed=3)
+    for lst in iv:
+        last = -1
+        for (b0, e0) in lst:
+            assert 0 <= b0 <= e0 < 256 and b0 >= last
+            last = e0

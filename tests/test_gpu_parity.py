@@ -1,0 +1,270 @@
+"""GPU parity tests (run on the MI355X box): the HIP path, called through the Python mirror and
+hence through the C ABI, against (a) golden vectors produced by the reference itself and
+(b) the C oracle on the same seeded inputs.  Decoded intervals: bit-exact.  logZ/logProb:
+1e-4 relative (BASELINE.json); we hold 1e-5.  Marginals: fp32 noise floor of the reference
+(2e-6 * |logZ|, see tests/test_oracle_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import EDGE_CASES, edge_inputs, grad_weights, load_golden, rel_err, unpack_lists
+
+pytestmark = pytest.mark.gpu
+
+LOGZ_TOL = 1e-5
+IMPLS = [1, 0]   # 1 = row-sequential reference kernels, 0 = auto (blocked kernels where valid)
+
+
+def grad_tol(logz):
+    return max(1e-4, 2e-6 * float(np.max(np.abs(logz))))
+
+
+@pytest.fixture(params=IMPLS, ids=lambda i: f"impl{i}")
+def impl(request, gpu):
+    from transkun_amd import _lib
+    _lib.set_impl(request.param)
+    yield request.param
+    _lib.set_impl(0)
+
+
+def _starts(g, key):
+    k = key + "_start"
+    return None if k not in g else [int(x) for x in g[k]]
+
+
+def _check_case(g, score, noise, oracle, check_oracle=True):
+    from transkun_amd import CRF
+    T, B = score.shape[0], score.shape[2]
+    s = score.clone().requires_grad_()
+    n = noise.clone().requires_grad_()
+    crf = CRF.NeuralSemiCRFInterval(s, n)
+    gt = grad_tol(g["fb_logZ"])
+
+    # decode: bit-exact against the reference's lists, both directions, every forcedStartPos variant
+    if T > 1:
+        keys = [k[:-6] for k in g if k.startswith("decode_") and k.endswith("_pairs")]
+        assert keys
+        for key in keys:
+            want = unpack_lists(g[key + "_pairs"], g[key + "_offsets"])
+            got = crf.decode(forcedStartPos=_starts(g, key), forward=key.endswith("_fwd"))
+            assert got == want, key
+
+    # logZ, both API variants
+    logz = crf.computeLogZ()
+    assert rel_err(logz.detach().cpu().numpy(), g["fb_logZ"]) < LOGZ_TOL
+    assert rel_err(crf.computeLogZ(noBackward=True).detach().cpu().numpy(), g["logZ_noBackward"]) < LOGZ_TOL
+
+    # forward_backward: marginals
+    from transkun_amd.CRF import forward_backward
+    lz, grad, gn = forward_backward(score, noise)
+    grad_h = grad.cpu().numpy()
+    assert rel_err(gn.cpu().numpy(), g["fb_gradNoise"]) < gt
+    if "fb_grad" in g:
+        assert rel_err(grad_h, g["fb_grad"]) < gt
+    assert np.all(np.triu(grad_h.transpose(2, 0, 1), 1) == 0.0), "upper triangle must be exactly 0"
+    w = grad_weights(T)
+    assert rel_err(grad_h.astype(np.float64).sum(axis=(0, 1)), g["fb_grad_sum"]) < gt * 4
+    assert rel_err((grad_h.astype(np.float64) * w[:, :, None]).sum(axis=(0, 1)), g["fb_grad_wsum"]) < gt * 4
+
+    # logProb (fused node) and its gradient
+    iv = unpack_lists(g["intervals_pairs"], g["intervals_offsets"])
+    lp = crf.logProb(iv)
+    assert rel_err(lp.detach().cpu().numpy(), g["logProb"]) < LOGZ_TOL
+    (-lp.sum()).backward()
+    assert rel_err(n.grad.cpu().numpy(), g["dNoise_logProb"]) < gt
+    ds = s.grad.cpu().numpy()
+    if "dScore_logProb" in g:
+        assert rel_err(ds, g["dScore_logProb"]) < gt
+    assert rel_err(ds.astype(np.float64).sum(axis=(0, 1)), g["dScore_logProb_sum"]) < gt * 4
+    assert np.all(np.triu(ds.transpose(2, 0, 1), 1) == 0.0)
+
+    # evalPath + computeLogZ as separate nodes (the way ModelTransformer.py:263-265 calls them)
+    s2 = score.clone().requires_grad_(); n2 = noise.clone().requires_grad_()
+    crf2 = CRF.NeuralSemiCRFInterval(s2, n2)
+    path = crf2.evalPath(iv)
+    assert rel_err(path.detach().cpu().numpy(), g["evalPath"]) < LOGZ_TOL
+    (-(path - crf2.computeLogZ()).sum()).backward()
+    assert rel_err(s2.grad.cpu().numpy(), ds) < 1e-6
+    assert rel_err(n2.grad.cpu().numpy(), n.grad.cpu().numpy()) < 1e-6
+
+    if check_oracle:
+        lz64, grad64, gn64, v64, q64 = oracle.forward_backward_f64(score.cpu().numpy(), noise.cpu().numpy())
+        assert rel_err(lz.cpu().numpy(), lz64) < LOGZ_TOL
+        assert rel_err(grad_h, grad64) < gt
+        assert crf.decode() == oracle.viterbi(score.cpu().numpy(), noise.cpu().numpy()) or T == 1
+
+
+def test_minimal_example(gpu, impl, oracle):
+    """BASELINE.json configs[0]: crfMinimalExample.py (T=200, NBatch=4) with the example's intervals."""
+    g = load_golden("minimal_T200_B4")
+    score = torch.from_numpy(g["score"]).to(gpu)
+    noise = torch.from_numpy(g["noise"]).to(gpu)
+    _check_case(g, score, noise, oracle)
+    from transkun_amd import CRF
+    _, grad, _ = CRF.forward_backward(score, noise)
+    assert rel_err(grad.cpu().numpy()[g["rows"]], g["fb_grad_rows"]) < grad_tol(g["fb_logZ"])
+
+
+@pytest.mark.parametrize("case", EDGE_CASES, ids=[c[0] for c in EDGE_CASES])
+def test_edge_cases(gpu, impl, oracle, case):
+    name, T, B, kind, seed, tr = case
+    g = load_golden("edge_" + name)
+    score, noise = edge_inputs(T, B, kind, seed, tr, gpu)
+    _check_case(g, score, noise, oracle)
+
+
+@pytest.mark.parametrize("kind", ["randn", "model"])
+def test_medium(gpu, impl, oracle, kind):
+    from transkun_amd import synth
+    g = load_golden(f"medium_T256_B90_{kind}")
+    T, B, seed = (int(x) for x in g["meta"])
+    score, noise = synth.crf_inputs(T, B, seed, gpu, kind)
+    _check_case(g, score, noise, oracle, check_oracle=False)
+
+
+def test_T1(gpu, impl):
+    """T == 1: the reference's computeLogZ/evalPath work, its decode raises; we return the obvious answer."""
+    from transkun_amd import CRF
+    score = torch.tensor([[[0.5, -0.25, 2.0]]], device=gpu)
+    noise = torch.zeros(0, 3, device=gpu)
+    crf = CRF.NeuralSemiCRFInterval(score, noise)
+    want = torch.nn.functional.softplus(score[0, 0])
+    assert torch.allclose(crf.computeLogZ(), want, atol=1e-6)
+    assert crf.decode() == [[(0, 0)], [], [(0, 0)]]
+    assert crf.decode(forward=True) == [[(0, 0)], [], [(0, 0)]]
+    assert torch.allclose(crf.evalPath([[(0, 0)], [], []]), torch.tensor([0.5, 0.0, 0.0], device=gpu))
+
+
+def test_generator_same_bits_on_gpu(gpu):
+    from transkun_amd import synth
+    a = synth.hash_normal(100003, 1234, gpu).cpu().numpy()
+    b = synth.hash_normal_numpy(100003, 1234)
+    assert np.array_equal(a, b)
+
+
+def test_grad_output_broadcast_and_no_grad(gpu, impl):
+    from transkun_amd import CRF, synth
+    score, noise = synth.crf_inputs(40, 7, 5, gpu)
+    s = score.clone().requires_grad_(); n = noise.clone().requires_grad_()
+    w = torch.linspace(-1, 2, 7, device=gpu)
+    (CRF.NeuralSemiCRFInterval(s, n).computeLogZ() * w).sum().backward()
+    _, grad, gn = CRF.forward_backward(score, noise)
+    assert torch.allclose(s.grad, grad * w, atol=1e-6)
+    assert torch.allclose(n.grad, gn * w, atol=1e-6)
+    with torch.no_grad():
+        lz = CRF.NeuralSemiCRFInterval(s, n).computeLogZ()
+        assert not lz.requires_grad
+    with pytest.raises(AssertionError):
+        CRF.NeuralSemiCRFInterval(s, n).logProb([[]] * 6)
+
+
+# ---- size-independent properties at BASELINE.json's full sizes -----------------------------
+
+def _gap_coverage(grad, gn):
+    """For sampled gaps t: gradNoise[t] + sum_{b<=t<e} grad[e,b] == 1 (SURVEY 8c identity)."""
+    T = grad.shape[0]
+    idx = list(range(0, T - 1, max(1, (T - 1) // 16)))
+    return torch.stack([grad[t + 1:, :t + 1].double().sum(dim=(0, 1)) + gn[t].double() for t in idx])
+
+
+@pytest.mark.parametrize("T,B", [(1024, 88), (1024, 352)])
+def test_full_size_logprob(gpu, T, B):
+    """BASELINE.json configs[1] (T=1024,B=88) and the headline size (B=352): logProb fwd+bwd against the
+    reference's outputs on the same generated inputs + structural identities."""
+    from transkun_amd import CRF, synth
+    g = load_golden(f"large_T{T}_B{B}_randn")
+    seed = int(g["meta"][2])
+    score, noise = synth.crf_inputs(T, B, seed, gpu, "randn")
+    iv = synth.synthetic_intervals(T, B, seed=seed)
+    s = score.requires_grad_(); n = noise.requires_grad_()
+    crf = CRF.NeuralSemiCRFInterval(s, n)
+    lp = crf.logProb(iv)
+    assert rel_err(lp.detach().cpu().numpy(), g["logProb"]) < LOGZ_TOL
+    assert rel_err(crf.computeLogZ().detach().cpu().numpy(), g["logZ"]) < LOGZ_TOL
+    assert rel_err(crf.evalPath(iv).detach().cpu().numpy(), g["evalPath"]) < LOGZ_TOL
+    (-lp.sum()).backward()
+    gt = grad_tol(g["logZ"])
+    assert rel_err(n.grad.cpu().numpy(), g["dNoise_logProb"]) < gt
+    rows = [int(x) for x in g["dScore_rows"]]
+    assert rel_err(s.grad[rows][:, :, :8].cpu().numpy(), g["dScore_logProb_rows"]) < gt
+    ssum = s.grad.double().sum(dim=(0, 1)).cpu().numpy()
+    assert rel_err(ssum, g["dScore_logProb_sum"]) < 2 * gt   # correlated fp32 noise of the reference itself
+    # upper triangle exactly zero
+    iu = torch.triu_indices(T, T, 1, device=gpu)
+    assert float(s.grad[iu[0], iu[1]].abs().max()) == 0.0
+    # gap coverage identity on the logZ gradient alone
+    with torch.no_grad():
+        _, grad, gn = CRF.forward_backward(s.detach(), n.detach())
+        cov = _gap_coverage(grad, gn)
+        assert float((cov - 1.0).abs().max()) < 3 * gt   # fp32 noise floor ~2e-6*|logZ| per marginal
+
+
+def test_full_size_decode(gpu):
+    """BASELINE.json configs[2]: Viterbi decode T=2048, NBatch=352, forcedStartPos set: digests of the
+    reference's lists + forward/backward agreement + evalPath(decode) <= logZ."""
+    import hashlib
+    from transkun_amd import CRF, synth
+    from transkun_amd.CRF.NeuralSemiCRFInterval import pack_intervals
+    g = load_golden("large_T2048_B352_decode")
+    T, B, seed = (int(x) for x in g["meta"])
+    score, noise = synth.crf_inputs(T, B, seed, gpu, "randn")
+    crf = CRF.NeuralSemiCRFInterval(score, noise)
+    for name in ("four", "mixed"):
+        st = [int(x) for x in g[f"decode_{name}_start"]]
+        res = crf.decode(forcedStartPos=st)
+        counts = [len(x) for x in res]
+        off = np.zeros(B + 1, np.int64); np.cumsum(counts, out=off[1:])
+        assert np.array_equal(off, g[f"decode_{name}_offsets"])
+        pairs = np.asarray([p for l in res for p in l], dtype=np.int32).reshape(-1, 2)
+        h = hashlib.sha256(); h.update(off.astype("<i8").tobytes()); h.update(pairs.astype("<i4").tobytes())
+        assert h.hexdigest() == str(g[f"decode_{name}_sha256"])
+        assert np.array_equal(pairs[:64], g[f"decode_{name}_head"])
+    full_b = crf.decode()
+    full_f = crf.decode(forward=True)
+    assert full_b == full_f
+    path = crf.evalPath(full_b)
+    logz = crf.computeLogZ()
+    assert bool((path <= logz + 1e-3).all())
+
+
+# ---- interval scorer ------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", ["small", "sqrt", "none", "medium"])
+def test_scorer(gpu, impl, oracle, name):
+    """ScaledInnerProductIntervalScorer mirror vs the reference's outputs (LayersTransformer.py:381-441)."""
+    from test_oracle_golden import scorer_close
+    from transkun_amd import synth
+    from transkun_amd.scorer import ScaledInnerProductIntervalScorer
+    g = load_golden("scorer_" + name)
+    N, P, T, D = (int(x) for x in g["meta"])
+    ls = str(g["ls"])
+    m = ScaledInnerProductIntervalScorer(D, 1, lengthScaling=ls).to(gpu)
+    W = synth.hash_normal((2 * D + 1) * D, 41, "cpu").view(2 * D + 1, D) * (1.0 / D ** 0.5)
+    bvec = synth.hash_normal(2 * D + 1, 42, "cpu") * 0.1
+    with torch.no_grad():
+        m.map[0].weight.copy_(W); m.map[0].bias.copy_(bvec)
+    ctx = synth.hash_normal(N * P * T * D, 43, "cpu").view(N, P, T, D).to(gpu).requires_grad_()
+    for full in (False, True):
+        m.fullSquare = full
+        S, b = m(ctx)
+        assert S.shape == (T, T, N, P) and b.shape == (T - 1, N, P)
+        assert float(b.abs().max()) == 0.0
+        Sh = S.detach().cpu().numpy().reshape(T, T, N * P)
+        tril = np.tril(np.ones((T, T)))[:, :, None]
+        if "S" in g:
+            ref = g["S"].reshape(T, T, N * P)
+            assert scorer_close(Sh * (1 if full else tril), ref * (1 if full else tril))
+        assert rel_err((Sh.astype(np.float64) * tril).sum(axis=(0, 1)), g["S_tril_sum"]) < 1e-4
+        if full:
+            w = grad_weights(T)
+            assert rel_err((Sh.astype(np.float64) * w[:, :, None]).sum(axis=(0, 1)), g["S_wsum"]) < 1e-4
+    # backward with the fixture's lower-triangular cotangent
+    cot = synth.hash_normal(T * T * N * P, 44, "cpu").view(T, T, N, P)
+    cot = (cot * torch.ones(T, T).tril()[:, :, None, None]).to(gpu)
+    m.fullSquare = False
+    S, b = m(ctx)
+    (S * cot).sum().backward()
+    D2 = 2 * D
+    assert rel_err(ctx.grad.double().sum(dim=(2, 3)).cpu().numpy(), g["dctx_sum"]) < 1e-3
+    assert rel_err(m.map[0].weight.grad[[0, 1, D - 1, D, D2 - 1, D2]].cpu().numpy(), g["dW_rows"]) < 1e-3
+    assert rel_err(m.map[0].bias.grad.cpu().numpy(), g["dbias"]) < 1e-3

@@ -1,0 +1,102 @@
+"""ScaledInnerProductIntervalScorer -- host-side mirror of the reference module
+(/root/reference/transkun/LayersTransformer.py:381-441) on top of the HIP interval-score kernel.
+
+Same constructor arguments, same parameter names (`map.0.weight`, `map.0.bias`) so reference
+checkpoints load, same outputs: S [T, T, N, P] and the all-zero noise score [T-1, N, P].
+The Linear map stays a stock GEMM (hipBLASLt through torch); everything after it --
+scaling, the per-chain q.k^T contraction, length scaling, diagonal, and the permute to the
+CRF layout -- is one kernel that writes the chain-contiguous layout directly.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+
+def _interval_score_raw(q, k, diag, T: int, C: int, D: int, qscale: float, mode: int, full_square: bool):
+    """q,k: [C,T,D] views with unit stride in d; diag: [C,T] view.  Returns S [T,T,C], noise [T-1,C]."""
+    lib = _lib.load()
+    dev = q.device
+    assert q.stride(-1) == 1 and k.stride(-1) == 1
+    # when only the lower triangle is written the rest must still be defined: zero-fill
+    S = (torch.empty if full_square else torch.zeros)(T, T, C, dtype=torch.float32, device=dev)
+    noise = torch.empty(max(T - 1, 0), C, dtype=torch.float32, device=dev)
+    rc = lib.interval_score_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(diag), C, T, D, q.stride(-2), k.stride(-2),
+                                diag.stride(-1), qscale, mode, 1 if full_square else 0, _lib.ptr(S),
+                                _lib.ptr(noise), _lib.stream_of(q))
+    _lib.check(rc, "interval_score_fwd")
+    return S, noise
+
+
+class _IntervalScore(torch.autograd.Function):
+    """S = lenscale * (q*qscale) k^T + diag, chain-minor layout.  Backward is plain torch for now
+    (SURVEY 8(f) rank 1 replaces it with the fused loss-gradient kernel)."""
+
+    @staticmethod
+    def forward(ctx, y, N, P, T, D, mode, full_square):
+        # y: [N,P,T,2D+1] packed Linear output; q/k/diag are strided views (no split copy)
+        C = N * P
+        y3 = y.reshape(C, T, 2 * D + 1)
+        q, k, diag = y3[..., :D], y3[..., D:2 * D], y3[..., 2 * D]
+        qscale = 1.0 / math.sqrt(D)
+        S, noise = _interval_score_raw(q, k, diag, T, C, D, qscale, mode, full_square)
+        ctx.save_for_backward(y3)
+        ctx.meta = (N, P, T, D, mode)
+        return S.view(T, T, N, P), noise.view(max(T - 1, 0), N, P)
+
+    @staticmethod
+    def backward(ctx, dS, dnoise):
+        (y3,) = ctx.saved_tensors
+        N, P, T, D, mode = ctx.meta
+        C = N * P
+        q, k = y3[..., :D], y3[..., D:2 * D]
+        g = dS.reshape(T, T, C).permute(2, 0, 1)                     # [C, e, b]
+        t = torch.arange(T, device=g.device)
+        ln = (t[:, None] - t[None, :]).abs().to(torch.float32)
+        if mode == 1:
+            ln = ln.sqrt()
+        elif mode == 2:
+            ln = torch.ones_like(ln)
+        gl = g * ln
+        qs = 1.0 / math.sqrt(D)
+        dq = torch.bmm(gl, k) * qs                                    # [C,T,D]
+        dk = torch.bmm(gl.transpose(1, 2), q) * qs
+        ddiag = torch.diagonal(g, dim1=1, dim2=2)                     # [C,T]
+        dy = torch.cat([dq, dk, ddiag.unsqueeze(-1)], dim=-1)
+        return dy.view(N, P, T, 2 * D + 1), None, None, None, None, None, None
+
+
+class ScaledInnerProductIntervalScorer(nn.Module):
+    def __init__(self, size, expansionFactor=1, dropoutProb=0.0, withScoreEps=False, lengthScaling="linear"):
+        super().__init__()
+        self.size = size
+        if withScoreEps:
+            # the reference allocates one extra output it never uses (LayersTransformer.py:392-395)
+            self.map = nn.Sequential(nn.Linear(size, 2 * size * expansionFactor + 1 + 1))
+        else:
+            self.map = nn.Sequential(nn.Linear(size, 2 * size * expansionFactor + 1))
+        self.dropout = nn.Dropout(dropoutProb)      # defined but never applied, as in the reference (:397)
+        self.expansionFactor = expansionFactor
+        if lengthScaling not in _lib.LEN_MODES:
+            raise Exception("Unrecognized lengthScaling")
+        self.lengthScaling = lengthScaling
+        self.withScoreEps = withScoreEps
+        self.fullSquare = False   # True: also materialise e<b like the reference (the CRF never reads it)
+
+    def forward(self, ctx):
+        # ctx: [N, P, T, size]
+        assert ctx.dim() == 4
+        N, P, T, _ = ctx.shape
+        D = self.size * self.expansionFactor
+        _lib.require_gpu(ctx, "ctx")
+        y = self.map(ctx)
+        if self.withScoreEps:
+            y = y[..., :2 * D + 1]
+        y = y.float().contiguous()
+        S, b = _IntervalScore.apply(y, N, P, T, D, _lib.LEN_MODES[self.lengthScaling], self.fullSquare)
+        return S, b
