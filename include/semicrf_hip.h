@@ -59,6 +59,11 @@ size_t semicrf_workspace_bytes(int op, int T, int B);
 void semicrf_set_impl(int impl);
 int semicrf_get_impl(void);
 
+/* Debug/test hook, SYNCHRONISES the device: returns and clears the sticky device-side status word.
+ * 0 = no kernel ever gave up on a bounded spin; 2..5 = a hand-off wait timed out (results invalid);
+ * -1 = HIP error.  The persistent kernels never hang: every wait is bounded. */
+int semicrf_debug_device_status(void);
+
 /*
  * Log-partition, forward (alpha) sweep.
  * Replaces: computeLogZ (NeuralSemiCRFInterval.py:207-246) and the un-flipped half of

@@ -183,10 +183,16 @@ def test_full_size_logprob(gpu, T, B):
     assert rel_err(crf.computeLogZ().detach().cpu().numpy(), g["logZ"]) < LOGZ_TOL
     assert rel_err(crf.evalPath(iv).detach().cpu().numpy(), g["evalPath"]) < LOGZ_TOL
     (-lp.sum()).backward()
+    # At this size the reference's own fp32 marginals are ~2e-6*|logZ| = 4e-3 off the f64 truth (stored in
+    # the fixture).  Require: our error vs truth <= 1.5x the reference's, and within 2.5x of it vs the reference.
     gt = grad_tol(g["logZ"])
-    assert rel_err(n.grad.cpu().numpy(), g["dNoise_logProb"]) < gt
+    dn = n.grad.cpu().numpy()
+    ref_err = max(float(np.abs(g["dNoise_logProb"] - g["truth_dNoise_logProb"]).max()), 1e-4)
+    assert float(np.abs(dn - g["truth_dNoise_logProb"]).max()) < 1.5 * ref_err
+    assert rel_err(dn, g["dNoise_logProb"]) < 2.5 * ref_err
+    assert rel_err(crf.computeLogZ().detach().cpu().numpy(), g["truth_logZ"]) < LOGZ_TOL
     rows = [int(x) for x in g["dScore_rows"]]
-    assert rel_err(s.grad[rows][:, :, :8].cpu().numpy(), g["dScore_logProb_rows"]) < gt
+    assert rel_err(s.grad[rows][:, :, :8].cpu().numpy(), g["dScore_logProb_rows"]) < 2.5 * ref_err
     ssum = s.grad.double().sum(dim=(0, 1)).cpu().numpy()
     assert rel_err(ssum, g["dScore_logProb_sum"]) < 2 * gt   # correlated fp32 noise of the reference itself
     # upper triangle exactly zero
@@ -219,12 +225,15 @@ def test_full_size_decode(gpu):
         h = hashlib.sha256(); h.update(off.astype("<i8").tobytes()); h.update(pairs.astype("<i4").tobytes())
         assert h.hexdigest() == str(g[f"decode_{name}_sha256"])
         assert np.array_equal(pairs[:64], g[f"decode_{name}_head"])
+    # forward and backward Viterbi are both optimal up to fp32 round-off of their own sums, so the paths may
+    # differ at near-ties (the reference's do too); their scores must agree, and evalPath(decode) <= logZ.
     full_b = crf.decode()
     full_f = crf.decode(forward=True)
-    assert full_b == full_f
-    path = crf.evalPath(full_b)
+    path_b = crf.evalPath(full_b)
+    path_f = crf.evalPath(full_f)
+    assert float(((path_b - path_f).abs() / path_b.abs().clamp_min(1.0)).max()) < 1e-5
     logz = crf.computeLogZ()
-    assert bool((path <= logz + 1e-3).all())
+    assert bool((path_b <= logz + 1e-3).all())
 
 
 # ---- interval scorer ------------------------------------------------------------------------
@@ -268,3 +277,35 @@ def test_scorer(gpu, impl, oracle, name):
     assert rel_err(ctx.grad.double().sum(dim=(2, 3)).cpu().numpy(), g["dctx_sum"]) < 1e-3
     assert rel_err(m.map[0].weight.grad[[0, 1, D - 1, D, D2 - 1, D2]].cpu().numpy(), g["dW_rows"]) < 1e-3
     assert rel_err(m.map[0].bias.grad.cpu().numpy(), g["dbias"]) < 1e-3
+
+
+# ---- the persistent blocked kernels against the oracle over a grid of shapes -------------------
+
+PERSIST_SHAPES = [(1, 4), (2, 4), (15, 8), (16, 4), (17, 12), (33, 16), (48, 20), (63, 36), (64, 32), (65, 4),
+                  (100, 64), (129, 40), (200, 100), (256, 16), (300, 8)]
+
+
+@pytest.mark.parametrize("T,B", PERSIST_SHAPES, ids=[f"T{t}_B{b}" for t, b in PERSIST_SHAPES])
+@pytest.mark.parametrize("kind", ["randn", "model", "ties"])
+def test_persist_vs_oracle(gpu, oracle, T, B, kind):
+    """impl 0 (persistent kernels; B % 4 == 0) vs the C oracle: logZ, alpha/beta-derived marginals,
+    decode in both directions with a mixed forcedStartPos.  Also checks that no hand-off wait timed out."""
+    from transkun_amd import CRF, _lib, synth
+    _lib.set_impl(0)
+    _lib.device_status()
+    score, noise = synth.crf_inputs(T, B, 100 + T, gpu, kind)
+    sc, nc = score.cpu().numpy(), noise.cpu().numpy()
+    lz64, grad64, gn64, v64, q64 = oracle.forward_backward_f64(sc, nc)
+    lz, grad, gn = CRF.forward_backward(score, noise)
+    gt = grad_tol(lz64)
+    assert rel_err(lz.cpu().numpy(), lz64) < LOGZ_TOL
+    assert rel_err(grad.cpu().numpy(), grad64) < gt
+    if T > 1:
+        assert rel_err(gn.cpu().numpy(), gn64) < gt
+    crf = CRF.NeuralSemiCRFInterval(score, noise)
+    st = [(c * 7 + 3) % T for c in range(B)]
+    assert crf.decode() == oracle.viterbi(sc, nc)
+    assert crf.decode(forcedStartPos=st) == oracle.viterbi(sc, nc, st)
+    assert crf.decode(forward=True) == oracle.viterbi(sc, nc, forward=True)
+    assert crf.decode(forcedStartPos=st, forward=True) == oracle.viterbi(sc, nc, st, forward=True)
+    assert _lib.device_status() == 0

@@ -251,6 +251,19 @@ def case_large():
              "dScore_logProb_wsum": np.einsum("ebc,eb->c", g.astype(np.float64), w.astype(np.float64)),
              "dScore_rows": np.asarray([1, 500, T - 1]), "dScore_logProb_rows": g[[1, 500, T - 1]][:, :, :8].copy()}
         print(f"  T={T} B={B} reference logProb fwd+bwd took {time.time() - t0:.1f}s")
+        # f64 truth from the C oracle (REAL=double instantiation): lets the GPU test separate kernel
+        # error from the reference's own fp32 round-off (~2e-6*|logZ| per marginal at this size)
+        from oracle import oracle as cpu_oracle
+        t0 = time.time()
+        lz64, _, gn64, _, _ = cpu_oracle.forward_backward_f64(score.detach().numpy(), noise.detach().numpy())
+        unc = np.ones((T - 1, B))
+        for c, lst in enumerate(intervals):
+            for b0, e0 in lst:
+                unc[b0:e0, c] -= 1.0
+        d["truth_logZ"] = lz64
+        d["truth_dNoise_logProb"] = (gn64 - unc).astype(np.float32)      # d(-sum logProb)/d noise
+        print(f"  f64 truth took {time.time() - t0:.1f}s; reference dNoise err vs truth "
+              f"{np.abs(d['dNoise_logProb'] - d['truth_dNoise_logProb']).max():.2e}")
         save(f"large_T{T}_B{B}_randn", d)
         del g, s, n, crf, score, noise
     # configs[2]: Viterbi decode T=2048, NBatch=352, forcedStartPos set

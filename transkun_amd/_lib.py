@@ -29,6 +29,7 @@ _SIGS = {
     "semicrf_workspace_bytes": (_sz, [_i, _i, _i]),
     "semicrf_set_impl": (None, [_i]),
     "semicrf_get_impl": (ctypes.c_int, []),
+    "semicrf_debug_device_status": (ctypes.c_int, []),
     "semicrf_logz_fwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "semicrf_logz_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "semicrf_viterbi": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i64, _vp, _vp, _sz, _vp]),
@@ -90,6 +91,11 @@ def workspace(op: int, T: int, B: int, device) -> torch.Tensor:
 
 def set_impl(impl: int) -> None:
     load().semicrf_set_impl(int(impl))
+
+
+def device_status() -> int:
+    """Synchronising debug hook: sticky device status word (0 = OK), cleared on read."""
+    return int(load().semicrf_debug_device_status())
 
 
 def get_impl() -> int:

@@ -34,6 +34,15 @@ void launch_interval_score_naive(const float* q, const float* k, const float* di
                                  long long ldq, long long ldk, long long ldd, float qscale, int mode, int full,
                                  float* S, hipStream_t stream);
 
+size_t persist_workspace_bytes(int T, int B);
+bool persist_supported(int T, int B);
+int launch_persist_sweep(int mode, int dir, const float* score, const float* noise, int T, int B, float* u_out,
+                         float* last_out, int* code, void* ws, hipStream_t stream);
+
+int read_and_clear_device_status();
+
+static bool use_persist(int T, int B) { return g_impl.load() == 0 && persist_supported(T, B); }
+
 struct Carver {
     char* p;
     size_t left;
@@ -63,16 +72,18 @@ int semicrf_abi_version(void) { return SEMICRF_ABI_VERSION; }
 const char* semicrf_last_error(void) { return g_err; }
 void semicrf_set_impl(int impl) { g_impl.store(impl); }
 int semicrf_get_impl(void) { return g_impl.load(); }
+int semicrf_debug_device_status(void) { return read_and_clear_device_status(); }
 
 size_t semicrf_workspace_bytes(int op, int T, int B)
 {
     if (T <= 0 || B <= 0) return 0;
     switch (op) {
-        case SEMICRF_OP_LOGZ_FWD: return tb(T, B) + 4096;
-        case SEMICRF_OP_LOGZ_BWD: return tb(T, B) + 4096;
+        case SEMICRF_OP_LOGZ_FWD: return tb(T, B) + persist_workspace_bytes(T, B) + 4096;
+        case SEMICRF_OP_LOGZ_BWD: return tb(T, B) + persist_workspace_bytes(T, B) + 4096;
         case SEMICRF_OP_VITERBI:
-            // u [T][B] f32, code [B][T] i32, region [B][2T][2] i32, counts [B] i32
-            return tb(T, B) * 2 + align_up((size_t)B * 2 * T * 2 * 4) + align_up((size_t)B * 4) + 4096;
+            // u [T][B] f32, code [B][T] i32, region [B][2T][2] i32, counts [B] i32, persistent-sweep scratch
+            return tb(T, B) * 2 + align_up((size_t)B * 2 * T * 2 * 4) + align_up((size_t)B * 4) +
+                   persist_workspace_bytes(T, B) + 4096;
         case SEMICRF_OP_EVAL_PATH: return tb(T, B) + 4096;
         case SEMICRF_OP_INTERVAL_SCORE: return 4096;
         default: return 0;
@@ -96,9 +107,17 @@ int semicrf_logz_fwd(const float* score, const float* noise, int T, int B, float
     SEMICRF_CHECK_ARG(logZ != nullptr, "logZ is NULL");
     Carver cv(ws, ws_bytes);
     float* vv = v ? v : cv.take<float>((size_t)T * B);
-    if (!cv.ok || (!v && !ws)) { set_error("workspace too small for logz_fwd"); return SEMICRF_EWORKSPACE; }
+    const bool fast = use_persist(T, B);
+    void* pws = fast ? cv.take<char>(persist_workspace_bytes(T, B)) : nullptr;
+    if (!cv.ok || !ws) { set_error("workspace too small for logz_fwd"); return SEMICRF_EWORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
-    launch_rowseq_sweep(0, 0, score, noise, T, B, vv, nullptr, logZ, st);
+    if (fast) {
+        if (launch_persist_sweep(0, 0, score, noise, T, B, vv, logZ, nullptr, pws, st)) {
+            set_error("hipMemsetAsync failed"); return SEMICRF_ELAUNCH;
+        }
+    } else {
+        launch_rowseq_sweep(0, 0, score, noise, T, B, vv, nullptr, logZ, st);
+    }
     SEMICRF_CHECK_LAUNCH("semicrf_logz_fwd");
     return SEMICRF_OK;
 }
@@ -112,9 +131,17 @@ int semicrf_logz_bwd(const float* score, const float* noise, const float* v, con
     SEMICRF_CHECK_ARG(dNoise != nullptr || T == 1, "dNoise is NULL");
     Carver cv(ws, ws_bytes);
     float* q = q_out ? q_out : cv.take<float>((size_t)T * B);
-    if (!cv.ok || (!q_out && !ws)) { set_error("workspace too small for logz_bwd"); return SEMICRF_EWORKSPACE; }
+    const bool fast = use_persist(T, B);
+    void* pws = fast ? cv.take<char>(persist_workspace_bytes(T, B)) : nullptr;
+    if (!cv.ok || !ws) { set_error("workspace too small for logz_bwd"); return SEMICRF_EWORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
-    launch_rowseq_sweep(0, 1, score, noise, T, B, q, nullptr, nullptr, st);
+    if (fast) {
+        if (launch_persist_sweep(0, 1, score, noise, T, B, q, nullptr, nullptr, pws, st)) {
+            set_error("hipMemsetAsync failed"); return SEMICRF_ELAUNCH;
+        }
+    } else {
+        launch_rowseq_sweep(0, 1, score, noise, T, B, q, nullptr, nullptr, st);
+    }
     launch_marginals(score, noise, v, q, logZ, gout, T, B, dScore, dNoise, st);
     SEMICRF_CHECK_LAUNCH("semicrf_logz_bwd");
     return SEMICRF_OK;
@@ -132,9 +159,17 @@ int semicrf_viterbi(const float* score, const float* noise, int T, int B, const 
     int* code = cv.take<int>((size_t)T * B);
     int* region = cv.take<int>((size_t)B * 2 * T * 2);
     int* counts = cv.take<int>((size_t)B);
+    const bool fast = use_persist(T, B);
+    void* pws = fast ? cv.take<char>(persist_workspace_bytes(T, B)) : nullptr;
     if (!cv.ok || !ws) { set_error("workspace too small for viterbi"); return SEMICRF_EWORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
-    launch_rowseq_sweep(1, forward ? 0 : 1, score, noise, T, B, u, code, nullptr, st);
+    if (fast) {
+        if (launch_persist_sweep(1, forward ? 0 : 1, score, noise, T, B, nullptr, nullptr, code, pws, st)) {
+            set_error("hipMemsetAsync failed"); return SEMICRF_ELAUNCH;
+        }
+    } else {
+        launch_rowseq_sweep(1, forward ? 0 : 1, score, noise, T, B, u, code, nullptr, st);
+    }
     launch_backtrack(code, T, B, start, forward ? 1 : 0, region, counts, pairs, (long long)cap, offsets, st);
     SEMICRF_CHECK_LAUNCH("semicrf_viterbi");
     return SEMICRF_OK;
