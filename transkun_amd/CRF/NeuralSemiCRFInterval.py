@@ -15,6 +15,7 @@ What differs from the reference, invisibly at the API:
 """
 from __future__ import annotations
 
+import os
 from itertools import chain
 from typing import List, Optional, Sequence, Tuple
 
@@ -78,6 +79,9 @@ def unpack_intervals(pairs_host: torch.Tensor, offsets_host: torch.Tensor) -> In
 # raw kernel calls (no autograd)
 # --------------------------------------------------------------------------------------
 
+_DEBUG_WS = []      # test/diagnostic hook: when non-None-appendable and env SEMICRF_DEBUG_KEEP_WS is set, keeps workspaces
+
+
 def _logz_fwd_raw(score, noise, want_v: bool):
     T, B = score.shape[0], score.shape[2]
     lib = _lib.load()
@@ -87,6 +91,8 @@ def _logz_fwd_raw(score, noise, want_v: bool):
     rc = lib.semicrf_logz_fwd(_lib.ptr(score), _lib.ptr(noise), T, B, _lib.ptr(logz), _lib.ptr(v),
                               _lib.ptr(ws), ws.numel(), _lib.stream_of(score))
     _lib.check(rc, "semicrf_logz_fwd")
+    if os.environ.get("SEMICRF_DEBUG_KEEP_WS"):
+        _DEBUG_WS[:] = [ws]
     return logz, v
 
 

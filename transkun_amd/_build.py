@@ -16,6 +16,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsemicrf_hip.so")
 ARCH = "gfx950"
+# persist.hip never produces or consumes NaNs in its math; without this clang canonicalises every fmaxf
+# operand with an extra v_max (the dependent chain of the spine is instruction-count bound).
+EXTRA_FLAGS = {"persist.hip": ["-fno-honor-nans"]}
 
 
 def _hipcc() -> str:
@@ -37,6 +40,28 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name: str, defines, verbose: bool = False) -> str:
+    """Development helper: build libsemicrf_<name>.so with extra -D defines (timing ablations)."""
+    objdir = os.path.join(HERE, "csrc", "_obj_" + name)
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off",
+             "-Wno-unused-function"] + ["-D" + d for d in defines]
+    objs, procs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        cmd = [_hipcc()] + flags + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode())
+            raise RuntimeError("hipcc failed")
+    out = os.path.join(HERE, f"libsemicrf_{name}.so")
+    subprocess.check_call([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
@@ -53,7 +78,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if (not force and os.path.exists(obj)
                 and os.path.getmtime(obj) > max(os.path.getmtime(x) for x in [src] + hdrs)):
             continue
-        cmd = [_hipcc()] + flags + ["-c", src, "-o", obj]
+        extra = EXTRA_FLAGS.get(os.path.basename(src), [])
+        cmd = [_hipcc()] + flags + extra + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsemicrf_hip.so")
+LIB_PATH = os.environ.get("SEMICRF_LIB") or os.path.join(_HERE, "libsemicrf_hip.so")   # SEMICRF_LIB: development variants
 
 OP_LOGZ_FWD, OP_LOGZ_BWD, OP_VITERBI, OP_EVAL_PATH, OP_INTERVAL_SCORE = range(5)
 LEN_MODES = {"linear": 0, "sqrt": 1, "none": 2}

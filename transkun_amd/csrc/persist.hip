@@ -7,11 +7,14 @@
 // frames ascending (DIR 0) or descending (DIR 1); cell(p,j) is score[end][begin] of the two frames.
 //
 // Work decomposition (positions in blocks of 16):
-//   * SPINE workgroup, one per 16 chains: four waves form a ring, wave w owns position blocks
-//     k = w, w+4, ...; a lane is (row r of the block, 4 chains as one float4).  Every wave applies each
-//     newly finished u[j] to its own block's rows (band = the current block and the next three), the
-//     owner of the current block finalises one position per step and publishes it through LDS to its
-//     ring mates and through HBM to the panels.  The T-step dependent chain never leaves one CU.
+//   * SPINE workgroup, one per 8 chains: four waves form a ring, wave w owns position blocks
+//     k = w, w+4, ...; a lane is (row r of the block, 2 chains).  Every wave applies each newly
+//     finished u[j] to its own block's rows (band = the current block and the next three); the owner
+//     of the current block finalises one position per step (a ~35-instruction dependent step: a lone
+//     wave issues one instruction per ~4 cycles, so the step is kept that small) and publishes it
+//     through LDS to its ring mates; once per block it publishes 16 positions to HBM for the panels.
+//     The T-step dependent chain never leaves one CU.  Band cells are prefetched 16..32 steps ahead
+//     in registers.
 //   * PANEL workgroup, one per (position block k >= 4, 32 chains): streams the far field -- all cells
 //     (p in block k, j < 16(k-3)) -- tile by tile as the spine publishes u, keeps the partial
 //     accumulators in registers and hands ONE number per (position, chain) to the spine.
@@ -20,24 +23,31 @@
 //     Roles are drawn from an atomic ticket so that a workgroup only ever waits on lower tickets; every
 //     spin is bounded and raises the error word instead of hanging.
 //
-// HBM traffic: every lower-triangle cell is read exactly once (128-byte lines in the panels, 64-byte
+// HBM traffic: every lower-triangle cell is read exactly once (128-byte lines in the panels, 32-byte
 // segments in the band).  Algorithmic bytes per sweep: 4*B*(T(T+1)/2 + T-1).
 #include <atomic>
+#include <stdlib.h>
 #include "common.h"
+
+#ifndef SEMICRF_ABL
+#define SEMICRF_ABL 0      // timing-ablation bits for the LSE diagonal step (development only)
+#endif
 
 namespace semicrf {
 
 constexpr int PB = 16;             // positions per block
 constexpr int RING = 4;            // spine waves; band = RING-1 off-diagonal blocks + the diagonal block
-constexpr int GS = 16;             // chains per spine workgroup
-constexpr int GP = 32;             // chains per panel workgroup
+constexpr int GS = 8;              // chains per spine workgroup (2 per lane)
+constexpr int GP = 32;             // chains per panel workgroup (4 per lane)
+constexpr int TPT = 16;            // tiles (column blocks) per panel task
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
-constexpr int SPIN_LIMIT = 1 << 20;       // global-memory polls (with s_sleep 2..8): ~0.3 s
+constexpr int SPIN_LIMIT = 1 << 20;       // global-memory polls (with s_sleep): ~0.3 s
 constexpr int SPIN_LIMIT_LDS = 1 << 24;   // LDS polls (s_sleep 1): ~0.5 s
 constexpr float RESCALE_THR = 64.0f;
 
 typedef unsigned long long u64;
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 template <int V>
 struct IC { static constexpr int value = V; };
 
@@ -46,10 +56,16 @@ struct SweepParams {
     const float* noise;
     int T, B, K;
     int nSpine, nPanelGroups;
+    int nTasks;            // panel tasks (k ascending, then column part, then chain group)
     unsigned tag;          // nonzero launch epoch
-    unsigned* ctrl;        // [0] ticket, [1] error
+    unsigned dbg;          // SEMICRF_DEBUG_FLAGS (timing experiments only; results are wrong when set):
+                           // 1 spine ignores far partials, 2 panels exit at once, 4 panels do not wait for u,
+                           // 8 spine exits at once, 16 spine 0 records per-step timestamps,
+                           // 32 panels only stream their cells (no granules, no math)
+    unsigned* ctrl;        // [0] ticket, [1] error, [2] panel task queue head
+    u64* ts;               // [T] debug timestamps of the diagonal steps of spine 0 (dbg & 16)
     u64* ug;               // [T][B] granules of u (position-major: index p*B + c)
-    u64* farg;             // [T][B] granules of far-field partials
+    u64* farg;             // [parts][T][B] granules of far-field partials (part = column range of TPT tiles)
     float* u_out;          // [T][B] by FRAME (natural-log units for LSE) or nullptr
     float* last_out;       // [B] value at the last position (logZ for DIR 0) or nullptr
     int* code;             // MAX: [B][T] backtrack codes by frame
@@ -87,14 +103,14 @@ __device__ __forceinline__ size_t cell_index(int pi, int pj, int T)
 template <int DIR>
 __device__ __forceinline__ int gap_of(int p, int T) { return DIR == 0 ? p - 1 : T - 1 - p; }
 
-// log2-domain lazily rescaled accumulator: value = M + log2(S); empty = (-inf, 0)
-__device__ __forceinline__ void acc_push(float& M, float& S, float t)
+// log2-domain accumulator, exact running max, one exp per push: value = M + log2(S); empty = (-inf, 0)
+__device__ __forceinline__ void acc_push1(float& M, float& S, float t)
 {
-    if (t > M + RESCALE_THR) {
-        S = S * fexp2(M - t);   // M = -inf: exp2(-inf) = 0 and S = 0
-        M = t;
-    }
-    S += fexp2(t - M);
+    const float d = t - M;                       // M = -inf -> +inf
+    const float e = fexp2(-fabsf(d));
+    const bool up = d > 0.0f;
+    S = up ? fmaf(S, e, 1.0f) : S + e;
+    M = up ? t : M;
 }
 __device__ __forceinline__ void acc_merge(float& M, float& S, float M2, float S2)
 {
@@ -105,6 +121,12 @@ __device__ __forceinline__ void acc_merge(float& M, float& S, float M2, float S2
     } else {
         S += S2 * fexp2(M2 - M);
     }
+}
+// softplus in log2 units: log2(1 + 2^(x*log2e)), linear above the reference's threshold (20)
+__device__ __forceinline__ float softplus2(float x)
+{
+    const float x2 = x * LOG2E;
+    return x > 20.0f ? x2 : flog2(1.0f + fexp2(x2));
 }
 
 // sticky device-side status word (0 = fine); read and cleared by semicrf_debug_device_status()
@@ -131,193 +153,256 @@ __device__ __forceinline__ bool spin_abort(unsigned* ctrl, int& spins, int limit
 // ---------------------------------------------------------------------------------------------
 // SPINE role
 // ---------------------------------------------------------------------------------------------
+// LDS: ubuf[128][GS] ring of published positions, done = number of finalised positions,
+// dummy[64+] sink for address-predicated stores.
 template <int MODE, int DIR>
-__device__ void spine_role(const SweepParams& P, int sg, float (*ubuf)[GS], int* done_ptr)
+__device__ void spine_role(const SweepParams& P, int sg, float* ubuf, int* done_ptr, float* dummy)
 {
     const int T = P.T, B = P.B;
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int r = lane >> 2, qd = lane & 3;
-    const int c = sg * GS + qd * 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int r = lane >> 2, pr = lane & 3;
+    const int c = sg * GS + pr * 2;
     const bool cvalid = c < B;
     const size_t Bs = (size_t)B;
     const float* __restrict__ score = P.score;
     const float* __restrict__ noise = P.noise;
     const unsigned tag = P.tag;
+    const long long stride = DIR == 0 ? (long long)B : -(long long)T * B;   // floats per +1 in j
+    int avail = 0;                                                          // last observed value of done
 
+    const bool trace = (P.dbg & 16u) && sg == 0 && lane == 0;
     for (int k = wave; k < P.K; k += RING) {
+        u64* ev = P.ts + P.T + (size_t)k * 8;          // debug events of this block (8 slots)
+        if (trace) ev[0] = __builtin_readcyclecounter();
         const int prow = k * PB + r;
         const bool rvalid = cvalid && prow < T;
         const int frow = frame_of<DIR>(prow, T);
-
-        // diagonal cell and the singleton factor
-        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rvalid) d = *(const float4*)(score + ((size_t)frow * T + frow) * Bs + c);
-        float sp[4];
-        if (MODE == 0) {
-            sp[0] = softplus_f(d.x) * LOG2E; sp[1] = softplus_f(d.y) * LOG2E;
-            sp[2] = softplus_f(d.z) * LOG2E; sp[3] = softplus_f(d.w) * LOG2E;
-        } else {
-            sp[0] = d.x; sp[1] = d.y; sp[2] = d.z; sp[3] = d.w;
-        }
-        // skip weight between prow-1 and prow
-        float nz[4] = {0.f, 0.f, 0.f, 0.f};
-        if (rvalid && prow >= 1) {
-            const float4 n4 = *(const float4*)(noise + (size_t)gap_of<DIR>(prow, T) * Bs + c);
-            nz[0] = n4.x; nz[1] = n4.y; nz[2] = n4.z; nz[3] = n4.w;
-        }
-
-        float aM[4], aS[4];
-        int aK[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { aM[i] = SEMICRF_NEG_INF; aS[i] = 0.f; aK[i] = 0x7fffffff; }
-
-        const int jbeg = (k - (RING - 1)) > 0 ? (k - (RING - 1)) * PB : 0;
-        const int jend = (k * PB + PB < T ? k * PB + PB : T);   // exclusive
         const int own0 = k * PB;
+        const int jb0 = k - (RING - 1) > 0 ? k - (RING - 1) : 0;   // first block of the band
+        const float* rowp = score + cell_index<DIR>(rvalid ? prow : 0, 0, T) * Bs + (cvalid ? c : 0);
 
-        // register double buffer of cells: chunk of 8 columns
-        float xs[2][8][4];
-        auto load_chunk = [&](auto bufc, int j0) {
-            constexpr int buf = decltype(bufc)::value;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 + u;
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rvalid && j < prow) x = *(const float4*)(score + cell_index<DIR>(prow, j, T) * Bs + c);
+        // ---- per-row constants ----------------------------------------------------------------
+        float sp[2] = {0.f, 0.f};   // LSE: softplus2(diag); MAX: diag
+        float nz[2] = {0.f, 0.f};   // noise between prow-1 and prow (MAX: raw; LSE: folded into wl)
+        float wl[2] = {0.f, 0.f};   // LSE: log2(2^s[prow][prow-1] + 2^n): first sub-diagonal cell with the skip folded in
+        if (rvalid) {
+            const float2 d = *(const float2*)(score + ((size_t)frow * T + frow) * Bs + c);
+            if (MODE == 0) { sp[0] = softplus2(d.x); sp[1] = softplus2(d.y); }
+            else { sp[0] = d.x; sp[1] = d.y; }
+            if (prow >= 1) {
+                const float2 n2 = *(const float2*)(noise + (size_t)gap_of<DIR>(prow, T) * Bs + c);
+                nz[0] = n2.x; nz[1] = n2.y;
                 if (MODE == 0) {
-                    float v0 = x.x * LOG2E, v1 = x.y * LOG2E, v2 = x.z * LOG2E, v3 = x.w * LOG2E;
-                    if (j == prow - 1) {
-                        // fold the skip term into the first sub-diagonal cell: log2(2^s + 2^n)
-                        const float xv[4] = {v0, v1, v2, v3};
-                        float wv[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float n2 = nz[i] * LOG2E;
-                            const float m = fmaxf(xv[i], n2);
-                            wv[i] = m + flog2(1.0f + fexp2(-fabsf(xv[i] - n2)));
-                        }
-                        v0 = wv[0]; v1 = wv[1]; v2 = wv[2]; v3 = wv[3];
-                    }
-                    xs[buf][u][0] = v0; xs[buf][u][1] = v1; xs[buf][u][2] = v2; xs[buf][u][3] = v3;
-                } else {
-                    xs[buf][u][0] = x.x; xs[buf][u][1] = x.y; xs[buf][u][2] = x.z; xs[buf][u][3] = x.w;
+                    const float2 s1 = *(const float2*)(rowp + (long long)(prow - 1) * stride);
+                    const float a0 = s1.x * LOG2E, b0 = n2.x * LOG2E, a1 = s1.y * LOG2E, b1 = n2.y * LOG2E;
+                    wl[0] = fmaxf(a0, b0) + flog2(1.0f + fexp2(-fabsf(a0 - b0)));
+                    wl[1] = fmaxf(a1, b1) + flog2(1.0f + fexp2(-fabsf(a1 - b1)));
                 }
+            }
+        }
+
+        float aM[2] = {SEMICRF_NEG_INF, SEMICRF_NEG_INF}, aS[2] = {0.f, 0.f};
+        int aK[2] = {0x7fffffff, 0x7fffffff};
+        float myres[2] = {0.f, 0.f};
+        int mykey[2] = {-1, -1};
+
+        // ---- cell stream: one block (16 columns) per buffer, prefetched one to two blocks ahead ----
+        struct Blk { float2 v[PB]; };
+        // Loads are unconditional (addresses clamped into the tensor) so that all 16 are issued back to
+        // back; cells with j >= prow are only ever applied AFTER this lane's row has been finalised, and
+        // invalid lanes never publish, so what they accumulate is never read.
+        auto load_block = [&](int b) -> Blk {
+            Blk o;
+            const int j0 = b * PB;
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int j = j0 + u < T ? j0 + u : T - 1;
+                o.v[u] = *(const float2*)(rowp + (long long)j * stride);
+            }
+            return o;
+        };
+        const int jsub = prow - 1;          // the first sub-diagonal column carries the skip term
+
+        auto apply = [&](float u0, float u1, float2 x, int j) {
+            if (MODE == 0) {
+                float t0 = fmaf(x.x, LOG2E, u0), t1 = fmaf(x.y, LOG2E, u1);
+                if (j == jsub) { t0 = u0 + wl[0]; t1 = u1 + wl[1]; }
+                acc_push1(aM[0], aS[0], t0);
+                acc_push1(aM[1], aS[1], t1);
+            } else {
+                const int key = frame_of<DIR>(j, T);
+                if (j == jsub) {                             // the skip candidate goes first (key -1)
+                    max_push(aM[0], aK[0], u0 + nz[0], -1);
+                    max_push(aM[1], aK[1], u1 + nz[1], -1);
+                }
+                max_push(aM[0], aK[0], u0 + x.x, key);
+                max_push(aM[1], aK[1], u1 + x.y, key);
             }
         };
 
-        auto process_chunk = [&](auto bufc, int j0) {
-            constexpr int buf = decltype(bufc)::value;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 + u;
-                if (j >= jend) break;               // wave-uniform
-                float uj[4];
-                if (j < own0) {
-                    // shadow phase: wait for the ring mate that owns block j/PB to publish u[j]
-                    int spins = 0;
-                    while (__hip_atomic_load(done_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= j) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (spin_abort(P.ctrl, spins, SPIN_LIMIT_LDS, 2)) break;
-                    }
-                    const float4 uv = *(const float4*)&ubuf[j & 127][qd * 4];
-                    uj[0] = uv.x; uj[1] = uv.y; uj[2] = uv.z; uj[3] = uv.w;
-                } else {
-                    // diagonal phase: this wave finalises position j = own0 + jj
-                    const int jj = j - own0;
-                    if (jj == 0 && k >= RING) {
-                        // merge the far-field partial handed over by the panel workgroup
-                        if (rvalid) {
-                            int spins = 0;
-                            u64 g[4];
-                            bool ok = false;
-                            while (!ok) {
-                                ok = true;
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) {
-                                    g[i] = load_granule(P.farg + (size_t)prow * Bs + c + i);
-                                    if (MODE == 0) ok = ok && ((unsigned)(g[i] >> 32) == tag);
-                                    else ok = ok && ((unsigned)(g[i] >> 48) == (tag & 0xffffu));
-                                }
-                                if (!ok) {
-                                    __builtin_amdgcn_s_sleep(2);
-                                    if (spin_abort(P.ctrl, spins, SPIN_LIMIT, 3)) break;
-                                }
-                            }
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const float fv = __uint_as_float((unsigned)g[i]);
-                                if (MODE == 0) acc_push(aM[i], aS[i], fv);
-                                else max_push(aM[i], aK[i], fv, (int)((g[i] >> 32) & 0xffffu));
-                            }
-                        }
-                    }
-                    float res[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (MODE == 0) {
-                            res[i] = (prow == 0) ? sp[i] : (aM[i] + flog2(aS[i]) + sp[i]);
-                        } else {
-                            const float best = (prow == 0) ? 0.0f : aM[i];
-                            res[i] = sp[i] > 0.0f ? best + sp[i] : best;
-                        }
-                    }
-                    const int src = (jj << 2) | qd;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) uj[i] = __shfl(res[i], src);
-                    if (r == jj && rvalid) {
-                        // publish: LDS for the ring, granules for the panels, plain arrays for the caller
-                        *(float4*)&ubuf[j & 127][qd * 4] = make_float4(res[0], res[1], res[2], res[3]);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            store_granule(P.ug + (size_t)j * Bs + c + i, make_granule(tag, res[i]));
-                        if (P.u_out) {
-                            const float sc = MODE == 0 ? LN2 : 1.0f;
-                            *(float4*)(P.u_out + (size_t)frow * Bs + c) =
-                                make_float4(res[0] * sc, res[1] * sc, res[2] * sc, res[3] * sc);
-                        }
-                        if (P.last_out && j == T - 1) {
-                            const float sc = MODE == 0 ? LN2 : 1.0f;
-                            *(float4*)(P.last_out + c) = make_float4(res[0] * sc, res[1] * sc, res[2] * sc, res[3] * sc);
-                        }
-                        if (MODE == 1) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const int key = (prow == 0) ? -1 : aK[i];
-                                P.code[(size_t)(c + i) * T + frow] = (key + 1) | (sp[i] > 0.0f ? 0x40000000 : 0);
-                            }
-                        }
-                    }
-                    // make the LDS data visible before the progress counter moves (in-order DS queue)
-                    if (lane == (jj << 2))
-                        __hip_atomic_store(done_ptr, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                // apply u[j] to this lane's row
-                if (rvalid && j < prow) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (MODE == 0) {
-                            acc_push(aM[i], aS[i], uj[i] + xs[buf][u][i]);
-                        } else {
-                            const int key = frame_of<DIR>(j, T);
-                            if (j == prow - 1) max_push(aM[i], aK[i], uj[i] + nz[i], -1);
-                            max_push(aM[i], aK[i], uj[i] + xs[buf][u][i], key);
-                        }
-                    }
-                }
-            }
-        };
+        if (trace) ev[1] = __builtin_readcyclecounter();
+        Blk cur = load_block(jb0);
+        Blk nxt = cur;
+        if (jb0 + 1 <= k) nxt = load_block(jb0 + 1);
+        if (trace) ev[2] = __builtin_readcyclecounter();
 
-        int j0 = jbeg;
-        load_chunk(IC<0>{}, j0);
-        while (j0 < jend) {
-            load_chunk(IC<1>{}, j0 + 8);
-            process_chunk(IC<0>{}, j0);
-            j0 += 8;
-            if (j0 >= jend) break;
-            load_chunk(IC<0>{}, j0 + 8);
-            process_chunk(IC<1>{}, j0);
-            j0 += 8;
+        for (int b = jb0; b <= k; ++b) {
+            if (b < k) {
+                // ---------------- shadow phase: apply block b published by a ring mate -----------
+                if (trace) ev[3 + (b - jb0)] = __builtin_readcyclecounter();
+#pragma unroll
+                for (int u = 0; u < PB; ++u) {
+                    const int j = b * PB + u;
+                    if (avail <= j) {
+                        int spins = 0;
+                        while (true) {
+                            avail = __builtin_amdgcn_readfirstlane(
+                                __hip_atomic_load(done_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                            if (avail > j) break;
+                            __builtin_amdgcn_s_sleep(1);
+                            if (spin_abort(P.ctrl, spins, SPIN_LIMIT_LDS, 2)) break;
+                        }
+                    }
+                    const float2 uv = *(const float2*)&ubuf[(j & 127) * GS + pr * 2];
+                    apply(uv.x, uv.y, cur.v[u], j);
+                }
+                cur = nxt;
+                if (b + 2 <= k) nxt = load_block(b + 2);
+            } else {
+                // ---------------- diagonal phase: finalise the 16 positions of block k ------------
+                if (trace) ev[6] = __builtin_readcyclecounter();
+                if (k >= RING && !(P.dbg & 1u) && rvalid) {
+                    // merge the far-field partials handed over by the panel tasks of this block
+                    const int nparts = (k - RING) / TPT + 1;
+                    for (int part = 0; part < nparts; ++part) {
+                        const u64* fp = P.farg + ((size_t)part * T + prow) * Bs + c;
+                        int spins = 0;
+                        u64 g0 = 0, g1 = 0;
+                        while (true) {
+                            g0 = load_granule(fp);
+                            g1 = load_granule(fp + 1);
+                            bool ok;
+                            if (MODE == 0) ok = (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag;
+                            else ok = (unsigned)(g0 >> 48) == (tag & 0xffffu) && (unsigned)(g1 >> 48) == (tag & 0xffffu);
+                            if (ok) break;
+                            __builtin_amdgcn_s_sleep(2);
+                            if (spin_abort(P.ctrl, spins, SPIN_LIMIT, 3)) break;
+                        }
+                        if (MODE == 0) {
+                            acc_push1(aM[0], aS[0], __uint_as_float((unsigned)g0));
+                            acc_push1(aM[1], aS[1], __uint_as_float((unsigned)g1));
+                        } else {
+                            max_push(aM[0], aK[0], __uint_as_float((unsigned)g0), (int)((g0 >> 32) & 0xffffu));
+                            max_push(aM[1], aK[1], __uint_as_float((unsigned)g1), (int)((g1 >> 32) & 0xffffu));
+                        }
+                    }
+                }
+                if (MODE == 0) {
+                    // LSE diagonal steps.  Row jj+1 receives its last term (u[jj] + first sub-diagonal cell with the
+                    // skip folded in) through a short dependent chain: with Vp = value of everything but that
+                    // term (kept up to date one step ahead) the new value is logaddexp2(Vp, u + W), no (M,S)
+                    // round trip.  The generic (M,S) push of u[jj] into the later rows runs beside it (lazily
+                    // rescaled: one exp, no selects).  A lone wave issues ~1 instruction per 4 cycles, so the
+                    // step is kept to ~35 instructions.
+                    float W[2] = {wl[0] + sp[0], wl[1] + sp[1]};
+                    float Vp[2] = {aM[0] + flog2(aS[0]) + sp[0], aM[1] + flog2(aS[1]) + sp[1]};
+                    float vfin[2] = {prow == 0 ? sp[0] : Vp[0], prow == 0 ? sp[1] : Vp[1]};
+                    const int bp_addr = pr << 2;                    // ds_bpermute byte address of lane `pr`
+                    float* const my_u = &ubuf[pr * 2];              // + (j & 127) * GS
+                    float* const my_dummy = &dummy[lane * 2];
+#pragma unroll
+                    for (int jj = 0; jj < PB; ++jj) {
+                        const int j = own0 + jj;
+                        if (j < T) {                            // scalar; constant trip count keeps the loop unrollable
+                            int rr = r;
+                            asm volatile("" : "+v"(rr));        // keep the per-step lane predicates out of SGPRs
+#if (SEMICRF_ABL & 4)
+                            const float u0 = vfin[0], u1 = vfin[1];
+#else
+                            const float u0 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + (jj << 4), __float_as_int(vfin[0])));
+                            const float u1 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + (jj << 4), __float_as_int(vfin[1])));
+#endif
+                            // publish to the ring through LDS; lanes of other rows write to a private dummy slot
+#if !(SEMICRF_ABL & 1)
+                            float* up = rr == jj ? my_u + (j & 127) * GS : my_dummy;
+                            *(float2*)up = make_float2(vfin[0], vfin[1]);
+#endif
+#if !(SEMICRF_ABL & 2)
+                            int* dp = lane == (jj << 2) ? done_ptr : (int*)&dummy[128 + lane];
+                            __hip_atomic_store(dp, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+                            if (jj == PB - 1 || j == T - 1) {
+                                int* dp = lane == (jj << 2) ? done_ptr : (int*)&dummy[128 + lane];
+                                __hip_atomic_store(dp, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+#endif
+                            // critical chain for row jj+1
+#if (SEMICRF_ABL & 16)
+                            const float c0 = u0 + W[0], c1 = u1 + W[1];
+#else
+                            const float t0 = u0 + W[0], t1 = u1 + W[1];
+                            const float c0 = fmaxf(Vp[0], t0) + flog2(1.0f + fexp2(-fabsf(Vp[0] - t0)));
+                            const float c1 = fmaxf(Vp[1], t1) + flog2(1.0f + fexp2(-fabsf(Vp[1] - t1)));
+#endif
+                            if (rr == jj + 1) { vfin[0] = c0; vfin[1] = c1; }
+#if !(SEMICRF_ABL & 8)
+                            // generic push for the rows further down (lazy reference point), then refresh their Vp
+                            const float p0 = fmaf(cur.v[jj].x, LOG2E, u0), p1 = fmaf(cur.v[jj].y, LOG2E, u1);
+                            const float d0 = p0 - aM[0], d1 = p1 - aM[1];       // M = -inf -> +inf
+                            if (__any(fmaxf(d0, d1) > RESCALE_THR)) {
+                                // rare: move the reference point of the accumulators that fell too far behind
+                                if (d0 > RESCALE_THR) { aS[0] = aS[0] * fexp2(-d0) + 1.0f; aM[0] = p0; } else aS[0] += fexp2(d0);
+                                if (d1 > RESCALE_THR) { aS[1] = aS[1] * fexp2(-d1) + 1.0f; aM[1] = p1; } else aS[1] += fexp2(d1);
+                            } else {
+                                aS[0] += fexp2(d0);
+                                aS[1] += fexp2(d1);
+                            }
+                            Vp[0] = aM[0] + flog2(aS[0]) + sp[0];
+                            Vp[1] = aM[1] + flog2(aS[1]) + sp[1];
+#endif
+                        }
+                    }
+                    myres[0] = vfin[0]; myres[1] = vfin[1];
+                    if (trace) ev[7] = __builtin_readcyclecounter();
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < PB; ++jj) {
+                        const int j = own0 + jj;
+                        if (j < T) {
+                            const float b0 = prow == 0 ? 0.0f : aM[0], b1 = prow == 0 ? 0.0f : aM[1];
+                            const float res0 = sp[0] > 0.0f ? b0 + sp[0] : b0;
+                            const float res1 = sp[1] > 0.0f ? b1 + sp[1] : b1;
+                            const int src = (jj << 2) | pr;
+                            const float u0 = __shfl(res0, src), u1 = __shfl(res1, src);
+                            const bool mine = r == jj;
+                            float* up = mine ? &ubuf[(j & 127) * GS + pr * 2] : &dummy[lane * 2];
+                            *(float2*)up = make_float2(res0, res1);
+                            int* dp = lane == (jj << 2) ? done_ptr : (int*)&dummy[128 + lane];
+                            __hip_atomic_store(dp, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (mine) {
+                                myres[0] = res0; myres[1] = res1;
+                                mykey[0] = prow == 0 ? -1 : aK[0]; mykey[1] = prow == 0 ? -1 : aK[1];
+                            }
+                            apply(u0, u1, cur.v[jj], j);
+                        }
+                    }
+                }
+                avail = own0 + PB;
+            }
+        }
+
+        // ---- once per block: publish the 16 finished positions to HBM -----------------------------
+        if (rvalid) {
+            store_granule(P.ug + (size_t)prow * Bs + c, make_granule(tag, myres[0]));
+            store_granule(P.ug + (size_t)prow * Bs + c + 1, make_granule(tag, myres[1]));
+            const float sc = MODE == 0 ? LN2 : 1.0f;
+            if (P.u_out) *(float2*)(P.u_out + (size_t)frow * Bs + c) = make_float2(myres[0] * sc, myres[1] * sc);
+            if (P.last_out && prow == T - 1) *(float2*)(P.last_out + c) = make_float2(myres[0] * sc, myres[1] * sc);
+            if (MODE == 1) {
+                P.code[(size_t)c * T + frow] = (mykey[0] + 1) | (sp[0] > 0.0f ? 0x40000000 : 0);
+                P.code[(size_t)(c + 1) * T + frow] = (mykey[1] + 1) | (sp[1] > 0.0f ? 0x40000000 : 0);
+            }
         }
     }
 }
@@ -329,192 +414,248 @@ __device__ void spine_role(const SweepParams& P, int sg, float (*ubuf)[GS], int*
 // quad8 selects 4 of the 32 chains, so 8 consecutive lanes read one 128-byte line.
 //   DIR 0: wave w owns positions 16k+4w+r (r<4); per tile a lane holds columns pj = 16m+slot+8h.
 //   DIR 1: wave w owns tile rows pj = 16m+4w+r; a lane holds positions pi = 16k+slot+8h.
+// Cells and u-granules of tile m+1 are requested before tile m is processed.
 template <int MODE, int DIR>
-__device__ void panel_role(const SweepParams& P, int pidx, float* lds)
+__device__ void panel_role(const SweepParams& P, float* lds, int* s_task)
 {
     const int T = P.T, B = P.B;
-    const int k = RING + pidx / P.nPanelGroups;
-    const int g = pidx % P.nPanelGroups;
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
     const int slot = lane >> 3, q8 = lane & 7;
-    const int c = g * GP + q8 * 4;
-    const bool cvalid = c < B;
     const size_t Bs = (size_t)B;
     const float* __restrict__ score = P.score;
     const unsigned tag = P.tag;
-    const int nTiles = k - (RING - 1);          // tiles m = 0 .. k-RING
+    constexpr int NA = DIR == 0 ? 4 : 2;        // accumulators per chain: rows (DIR 0) or column halves (DIR 1)
+    constexpr int NU = DIR == 0 ? 2 : 4;        // u positions a lane needs per tile
+    const auto ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.ug, 0, (int)((size_t)T * Bs * 8), 0x00020000);
 
-    // accumulators: DIR 0 -> [r][chain], DIR 1 -> [h][chain] (only h < 2 used)
-    float aM[4][4], aS[4][4];
-    int aK[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { aM[a][i] = SEMICRF_NEG_INF; aS[a][i] = 0.f; aK[a][i] = 0x7fffffff; }
+    while (true) {
+        // ---- next task: (k, part, g), ordered so that a task only waits on spine progress below k-3 ----
+        __syncthreads();
+        if (tid == 0) *s_task = (int)atomicAdd(P.ctrl + 2, 1u);
+        __syncthreads();
+        const int task = *s_task;
+        if (task >= P.nTasks) break;
+        const int g = task % P.nPanelGroups;
+        int tt = task / P.nPanelGroups;
+        int a = 0;
+        while (tt >= TPT * (a + 1) * (a + 2) / 2) ++a;          // group a: blocks with a+1 parts
+        tt -= TPT * a * (a + 1) / 2;
+        const int q = a * TPT + tt / (a + 1);
+        const int part = tt % (a + 1);
+        const int k = RING + q;
+        const int m0 = part * TPT;
+        const int m1 = (m0 + TPT < q + 1) ? m0 + TPT : q + 1;   // tiles m0 .. m1-1 of the q+1 far tiles of block k
+        const int c = g * GP + q8 * 4;
+        const bool cvalid = c < B;
 
-    float4 x[2][4][2];   // [buffer][r][h]
-    auto pi_of = [&](int rr, int h) { return DIR == 0 ? k * PB + wave * 4 + rr : k * PB + slot + 8 * h; };
-    auto pj_of = [&](int m, int rr, int h) { return DIR == 0 ? m * PB + slot + 8 * h : m * PB + wave * 4 + rr; };
-    auto load_tile = [&](auto bufc, int m) {
-        constexpr int buf = decltype(bufc)::value;
+        float aM[NA][4], aS[NA][4];
+        int aK[NA][4];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
+        for (int ai = 0; ai < NA; ++ai)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int pi = pi_of(rr, h), pj = pj_of(m, rr, h);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (cvalid && pi < T) v = *(const float4*)(score + cell_index<DIR>(pi, pj, T) * Bs + c);
-                x[buf][rr][h] = v;
-            }
-    };
+            for (int i = 0; i < 4; ++i) { aM[ai][i] = SEMICRF_NEG_INF; aS[ai][i] = 0.f; aK[ai][i] = 0x7fffffff; }
 
-    auto process_tile = [&](auto bufc, int m) {
-        constexpr int buf = decltype(bufc)::value;
-        // wait for the spine(s) of these 32 chains to publish block m (poll its last position), then
-        // read the granules this lane needs; every granule carries its own tag.
-        const int plast = m * PB + PB - 1;
-        if (lane == 0) {
-            int spins = 0;
-            for (int half = 0; half < 2; ++half) {
-                const int cc = g * GP + half * GS;
-                if (cc >= B) break;
-                while ((unsigned)(load_granule(P.ug + (size_t)plast * Bs + cc) >> 32) != tag) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (spin_abort(P.ctrl, spins, SPIN_LIMIT, 4)) break;
+        float4 x[2][4][2];    // [buffer][r][h] cells
+        v4u gq[2][NU][2];     // [buffer][u position][chain pair] granules (2 granules per 16-byte load)
+        auto pi_of = [&](int rr, int h) { return DIR == 0 ? k * PB + wave * 4 + rr : k * PB + slot + 8 * h; };
+        auto pj_of = [&](int m, int rr, int h) { return DIR == 0 ? m * PB + slot + 8 * h : m * PB + wave * 4 + rr; };
+        auto pu_of = [&](int m, int ai) { return DIR == 0 ? m * PB + slot + 8 * ai : m * PB + wave * 4 + ai; };
+
+        auto load_tile = [&](auto bufc, int m) {
+            constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int pi = pi_of(rr, h), pj = pj_of(m, rr, h);
+                    const size_t ci = cell_index<DIR>(pi < T ? pi : T - 1, pj, T);
+                    x[buf][rr][h] = *(const float4*)(score + ci * Bs + (cvalid ? c : 0));
                 }
+        };
+        auto load_gran = [&](auto bufc, int m) {
+            constexpr int buf = decltype(bufc)::value;
+            if (P.dbg & 32u) return;
+#pragma unroll
+            for (int ai = 0; ai < NU; ++ai) {
+                const int off = (int)(((size_t)pu_of(m, ai) * Bs + (cvalid ? c : 0)) * 8);
+                gq[buf][ai][0] = __builtin_amdgcn_raw_buffer_load_b128(ursrc, off, 0, 16);        // sc1
+                gq[buf][ai][1] = __builtin_amdgcn_raw_buffer_load_b128(ursrc, off + 16, 0, 16);
+            }
+        };
+
+        auto process_tile = [&](auto bufc, int m) {
+            constexpr int buf = decltype(bufc)::value;
+            if (P.dbg & 32u) {          // streaming probe: touch the data, nothing else
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        aS[0][0] += x[buf][rr][h].x + x[buf][rr][h].y + x[buf][rr][h].z + x[buf][rr][h].w;
+                return;
+            }
+            // every granule carries its own tag: retry until the spine has published block m
+            if (!(P.dbg & 4u)) {
+                int spins = 0;
+                while (true) {
+                    bool ok = true;
+#pragma unroll
+                    for (int ai = 0; ai < NU; ++ai)
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh)
+                            ok = ok && gq[buf][ai][hh].y == tag && gq[buf][ai][hh].w == tag;
+                    if (__all(ok || !cvalid)) break;
+                    __builtin_amdgcn_s_sleep(16);
+                    if (spin_abort(P.ctrl, spins, SPIN_LIMIT, 5)) break;
+                    load_gran(bufc, m);
+                }
+            }
+            float uv[NU][4];
+#pragma unroll
+            for (int ai = 0; ai < NU; ++ai) {
+                uv[ai][0] = __uint_as_float(gq[buf][ai][0].x); uv[ai][1] = __uint_as_float(gq[buf][ai][0].z);
+                uv[ai][2] = __uint_as_float(gq[buf][ai][1].x); uv[ai][3] = __uint_as_float(gq[buf][ai][1].z);
+            }
+
+            if (MODE == 0) {
+                // t = u + cell*log2e; lazily rescaled accumulators: one exp per cell, rare rescale branch
+                float t[4][2][4];
+                float exc = 0.0f;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float4 xv = x[buf][rr][h];
+                        const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+                        const int ai = DIR == 0 ? rr : h, ui = DIR == 0 ? h : rr;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            t[rr][h][i] = fmaf(xe[i], LOG2E, uv[ui][i]);
+                            exc = fmaxf(exc, t[rr][h][i] - (aM[ai][i] + RESCALE_THR));
+                        }
+                    }
+                if (__any(exc > 0.0f)) {
+                    // some accumulator's reference point is too low (always on the first tile): move it up
+#pragma unroll
+                    for (int ai = 0; ai < NA; ++ai)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float mx = aM[ai][i];
+#pragma unroll
+                            for (int e = 0; e < (DIR == 0 ? 2 : 4); ++e)
+                                mx = fmaxf(mx, DIR == 0 ? t[ai][e][i] : t[e][ai][i]);
+                            if (mx > aM[ai][i] + RESCALE_THR) {
+                                aS[ai][i] = aS[ai][i] * fexp2(aM[ai][i] - mx);     // -inf - mx -> exp2 = 0, S = 0
+                                aM[ai][i] = mx;
+                            }
+                        }
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int ai = DIR == 0 ? rr : h;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) aS[ai][i] += fexp2(t[rr][h][i] - aM[ai][i]);
+                    }
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float4 xv = x[buf][rr][h];
+                        const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+                        const int ai = DIR == 0 ? rr : h, ui = DIR == 0 ? h : rr;
+                        const int key = frame_of<DIR>(pj_of(m, rr, h), T);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) max_push(aM[ai][i], aK[ai][i], uv[ui][i] + xe[i], key);
+                    }
+            }
+        };
+
+        {
+            int m = m0;
+            load_tile(IC<0>{}, m);
+            load_gran(IC<0>{}, m);
+            while (m < m1) {
+                if (m + 1 < m1) { load_tile(IC<1>{}, m + 1); load_gran(IC<1>{}, m + 1); }
+                process_tile(IC<0>{}, m);
+                ++m;
+                if (m >= m1) break;
+                if (m + 1 < m1) { load_tile(IC<0>{}, m + 1); load_gran(IC<0>{}, m + 1); }
+                process_tile(IC<1>{}, m);
+                ++m;
             }
         }
-        // lanes reconverge here; now fetch u for the columns/rows of this tile
-        constexpr int NU = DIR == 0 ? 2 : 4;
-        float uv[NU][4];
-        if (cvalid) {
-            int spins = 0;
-            bool ok = false;
-            while (!ok) {
-                ok = true;
+
+        // ---- reduce the partials and hand them to the spine ------------------------------------------
+        u64* fbase = P.farg + (size_t)part * T * Bs;
+        if (DIR == 0) {
+            // across the 8 column slots of the wave (lane bits 3..5)
 #pragma unroll
-                for (int a = 0; a < NU; ++a) {
-                    const int pj = DIR == 0 ? m * PB + slot + 8 * a : m * PB + wave * 4 + a;
+            for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const u64 gr = load_granule(P.ug + (size_t)pj * Bs + c + i);
-                        ok = ok && ((unsigned)(gr >> 32) == tag);
-                        uv[a][i] = __uint_as_float((unsigned)gr);
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int off = 8; off < 64; off <<= 1) {
+                        const float oM = __shfl_xor(aM[rr][i], off);
+                        if (MODE == 0) {
+                            const float oS = __shfl_xor(aS[rr][i], off);
+                            acc_merge(aM[rr][i], aS[rr][i], oM, oS);
+                        } else {
+                            const int oK = __shfl_xor(aK[rr][i], off);
+                            max_push(aM[rr][i], aK[rr][i], oM, oK);
+                        }
                     }
                 }
-                if (!ok) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (spin_abort(P.ctrl, spins, SPIN_LIMIT, 5)) break;
+            if (slot == 0 && cvalid) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int pi = k * PB + wave * 4 + rr;
+                    if (pi >= T) continue;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        u64 gr;
+                        if (MODE == 0) gr = make_granule(tag, aM[rr][i] + flog2(aS[rr][i]));
+                        else gr = ((u64)(((tag & 0xffffu) << 16) | ((unsigned)aK[rr][i] & 0xffffu)) << 32) |
+                                  (u64)__float_as_uint(aM[rr][i]);
+                        store_granule(fbase + (size_t)pi * Bs + c + i, gr);
+                    }
                 }
             }
         } else {
+            // across the 4 waves through LDS: lds[wave][h][slot][q8*4+i] x {M, S/K}
+            float* lm = lds;
+            float* ls = lds + 4 * 2 * 8 * 32;
 #pragma unroll
-            for (int a = 0; a < NU; ++a)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) uv[a][i] = 0.f;
-        }
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int pi = pi_of(rr, h);
-                if (!(cvalid && pi < T)) continue;
-                const int ai = DIR == 0 ? rr : h;
-                const int ui = DIR == 0 ? h : rr;
-                const float4 xv = x[buf][rr][h];
-                const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    if (MODE == 0) {
-                        acc_push(aM[ai][i], aS[ai][i], fmaf(xe[i], LOG2E, uv[ui][i]));
-                    } else {
-                        const int pj = pj_of(m, rr, h);
-                        max_push(aM[ai][i], aK[ai][i], uv[ui][i] + xe[i], frame_of<DIR>(pj, T));
-                    }
+                    const int idx = ((wave * 2 + h) * 8 + slot) * 32 + q8 * 4 + i;
+                    lm[idx] = aM[h][i];
+                    ls[idx] = MODE == 0 ? aS[h][i] : __int_as_float(aK[h][i]);
                 }
-            }
-    };
-
-    if (nTiles > 0) {
-        int m = 0;
-        load_tile(IC<0>{}, 0);
-        while (m < nTiles) {
-            if (m + 1 < nTiles) load_tile(IC<1>{}, m + 1);
-            process_tile(IC<0>{}, m);
-            ++m;
-            if (m >= nTiles) break;
-            if (m + 1 < nTiles) load_tile(IC<0>{}, m + 1);
-            process_tile(IC<1>{}, m);
-            ++m;
-        }
-    }
-
-    // ---- reduce the partials and hand them to the spine ------------------------------------------
-    if (DIR == 0) {
-        // across the 8 column slots of the wave (lane bits 3..5)
+            __syncthreads();
+            // 16 positions x 32 chains = 512 results, 2 per thread
+            for (int e = tid; e < 2 * 8 * 32; e += 256) {
+                const int ch = e & 31, sl = (e >> 5) & 7, h = e >> 8;
+                float M = SEMICRF_NEG_INF, S = 0.f;
+                int Kk = 0x7fffffff;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int off = 8; off < 64; off <<= 1) {
-                    const float oM = __shfl_xor(aM[rr][i], off);
-                    if (MODE == 0) {
-                        const float oS = __shfl_xor(aS[rr][i], off);
-                        acc_merge(aM[rr][i], aS[rr][i], oM, oS);
-                    } else {
-                        const int oK = __shfl_xor(aK[rr][i], off);
-                        max_push(aM[rr][i], aK[rr][i], oM, oK);
-                    }
+                for (int w = 0; w < 4; ++w) {
+                    const int idx = ((w * 2 + h) * 8 + sl) * 32 + ch;
+                    if (MODE == 0) acc_merge(M, S, lm[idx], ls[idx]);
+                    else max_push(M, Kk, lm[idx], __float_as_int(ls[idx]));
                 }
-            }
-        if (slot == 0 && cvalid) {
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int pi = k * PB + wave * 4 + rr;
-                if (pi >= T) continue;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                const int pi = k * PB + sl + 8 * h;
+                const int cc = g * GP + ch;
+                if (pi < T && cc < B) {
                     u64 gr;
-                    if (MODE == 0) gr = make_granule(tag, aM[rr][i] + flog2(aS[rr][i]));
-                    else gr = ((u64)(((tag & 0xffffu) << 16) | ((unsigned)aK[rr][i] & 0xffffu)) << 32) |
-                              (u64)__float_as_uint(aM[rr][i]);
-                    store_granule(P.farg + (size_t)pi * Bs + c + i, gr);
+                    if (MODE == 0) gr = make_granule(tag, M + flog2(S));
+                    else gr = ((u64)(((tag & 0xffffu) << 16) | ((unsigned)Kk & 0xffffu)) << 32) | (u64)__float_as_uint(M);
+                    store_granule(fbase + (size_t)pi * Bs + cc, gr);
                 }
-            }
-        }
-    } else {
-        // across the 4 waves through LDS: lds[wave][h][slot][q8*4+i] x {M, S/K}
-        float* lm = lds;
-        float* ls = lds + 4 * 2 * 8 * 32;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = ((wave * 2 + h) * 8 + slot) * 32 + q8 * 4 + i;
-                lm[idx] = aM[h][i];
-                ls[idx] = MODE == 0 ? aS[h][i] : __int_as_float(aK[h][i]);
-            }
-        __syncthreads();
-        // 16 positions x 32 chains = 512 results, 2 per thread
-        for (int e = tid; e < 2 * 8 * 32; e += 256) {
-            const int ch = e & 31, sl = (e >> 5) & 7, h = e >> 8;
-            float M = SEMICRF_NEG_INF, S = 0.f;
-            int Kk = 0x7fffffff;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const int idx = ((w * 2 + h) * 8 + sl) * 32 + ch;
-                if (MODE == 0) acc_merge(M, S, lm[idx], ls[idx]);
-                else max_push(M, Kk, lm[idx], __float_as_int(ls[idx]));
-            }
-            const int pi = k * PB + sl + 8 * h;
-            const int cc = g * GP + ch;
-            if (pi < T && cc < B) {
-                u64 gr;
-                if (MODE == 0) gr = make_granule(tag, M + flog2(S));
-                else gr = ((u64)(((tag & 0xffffu) << 16) | ((unsigned)Kk & 0xffffu)) << 32) | (u64)__float_as_uint(M);
-                store_granule(P.farg + (size_t)pi * Bs + cc, gr);
             }
         }
     }
@@ -526,26 +667,38 @@ __device__ void panel_role(const SweepParams& P, int pidx, float* lds)
 template <int MODE, int DIR>
 __global__ __launch_bounds__(256, 2) void persist_sweep_kernel(SweepParams P)
 {
-    __shared__ float s_ubuf[128][GS];     // spine: ring of the last 128 published positions
+    __shared__ __attribute__((aligned(16))) float s_ubuf[128 * GS];            // spine: ring of the last 128 published positions
+    __shared__ __attribute__((aligned(16))) float s_dummy[256];                // spine: sink of address-predicated stores
     __shared__ float s_red[2 * 4 * 2 * 8 * 32];   // panel DIR 1 reduction
     __shared__ int s_ticket;
     __shared__ int s_done;
+    __shared__ int s_task;
     if (threadIdx.x == 0) {
         s_ticket = (int)atomicAdd(P.ctrl, 1u);
         s_done = 0;
     }
     __syncthreads();
     const int ticket = s_ticket;
-    if (ticket < P.nSpine) spine_role<MODE, DIR>(P, ticket, s_ubuf, &s_done);
-    else panel_role<MODE, DIR>(P, ticket - P.nSpine, s_red);
+    if (ticket < P.nSpine) {
+        if (!(P.dbg & 8u)) spine_role<MODE, DIR>(P, ticket, s_ubuf, &s_done, s_dummy);
+    } else {
+        if (!(P.dbg & 2u)) panel_role<MODE, DIR>(P, s_red, &s_task);
+    }
+}
+
+static int max_parts(int T)
+{
+    const int K = (T + PB - 1) / PB;
+    return K > RING ? (K - 1 - RING) / TPT + 1 : 1;
 }
 
 size_t persist_workspace_bytes(int T, int B)
 {
-    return align_up(256) + 2 * align_up((size_t)T * B * sizeof(u64));
+    return align_up(256) + align_up((size_t)2 * T * sizeof(u64)) +
+           (size_t)(1 + max_parts(T)) * align_up((size_t)T * B * sizeof(u64));
 }
 
-bool persist_supported(int T, int B) { return (B % 4 == 0) && T >= 1 && T < 65535; }
+bool persist_supported(int T, int B) { return (B % 4 == 0) && T >= 1 && T < 65535 && (long long)T * B * 8 < (1ll << 31); }
 
 static unsigned next_tag()
 {
@@ -563,15 +716,31 @@ int launch_persist_sweep(int mode, int dir, const float* score, const float* noi
     P.nSpine = (B + GS - 1) / GS;
     P.nPanelGroups = (B + GP - 1) / GP;
     P.tag = next_tag();
+    const char* dbg = getenv("SEMICRF_DEBUG_FLAGS");
+    P.dbg = dbg ? (unsigned)atoi(dbg) : 0u;
     char* w = (char*)ws;
     P.ctrl = (unsigned*)w;
-    P.ug = (u64*)(w + align_up(256));
-    P.farg = (u64*)(w + align_up(256) + align_up((size_t)T * B * sizeof(u64)));
+    P.ts = (u64*)(w + align_up(256));
+    const size_t ts_bytes = align_up((size_t)2 * T * sizeof(u64));
+    P.ug = (u64*)(w + align_up(256) + ts_bytes);
+    P.farg = (u64*)(w + align_up(256) + ts_bytes + align_up((size_t)T * B * sizeof(u64)));
     P.u_out = u_out; P.last_out = last_out; P.code = code;
     const size_t zbytes = persist_workspace_bytes(T, B);
     if (hipMemsetAsync(ws, 0, zbytes, stream) != hipSuccess) return 1;
-    const int nPanelBlocks = P.K > RING ? P.K - RING : 0;
-    const int grid = P.nSpine + nPanelBlocks * P.nPanelGroups;
+    // panel tasks: block k = RING + q has q/TPT + 1 column parts
+    long long ntask = 0;
+    for (int q = 0; q < P.K - RING; ++q) ntask += (q / TPT + 1);
+    P.nTasks = (int)(ntask * P.nPanelGroups);
+    // persistent panel workgroups: fill the chip at the kernel's occupancy (2 workgroups per CU)
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+    }
+    int nPanelWG = 2 * ncu - P.nSpine;
+    if (nPanelWG < ncu / 2) nPanelWG = ncu / 2;
+    if (nPanelWG > P.nTasks) nPanelWG = P.nTasks;
+    const int grid = P.nSpine + nPanelWG;
     dim3 g(grid), b(256);
     if (mode == 0 && dir == 0) hipLaunchKernelGGL((persist_sweep_kernel<0, 0>), g, b, 0, stream, P);
     else if (mode == 0 && dir == 1) hipLaunchKernelGGL((persist_sweep_kernel<0, 1>), g, b, 0, stream, P);
