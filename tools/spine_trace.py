@@ -15,8 +15,9 @@ for _ in range(3):
     nsci._logz_fwd_raw(s, n, True)
 torch.cuda.synchronize()
 ws = nsci._DEBUG_WS[0]
-ts = ws[256:256 + a.T * 8].view(torch.int64).cpu().numpy()
-d = np.diff(ts)
+CT = (64 + 4096) * 4
+ts = ws[CT:CT + a.T * 8].view(torch.int64).cpu().numpy()
+d = np.diff(ts) if ts.any() else np.zeros(a.T - 1)
 print(f"T={a.T} B={a.B} flags={a.flags}: total {ts[-1]-ts[0]} ticks over {a.T-1} steps; mean {d.mean():.1f} median {np.median(d):.1f}")
 j = np.arange(1, a.T)
 for mod, name in ((16, "j%16==0 (block start)"), (8, "j%8==0 (chunk start)")):
@@ -28,7 +29,7 @@ print("  first 40 deltas:", d[:40].tolist())
 print("  deltas 512..552:", d[512:552].tolist())
 
 K = (a.T + 15) // 16
-ev = ws[256 + a.T * 8:256 + a.T * 8 + K * 64].view(torch.int64).cpu().numpy().reshape(K, 8)
+ev = ws[CT + a.T * 8:CT + a.T * 8 + K * 64].view(torch.int64).cpu().numpy().reshape(K, 8)
 t0 = ev[0, 0]
 print("  per-block events (cycles since start): iter_start, consts_done, loads_issued, shadow0, shadow1, shadow2, diag_start, diag_end")
 for k in list(range(0, 12)) + list(range(32, 38)):

@@ -62,7 +62,8 @@ struct SweepParams {
                            // 1 spine ignores far partials, 2 panels exit at once, 4 panels do not wait for u,
                            // 8 spine exits at once, 16 spine 0 records per-step timestamps,
                            // 32 panels only stream their cells (no granules, no math)
-    unsigned* ctrl;        // [0] ticket, [1] error, [2] panel task queue head
+    unsigned* ctrl;        // [0] ticket, [1] error, [2] panel task queue head, [3] panels that stepped aside,
+                           // [64 .. 64+4096) one flag per compute unit: a spine lives here
     u64* ts;               // [T] debug timestamps of the diagonal steps of spine 0 (dbg & 16)
     u64* ug;               // [T][B] granules of u (position-major: index p*B + c)
     u64* farg;             // [parts][T][B] granules of far-field partials (part = column range of TPT tiles)
@@ -129,6 +130,15 @@ __device__ __forceinline__ float softplus2(float x)
     return x > 20.0f ? x2 : flog2(1.0f + fexp2(x2));
 }
 
+// identifies the compute unit this wave runs on: (XCC id, SE/SH/CU ids of HW_ID) -- used only to keep panel
+// workgroups off the CUs that host a spine (they would steal issue slots from the latency-critical wave)
+__device__ __forceinline__ unsigned cu_key()
+{
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
+    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+    return ((xcc & 15u) << 8) | ((hw >> 8) & 255u);
+}
+
 // sticky device-side status word (0 = fine); read and cleared by semicrf_debug_device_status()
 __device__ unsigned g_dev_status = 0;
 
@@ -153,12 +163,36 @@ __device__ __forceinline__ bool spin_abort(unsigned* ctrl, int& spins, int limit
 // ---------------------------------------------------------------------------------------------
 // SPINE role
 // ---------------------------------------------------------------------------------------------
-// LDS: ubuf[128][GS] ring of published positions, done = number of finalised positions,
-// dummy[64+] sink for address-predicated stores.
+// LDS ring: 128 positions x 4 chain pairs x 16 bytes {u0, u1, seq = position+1, pad}.  A position is
+// published with ONE 16-byte DS write per lane by the four lanes r == 0 of the owning wave (after the
+// broadcast every lane holds u[j] of its pair); consumers read their pair's 16 bytes and check seq.
+//
+// A lone wave issues about one instruction per 4 cycles, so the T-step dependent chain is bounded by the
+// instruction count of a step; the step bodies below are written to stay near 30 instructions:
+//   * cell buffers rotate A/B/C over the four blocks of the band (fully unrolled, no register moves),
+//   * the diagonal step needs no lane predicates: the broadcast value is what gets published and the
+//     next broadcast simply reads the lanes of the next row,
+//   * row jj+1 receives its last term through logaddexp2(Vp, u + W) where Vp (everything but that term)
+//     is refreshed one step ahead by the lazily rescaled (M,S) push that runs beside it,
+//   * far-field partials are requested one block ahead of the diagonal phase.
+constexpr int FAR_PREFETCH = 4;     // parts whose far granules are requested ahead of time
+
+struct SpineBlk { float2 v[PB]; };
+
 template <int MODE, int DIR>
-__device__ void spine_role(const SweepParams& P, int sg, float* ubuf, int* done_ptr, float* dummy)
+__device__ __forceinline__ void spine_role(const SweepParams& P, int sg, float* ring, float* dummy)
 {
-    const int T = P.T, B = P.B;
+    // kernel arguments are copied into locals: lambdas that capture the struct by reference make the
+    // compiler spill it to scratch and reload fields inside the step loops
+    const int T = P.T, B = P.B, K = P.K;
+    const unsigned dbg = P.dbg;
+    unsigned* const ctrl = P.ctrl;
+    u64* const ts = P.ts;
+    u64* const ug = P.ug;
+    const u64* const farg = P.farg;
+    float* const u_out = P.u_out;
+    float* const last_out = P.last_out;
+    int* const code = P.code;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const int r = lane >> 2, pr = lane & 3;
@@ -169,22 +203,42 @@ __device__ void spine_role(const SweepParams& P, int sg, float* ubuf, int* done_
     const float* __restrict__ noise = P.noise;
     const unsigned tag = P.tag;
     const long long stride = DIR == 0 ? (long long)B : -(long long)T * B;   // floats per +1 in j
-    int avail = 0;                                                          // last observed value of done
+    const bool trace = (dbg & 16u) && sg == 0 && lane == 0;
+    if (threadIdx.x == 0) __hip_atomic_store(ctrl + 64 + cu_key(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float* rd_base = ring + pr * 4;                                   // + (j & 127) * 16 floats
+    float* wr_base = r == 0 ? ring + pr * 4 : dummy + lane * 4;             // writers: the four lanes of row 0
+    const int bp_addr = pr << 2;                                            // ds_bpermute byte address of lane pr
 
-    const bool trace = (P.dbg & 16u) && sg == 0 && lane == 0;
-    for (int k = wave; k < P.K; k += RING) {
-        u64* ev = P.ts + P.T + (size_t)k * 8;          // debug events of this block (8 slots)
+    for (int k = wave; k < K; k += RING) {
+        u64* ev = ts + T + (size_t)k * 8;          // debug events of this block (8 slots)
         if (trace) ev[0] = __builtin_readcyclecounter();
         const int prow = k * PB + r;
         const bool rvalid = cvalid && prow < T;
-        const int frow = frame_of<DIR>(prow, T);
+        const int frow = frame_of<DIR>(prow < T ? prow : T - 1, T);
         const int own0 = k * PB;
-        const int jb0 = k - (RING - 1) > 0 ? k - (RING - 1) : 0;   // first block of the band
         const float* rowp = score + cell_index<DIR>(rvalid ? prow : 0, 0, T) * Bs + (cvalid ? c : 0);
+
+        // loads are unconditional (addresses clamped into the tensor) so that all 16 are issued back to back;
+        // cells with j >= prow are only ever applied AFTER this lane's row has been finalised, and invalid
+        // lanes never publish, so what they accumulate is never read.
+        auto load_block = [&](int b) -> SpineBlk {
+            SpineBlk o;
+            const int j0 = b * PB;
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int j = j0 + u < T ? j0 + u : T - 1;
+                o.v[u] = *(const float2*)(rowp + (long long)j * stride);
+            }
+            return o;
+        };
+        SpineBlk A, Bk, C;
+        if (k >= 3) A = load_block(k - 3);
+        if (k >= 2) Bk = load_block(k - 2);
+        if (k >= 1) C = load_block(k - 1);
 
         // ---- per-row constants ----------------------------------------------------------------
         float sp[2] = {0.f, 0.f};   // LSE: softplus2(diag); MAX: diag
-        float nz[2] = {0.f, 0.f};   // noise between prow-1 and prow (MAX: raw; LSE: folded into wl)
+        float nz[2] = {0.f, 0.f};   // MAX: noise between prow-1 and prow
         float wl[2] = {0.f, 0.f};   // LSE: log2(2^s[prow][prow-1] + 2^n): first sub-diagonal cell with the skip folded in
         if (rvalid) {
             const float2 d = *(const float2*)(score + ((size_t)frow * T + frow) * Bs + c);
@@ -201,207 +255,181 @@ __device__ void spine_role(const SweepParams& P, int sg, float* ubuf, int* done_
                 }
             }
         }
+        if (trace) ev[1] = __builtin_readcyclecounter();
 
         float aM[2] = {SEMICRF_NEG_INF, SEMICRF_NEG_INF}, aS[2] = {0.f, 0.f};
         int aK[2] = {0x7fffffff, 0x7fffffff};
-        float myres[2] = {0.f, 0.f};
-        int mykey[2] = {-1, -1};
 
-        // ---- cell stream: one block (16 columns) per buffer, prefetched one to two blocks ahead ----
-        struct Blk { float2 v[PB]; };
-        // Loads are unconditional (addresses clamped into the tensor) so that all 16 are issued back to
-        // back; cells with j >= prow are only ever applied AFTER this lane's row has been finalised, and
-        // invalid lanes never publish, so what they accumulate is never read.
-        auto load_block = [&](int b) -> Blk {
-            Blk o;
-            const int j0 = b * PB;
+        // lazily rescaled LSE push of (p0,p1) into (aM,aS): one exp per chain, rare wave-uniform slow path
+        auto lse_push2 = [&](float p0, float p1) {
+            const float d0 = p0 - aM[0], d1 = p1 - aM[1];       // M = -inf -> +inf
+            if (__any(fmaxf(d0, d1) > RESCALE_THR)) {
+                if (d0 > RESCALE_THR) { aS[0] = aS[0] * fexp2(-d0) + 1.0f; aM[0] = p0; } else aS[0] += fexp2(d0);
+                if (d1 > RESCALE_THR) { aS[1] = aS[1] * fexp2(-d1) + 1.0f; aM[1] = p1; } else aS[1] += fexp2(d1);
+            } else {
+                aS[0] += fexp2(d0);
+                aS[1] += fexp2(d1);
+            }
+        };
+
+        // wait for position j in the ring and return this lane's pair
+        auto ring_get = [&](int j) -> float2 {
+            const float4* e = (const float4*)(rd_base + (j & 127) * 16);
+            float4 v = *e;
+            if (!__all(__float_as_int(v.z) == j + 1)) {
+                int spins = 0;
+                while (true) {
+                    __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");           // force a fresh LDS read
+                    v = *e;
+                    if (__all(__float_as_int(v.z) == j + 1)) break;
+                    if (spin_abort(ctrl, spins, SPIN_LIMIT_LDS, 2)) break;
+                }
+            }
+            return make_float2(v.x, v.y);
+        };
+
+        // ---------------- shadow phase: apply a block published by a ring mate ---------------------
+        // `last`: block k-1, whose final column own0-1 is the first sub-diagonal cell of row 0 (skip folded in)
+        auto shadow = [&](const SpineBlk& X, int b, bool last) {
+            if (trace) ev[3 + (b - (k - 3))] = __builtin_readcyclecounter();
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
-                const int j = j0 + u < T ? j0 + u : T - 1;
-                o.v[u] = *(const float2*)(rowp + (long long)j * stride);
-            }
-            return o;
-        };
-        const int jsub = prow - 1;          // the first sub-diagonal column carries the skip term
-
-        auto apply = [&](float u0, float u1, float2 x, int j) {
-            if (MODE == 0) {
-                float t0 = fmaf(x.x, LOG2E, u0), t1 = fmaf(x.y, LOG2E, u1);
-                if (j == jsub) { t0 = u0 + wl[0]; t1 = u1 + wl[1]; }
-                acc_push1(aM[0], aS[0], t0);
-                acc_push1(aM[1], aS[1], t1);
-            } else {
-                const int key = frame_of<DIR>(j, T);
-                if (j == jsub) {                             // the skip candidate goes first (key -1)
-                    max_push(aM[0], aK[0], u0 + nz[0], -1);
-                    max_push(aM[1], aK[1], u1 + nz[1], -1);
+                const int j = b * PB + u;
+                const float2 uv = ring_get(j);
+                if (MODE == 0) {
+                    float p0 = fmaf(X.v[u].x, LOG2E, uv.x), p1 = fmaf(X.v[u].y, LOG2E, uv.y);
+                    if (last && u == PB - 1 && r == 0) { p0 = uv.x + wl[0]; p1 = uv.y + wl[1]; }
+                    lse_push2(p0, p1);
+                } else {
+                    const int key = frame_of<DIR>(j, T);
+                    if (last && u == PB - 1 && r == 0) {         // the skip candidate goes first (key -1)
+                        max_push(aM[0], aK[0], uv.x + nz[0], -1);
+                        max_push(aM[1], aK[1], uv.y + nz[1], -1);
+                    }
+                    max_push(aM[0], aK[0], uv.x + X.v[u].x, key);
+                    max_push(aM[1], aK[1], uv.y + X.v[u].y, key);
                 }
-                max_push(aM[0], aK[0], u0 + x.x, key);
-                max_push(aM[1], aK[1], u1 + x.y, key);
             }
         };
 
-        if (trace) ev[1] = __builtin_readcyclecounter();
-        Blk cur = load_block(jb0);
-        Blk nxt = cur;
-        if (jb0 + 1 <= k) nxt = load_block(jb0 + 1);
-        if (trace) ev[2] = __builtin_readcyclecounter();
+        if (k >= 3) shadow(A, k - 3, false);
+        A = load_block(k);                               // own block: two blocks of lead
+        if (k >= 2) shadow(Bk, k - 2, false);
 
-        for (int b = jb0; b <= k; ++b) {
-            if (b < k) {
-                // ---------------- shadow phase: apply block b published by a ring mate -----------
-                if (trace) ev[3 + (b - jb0)] = __builtin_readcyclecounter();
+        // far-field partials of this block: request them one block ahead of the diagonal phase
+        const int nparts = k >= RING ? (k - RING) / TPT + 1 : 0;
+        u64 fg[FAR_PREFETCH][2];
 #pragma unroll
-                for (int u = 0; u < PB; ++u) {
-                    const int j = b * PB + u;
-                    if (avail <= j) {
-                        int spins = 0;
-                        while (true) {
-                            avail = __builtin_amdgcn_readfirstlane(
-                                __hip_atomic_load(done_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                            if (avail > j) break;
-                            __builtin_amdgcn_s_sleep(1);
-                            if (spin_abort(P.ctrl, spins, SPIN_LIMIT_LDS, 2)) break;
-                        }
-                    }
-                    const float2 uv = *(const float2*)&ubuf[(j & 127) * GS + pr * 2];
-                    apply(uv.x, uv.y, cur.v[u], j);
-                }
-                cur = nxt;
-                if (b + 2 <= k) nxt = load_block(b + 2);
-            } else {
-                // ---------------- diagonal phase: finalise the 16 positions of block k ------------
-                if (trace) ev[6] = __builtin_readcyclecounter();
-                if (k >= RING && !(P.dbg & 1u) && rvalid) {
-                    // merge the far-field partials handed over by the panel tasks of this block
-                    const int nparts = (k - RING) / TPT + 1;
-                    for (int part = 0; part < nparts; ++part) {
-                        const u64* fp = P.farg + ((size_t)part * T + prow) * Bs + c;
-                        int spins = 0;
-                        u64 g0 = 0, g1 = 0;
-                        while (true) {
-                            g0 = load_granule(fp);
-                            g1 = load_granule(fp + 1);
-                            bool ok;
-                            if (MODE == 0) ok = (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag;
-                            else ok = (unsigned)(g0 >> 48) == (tag & 0xffffu) && (unsigned)(g1 >> 48) == (tag & 0xffffu);
-                            if (ok) break;
-                            __builtin_amdgcn_s_sleep(2);
-                            if (spin_abort(P.ctrl, spins, SPIN_LIMIT, 3)) break;
-                        }
-                        if (MODE == 0) {
-                            acc_push1(aM[0], aS[0], __uint_as_float((unsigned)g0));
-                            acc_push1(aM[1], aS[1], __uint_as_float((unsigned)g1));
-                        } else {
-                            max_push(aM[0], aK[0], __uint_as_float((unsigned)g0), (int)((g0 >> 32) & 0xffffu));
-                            max_push(aM[1], aK[1], __uint_as_float((unsigned)g1), (int)((g1 >> 32) & 0xffffu));
-                        }
-                    }
+        for (int part = 0; part < FAR_PREFETCH; ++part) {
+            fg[part][0] = 0; fg[part][1] = 0;
+            if (part < nparts && rvalid && !(dbg & 1u)) {
+                const u64* fp = farg + ((size_t)part * T + prow) * Bs + c;
+                fg[part][0] = load_granule(fp);
+                fg[part][1] = load_granule(fp + 1);
+            }
+        }
+        if (k >= 1) shadow(C, k - 1, true);
+
+        // ---------------- diagonal phase: finalise the 16 positions of block k ------------------------
+        if (trace) ev[6] = __builtin_readcyclecounter();
+        if (nparts > 0 && !(dbg & 1u) && rvalid) {
+            for (int part = 0; part < nparts; ++part) {
+                const u64* fp = farg + ((size_t)part * T + prow) * Bs + c;
+                u64 g0 = 0, g1 = 0;
+#pragma unroll
+                for (int q = 0; q < FAR_PREFETCH; ++q) if (q == part) { g0 = fg[q][0]; g1 = fg[q][1]; }
+                int spins = 0;
+                while (true) {
+                    bool ok;
+                    if (MODE == 0) ok = (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag;
+                    else ok = (unsigned)(g0 >> 48) == (tag & 0xffffu) && (unsigned)(g1 >> 48) == (tag & 0xffffu);
+                    if (ok) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    if (spin_abort(ctrl, spins, SPIN_LIMIT, 3)) break;
+                    g0 = load_granule(fp);
+                    g1 = load_granule(fp + 1);
                 }
                 if (MODE == 0) {
-                    // LSE diagonal steps.  Row jj+1 receives its last term (u[jj] + first sub-diagonal cell with the
-                    // skip folded in) through a short dependent chain: with Vp = value of everything but that
-                    // term (kept up to date one step ahead) the new value is logaddexp2(Vp, u + W), no (M,S)
-                    // round trip.  The generic (M,S) push of u[jj] into the later rows runs beside it (lazily
-                    // rescaled: one exp, no selects).  A lone wave issues ~1 instruction per 4 cycles, so the
-                    // step is kept to ~35 instructions.
-                    float W[2] = {wl[0] + sp[0], wl[1] + sp[1]};
-                    float Vp[2] = {aM[0] + flog2(aS[0]) + sp[0], aM[1] + flog2(aS[1]) + sp[1]};
-                    float vfin[2] = {prow == 0 ? sp[0] : Vp[0], prow == 0 ? sp[1] : Vp[1]};
-                    const int bp_addr = pr << 2;                    // ds_bpermute byte address of lane `pr`
-                    float* const my_u = &ubuf[pr * 2];              // + (j & 127) * GS
-                    float* const my_dummy = &dummy[lane * 2];
-#pragma unroll
-                    for (int jj = 0; jj < PB; ++jj) {
-                        const int j = own0 + jj;
-                        if (j < T) {                            // scalar; constant trip count keeps the loop unrollable
-                            int rr = r;
-                            asm volatile("" : "+v"(rr));        // keep the per-step lane predicates out of SGPRs
-#if (SEMICRF_ABL & 4)
-                            const float u0 = vfin[0], u1 = vfin[1];
-#else
-                            const float u0 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + (jj << 4), __float_as_int(vfin[0])));
-                            const float u1 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + (jj << 4), __float_as_int(vfin[1])));
-#endif
-                            // publish to the ring through LDS; lanes of other rows write to a private dummy slot
-#if !(SEMICRF_ABL & 1)
-                            float* up = rr == jj ? my_u + (j & 127) * GS : my_dummy;
-                            *(float2*)up = make_float2(vfin[0], vfin[1]);
-#endif
-#if !(SEMICRF_ABL & 2)
-                            int* dp = lane == (jj << 2) ? done_ptr : (int*)&dummy[128 + lane];
-                            __hip_atomic_store(dp, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-                            if (jj == PB - 1 || j == T - 1) {
-                                int* dp = lane == (jj << 2) ? done_ptr : (int*)&dummy[128 + lane];
-                                __hip_atomic_store(dp, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            }
-#endif
-                            // critical chain for row jj+1
-#if (SEMICRF_ABL & 16)
-                            const float c0 = u0 + W[0], c1 = u1 + W[1];
-#else
-                            const float t0 = u0 + W[0], t1 = u1 + W[1];
-                            const float c0 = fmaxf(Vp[0], t0) + flog2(1.0f + fexp2(-fabsf(Vp[0] - t0)));
-                            const float c1 = fmaxf(Vp[1], t1) + flog2(1.0f + fexp2(-fabsf(Vp[1] - t1)));
-#endif
-                            if (rr == jj + 1) { vfin[0] = c0; vfin[1] = c1; }
-#if !(SEMICRF_ABL & 8)
-                            // generic push for the rows further down (lazy reference point), then refresh their Vp
-                            const float p0 = fmaf(cur.v[jj].x, LOG2E, u0), p1 = fmaf(cur.v[jj].y, LOG2E, u1);
-                            const float d0 = p0 - aM[0], d1 = p1 - aM[1];       // M = -inf -> +inf
-                            if (__any(fmaxf(d0, d1) > RESCALE_THR)) {
-                                // rare: move the reference point of the accumulators that fell too far behind
-                                if (d0 > RESCALE_THR) { aS[0] = aS[0] * fexp2(-d0) + 1.0f; aM[0] = p0; } else aS[0] += fexp2(d0);
-                                if (d1 > RESCALE_THR) { aS[1] = aS[1] * fexp2(-d1) + 1.0f; aM[1] = p1; } else aS[1] += fexp2(d1);
-                            } else {
-                                aS[0] += fexp2(d0);
-                                aS[1] += fexp2(d1);
-                            }
-                            Vp[0] = aM[0] + flog2(aS[0]) + sp[0];
-                            Vp[1] = aM[1] + flog2(aS[1]) + sp[1];
-#endif
-                        }
-                    }
-                    myres[0] = vfin[0]; myres[1] = vfin[1];
-                    if (trace) ev[7] = __builtin_readcyclecounter();
+                    acc_push1(aM[0], aS[0], __uint_as_float((unsigned)g0));
+                    acc_push1(aM[1], aS[1], __uint_as_float((unsigned)g1));
                 } else {
-#pragma unroll
-                    for (int jj = 0; jj < PB; ++jj) {
-                        const int j = own0 + jj;
-                        if (j < T) {
-                            const float b0 = prow == 0 ? 0.0f : aM[0], b1 = prow == 0 ? 0.0f : aM[1];
-                            const float res0 = sp[0] > 0.0f ? b0 + sp[0] : b0;
-                            const float res1 = sp[1] > 0.0f ? b1 + sp[1] : b1;
-                            const int src = (jj << 2) | pr;
-                            const float u0 = __shfl(res0, src), u1 = __shfl(res1, src);
-                            const bool mine = r == jj;
-                            float* up = mine ? &ubuf[(j & 127) * GS + pr * 2] : &dummy[lane * 2];
-                            *(float2*)up = make_float2(res0, res1);
-                            int* dp = lane == (jj << 2) ? done_ptr : (int*)&dummy[128 + lane];
-                            __hip_atomic_store(dp, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (mine) {
-                                myres[0] = res0; myres[1] = res1;
-                                mykey[0] = prow == 0 ? -1 : aK[0]; mykey[1] = prow == 0 ? -1 : aK[1];
-                            }
-                            apply(u0, u1, cur.v[jj], j);
-                        }
-                    }
+                    max_push(aM[0], aK[0], __uint_as_float((unsigned)g0), (int)((g0 >> 32) & 0xffffu));
+                    max_push(aM[1], aK[1], __uint_as_float((unsigned)g1), (int)((g1 >> 32) & 0xffffu));
                 }
-                avail = own0 + PB;
             }
         }
 
+        float* const wr = wr_base + (own0 & 127) * 16;       // ring entry of position own0 (+16 floats per step)
+        int mykey[2] = {-1, -1};
+        if (MODE == 0) {
+            const float W[2] = {wl[0] + sp[0], wl[1] + sp[1]};
+            float Vp[2] = {aM[0] + flog2(aS[0]) + sp[0], aM[1] + flog2(aS[1]) + sp[1]};
+            float cv[2] = {prow == 0 ? sp[0] : Vp[0], prow == 0 ? sp[1] : Vp[1]};      // value of row 0 (lanes r == 0)
+#pragma unroll
+            for (int jj = 0; jj < PB; ++jj) {
+                const int j = own0 + jj;
+                // broadcast u[j] from the lanes of row jj to everybody
+                const float u0 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + (jj << 4), __float_as_int(cv[0])));
+                const float u1 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + (jj << 4), __float_as_int(cv[1])));
+                // publish it: data, then sequence number (in-order DS queue)
+                *(float4*)(wr + jj * 16) = make_float4(u0, u1, __int_as_float(j + 1), 0.0f);   // one DS write: data + seq
+                // critical chain: value of row jj+1 = logaddexp2(Vp, u + W) (only its lanes matter)
+                const float t0 = u0 + W[0], t1 = u1 + W[1];
+                cv[0] = fmaxf(Vp[0], t0) + flog2(1.0f + fexp2(-fabsf(Vp[0] - t0)));
+                cv[1] = fmaxf(Vp[1], t1) + flog2(1.0f + fexp2(-fabsf(Vp[1] - t1)));
+                // generic push for the rows further down (branch-free exact-max form: the whole step stays one
+                // basic block so that the scheduler can overlap it with the critical chain), then refresh Vp
+                {
+                    const float p0 = fmaf(A.v[jj].x, LOG2E, u0), p1 = fmaf(A.v[jj].y, LOG2E, u1);
+                    const float n0 = fmaxf(aM[0], p0), n1 = fmaxf(aM[1], p1);
+                    aS[0] = fmaf(aS[0], fexp2(aM[0] - n0), fexp2(p0 - n0));      // M = -inf: exp2(-inf) = 0, S = 0
+                    aS[1] = fmaf(aS[1], fexp2(aM[1] - n1), fexp2(p1 - n1));
+                    aM[0] = n0; aM[1] = n1;
+                }
+                Vp[0] = aM[0] + flog2(aS[0]) + sp[0];
+                Vp[1] = aM[1] + flog2(aS[1]) + sp[1];
+            }
+        } else {
+            // (max,+): after the push of u[jj] the accumulator of row jj+1 is complete
+            float cv[2];
+            {
+                const float b0 = prow == 0 ? 0.0f : aM[0], b1 = prow == 0 ? 0.0f : aM[1];
+                cv[0] = sp[0] > 0.0f ? b0 + sp[0] : b0;
+                cv[1] = sp[1] > 0.0f ? b1 + sp[1] : b1;
+                if (r == 0) { mykey[0] = prow == 0 ? -1 : aK[0]; mykey[1] = prow == 0 ? -1 : aK[1]; }
+            }
+#pragma unroll
+            for (int jj = 0; jj < PB; ++jj) {
+                const int j = own0 + jj;
+                const float u0 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + (jj << 4), __float_as_int(cv[0])));
+                const float u1 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + (jj << 4), __float_as_int(cv[1])));
+                *(float4*)(wr + jj * 16) = make_float4(u0, u1, __int_as_float(j + 1), 0.0f);
+                const int key = frame_of<DIR>(j < T ? j : T - 1, T);
+                if (r == jj + 1) {                               // the skip candidate goes first (key -1)
+                    max_push(aM[0], aK[0], u0 + nz[0], -1);
+                    max_push(aM[1], aK[1], u1 + nz[1], -1);
+                }
+                max_push(aM[0], aK[0], u0 + A.v[jj].x, key);
+                max_push(aM[1], aK[1], u1 + A.v[jj].y, key);
+                cv[0] = sp[0] > 0.0f ? aM[0] + sp[0] : aM[0];
+                cv[1] = sp[1] > 0.0f ? aM[1] + sp[1] : aM[1];
+                if (r == jj + 1) { mykey[0] = aK[0]; mykey[1] = aK[1]; }
+            }
+        }
+        if (trace) ev[7] = __builtin_readcyclecounter();
+
         // ---- once per block: publish the 16 finished positions to HBM -----------------------------
         if (rvalid) {
-            store_granule(P.ug + (size_t)prow * Bs + c, make_granule(tag, myres[0]));
-            store_granule(P.ug + (size_t)prow * Bs + c + 1, make_granule(tag, myres[1]));
+            const float2 mine = *(const float2*)(rd_base + (prow & 127) * 16);
+            store_granule(ug + (size_t)prow * Bs + c, make_granule(tag, mine.x));
+            store_granule(ug + (size_t)prow * Bs + c + 1, make_granule(tag, mine.y));
             const float sc = MODE == 0 ? LN2 : 1.0f;
-            if (P.u_out) *(float2*)(P.u_out + (size_t)frow * Bs + c) = make_float2(myres[0] * sc, myres[1] * sc);
-            if (P.last_out && prow == T - 1) *(float2*)(P.last_out + c) = make_float2(myres[0] * sc, myres[1] * sc);
+            if (u_out) *(float2*)(u_out + (size_t)frow * Bs + c) = make_float2(mine.x * sc, mine.y * sc);
+            if (last_out && prow == T - 1) *(float2*)(last_out + c) = make_float2(mine.x * sc, mine.y * sc);
             if (MODE == 1) {
-                P.code[(size_t)c * T + frow] = (mykey[0] + 1) | (sp[0] > 0.0f ? 0x40000000 : 0);
-                P.code[(size_t)(c + 1) * T + frow] = (mykey[1] + 1) | (sp[1] > 0.0f ? 0x40000000 : 0);
+                code[(size_t)c * T + frow] = (mykey[0] + 1) | (sp[0] > 0.0f ? 0x40000000 : 0);
+                code[(size_t)(c + 1) * T + frow] = (mykey[1] + 1) | (sp[1] > 0.0f ? 0x40000000 : 0);
             }
         }
     }
@@ -416,9 +444,14 @@ __device__ void spine_role(const SweepParams& P, int sg, float* ubuf, int* done_
 //   DIR 1: wave w owns tile rows pj = 16m+4w+r; a lane holds positions pi = 16k+slot+8h.
 // Cells and u-granules of tile m+1 are requested before tile m is processed.
 template <int MODE, int DIR>
-__device__ void panel_role(const SweepParams& P, float* lds, int* s_task)
+__device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int* s_task)
 {
     const int T = P.T, B = P.B;
+    const unsigned dbg = P.dbg;
+    unsigned* const ctrl = P.ctrl;
+    u64* const farg = P.farg;
+    const int nTasks = P.nTasks, nPanelGroups = P.nPanelGroups;
+    const int maxAside = P.nSpine;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -433,12 +466,19 @@ __device__ void panel_role(const SweepParams& P, float* lds, int* s_task)
     while (true) {
         // ---- next task: (k, part, g), ordered so that a task only waits on spine progress below k-3 ----
         __syncthreads();
-        if (tid == 0) *s_task = (int)atomicAdd(P.ctrl + 2, 1u);
+        if (tid == 0) {
+            int t = -1;
+            // leave the CU to the spine if one lives here (at most maxAside panels do so, the rest keep working)
+            if (!(dbg & 64u) && __hip_atomic_load(ctrl + 64 + cu_key(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u &&
+                atomicAdd(ctrl + 3, 1u) < (unsigned)maxAside) t = 0x7fffffff;
+            if (t < 0) t = (int)atomicAdd(ctrl + 2, 1u);
+            *s_task = t;
+        }
         __syncthreads();
         const int task = *s_task;
-        if (task >= P.nTasks) break;
-        const int g = task % P.nPanelGroups;
-        int tt = task / P.nPanelGroups;
+        if (task >= nTasks) break;
+        const int g = task % nPanelGroups;
+        int tt = task / nPanelGroups;
         int a = 0;
         while (tt >= TPT * (a + 1) * (a + 2) / 2) ++a;          // group a: blocks with a+1 parts
         tt -= TPT * a * (a + 1) / 2;
@@ -476,7 +516,7 @@ __device__ void panel_role(const SweepParams& P, float* lds, int* s_task)
         };
         auto load_gran = [&](auto bufc, int m) {
             constexpr int buf = decltype(bufc)::value;
-            if (P.dbg & 32u) return;
+            if (dbg & 32u) return;
 #pragma unroll
             for (int ai = 0; ai < NU; ++ai) {
                 const int off = (int)(((size_t)pu_of(m, ai) * Bs + (cvalid ? c : 0)) * 8);
@@ -487,7 +527,7 @@ __device__ void panel_role(const SweepParams& P, float* lds, int* s_task)
 
         auto process_tile = [&](auto bufc, int m) {
             constexpr int buf = decltype(bufc)::value;
-            if (P.dbg & 32u) {          // streaming probe: touch the data, nothing else
+            if (dbg & 32u) {          // streaming probe: touch the data, nothing else
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
@@ -496,7 +536,7 @@ __device__ void panel_role(const SweepParams& P, float* lds, int* s_task)
                 return;
             }
             // every granule carries its own tag: retry until the spine has published block m
-            if (!(P.dbg & 4u)) {
+            if (!(dbg & 4u)) {
                 int spins = 0;
                 while (true) {
                     bool ok = true;
@@ -507,7 +547,7 @@ __device__ void panel_role(const SweepParams& P, float* lds, int* s_task)
                             ok = ok && gq[buf][ai][hh].y == tag && gq[buf][ai][hh].w == tag;
                     if (__all(ok || !cvalid)) break;
                     __builtin_amdgcn_s_sleep(16);
-                    if (spin_abort(P.ctrl, spins, SPIN_LIMIT, 5)) break;
+                    if (spin_abort(ctrl, spins, SPIN_LIMIT, 5)) break;
                     load_gran(bufc, m);
                 }
             }
@@ -590,7 +630,7 @@ __device__ void panel_role(const SweepParams& P, float* lds, int* s_task)
         }
 
         // ---- reduce the partials and hand them to the spine ------------------------------------------
-        u64* fbase = P.farg + (size_t)part * T * Bs;
+        u64* fbase = farg + (size_t)part * T * Bs;
         if (DIR == 0) {
             // across the 8 column slots of the wave (lane bits 3..5)
 #pragma unroll
@@ -667,24 +707,23 @@ __device__ void panel_role(const SweepParams& P, float* lds, int* s_task)
 template <int MODE, int DIR>
 __global__ __launch_bounds__(256, 2) void persist_sweep_kernel(SweepParams P)
 {
-    __shared__ __attribute__((aligned(16))) float s_ubuf[128 * GS];            // spine: ring of the last 128 published positions
-    __shared__ __attribute__((aligned(16))) float s_dummy[256];                // spine: sink of address-predicated stores
+    __shared__ __attribute__((aligned(16))) float s_ring[128 * 16];            // spine: ring of the last 128 published positions
+    __shared__ __attribute__((aligned(16))) float s_dummy[64 * 4 + 16 * 16];   // spine: sink of the non-writer lanes' stores
     __shared__ float s_red[2 * 4 * 2 * 8 * 32];   // panel DIR 1 reduction
     __shared__ int s_ticket;
-    __shared__ int s_done;
     __shared__ int s_task;
-    if (threadIdx.x == 0) {
-        s_ticket = (int)atomicAdd(P.ctrl, 1u);
-        s_done = 0;
-    }
+    if (threadIdx.x == 0) s_ticket = (int)atomicAdd(P.ctrl, 1u);
+    for (int i = threadIdx.x; i < 128 * 16; i += 256) s_ring[i] = 0.0f;      // sequence numbers start at 0
     __syncthreads();
     const int ticket = s_ticket;
     if (ticket < P.nSpine) {
-        if (!(P.dbg & 8u)) spine_role<MODE, DIR>(P, ticket, s_ubuf, &s_done, s_dummy);
+        if (!(P.dbg & 8u)) spine_role<MODE, DIR>(P, ticket, s_ring, s_dummy);
     } else {
         if (!(P.dbg & 2u)) panel_role<MODE, DIR>(P, s_red, &s_task);
     }
 }
+
+constexpr size_t CTRL_BYTES = (64 + 4096) * sizeof(unsigned);
 
 static int max_parts(int T)
 {
@@ -694,7 +733,7 @@ static int max_parts(int T)
 
 size_t persist_workspace_bytes(int T, int B)
 {
-    return align_up(256) + align_up((size_t)2 * T * sizeof(u64)) +
+    return CTRL_BYTES + align_up((size_t)2 * T * sizeof(u64)) +
            (size_t)(1 + max_parts(T)) * align_up((size_t)T * B * sizeof(u64));
 }
 
@@ -720,10 +759,10 @@ int launch_persist_sweep(int mode, int dir, const float* score, const float* noi
     P.dbg = dbg ? (unsigned)atoi(dbg) : 0u;
     char* w = (char*)ws;
     P.ctrl = (unsigned*)w;
-    P.ts = (u64*)(w + align_up(256));
+    P.ts = (u64*)(w + CTRL_BYTES);
     const size_t ts_bytes = align_up((size_t)2 * T * sizeof(u64));
-    P.ug = (u64*)(w + align_up(256) + ts_bytes);
-    P.farg = (u64*)(w + align_up(256) + ts_bytes + align_up((size_t)T * B * sizeof(u64)));
+    P.ug = (u64*)(w + CTRL_BYTES + ts_bytes);
+    P.farg = (u64*)(w + CTRL_BYTES + ts_bytes + align_up((size_t)T * B * sizeof(u64)));
     P.u_out = u_out; P.last_out = last_out; P.code = code;
     const size_t zbytes = persist_workspace_bytes(T, B);
     if (hipMemsetAsync(ws, 0, zbytes, stream) != hipSuccess) return 1;
