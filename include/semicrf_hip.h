@@ -116,10 +116,11 @@ int semicrf_eval_path(const float* score, const float* noise, int T, int B,
  * Gradient of sum_c gout[c]*evalPath[c], ACCUMULATED (+=) into dScore / dNoise (autograd of the
  * gathers at :540-548).  dScore[end,begin,c] += gout[c] per path interval;
  * dNoise[t,c] += gout[c] * [gap t not covered by an interval of the path].
+ * K = number of intervals in pairs (= offsets[B], known to the host that packed them).
  * Either output may be NULL.  Callers that want a fresh gradient zero the buffers first.
  */
-int semicrf_eval_path_bwd(const float* gout, int T, int B, const int32_t* pairs, const int32_t* offsets,
-                          float* dScore, float* dNoise, semicrf_stream_t stream);
+int semicrf_eval_path_bwd(const float* gout, int T, int B, const int32_t* pairs, int64_t K,
+                          const int32_t* offsets, float* dScore, float* dNoise, semicrf_stream_t stream);
 
 /*
  * Interval-score construction.  Replaces: ScaledInnerProductIntervalScorer.forward after the

@@ -64,7 +64,9 @@ def pack_intervals(intervals: Sequence[Sequence[Tuple[int, int]]], T: int, B: in
             raise IndexError(f"interval index out of range for T={T}")   # reference: gather index error
     pairs_t = torch.from_numpy(flat.astype(np.int32).reshape(K, 2) if K else np.zeros((1, 2), np.int32))
     offsets_t = torch.from_numpy(offsets)
-    return pairs_t.to(device, non_blocking=True), offsets_t.to(device, non_blocking=True)
+    pairs_d = pairs_t.to(device, non_blocking=True)
+    pairs_d._semicrf_K = K          # number of real intervals (the tensor holds one dummy row when K == 0)
+    return pairs_d, offsets_t.to(device, non_blocking=True)
 
 
 def unpack_intervals(pairs_host: torch.Tensor, offsets_host: torch.Tensor) -> Intervals:
@@ -121,9 +123,9 @@ def _eval_path_raw(score, noise, pairs, offsets):
     return out
 
 
-def _eval_path_bwd_raw(gout, T, B, pairs, offsets, dscore, dnoise):
+def _eval_path_bwd_raw(gout, T, B, pairs, offsets, dscore, dnoise, K: int):
     lib = _lib.load()
-    rc = lib.semicrf_eval_path_bwd(_lib.ptr(gout), T, B, _lib.ptr(pairs), _lib.ptr(offsets), _lib.ptr(dscore),
+    rc = lib.semicrf_eval_path_bwd(_lib.ptr(gout), T, B, _lib.ptr(pairs), int(K), _lib.ptr(offsets), _lib.ptr(dscore),
                                    _lib.ptr(dnoise), _lib.stream_of(gout))
     _lib.check(rc, "semicrf_eval_path_bwd")
 
@@ -169,6 +171,7 @@ class _EvalPath(torch.autograd.Function):
         score_c, noise_c = _prep(score), _prep(noiseScore)
         ctx.save_for_backward(pairs, offsets)
         ctx.shape = (score_c.shape[0], score_c.shape[2])
+        ctx.K = getattr(pairs, "_semicrf_K", pairs.shape[0])
         return _eval_path_raw(score_c, noise_c, pairs, offsets)
 
     @staticmethod
@@ -178,7 +181,7 @@ class _EvalPath(torch.autograd.Function):
         g = _gout(grad_output, B)
         dscore = torch.zeros(T, T, B, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
         dnoise = torch.zeros(max(T - 1, 0), B, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1] else None
-        _eval_path_bwd_raw(g, T, B, pairs, offsets, dscore, dnoise)
+        _eval_path_bwd_raw(g, T, B, pairs, offsets, dscore, dnoise, ctx.K)
         return dscore, dnoise, None, None
 
 
@@ -193,6 +196,7 @@ class _LogProb(torch.autograd.Function):
         path = _eval_path_raw(score_c, noise_c, pairs, offsets)
         if need:
             ctx.save_for_backward(score_c, noise_c, v, logz, pairs, offsets)
+            ctx.K = getattr(pairs, "_semicrf_K", pairs.shape[0])
         return path - logz
 
     @staticmethod
@@ -201,7 +205,7 @@ class _LogProb(torch.autograd.Function):
         T, B = score.shape[0], score.shape[2]
         g = _gout(grad_output, B)
         dscore, dnoise, _ = _logz_bwd_raw(score, noise, v, logz, -g)
-        _eval_path_bwd_raw(g, T, B, pairs, offsets, dscore, dnoise)
+        _eval_path_bwd_raw(g, T, B, pairs, offsets, dscore, dnoise, ctx.K)
         return dscore, dnoise, None, None
 
 

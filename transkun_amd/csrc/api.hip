@@ -28,7 +28,7 @@ void launch_backtrack(const int* code, int T, int B, const int* start, int forwa
                       int* pairs, long long cap, int* offsets, hipStream_t stream);
 void launch_eval_path(const float* score, const float* noise, int T, int B, const int* pairs,
                       const int* offsets, float* cum, float* out, hipStream_t stream);
-void launch_eval_path_bwd(const float* gout, int T, int B, const int* pairs, const int* offsets,
+void launch_eval_path_bwd(const float* gout, int T, int B, int K, const int* pairs, const int* offsets,
                           float* dScore, float* dNoise, hipStream_t stream);
 void launch_interval_score_naive(const float* q, const float* k, const float* diag, int C, int T, int D,
                                  long long ldq, long long ldk, long long ldd, float qscale, int mode, int full,
@@ -40,6 +40,10 @@ int launch_persist_sweep(int mode, int dir, const float* score, const float* noi
                          float* last_out, int* code, void* ws, hipStream_t stream);
 
 int read_and_clear_device_status();
+
+int launch_persist_logz_bwd(const float* score, const float* noise, const float* v, const float* logZ,
+                            const float* gout, int T, int B, float* dScore, float* dNoise, float* q_out, void* ws,
+                            hipStream_t stream);
 
 static bool use_persist(int T, int B) { return g_impl.load() == 0 && persist_supported(T, B); }
 
@@ -136,13 +140,14 @@ int semicrf_logz_bwd(const float* score, const float* noise, const float* v, con
     if (!cv.ok || !ws) { set_error("workspace too small for logz_bwd"); return SEMICRF_EWORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     if (fast) {
-        if (launch_persist_sweep(0, 1, score, noise, T, B, q, nullptr, nullptr, pws, st)) {
+        // beta sweep fused with the marginals: score is read once, dScore written once
+        if (launch_persist_logz_bwd(score, noise, v, logZ, gout, T, B, dScore, dNoise, q, pws, st)) {
             set_error("hipMemsetAsync failed"); return SEMICRF_ELAUNCH;
         }
     } else {
         launch_rowseq_sweep(0, 1, score, noise, T, B, q, nullptr, nullptr, st);
+        launch_marginals(score, noise, v, q, logZ, gout, T, B, dScore, dNoise, st);
     }
-    launch_marginals(score, noise, v, q, logZ, gout, T, B, dScore, dNoise, st);
     SEMICRF_CHECK_LAUNCH("semicrf_logz_bwd");
     return SEMICRF_OK;
 }
@@ -188,12 +193,13 @@ int semicrf_eval_path(const float* score, const float* noise, int T, int B, cons
     return SEMICRF_OK;
 }
 
-int semicrf_eval_path_bwd(const float* gout, int T, int B, const int32_t* pairs, const int32_t* offsets,
+int semicrf_eval_path_bwd(const float* gout, int T, int B, const int32_t* pairs, int64_t K, const int32_t* offsets,
                           float* dScore, float* dNoise, semicrf_stream_t stream)
 {
     SEMICRF_CHECK_ARG(T >= 1 && B >= 1, "T=%d, B=%d must be >= 1", T, B);
     SEMICRF_CHECK_ARG(gout && offsets, "gout/offsets must be non-NULL");
-    launch_eval_path_bwd(gout, T, B, pairs, offsets, dScore, dNoise, (hipStream_t)stream);
+    SEMICRF_CHECK_ARG(K >= 0 && K < (1ll << 31) && (K == 0 || pairs), "bad interval count");
+    launch_eval_path_bwd(gout, T, B, (int)K, pairs, offsets, dScore, dNoise, (hipStream_t)stream);
     SEMICRF_CHECK_LAUNCH("semicrf_eval_path_bwd");
     return SEMICRF_OK;
 }

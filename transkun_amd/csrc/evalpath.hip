@@ -1,70 +1,91 @@
 // evalpath.hip -- unnormalised path score and its gradient (NeuralSemiCRFInterval.py:508-550).
 // The reference builds four Python index lists per call and issues three gathers and a
-// scatter_add; here the host packs the interval lists once into CSR form (pairs, offsets) and
-// a single kernel does prefix sums of the noise and the per-chain gather/accumulate.
+// scatter_add; here the host packs the interval lists once into CSR form (pairs, offsets).
+//
+//   out[c] = sum_{(b,e) in path_c} ( s[e,b,c] - (cum[e]-cum[b]) ) + cum[T-1],  cum = prefix sums of noise
+//          = sum_path s[e,b,c]  -  sum_path sum_{t=b}^{e-1} noise[t,c]  +  sum_t noise[t,c]
+// The second form needs no prefix array: intervals are short and never overlap, so the inner sums touch
+// at most T-1 values per chain.  Sums are accumulated in double (torch's CPU cumsum does the same).
 #include "common.h"
 
 namespace semicrf {
 
-// One thread per chain: lanes are consecutive chains, so noise[t][c] loads are coalesced.
-// cum [B][T] scratch: cum[c][t] = fp32( sum_{u<t} noise[u][c] accumulated in double ), which is
-// what torch's CPU cumsum produces (double accumulator, fp32 store).
+// One thread per chain: lanes are consecutive chains, so noise[t][c] loads are coalesced; there are no
+// stores inside the loops, so the loads pipeline freely.
 __global__ __launch_bounds__(64) void eval_path_kernel(const float* __restrict__ score,
                                                         const float* __restrict__ noise, int T, int B,
                                                         const int* __restrict__ pairs,
                                                         const int* __restrict__ offsets,
-                                                        float* __restrict__ cum, float* __restrict__ out)
+                                                        float* __restrict__ out)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= B) return;
-    float* cc = cum + (size_t)c * T;
-    double acc = 0.0;
-    cc[0] = 0.0f;
-    for (int t = 1; t < T; ++t) {
-        acc += (double)noise[(size_t)(t - 1) * B + c];
-        cc[t] = (float)acc;
-    }
-    float r = 0.0f;
+    double total = 0.0;
+#pragma unroll 8
+    for (int t = 0; t < T - 1; ++t) total += (double)noise[(size_t)t * B + c];
+    double r = 0.0;
     const int k0 = offsets[c], k1 = offsets[c + 1];
     for (int k = k0; k < k1; ++k) {
-        const int i = pairs[2 * k], j = pairs[2 * k + 1];
-        r += score[((size_t)j * T + i) * B + c] - (cc[j] - cc[i]);
+        const int b = pairs[2 * k], e = pairs[2 * k + 1];
+        double covered = 0.0;
+        for (int t = b; t < e; ++t) covered += (double)noise[(size_t)t * B + c];
+        r += (double)score[((size_t)e * T + b) * B + c] - covered;
     }
-    out[c] = r + cc[T - 1];
+    out[c] = (float)(r + total);
 }
 
-__global__ __launch_bounds__(64) void eval_path_bwd_kernel(const float* __restrict__ gout, int T, int B,
-                                                            const int* __restrict__ pairs,
-                                                            const int* __restrict__ offsets,
-                                                            float* dScore, float* dNoise)
+// dNoise[t][c] += gout[c]  (d cum[T-1] / d noise): fully parallel
+__global__ __launch_bounds__(256) void eval_path_bwd_noise_kernel(const float* __restrict__ gout, int T, int B,
+                                                                  float* __restrict__ dNoise)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= B) return;
+    const size_t n = (size_t)(T - 1) * B;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dNoise[i] += gout[i % B];
+}
+
+// One thread per interval: dScore[e][b][c] += g; dNoise[t][c] -= g for the covered gaps t in [b, e).
+// Atomics keep the (rare, caller-error) duplicate/overlapping intervals exact and let the stores pipeline.
+__global__ __launch_bounds__(256) void eval_path_bwd_pairs_kernel(const float* __restrict__ gout, int T, int B, int K,
+                                                                  const int* __restrict__ pairs,
+                                                                  const int* __restrict__ offsets,
+                                                                  float* dScore, float* dNoise)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    // chain of interval k: largest c with offsets[c] <= k
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offsets[mid] <= k) lo = mid; else hi = mid;
+    }
+    const int c = lo;
     const float g = gout[c];
-    const int k0 = offsets[c], k1 = offsets[c + 1];
-    if (dNoise) {
-        for (int t = 0; t < T - 1; ++t) dNoise[(size_t)t * B + c] += g;      // d cum[T-1]
-    }
-    for (int k = k0; k < k1; ++k) {
-        const int i = pairs[2 * k], j = pairs[2 * k + 1];
-        if (dScore) dScore[((size_t)j * T + i) * B + c] += g;
-        if (dNoise)
-            for (int t = i; t < j; ++t) dNoise[(size_t)t * B + c] -= g;      // -(cum[j]-cum[i])
-    }
+    const int b = pairs[2 * k], e = pairs[2 * k + 1];
+    if (dScore) atomicAdd(dScore + ((size_t)e * T + b) * B + c, g);
+    if (dNoise)
+        for (int t = b; t < e; ++t) atomicAdd(dNoise + (size_t)t * B + c, -g);
 }
 
 void launch_eval_path(const float* score, const float* noise, int T, int B, const int* pairs,
                       const int* offsets, float* cum, float* out, hipStream_t stream)
 {
+    (void)cum;
     hipLaunchKernelGGL(eval_path_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, score, noise, T, B, pairs,
-                       offsets, cum, out);
+                       offsets, out);
 }
 
-void launch_eval_path_bwd(const float* gout, int T, int B, const int* pairs, const int* offsets,
+void launch_eval_path_bwd(const float* gout, int T, int B, int K, const int* pairs, const int* offsets,
                           float* dScore, float* dNoise, hipStream_t stream)
 {
-    hipLaunchKernelGGL(eval_path_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, gout, T, B, pairs, offsets,
-                       dScore, dNoise);
+    if (dNoise && T > 1) {
+        const size_t n = (size_t)(T - 1) * B;
+        int g = (int)((n + 255) / 256);
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(eval_path_bwd_noise_kernel, dim3(g), dim3(256), 0, stream, gout, T, B, dNoise);
+    }
+    if (K > 0)
+        hipLaunchKernelGGL(eval_path_bwd_pairs_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, gout, T, B, K,
+                           pairs, offsets, dScore, dNoise);
 }
 
 }  // namespace semicrf

@@ -70,6 +70,12 @@ struct SweepParams {
     float* u_out;          // [T][B] by FRAME (natural-log units for LSE) or nullptr
     float* last_out;       // [B] value at the last position (logZ for DIR 0) or nullptr
     int* code;             // MAX: [B][T] backtrack codes by frame
+    // GRAD (LSE, DIR 1 only): marginals are a by-product of the beta sweep (NeuralSemiCRFInterval.py:424-447, :469-472)
+    const float* vfwd;     // [T][B] alpha values by frame (natural log)
+    const float* logZ;     // [B]
+    const float* gout;     // [B] upstream gradient
+    float* dScore;         // [T][T][B]: lower triangle + diagonal written here (the upper triangle by zero_upper_kernel)
+    float* dNoise;         // [T-1][B]
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -179,7 +185,7 @@ constexpr int FAR_PREFETCH = 4;     // parts whose far granules are requested ah
 
 struct SpineBlk { float2 v[PB]; };
 
-template <int MODE, int DIR>
+template <int MODE, int DIR, bool GRAD>
 __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, float* ring, float* dummy)
 {
     // kernel arguments are copied into locals: lambdas that capture the struct by reference make the
@@ -193,6 +199,11 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, float* 
     float* const u_out = P.u_out;
     float* const last_out = P.last_out;
     int* const code = P.code;
+    const float* const vfwd = P.vfwd;
+    const float* const logZp = P.logZ;
+    const float* const goutp = P.gout;
+    float* const dScore = P.dScore;
+    float* const dNoise = P.dNoise;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const int r = lane >> 2, pr = lane & 3;
@@ -255,6 +266,18 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, float* 
                 }
             }
         }
+        // GRAD: marginal(prow, j) = gz * exp2(t + arow) with t = u[j] + cell*log2e, arow = (alpha[frame] - logZ)*log2e
+        float arow[2] = {0.f, 0.f}, gz[2] = {0.f, 0.f}, draw[2] = {0.f, 0.f};
+        float* const growp = GRAD ? dScore + (rowp - score) : nullptr;
+        if (GRAD && rvalid) {
+            const float2 vv = *(const float2*)(vfwd + (size_t)frow * Bs + c);
+            const float2 lz = *(const float2*)(logZp + c);
+            const float2 go = *(const float2*)(goutp + c);
+            arow[0] = (vv.x - lz.x) * LOG2E; arow[1] = (vv.y - lz.y) * LOG2E;
+            gz[0] = go.x; gz[1] = go.y;
+            const float2 d = *(const float2*)(score + ((size_t)frow * T + frow) * Bs + c);
+            draw[0] = d.x * LOG2E; draw[1] = d.y * LOG2E;
+        }
         if (trace) ev[1] = __builtin_readcyclecounter();
 
         float aM[2] = {SEMICRF_NEG_INF, SEMICRF_NEG_INF}, aS[2] = {0.f, 0.f};
@@ -299,7 +322,16 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, float* 
                 const float2 uv = ring_get(j);
                 if (MODE == 0) {
                     float p0 = fmaf(X.v[u].x, LOG2E, uv.x), p1 = fmaf(X.v[u].y, LOG2E, uv.y);
-                    if (last && u == PB - 1 && r == 0) { p0 = uv.x + wl[0]; p1 = uv.y + wl[1]; }
+                    if (GRAD && rvalid && j < prow)
+                        *(float2*)(growp + (long long)j * stride) =
+                            make_float2(gz[0] * fexp2(p0 + arow[0]), gz[1] * fexp2(p1 + arow[1]));
+                    if (last && u == PB - 1 && r == 0) {
+                        if (GRAD && rvalid)       // noise marginal of the gap between prow-1 and prow
+                            *(float2*)(dNoise + (size_t)gap_of<DIR>(prow, T) * Bs + c) =
+                                make_float2(gz[0] * fexp2(uv.x + nz[0] * LOG2E + arow[0]),
+                                            gz[1] * fexp2(uv.y + nz[1] * LOG2E + arow[1]));
+                        p0 = uv.x + wl[0]; p1 = uv.y + wl[1];
+                    }
                     lse_push2(p0, p1);
                 } else {
                     const int key = frame_of<DIR>(j, T);
@@ -382,6 +414,15 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, float* 
                 // basic block so that the scheduler can overlap it with the critical chain), then refresh Vp
                 {
                     const float p0 = fmaf(A.v[jj].x, LOG2E, u0), p1 = fmaf(A.v[jj].y, LOG2E, u1);
+                    if (GRAD) {
+                        if (rvalid && r > jj)
+                            *(float2*)(growp + (long long)j * stride) =
+                                make_float2(gz[0] * fexp2(p0 + arow[0]), gz[1] * fexp2(p1 + arow[1]));
+                        if (rvalid && r == jj + 1)
+                            *(float2*)(dNoise + (size_t)gap_of<DIR>(prow, T) * Bs + c) =
+                                make_float2(gz[0] * fexp2(u0 + nz[0] * LOG2E + arow[0]),
+                                            gz[1] * fexp2(u1 + nz[1] * LOG2E + arow[1]));
+                    }
                     const float n0 = fmaxf(aM[0], p0), n1 = fmaxf(aM[1], p1);
                     aS[0] = fmaf(aS[0], fexp2(aM[0] - n0), fexp2(p0 - n0));      // M = -inf: exp2(-inf) = 0, S = 0
                     aS[1] = fmaf(aS[1], fexp2(aM[1] - n1), fexp2(p1 - n1));
@@ -427,6 +468,10 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, float* 
             const float sc = MODE == 0 ? LN2 : 1.0f;
             if (u_out) *(float2*)(u_out + (size_t)frow * Bs + c) = make_float2(mine.x * sc, mine.y * sc);
             if (last_out && prow == T - 1) *(float2*)(last_out + c) = make_float2(mine.x * sc, mine.y * sc);
+            if (GRAD)      // diagonal: gout * exp(alpha + beta - logZ + s - 2 softplus(s))
+                *(float2*)(dScore + ((size_t)frow * T + frow) * Bs + c) =
+                    make_float2(gz[0] * fexp2(arow[0] + mine.x + draw[0] - 2.0f * sp[0]),
+                                gz[1] * fexp2(arow[1] + mine.y + draw[1] - 2.0f * sp[1]));
             if (MODE == 1) {
                 code[(size_t)c * T + frow] = (mykey[0] + 1) | (sp[0] > 0.0f ? 0x40000000 : 0);
                 code[(size_t)(c + 1) * T + frow] = (mykey[1] + 1) | (sp[1] > 0.0f ? 0x40000000 : 0);
@@ -443,7 +488,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, float* 
 //   DIR 0: wave w owns positions 16k+4w+r (r<4); per tile a lane holds columns pj = 16m+slot+8h.
 //   DIR 1: wave w owns tile rows pj = 16m+4w+r; a lane holds positions pi = 16k+slot+8h.
 // Cells and u-granules of tile m+1 are requested before tile m is processed.
-template <int MODE, int DIR>
+template <int MODE, int DIR, bool GRAD>
 __device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int* s_task)
 {
     const int T = P.T, B = P.B;
@@ -452,6 +497,10 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int
     u64* const farg = P.farg;
     const int nTasks = P.nTasks, nPanelGroups = P.nPanelGroups;
     const int maxAside = P.nSpine;
+    const float* const vfwd = P.vfwd;
+    const float* const logZp = P.logZ;
+    const float* const goutp = P.gout;
+    float* const dScore = P.dScore;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -461,6 +510,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int
     const unsigned tag = P.tag;
     constexpr int NA = DIR == 0 ? 4 : 2;        // accumulators per chain: rows (DIR 0) or column halves (DIR 1)
     constexpr int NU = DIR == 0 ? 2 : 4;        // u positions a lane needs per tile
+    constexpr int NL = DIR == 0 ? 2 : 1;        // u positions a lane LOADS per tile (DIR 1: position slot&3, shared by shuffles)
     const auto ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.ug, 0, (int)((size_t)T * Bs * 8), 0x00020000);
 
     while (true) {
@@ -497,8 +547,23 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int
 #pragma unroll
             for (int i = 0; i < 4; ++i) { aM[ai][i] = SEMICRF_NEG_INF; aS[ai][i] = 0.f; aK[ai][i] = 0x7fffffff; }
 
+        // GRAD (DIR 1): marginal(pi, pj) = gz * exp2(t + arow[h]), arow = (alpha[frame(pi)] - logZ) * log2e
+        float arow[2][4], gz[4];
+        if (GRAD) {
+            const float4 lz = cvalid ? *(const float4*)(logZp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 go = cvalid ? *(const float4*)(goutp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            gz[0] = go.x; gz[1] = go.y; gz[2] = go.z; gz[3] = go.w;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pi = k * PB + slot + 8 * h;
+                const float4 vv = (cvalid && pi < T) ? *(const float4*)(vfwd + (size_t)frame_of<DIR>(pi, T) * Bs + c)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                arow[h][0] = (vv.x - lz.x) * LOG2E; arow[h][1] = (vv.y - lz.y) * LOG2E;
+                arow[h][2] = (vv.z - lz.z) * LOG2E; arow[h][3] = (vv.w - lz.w) * LOG2E;
+            }
+        }
         float4 x[2][4][2];    // [buffer][r][h] cells
-        v4u gq[2][NU][2];     // [buffer][u position][chain pair] granules (2 granules per 16-byte load)
+        v4u gq[2][NL][2];     // [buffer][loaded u position][chain pair] granules (2 granules per 16-byte load)
         auto pi_of = [&](int rr, int h) { return DIR == 0 ? k * PB + wave * 4 + rr : k * PB + slot + 8 * h; };
         auto pj_of = [&](int m, int rr, int h) { return DIR == 0 ? m * PB + slot + 8 * h : m * PB + wave * 4 + rr; };
         auto pu_of = [&](int m, int ai) { return DIR == 0 ? m * PB + slot + 8 * ai : m * PB + wave * 4 + ai; };
@@ -518,8 +583,9 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int
             constexpr int buf = decltype(bufc)::value;
             if (dbg & 32u) return;
 #pragma unroll
-            for (int ai = 0; ai < NU; ++ai) {
-                const int off = (int)(((size_t)pu_of(m, ai) * Bs + (cvalid ? c : 0)) * 8);
+            for (int ai = 0; ai < NL; ++ai) {
+                const int pu = DIR == 0 ? pu_of(m, ai) : m * PB + wave * 4 + (slot & 3);
+                const int off = (int)(((size_t)pu * Bs + (cvalid ? c : 0)) * 8);
                 gq[buf][ai][0] = __builtin_amdgcn_raw_buffer_load_b128(ursrc, off, 0, 16);        // sc1
                 gq[buf][ai][1] = __builtin_amdgcn_raw_buffer_load_b128(ursrc, off + 16, 0, 16);
             }
@@ -541,7 +607,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int
                 while (true) {
                     bool ok = true;
 #pragma unroll
-                    for (int ai = 0; ai < NU; ++ai)
+                    for (int ai = 0; ai < NL; ++ai)
 #pragma unroll
                         for (int hh = 0; hh < 2; ++hh)
                             ok = ok && gq[buf][ai][hh].y == tag && gq[buf][ai][hh].w == tag;
@@ -552,10 +618,20 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int
                 }
             }
             float uv[NU][4];
+            if (DIR == 0) {
 #pragma unroll
-            for (int ai = 0; ai < NU; ++ai) {
-                uv[ai][0] = __uint_as_float(gq[buf][ai][0].x); uv[ai][1] = __uint_as_float(gq[buf][ai][0].z);
-                uv[ai][2] = __uint_as_float(gq[buf][ai][1].x); uv[ai][3] = __uint_as_float(gq[buf][ai][1].z);
+                for (int ai = 0; ai < NL; ++ai) {
+                    uv[ai][0] = __uint_as_float(gq[buf][ai][0].x); uv[ai][1] = __uint_as_float(gq[buf][ai][0].z);
+                    uv[ai][2] = __uint_as_float(gq[buf][ai][1].x); uv[ai][3] = __uint_as_float(gq[buf][ai][1].z);
+                }
+            } else {
+                // position a lives in the lanes with slot == a (and a+4): fetch it from lane (a << 3) | q8
+                const float own[4] = {__uint_as_float(gq[buf][0][0].x), __uint_as_float(gq[buf][0][0].z),
+                                      __uint_as_float(gq[buf][0][1].x), __uint_as_float(gq[buf][0][1].z)};
+#pragma unroll
+                for (int ai = 0; ai < NU; ++ai)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) uv[ai][i] = __shfl(own[i], (ai << 3) | q8);
             }
 
             if (MODE == 0) {
@@ -575,6 +651,18 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int
                             exc = fmaxf(exc, t[rr][h][i] - (aM[ai][i] + RESCALE_THR));
                         }
                     }
+                if (GRAD) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int pi = pi_of(rr, h), pj = pj_of(m, rr, h);
+                            if (cvalid && pi < T)
+                                *(float4*)(dScore + cell_index<DIR>(pi, pj, T) * Bs + c) =
+                                    make_float4(gz[0] * fexp2(t[rr][h][0] + arow[h][0]), gz[1] * fexp2(t[rr][h][1] + arow[h][1]),
+                                                gz[2] * fexp2(t[rr][h][2] + arow[h][2]), gz[3] * fexp2(t[rr][h][3] + arow[h][3]));
+                        }
+                }
                 if (__any(exc > 0.0f)) {
                     // some accumulator's reference point is too low (always on the first tile): move it up
 #pragma unroll
@@ -704,7 +792,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int
 // ---------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------
-template <int MODE, int DIR>
+template <int MODE, int DIR, bool GRAD>
 __global__ __launch_bounds__(256, 2) void persist_sweep_kernel(SweepParams P)
 {
     __shared__ __attribute__((aligned(16))) float s_ring[128 * 16];            // spine: ring of the last 128 published positions
@@ -717,9 +805,9 @@ __global__ __launch_bounds__(256, 2) void persist_sweep_kernel(SweepParams P)
     __syncthreads();
     const int ticket = s_ticket;
     if (ticket < P.nSpine) {
-        if (!(P.dbg & 8u)) spine_role<MODE, DIR>(P, ticket, s_ring, s_dummy);
+        if (!(P.dbg & 8u)) spine_role<MODE, DIR, GRAD>(P, ticket, s_ring, s_dummy);
     } else {
-        if (!(P.dbg & 2u)) panel_role<MODE, DIR>(P, s_red, &s_task);
+        if (!(P.dbg & 2u)) panel_role<MODE, DIR, GRAD>(P, s_red, &s_task);
     }
 }
 
@@ -729,6 +817,18 @@ static int max_parts(int T)
 {
     const int K = (T + PB - 1) / PB;
     return K > RING ? (K - 1 - RING) / TPT + 1 : 1;
+}
+
+// writes the exact zeros of the upper triangle (begin > end) of the dense gradient: row e, columns e+1..T-1
+__global__ __launch_bounds__(256) void zero_upper_kernel(float* __restrict__ dScore, int T, int B)
+{
+    const int e = blockIdx.y;
+    const size_t n = (size_t)(T - 1 - e) * B;                 // floats to clear in this row
+    float* rowp = dScore + ((size_t)e * T + e + 1) * B;
+    const size_t n4 = ((uintptr_t)rowp & 15) == 0 ? n / 4 : 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+        ((float4*)rowp)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) rowp[i] = 0.f;
 }
 
 size_t persist_workspace_bytes(int T, int B)
@@ -747,10 +847,17 @@ static unsigned next_tag()
 }
 
 // mode 0 = LSE, 1 = MAX.  ws must hold persist_workspace_bytes().  Enqueues a memset + one kernel.
-int launch_persist_sweep(int mode, int dir, const float* score, const float* noise, int T, int B, float* u_out,
-                         float* last_out, int* code, void* ws, hipStream_t stream)
+struct GradArgs {
+    const float* vfwd; const float* logZ; const float* gout; float* dScore; float* dNoise;
+};
+
+static int launch_persist_sweep_impl(int mode, int dir, const float* score, const float* noise, int T, int B,
+                                     float* u_out, float* last_out, int* code, void* ws, hipStream_t stream,
+                                     const GradArgs* grad)
 {
     SweepParams P;
+    P.vfwd = nullptr; P.logZ = nullptr; P.gout = nullptr; P.dScore = nullptr; P.dNoise = nullptr;
+    if (grad) { P.vfwd = grad->vfwd; P.logZ = grad->logZ; P.gout = grad->gout; P.dScore = grad->dScore; P.dNoise = grad->dNoise; }
     P.score = score; P.noise = noise; P.T = T; P.B = B; P.K = (T + PB - 1) / PB;
     P.nSpine = (B + GS - 1) / GS;
     P.nPanelGroups = (B + GP - 1) / GP;
@@ -781,11 +888,33 @@ int launch_persist_sweep(int mode, int dir, const float* score, const float* noi
     if (nPanelWG > P.nTasks) nPanelWG = P.nTasks;
     const int grid = P.nSpine + nPanelWG;
     dim3 g(grid), b(256);
-    if (mode == 0 && dir == 0) hipLaunchKernelGGL((persist_sweep_kernel<0, 0>), g, b, 0, stream, P);
-    else if (mode == 0 && dir == 1) hipLaunchKernelGGL((persist_sweep_kernel<0, 1>), g, b, 0, stream, P);
-    else if (mode == 1 && dir == 0) hipLaunchKernelGGL((persist_sweep_kernel<1, 0>), g, b, 0, stream, P);
-    else hipLaunchKernelGGL((persist_sweep_kernel<1, 1>), g, b, 0, stream, P);
+    if (grad) {
+        if (T > 1) {
+            int gx = (int)(((size_t)T * B / 4 + 255) / 256);
+            if (gx > 8) gx = 8;
+            hipLaunchKernelGGL(zero_upper_kernel, dim3(gx, T - 1), dim3(256), 0, stream, grad->dScore, T, B);
+        }
+        hipLaunchKernelGGL((persist_sweep_kernel<0, 1, true>), g, b, 0, stream, P);
+    } else if (mode == 0 && dir == 0) hipLaunchKernelGGL((persist_sweep_kernel<0, 0, false>), g, b, 0, stream, P);
+    else if (mode == 0 && dir == 1) hipLaunchKernelGGL((persist_sweep_kernel<0, 1, false>), g, b, 0, stream, P);
+    else if (mode == 1 && dir == 0) hipLaunchKernelGGL((persist_sweep_kernel<1, 0, false>), g, b, 0, stream, P);
+    else hipLaunchKernelGGL((persist_sweep_kernel<1, 1, false>), g, b, 0, stream, P);
     return 0;
+}
+
+int launch_persist_sweep(int mode, int dir, const float* score, const float* noise, int T, int B, float* u_out,
+                         float* last_out, int* code, void* ws, hipStream_t stream)
+{
+    return launch_persist_sweep_impl(mode, dir, score, noise, T, B, u_out, last_out, code, ws, stream, nullptr);
+}
+
+// Fused backward: beta sweep + marginals (dScore fully written incl. the zero upper triangle, dNoise).
+int launch_persist_logz_bwd(const float* score, const float* noise, const float* v, const float* logZ,
+                            const float* gout, int T, int B, float* dScore, float* dNoise, float* q_out, void* ws,
+                            hipStream_t stream)
+{
+    GradArgs ga{v, logZ, gout, dScore, dNoise};
+    return launch_persist_sweep_impl(0, 1, score, noise, T, B, q_out, nullptr, nullptr, ws, stream, &ga);
 }
 
 int read_and_clear_device_status()
