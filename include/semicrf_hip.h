@@ -107,9 +107,10 @@ int semicrf_viterbi(const float* score, const float* noise, int T, int B, const 
  * Unnormalised path score.  Replaces: evalPath (:508-550).
  *   pairs int32 [K][2] (begin,end), offsets int32 [B+1] (chain c owns pairs[offsets[c]:offsets[c+1]]).
  *   out[c] = sum_path ( s[end,begin,c] - (cum[end]-cum[begin]) ) + cum[T-1],  cum = prefix sums of noise.
+ *   K = number of intervals in pairs (= offsets[B]).
  */
 int semicrf_eval_path(const float* score, const float* noise, int T, int B,
-                      const int32_t* pairs, const int32_t* offsets, float* out,
+                      const int32_t* pairs, int64_t K, const int32_t* offsets, float* out,
                       void* ws, size_t ws_bytes, semicrf_stream_t stream);
 
 /*

@@ -117,7 +117,8 @@ def _eval_path_raw(score, noise, pairs, offsets):
     lib = _lib.load()
     out = torch.empty(B, dtype=torch.float32, device=score.device)
     ws = _lib.workspace(_lib.OP_EVAL_PATH, T, B, score.device)
-    rc = lib.semicrf_eval_path(_lib.ptr(score), _lib.ptr(noise), T, B, _lib.ptr(pairs), _lib.ptr(offsets),
+    K = getattr(pairs, "_semicrf_K", pairs.shape[0])
+    rc = lib.semicrf_eval_path(_lib.ptr(score), _lib.ptr(noise), T, B, _lib.ptr(pairs), int(K), _lib.ptr(offsets),
                                _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_of(score))
     _lib.check(rc, "semicrf_eval_path")
     return out

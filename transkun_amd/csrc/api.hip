@@ -26,8 +26,8 @@ void launch_marginals(const float* score, const float* noise, const float* v, co
                       hipStream_t stream);
 void launch_backtrack(const int* code, int T, int B, const int* start, int forward, int* region, int* counts,
                       int* pairs, long long cap, int* offsets, hipStream_t stream);
-void launch_eval_path(const float* score, const float* noise, int T, int B, const int* pairs,
-                      const int* offsets, float* cum, float* out, hipStream_t stream);
+void launch_eval_path(const float* score, const float* noise, int T, int B, int K, const int* pairs,
+                      const int* offsets, float* out, hipStream_t stream);
 void launch_eval_path_bwd(const float* gout, int T, int B, int K, const int* pairs, const int* offsets,
                           float* dScore, float* dNoise, hipStream_t stream);
 void launch_interval_score_naive(const float* q, const float* k, const float* diag, int C, int T, int D,
@@ -88,7 +88,7 @@ size_t semicrf_workspace_bytes(int op, int T, int B)
             // u [T][B] f32, code [B][T] i32, region [B][2T][2] i32, counts [B] i32, persistent-sweep scratch
             return tb(T, B) * 2 + align_up((size_t)B * 2 * T * 2 * 4) + align_up((size_t)B * 4) +
                    persist_workspace_bytes(T, B) + 4096;
-        case SEMICRF_OP_EVAL_PATH: return tb(T, B) + 4096;
+        case SEMICRF_OP_EVAL_PATH: return 4096;
         case SEMICRF_OP_INTERVAL_SCORE: return 4096;
         default: return 0;
     }
@@ -180,15 +180,14 @@ int semicrf_viterbi(const float* score, const float* noise, int T, int B, const 
     return SEMICRF_OK;
 }
 
-int semicrf_eval_path(const float* score, const float* noise, int T, int B, const int32_t* pairs,
+int semicrf_eval_path(const float* score, const float* noise, int T, int B, const int32_t* pairs, int64_t K,
                       const int32_t* offsets, float* out, void* ws, size_t ws_bytes, semicrf_stream_t stream)
 {
     if (int rc = check_common(score, noise, T, B)) return rc;
     SEMICRF_CHECK_ARG(offsets && out, "offsets/out must be non-NULL");
-    Carver cv(ws, ws_bytes);
-    float* cum = cv.take<float>((size_t)T * B);
-    if (!cv.ok || !ws) { set_error("workspace too small for eval_path"); return SEMICRF_EWORKSPACE; }
-    launch_eval_path(score, noise, T, B, pairs, offsets, cum, out, (hipStream_t)stream);
+    SEMICRF_CHECK_ARG(K >= 0 && K < (1ll << 31) && (K == 0 || pairs), "bad interval count");
+    (void)ws; (void)ws_bytes;
+    launch_eval_path(score, noise, T, B, (int)K, pairs, offsets, out, (hipStream_t)stream);
     SEMICRF_CHECK_LAUNCH("semicrf_eval_path");
     return SEMICRF_OK;
 }

@@ -10,28 +10,38 @@
 
 namespace semicrf {
 
-// One thread per chain: lanes are consecutive chains, so noise[t][c] loads are coalesced; there are no
-// stores inside the loops, so the loads pipeline freely.
+// blockIdx.y < NCHUNK: partial column sums of noise (chain = lane, a chunk of time steps per block row), folded
+// into out[c] with one float atomic per (chunk, chain); blockIdx.y == NCHUNK: one thread per interval adds
+// s[e,b,c] - sum_{t in [b,e)} noise[t,c].  out must be zeroed before the launch.
+constexpr int EP_NCHUNK = 64;
+
 __global__ __launch_bounds__(64) void eval_path_kernel(const float* __restrict__ score,
-                                                        const float* __restrict__ noise, int T, int B,
+                                                        const float* __restrict__ noise, int T, int B, int K,
                                                         const int* __restrict__ pairs,
-                                                        const int* __restrict__ offsets,
-                                                        float* __restrict__ out)
+                                                        const int* __restrict__ offsets, float* out)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= B) return;
-    double total = 0.0;
-#pragma unroll 8
-    for (int t = 0; t < T - 1; ++t) total += (double)noise[(size_t)t * B + c];
-    double r = 0.0;
-    const int k0 = offsets[c], k1 = offsets[c + 1];
-    for (int k = k0; k < k1; ++k) {
+    if (blockIdx.y < EP_NCHUNK) {
+        const int c = blockIdx.x * 64 + threadIdx.x;
+        if (c >= B) return;
+        const int per = (T - 1 + EP_NCHUNK - 1) / EP_NCHUNK;
+        const int t0 = blockIdx.y * per, t1 = (t0 + per < T - 1) ? t0 + per : T - 1;
+        double acc = 0.0;
+        for (int t = t0; t < t1; ++t) acc += (double)noise[(size_t)t * B + c];
+        if (t1 > t0) atomicAdd(out + c, (float)acc);
+    } else {
+        const int k = blockIdx.x * 64 + threadIdx.x;
+        if (k >= K) return;
+        int lo = 0, hi = B;                       // chain of interval k: largest c with offsets[c] <= k
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (offsets[mid] <= k) lo = mid; else hi = mid;
+        }
+        const int c = lo;
         const int b = pairs[2 * k], e = pairs[2 * k + 1];
         double covered = 0.0;
         for (int t = b; t < e; ++t) covered += (double)noise[(size_t)t * B + c];
-        r += (double)score[((size_t)e * T + b) * B + c] - covered;
+        atomicAdd(out + c, (float)((double)score[((size_t)e * T + b) * B + c] - covered));
     }
-    out[c] = (float)(r + total);
 }
 
 // dNoise[t][c] += gout[c]  (d cum[T-1] / d noise): fully parallel
@@ -66,11 +76,12 @@ __global__ __launch_bounds__(256) void eval_path_bwd_pairs_kernel(const float* _
         for (int t = b; t < e; ++t) atomicAdd(dNoise + (size_t)t * B + c, -g);
 }
 
-void launch_eval_path(const float* score, const float* noise, int T, int B, const int* pairs,
-                      const int* offsets, float* cum, float* out, hipStream_t stream)
+void launch_eval_path(const float* score, const float* noise, int T, int B, int K, const int* pairs,
+                      const int* offsets, float* out, hipStream_t stream)
 {
-    (void)cum;
-    hipLaunchKernelGGL(eval_path_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, score, noise, T, B, pairs,
+    (void)hipMemsetAsync(out, 0, (size_t)B * sizeof(float), stream);
+    const int gx = ((B > K ? B : K) + 63) / 64;
+    hipLaunchKernelGGL(eval_path_kernel, dim3(gx, EP_NCHUNK + 1), dim3(64), 0, stream, score, noise, T, B, K, pairs,
                        offsets, out);
 }
 
