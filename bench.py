@@ -80,6 +80,7 @@ def main():
 
     import importlib
     from transkun_amd import CRF, _lib, synth
+    from transkun_amd.dist import fused_loss_allreduce, max_over_ranks
     nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")   # the module, not the class
     _lib.set_impl(args.impl)
 
@@ -96,8 +97,7 @@ def main():
         lp = nsci._LogProb.apply(score, noise, pairs, offsets)          # == crf.logProb(intervals), pre-packed
         loss = -lp.sum() / nseg                                          # train.py:187
         if dist is not None:
-            stats = torch.stack([loss.detach(), lp.detach().new_tensor(float(T)), lp.detach().new_tensor(float(nseg))])
-            dist.all_reduce(stats)                                       # train.py:215-217, fused to one [3]
+            fused_loss_allreduce(loss, float(T), float(nseg))            # train.py:215-217, fused to one [3] over RCCL
         loss.backward()
 
     def sync_all():
@@ -116,10 +116,7 @@ def main():
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = max_over_ranks(elapsed, dev)
     value = world * args.steps / elapsed
     log(f"timed region done: {elapsed / args.steps * 1e3:.3f} ms/step")
 
