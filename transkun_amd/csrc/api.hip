@@ -34,6 +34,10 @@ void launch_interval_score_naive(const float* q, const float* k, const float* di
                                  long long ldq, long long ldk, long long ldd, float qscale, int mode, int full,
                                  float* S, hipStream_t stream);
 
+bool interval_score_mfma_supported(int C, int T, int D);
+void launch_interval_score_mfma(const float* q, const float* k, const float* diag, int C, int T, int D,
+                                long long ldq, long long ldk, long long ldd, float qscale, int mode, int full,
+                                float* S, hipStream_t stream);
 size_t persist_workspace_bytes(int T, int B);
 bool persist_supported(int T, int B);
 int launch_persist_sweep(int mode, int dir, const float* score, const float* noise, int T, int B, float* u_out,
@@ -212,7 +216,10 @@ int interval_score_fwd(const float* q, const float* k, const float* diag, int C,
     SEMICRF_CHECK_ARG(ldq >= D && ldk >= D && ldd >= 1, "bad leading dimensions");
     SEMICRF_CHECK_ARG(length_scaling >= 0 && length_scaling <= 2, "bad length_scaling %d", length_scaling);
     hipStream_t st = (hipStream_t)stream;
-    launch_interval_score_naive(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, length_scaling, full_square, S, st);
+    if (g_impl.load() == 0 && interval_score_mfma_supported(C, T, D))
+        launch_interval_score_mfma(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, length_scaling, full_square, S, st);
+    else
+        launch_interval_score_naive(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, length_scaling, full_square, S, st);
     if (noise_out && T > 1) {
         if (hipMemsetAsync(noise_out, 0, (size_t)(T - 1) * C * sizeof(float), st) != hipSuccess) {
             set_error("hipMemsetAsync failed");

@@ -38,23 +38,21 @@ class _IntervalScore(torch.autograd.Function):
     (SURVEY 8(f) rank 1 replaces it with the fused loss-gradient kernel)."""
 
     @staticmethod
-    def forward(ctx, y, N, P, T, D, mode, full_square):
-        # y: [N,P,T,2D+1] packed Linear output; q/k/diag are strided views (no split copy)
+    def forward(ctx, q, k, diag, N, P, T, D, mode, full_square):
+        # q, k: [N,P,T,D] contiguous (separate GEMM outputs: 16-byte aligned rows for the MFMA kernel), diag [N,P,T]
         C = N * P
-        y3 = y.reshape(C, T, 2 * D + 1)
-        q, k, diag = y3[..., :D], y3[..., D:2 * D], y3[..., 2 * D]
+        q3, k3, d2 = q.reshape(C, T, D), k.reshape(C, T, D), diag.reshape(C, T)
         qscale = 1.0 / math.sqrt(D)
-        S, noise = _interval_score_raw(q, k, diag, T, C, D, qscale, mode, full_square)
-        ctx.save_for_backward(y3)
+        S, noise = _interval_score_raw(q3, k3, d2, T, C, D, qscale, mode, full_square)
+        ctx.save_for_backward(q3, k3)
         ctx.meta = (N, P, T, D, mode)
         return S.view(T, T, N, P), noise.view(max(T - 1, 0), N, P)
 
     @staticmethod
     def backward(ctx, dS, dnoise):
-        (y3,) = ctx.saved_tensors
+        q, k = ctx.saved_tensors
         N, P, T, D, mode = ctx.meta
         C = N * P
-        q, k = y3[..., :D], y3[..., D:2 * D]
         g = dS.reshape(T, T, C).permute(2, 0, 1)                     # [C, e, b]
         t = torch.arange(T, device=g.device)
         ln = (t[:, None] - t[None, :]).abs().to(torch.float32)
@@ -67,8 +65,8 @@ class _IntervalScore(torch.autograd.Function):
         dq = torch.bmm(gl, k) * qs                                    # [C,T,D]
         dk = torch.bmm(gl.transpose(1, 2), q) * qs
         ddiag = torch.diagonal(g, dim1=1, dim2=2)                     # [C,T]
-        dy = torch.cat([dq, dk, ddiag.unsqueeze(-1)], dim=-1)
-        return dy.view(N, P, T, 2 * D + 1), None, None, None, None, None, None
+        return (dq.view(N, P, T, D), dk.view(N, P, T, D), ddiag.reshape(N, P, T).contiguous(),
+                None, None, None, None, None, None)
 
 
 class ScaledInnerProductIntervalScorer(nn.Module):
@@ -94,9 +92,13 @@ class ScaledInnerProductIntervalScorer(nn.Module):
         N, P, T, _ = ctx.shape
         D = self.size * self.expansionFactor
         _lib.require_gpu(ctx, "ctx")
-        y = self.map(ctx)
-        if self.withScoreEps:
-            y = y[..., :2 * D + 1]
-        y = y.float().contiguous()
-        S, b = _IntervalScore.apply(y, N, P, T, D, _lib.LEN_MODES[self.lengthScaling], self.fullSquare)
+        # the Linear map as three GEMMs over slices of the same parameter (state_dict stays map.0.weight/bias):
+        # q and k come out contiguous with 16-byte aligned rows, no split copy of a packed [.., 2D+1] tensor
+        lin = self.map[0]
+        W, bias = lin.weight, lin.bias
+        x = ctx.float()
+        q = F.linear(x, W[:D], bias[:D])
+        k = F.linear(x, W[D:2 * D], bias[D:2 * D])
+        diag = F.linear(x, W[2 * D:2 * D + 1], bias[2 * D:2 * D + 1]).squeeze(-1)
+        S, b = _IntervalScore.apply(q, k, diag, N, P, T, D, _lib.LEN_MODES[self.lengthScaling], self.fullSquare)
         return S, b
