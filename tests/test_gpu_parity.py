@@ -282,13 +282,14 @@ def test_scorer(gpu, impl, oracle, name):
 # ---- the persistent blocked kernels against the oracle over a grid of shapes -------------------
 
 PERSIST_SHAPES = [(1, 4), (2, 4), (15, 8), (16, 4), (17, 12), (33, 16), (48, 20), (63, 36), (64, 32), (65, 4),
-                  (100, 64), (129, 40), (200, 100), (256, 16), (300, 8)]
+                  (100, 64), (129, 40), (200, 100), (256, 16), (300, 8),
+                  (70, 2), (97, 6), (130, 90), (200, 34), (256, 90)]       # B % 4 == 2: 16-byte panel loads at 8-byte alignment
 
 
 @pytest.mark.parametrize("T,B", PERSIST_SHAPES, ids=[f"T{t}_B{b}" for t, b in PERSIST_SHAPES])
 @pytest.mark.parametrize("kind", ["randn", "model", "ties"])
 def test_persist_vs_oracle(gpu, oracle, T, B, kind):
-    """impl 0 (persistent kernels; B % 4 == 0) vs the C oracle: logZ, alpha/beta-derived marginals,
+    """impl 0 (persistent kernels; B even) vs the C oracle: logZ, alpha/beta-derived marginals,
     decode in both directions with a mixed forcedStartPos.  Also checks that no hand-off wait timed out."""
     from transkun_amd import CRF, _lib, synth
     _lib.set_impl(0)

@@ -550,16 +550,21 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int
         // GRAD (DIR 1): marginal(pi, pj) = gz * exp2(t + arow[h]), arow = (alpha[frame(pi)] - logZ) * log2e
         float arow[2][4], gz[4];
         if (GRAD) {
-            const float4 lz = cvalid ? *(const float4*)(logZp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 go = cvalid ? *(const float4*)(goutp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            gz[0] = go.x; gz[1] = go.y; gz[2] = go.z; gz[3] = go.w;
+            float lz[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = c + i < B;
+                lz[i] = ok ? logZp[c + i] : 0.f;
+                gz[i] = ok ? goutp[c + i] : 0.f;
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int pi = k * PB + slot + 8 * h;
-                const float4 vv = (cvalid && pi < T) ? *(const float4*)(vfwd + (size_t)frame_of<DIR>(pi, T) * Bs + c)
-                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-                arow[h][0] = (vv.x - lz.x) * LOG2E; arow[h][1] = (vv.y - lz.y) * LOG2E;
-                arow[h][2] = (vv.z - lz.z) * LOG2E; arow[h][3] = (vv.w - lz.w) * LOG2E;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float vv = (c + i < B && pi < T) ? vfwd[(size_t)frame_of<DIR>(pi, T) * Bs + c + i] : 0.f;
+                    arow[h][i] = (vv - lz[i]) * LOG2E;
+                }
             }
         }
         float4 x[2][4][2];    // [buffer][r][h] cells
@@ -610,7 +615,8 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int
                     for (int ai = 0; ai < NL; ++ai)
 #pragma unroll
                         for (int hh = 0; hh < 2; ++hh)
-                            ok = ok && gq[buf][ai][hh].y == tag && gq[buf][ai][hh].w == tag;
+                            ok = ok && (gq[buf][ai][hh].y == tag || c + 2 * hh >= B) &&
+                                 (gq[buf][ai][hh].w == tag || c + 2 * hh + 1 >= B);
                     if (__all(ok || !cvalid)) break;
                     __builtin_amdgcn_s_sleep(16);
                     if (spin_abort(ctrl, spins, SPIN_LIMIT, 5)) break;
@@ -657,10 +663,13 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const int pi = pi_of(rr, h), pj = pj_of(m, rr, h);
-                            if (cvalid && pi < T)
-                                *(float4*)(dScore + cell_index<DIR>(pi, pj, T) * Bs + c) =
-                                    make_float4(gz[0] * fexp2(t[rr][h][0] + arow[h][0]), gz[1] * fexp2(t[rr][h][1] + arow[h][1]),
-                                                gz[2] * fexp2(t[rr][h][2] + arow[h][2]), gz[3] * fexp2(t[rr][h][3] + arow[h][3]));
+                            if (cvalid && pi < T) {
+                                float* dst = dScore + cell_index<DIR>(pi, pj, T) * Bs + c;
+                                const float g0 = gz[0] * fexp2(t[rr][h][0] + arow[h][0]), g1 = gz[1] * fexp2(t[rr][h][1] + arow[h][1]);
+                                const float g2 = gz[2] * fexp2(t[rr][h][2] + arow[h][2]), g3 = gz[3] * fexp2(t[rr][h][3] + arow[h][3]);
+                                if (c + 3 < B) *(float4*)dst = make_float4(g0, g1, g2, g3);
+                                else *(float2*)dst = make_float2(g0, g1);            // B % 4 == 2: last pair only
+                            }
                         }
                 }
                 if (__any(exc > 0.0f)) {
@@ -744,6 +753,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int
                     if (pi >= T) continue;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
+                        if (c + i >= B) continue;
                         u64 gr;
                         if (MODE == 0) gr = make_granule(tag, aM[rr][i] + flog2(aS[rr][i]));
                         else gr = ((u64)(((tag & 0xffffu) << 16) | ((unsigned)aK[rr][i] & 0xffffu)) << 32) |
@@ -837,7 +847,9 @@ size_t persist_workspace_bytes(int T, int B)
            (size_t)(1 + max_parts(T)) * align_up((size_t)T * B * sizeof(u64));
 }
 
-bool persist_supported(int T, int B) { return (B % 4 == 0) && T >= 1 && T < 65535 && (long long)T * B * 8 < (1ll << 31); }
+// B even: the spine reads chain pairs; a panel lane reads 4 chains and masks the ones past B (B % 4 == 2: the
+// 16-byte loads are then only 8-byte aligned, which global memory accepts)
+bool persist_supported(int T, int B) { return (B % 2 == 0) && T >= 1 && T < 65535 && (long long)T * B * 8 < (1ll << 31); }
 
 static unsigned next_tag()
 {
