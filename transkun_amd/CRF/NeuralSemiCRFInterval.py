@@ -69,12 +69,24 @@ def pack_intervals(intervals: Sequence[Sequence[Tuple[int, int]]], T: int, B: in
     return pairs_d, offsets_t.to(device, non_blocking=True)
 
 
+_PAIR_DTYPE = np.dtype([("b", "<i4"), ("e", "<i4")])
+
+
 def unpack_intervals(pairs_host: torch.Tensor, offsets_host: torch.Tensor) -> Intervals:
-    flat = pairs_host.reshape(-1).tolist()
-    it = iter(flat)
-    tuples = list(zip(it, it))
-    off = offsets_host.tolist()
-    return [tuples[off[c]:off[c + 1]] for c in range(len(off) - 1)]
+    """packed int32 [K,2] + offsets [B+1] -> List[List[Tuple[int,int]]] (the reference's result type).
+    A structured-dtype tolist() builds the (begin, end) tuples in C; the cyclic GC is paused meanwhile
+    (hundreds of thousands of fresh tuples would otherwise trigger several full collections)."""
+    import gc
+    arr = np.ascontiguousarray(pairs_host.numpy().reshape(-1, 2).astype(np.int32, copy=False))
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        tuples = arr.view(_PAIR_DTYPE).reshape(-1).tolist()
+        off = offsets_host.tolist()
+        return [tuples[off[c]:off[c + 1]] for c in range(len(off) - 1)]
+    finally:
+        if was:
+            gc.enable()
 
 
 # --------------------------------------------------------------------------------------
@@ -214,6 +226,22 @@ class _LogProb(torch.autograd.Function):
 # module-level functions with the reference's names
 # --------------------------------------------------------------------------------------
 
+def _viterbi_raw(score_c, noise_c, start, forward: bool):
+    """Enqueue the Viterbi sweep + on-device backtrack; returns device tensors (pairs [cap,2], offsets [B+1])."""
+    T, B = score_c.shape[0], score_c.shape[2]
+    dev = score_c.device
+    cap = B * 2 * T
+    pairs = torch.empty(cap, 2, dtype=torch.int32, device=dev)
+    offsets = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    ws = _lib.workspace(_lib.OP_VITERBI, T, B, dev)
+    lib = _lib.load()
+    rc = lib.semicrf_viterbi(_lib.ptr(score_c), _lib.ptr(noise_c), T, B, _lib.ptr(start), 1 if forward else 0,
+                             _lib.ptr(pairs), cap, _lib.ptr(offsets), _lib.ptr(ws), ws.numel(),
+                             _lib.stream_of(score_c))
+    _lib.check(rc, "semicrf_viterbi")
+    return pairs, offsets
+
+
 def _decode(score, noiseScore, forcedStartPos: Optional[Sequence[int]], forward: bool) -> Intervals:
     assert len(score.shape) == 3
     assert score.shape[0] == score.shape[1]
@@ -228,15 +256,7 @@ def _decode(score, noiseScore, forcedStartPos: Optional[Sequence[int]], forward:
             if (st < 0).any() or (st > T - 1).any():
                 raise IndexError(f"forcedStartPos out of range for T={T}")
             start = torch.from_numpy(st.astype(np.int32)).to(dev, non_blocking=True)
-        cap = B * 2 * T
-        pairs = torch.empty(cap, 2, dtype=torch.int32, device=dev)
-        offsets = torch.empty(B + 1, dtype=torch.int32, device=dev)
-        ws = _lib.workspace(_lib.OP_VITERBI, T, B, dev)
-        lib = _lib.load()
-        rc = lib.semicrf_viterbi(_lib.ptr(score_c), _lib.ptr(noise_c), T, B, _lib.ptr(start), 1 if forward else 0,
-                                 _lib.ptr(pairs), cap, _lib.ptr(offsets), _lib.ptr(ws), ws.numel(),
-                                 _lib.stream_of(score_c))
-        _lib.check(rc, "semicrf_viterbi")
+        pairs, offsets = _viterbi_raw(score_c, noise_c, start, forward)
         off_h = offsets.cpu()                      # the one host sync of decode
         total = int(off_h[-1])
         pairs_h = pairs[:total].cpu()

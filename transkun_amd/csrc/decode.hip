@@ -1,9 +1,8 @@
 // decode.hip -- on-device backtrack of the Viterbi pointer table and packing of the result.
 // The reference copies the [T-1][B] pointer table and the diagonal mask to the host and walks
-// them in TorchScript (NeuralSemiCRFInterval.py:56-102 / :150-199).  Here one thread per chain
-// walks its own contiguous code row code[c][0..T) (written transposed by the DP kernels so the
-// walk is cache-line local), then the per-chain lists are packed so that only
-// O(#intervals) int32 cross PCIe.
+// them in TorchScript (NeuralSemiCRFInterval.py:56-102 / :150-199).  Here one workgroup per chain
+// stages its contiguous code row code[c][0..T) (written transposed by the DP kernels) in LDS and walks
+// it there; the per-chain lists are then packed so that only O(#intervals) int32 cross PCIe.
 //
 // code[c][t] = (key+1) | (s[t,t]>0 ? 1<<30 : 0), key = -1 (skip) or the absolute index of the
 // other endpoint chosen at t.
@@ -15,37 +14,49 @@ constexpr int CODE_DIAG = 0x40000000;
 constexpr int CODE_MASK = 0x3fffffff;
 
 // region: [B][2T][2] int32, counts: [B]
+// One 64-thread workgroup per chain: the chain's code row is first copied into LDS with coalesced loads
+// (T*4 bytes; rows longer than BT_LDS_MAX ints are walked in global memory instead), then lane 0 walks it:
+// a dependent LDS read per step (~100 cycles) instead of a dependent global load (~1 us).
+constexpr int BT_LDS_MAX = 16384;
+
 __global__ __launch_bounds__(64) void backtrack_kernel(const int* __restrict__ code, int T, int B,
                                                         const int* __restrict__ start, int forward,
                                                         int* __restrict__ region, int* __restrict__ counts)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= B) return;
+    extern __shared__ int s_code[];
+    const int c = blockIdx.x;
     const int* cc = code + (size_t)c * T;
+    const bool in_lds = T <= BT_LDS_MAX;
+    if (in_lds) {
+        for (int t = threadIdx.x; t < T; t += 64) s_code[t] = cc[t];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    auto rd = [&](int t) { return in_lds ? s_code[t] : cc[t]; };
     int* out = region + (size_t)c * (size_t)(2 * T) * 2;
     int n = 0;
     if (!forward) {
         // viterbiBackward walk, :70-98
         int j = start ? start[c] : 0;
         while (j < T - 1) {
-            const int w = cc[j];
+            const int w = rd(j);
             if (w & CODE_DIAG) { out[2 * n] = j; out[2 * n + 1] = j; ++n; }
             const int key = (w & CODE_MASK) - 1;
             if (key < 0) j += 1;
             else { out[2 * n] = j; out[2 * n + 1] = key; ++n; j = key; }
         }
-        if (cc[T - 1] & CODE_DIAG) { out[2 * n] = T - 1; out[2 * n + 1] = T - 1; ++n; }
+        if (rd(T - 1) & CODE_DIAG) { out[2 * n] = T - 1; out[2 * n + 1] = T - 1; ++n; }
     } else {
         // viterbi walk, :164-196; emitted descending here, reversed by the pack kernel
         int j = start ? start[c] : T - 1;
         while (j > 0) {
-            const int w = cc[j];
+            const int w = rd(j);
             if (w & CODE_DIAG) { out[2 * n] = j; out[2 * n + 1] = j; ++n; }
             const int key = (w & CODE_MASK) - 1;
             if (key < 0) j -= 1;
             else { out[2 * n] = key; out[2 * n + 1] = j; ++n; j = key; }
         }
-        if (cc[0] & CODE_DIAG) { out[2 * n] = 0; out[2 * n + 1] = 0; ++n; }
+        if (rd(0) & CODE_DIAG) { out[2 * n] = 0; out[2 * n + 1] = 0; ++n; }
     }
     counts[c] = n;
 }
@@ -99,8 +110,14 @@ __global__ __launch_bounds__(256) void pack_kernel(const int* __restrict__ regio
 void launch_backtrack(const int* code, int T, int B, const int* start, int forward, int* region,
                       int* counts, int* pairs, long long cap, int* offsets, hipStream_t stream)
 {
-    hipLaunchKernelGGL(backtrack_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, code, T, B, start, forward,
-                       region, counts);
+    const size_t lds = T <= BT_LDS_MAX ? (size_t)T * sizeof(int) : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)backtrack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  BT_LDS_MAX * (int)sizeof(int));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(backtrack_kernel, dim3(B), dim3(64), lds, stream, code, T, B, start, forward, region, counts);
     hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(256), 0, stream, counts, B, offsets);
     hipLaunchKernelGGL(pack_kernel, dim3(B), dim3(256), 0, stream, region, counts, offsets, T, B, forward, pairs,
                        cap);
