@@ -513,6 +513,13 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int
     constexpr int NL = DIR == 0 ? 2 : 1;        // u positions a lane LOADS per tile (DIR 1: position slot&3, shared by shuffles)
     const auto ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.ug, 0, (int)((size_t)T * Bs * 8), 0x00020000);
 
+    if (dbg & 128u) {
+        // power probe: burn ALU cycles for ~300 us without touching memory (is the spine slowed by clocks or by traffic?)
+        float a = (float)threadIdx.x, b = 1.0001f;
+        for (int i = 0; i < 20000; ++i) { a = fmaf(a, b, 0.5f); b = fmaf(b, 0.9999f, 0.0001f); }
+        if (a == 12345.678f) ctrl[5] = 1;
+        return;
+    }
     while (true) {
         // ---- next task: (k, part, g), ordered so that a task only waits on spine progress below k-3 ----
         __syncthreads();
@@ -895,7 +902,17 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
     }
-    int nPanelWG = 2 * ncu - P.nSpine;
+    // Panel workgroups.  More of them means more loads in flight than the ~8 MB that saturate HBM, i.e. only
+    // longer queues -- and the spine's band loads and hand-offs wait in the same queues.  Measured at T=1024,
+    // NBatch=352: forward 292 us with 1 panel workgroup per CU vs 336 us with 2; the gradient sweep (which also
+    // stores a tile per tile loaded) is best around 1.25 per CU.
+    // The far field grows with T^2 and the spine's chain with T, so longer sequences get more panel workgroups.
+    float per_cu = (float)T / 1024.0f;
+    per_cu = per_cu < 0.75f ? 0.75f : (per_cu > 2.0f ? 2.0f : per_cu);
+    if (grad) per_cu *= 1.25f;
+    int nPanelWG = (int)(per_cu * ncu);
+    if (nPanelWG > 2 * ncu - P.nSpine) nPanelWG = 2 * ncu - P.nSpine;
+    if (const char* e = getenv("SEMICRF_PANEL_WGS")) { const int v = atoi(e); if (v > 0) nPanelWG = v; }   // tuning knob
     if (nPanelWG < ncu / 2) nPanelWG = ncu / 2;
     if (nPanelWG > P.nTasks) nPanelWG = P.nTasks;
     const int grid = P.nSpine + nPanelWG;
