@@ -6,40 +6,46 @@
 // (max,+) semiring with argmax (viterbi / viterbiBackward, :27-51, :122-144).  Positions run over
 // frames ascending (DIR 0) or descending (DIR 1); cell(p,j) is score[end][begin] of the two frames.
 //
-// Work decomposition (positions in blocks of 16):
-//   * SPINE workgroup, one per 8 chains: four waves form a ring, wave w owns position blocks
-//     k = w, w+4, ...; a lane is (row r of the block, 2 chains).  Every wave applies each newly
-//     finished u[j] to its own block's rows (band = the current block and the next three); the owner
-//     of the current block finalises one position per step (a ~35-instruction dependent step: a lone
-//     wave issues one instruction per ~4 cycles, so the step is kept that small) and publishes it
-//     through LDS to its ring mates; once per block it publishes 16 positions to HBM for the panels.
-//     The T-step dependent chain never leaves one CU.  Band cells are prefetched 16..32 steps ahead
+// Work decomposition (positions in blocks of 16, workgroups of 8 waves, ONE workgroup per compute unit):
+//   * SPINE workgroup, one per 8 chains: two rings of four waves, a ring serves 4 chains; wave w of a ring
+//     owns position blocks k = w, w+4, ...; a lane is (row r of the block, ONE chain).  Every wave applies
+//     each newly finished u[j] to its own block's rows (band = the current block and the next three); the
+//     owner of the current block finalises one position per step and publishes it through LDS to its ring
+//     mates; once per block it publishes 16 positions to HBM for the panels.  The T-step dependent chain
+//     never leaves one CU.  A lone wave issues one plain instruction per ~4.5 cycles and one transcendental
+//     per ~16, so the step is kept at ~22 instructions with 4 transcendentals (one chain per lane: with two
+//     chains per lane the step simply costs twice as much).  Band cells are prefetched 16..32 steps ahead
 //     in registers.
-//   * PANEL workgroup, one per (position block k >= 4, 32 chains): streams the far field -- all cells
-//     (p in block k, j < 16(k-3)) -- tile by tile as the spine publishes u, keeps the partial
-//     accumulators in registers and hands ONE number per (position, chain) to the spine.
+//   * PANEL waves (every wave pulls its own tasks, no workgroup-level synchronisation): a task is
+//     (position block k >= 4, column part of <= 16 tiles, 32 chains, 4 of the 16 rows).  The wave streams the
+//     far field -- cells (p in its rows, j < 16(k-3)) -- tile by tile as the spine publishes u, keeps the
+//     partial accumulators in registers and hands ONE number per (position, chain, part) to the spine.
 //   * Hand-offs are 8-byte {tag, value} granules written with relaxed agent-scope atomic stores and
 //     polled with relaxed agent-scope atomic loads (data is the flag; no fences, placement independent).
 //     Roles are drawn from an atomic ticket so that a workgroup only ever waits on lower tickets; every
 //     spin is bounded and raises the error word instead of hanging.
 //
-// HBM traffic: every lower-triangle cell is read exactly once (128-byte lines in the panels, 32-byte
-// segments in the band).  Algorithmic bytes per sweep: 4*B*(T(T+1)/2 + T-1).
+// HBM traffic: every lower-triangle cell is read exactly once (128-byte lines in the panels, 16-byte
+// segments -- two rings share a 32-byte sector -- in the band).  Algorithmic bytes per sweep:
+// 4*B*(T(T+1)/2 + T-1).
 #include <atomic>
 #include <stdlib.h>
 #include "common.h"
 
-#ifndef SEMICRF_ABL
-#define SEMICRF_ABL 0      // timing-ablation bits for the LSE diagonal step (development only)
+#ifndef SEMICRF_PANEL_PROBES
+#define SEMICRF_PANEL_PROBES 0      // 1: keep the panel timing probes (debug flags 4 and 32) in the hot loop
 #endif
 
 namespace semicrf {
 
 constexpr int PB = 16;             // positions per block
-constexpr int RING = 4;            // spine waves; band = RING-1 off-diagonal blocks + the diagonal block
-constexpr int GS = 8;              // chains per spine workgroup (2 per lane)
-constexpr int GP = 32;             // chains per panel workgroup (4 per lane)
+constexpr int RING = 4;            // waves per ring; band = RING-1 off-diagonal blocks + the diagonal block
+constexpr int RS = 4;              // chains per ring (one per lane)
+constexpr int GS = RS;              // chains per spine workgroup
+constexpr int GP = 32;             // chains per panel task (4 per lane)
 constexpr int TPT = 16;            // tiles (column blocks) per panel task
+constexpr int NT = 512;            // threads per workgroup (8 waves, 2 per SIMD)
+constexpr int MAX_CHUNKS = 16;     // chain chunks (launches) per call
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr int SPIN_LIMIT = 1 << 20;       // global-memory polls (with s_sleep): ~0.3 s
@@ -55,16 +61,18 @@ struct SweepParams {
     const float* score;
     const float* noise;
     int T, B, K;
+    int c0, c1;            // chains [c0, c1) of the batch are handled by this launch
     int nSpine, nPanelGroups;
-    int nTasks;            // panel tasks (k ascending, then column part, then chain group)
+    int nTasks;            // panel tasks (k ascending, then column part, then chain group, then row quarter)
+    int panelWaves;        // waves per non-spine workgroup that work as panels (the rest exit at once)
+    int hybridPanelWaves;  // panel waves of a spine workgroup (0..2)
     unsigned tag;          // nonzero launch epoch
     unsigned dbg;          // SEMICRF_DEBUG_FLAGS (timing experiments only; results are wrong when set):
                            // 1 spine ignores far partials, 2 panels exit at once, 4 panels do not wait for u,
-                           // 8 spine exits at once, 16 spine 0 records per-step timestamps,
+                           // 8 spine exits at once, 16 spine 0 records per-block timestamps,
                            // 32 panels only stream their cells (no granules, no math)
-    unsigned* ctrl;        // [0] ticket, [1] error, [2] panel task queue head, [3] panels that stepped aside,
-                           // [64 .. 64+4096) one flag per compute unit: a spine lives here
-    u64* ts;               // [T] debug timestamps of the diagonal steps of spine 0 (dbg & 16)
+    unsigned* ctrl;        // [0] ticket, [1] error, [2] panel task queue head
+    u64* ts;               // [2T] debug timestamps of spine 0, ring 0 (dbg & 16)
     u64* ug;               // [T][B] granules of u (position-major: index p*B + c)
     u64* farg;             // [parts][T][B] granules of far-field partials (part = column range of TPT tiles)
     float* u_out;          // [T][B] by FRAME (natural-log units for LSE) or nullptr
@@ -87,6 +95,10 @@ __device__ __forceinline__ float flog2(float x) { return __builtin_amdgcn_logf(x
 __device__ __forceinline__ u64 make_granule(unsigned tag, float v)
 {
     return ((u64)tag << 32) | (u64)__float_as_uint(v);
+}
+__device__ __forceinline__ u64 make_granule_key(unsigned tag, float v, int key)
+{
+    return ((u64)(((tag & 0xffffu) << 16) | ((unsigned)key & 0xffffu)) << 32) | (u64)__float_as_uint(v);
 }
 __device__ __forceinline__ void store_granule(u64* p, u64 g)
 {
@@ -115,9 +127,8 @@ __device__ __forceinline__ void acc_push1(float& M, float& S, float t)
 {
     const float d = t - M;                       // M = -inf -> +inf
     const float e = fexp2(-fabsf(d));
-    const bool up = d > 0.0f;
-    S = up ? fmaf(S, e, 1.0f) : S + e;
-    M = up ? t : M;
+    S = d > 0.0f ? fmaf(S, e, 1.0f) : S + e;
+    M = fmaxf(M, t);
 }
 __device__ __forceinline__ void acc_merge(float& M, float& S, float M2, float S2)
 {
@@ -134,15 +145,6 @@ __device__ __forceinline__ float softplus2(float x)
 {
     const float x2 = x * LOG2E;
     return x > 20.0f ? x2 : flog2(1.0f + fexp2(x2));
-}
-
-// identifies the compute unit this wave runs on: (XCC id, SE/SH/CU ids of HW_ID) -- used only to keep panel
-// workgroups off the CUs that host a spine (they would steal issue slots from the latency-critical wave)
-__device__ __forceinline__ unsigned cu_key()
-{
-    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
-    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
-    return ((xcc & 15u) << 8) | ((hw >> 8) & 255u);
 }
 
 // sticky device-side status word (0 = fine); read and cleared by semicrf_debug_device_status()
@@ -167,26 +169,176 @@ __device__ __forceinline__ bool spin_abort(unsigned* ctrl, int& spins, int limit
 }
 
 // ---------------------------------------------------------------------------------------------
-// SPINE role
+// SPINE workgroup: ring waves + loader wave + far-partial wave
 // ---------------------------------------------------------------------------------------------
-// LDS ring: 128 positions x 4 chain pairs x 16 bytes {u0, u1, seq = position+1, pad}.  A position is
-// published with ONE 16-byte DS write per lane by the four lanes r == 0 of the owning wave (after the
-// broadcast every lane holds u[j] of its pair); consumers read their pair's 16 bytes and check seq.
+// The ring waves never issue a global LOAD: vector-memory results return in order, so one request queued
+// behind a burst of HBM misses (several microseconds while the panels stream) would stall the dependent chain.
+//   * the LOADER wave copies the band cells of row block kr -- four 16x16x4-chain tiles -- and its per-row
+//     constants into LDS with asynchronous global->LDS loads, running up to NRBUF row blocks ahead of the ring;
+//   * the FAR wave polls the panels' partials for the upcoming blocks (its polls are the only requests it has
+//     in flight, so they see L2 latency) and leaves one combined value per (row, chain) in LDS;
+//   * a ring wave reads its four tiles from LDS into registers at the start of its iteration.
+// LDS ring: 128 positions x 4 chains x 8 bytes {u, seq = position+1}.  A position is published with ONE
+// 8-byte DS write per lane by the four lanes r == 0 of the owning wave (after the broadcast every lane holds
+// u[j] of its chain); consumers read their chain's 8 bytes and check seq.
 //
-// A lone wave issues about one instruction per 4 cycles, so the T-step dependent chain is bounded by the
-// instruction count of a step; the step bodies below are written to stay near 30 instructions:
-//   * cell buffers rotate A/B/C over the four blocks of the band (fully unrolled, no register moves),
+// The step bodies are written for a lone wave (issue-bound):
 //   * the diagonal step needs no lane predicates: the broadcast value is what gets published and the
 //     next broadcast simply reads the lanes of the next row,
 //   * row jj+1 receives its last term through logaddexp2(Vp, u + W) where Vp (everything but that term)
-//     is refreshed one step ahead by the lazily rescaled (M,S) push that runs beside it,
-//   * far-field partials are requested one block ahead of the diagonal phase.
-constexpr int FAR_PREFETCH = 4;     // parts whose far granules are requested ahead of time
+//     is refreshed one step ahead by the (M,S) push that runs beside it.
+constexpr int NRBUF = 6;                              // row-block buffers between the loader and the ring
+constexpr int TILE_BYTES = PB * PB * RS * 4;          // 4096: [column u][row r][chain] floats
+constexpr int NCONST = 3;                             // per-row constants: diagonal cell, noise, alpha (GRAD)
+constexpr int LDS_TILES = 0;
+constexpr int LDS_CONST = LDS_TILES + NRBUF * RING * TILE_BYTES;       // [NRBUF][NCONST][64] floats
+constexpr int LDS_FAR = LDS_CONST + NRBUF * NCONST * 256;              // [8][64] x {value, key, seq, pad}
+constexpr int LDS_RING = LDS_FAR + 8 * 64 * 16;                        // [128][RS] x {u, seq}
+constexpr int LDS_CTL = LDS_RING + 128 * RS * 8;                       // ready[NRBUF], cons[RING] (ints)
+constexpr int LDS_DUMMY = LDS_CTL + 256;                               // sink of the non-writer lanes' ring stores
+constexpr int LDS_SPINE_BYTES = LDS_DUMMY + (64 * 2 + PB * 8) * 4;
 
-struct SpineBlk { float2 v[PB]; };
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
 
+struct SpineBlk { float v[PB]; };
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// LDS word accessors for the flags (every poll must be a fresh DS read)
+__device__ __forceinline__ int lds_flag_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_flag_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// The same for the loader wave, as asm: the compiler orders every DS access it can see after ALL outstanding
+// global->LDS loads (s_waitcnt vmcnt(0)), which would serialise the loader's pipeline; it counts its loads itself.
+__device__ __forceinline__ unsigned lds_addr(const void* p)
+{
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ int lds_flag_load_asm(const int* p)
+{
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_addr(p)) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_flag_store_asm(int* p, int v)
+{
+    asm volatile("ds_write_b32 %0, %1" ::"v"(lds_addr(p)), "v"(v) : "memory");
+}
+
+// ---- loader wave ---------------------------------------------------------------------------------------
+template <int DIR, bool GRAD>
+__device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* lds)
+{
+    const int T = P.T, B = P.B, K = P.K;
+    unsigned* const ctrl = P.ctrl;
+    const size_t Bs = (size_t)B;
+    const float* const score = P.score;
+    const float* const noise = P.noise;
+    const float* const vfwd = P.vfwd;
+    const int lane = threadIdx.x & 63;
+    const int cbase = P.c0 + sg * GS;
+    const size_t last4 = (size_t)T * T * Bs - 4;                 // last element offset a 16-byte load may start at
+    // tile loads: instruction q covers columns 4q..4q+3, lane = (column within the group, row)
+    const int tu = lane >> 4, tr = lane & 15;
+    // constants: lane = (row, chain) like the ring waves
+    const int cr = lane >> 2, cch = lane & 3;
+    const int cc = cbase + cch < P.c1 ? cbase + cch : cbase;
+    int* const ready = (int*)(lds + LDS_CTL);
+    int* const cons = ready + NRBUF;
+    constexpr int NL = RING * 4 + 2 + (GRAD ? 1 : 0);            // loads per row block (exactly, the waits count them)
+
+    auto issue = [&](int kr) {
+        const int slot = kr % NRBUF;
+        const int prow_t = kr * PB + tr < T ? kr * PB + tr : T - 1;
+#pragma unroll
+        for (int i = 0; i < RING; ++i) {
+            const int kc = kr - (RING - 1) + i > 0 ? kr - (RING - 1) + i : 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int pj = kc * PB + 4 * q + tu;
+                pj = pj < prow_t ? pj : (prow_t > 0 ? prow_t - 1 : 0);       // only cells below the diagonal are used
+                size_t off = cell_index<DIR>(prow_t, pj, T) * Bs + cbase;
+                off = off < last4 ? off : last4;
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(score + off),
+                                                 (lds_void_t*)(lds + LDS_TILES + (slot * RING + i) * TILE_BYTES + q * 1024), 16, 0, 0);
+            }
+        }
+        const int prow_c = kr * PB + cr < T ? kr * PB + cr : T - 1;
+        const int frow = frame_of<DIR>(prow_c, T);
+        char* cb = lds + LDS_CONST + slot * NCONST * 256;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(score + ((size_t)frow * T + frow) * Bs + cc), (lds_void_t*)cb, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(noise + (size_t)gap_of<DIR>(prow_c >= 1 ? prow_c : 1, T) * Bs + cc),
+                                         (lds_void_t*)(cb + 256), 4, 0, 0);
+        if (GRAD)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(vfwd + (size_t)frow * Bs + cc), (lds_void_t*)(cb + 512), 4, 0, 0);
+    };
+    auto publish = [&](int kr) {
+        if (lane == 0) lds_flag_store_asm(ready + kr % NRBUF, kr + 1);
+    };
+
+    for (int kr = 0; kr < K; ++kr) {
+        if (kr >= NRBUF) {
+            // the buffer's previous row block (kr - NRBUF) must have been read by its ring wave
+            const int w = (kr - NRBUF) % RING;
+            int spins = 0;
+            while (lds_flag_load_asm(cons + w) < kr - NRBUF + 1) {
+                __builtin_amdgcn_s_sleep(2);
+                if (spin_abort(ctrl, spins, SPIN_LIMIT_LDS, 6)) return;
+            }
+        }
+        issue(kr);
+        if (kr >= 2) { wait_vmcnt<2 * NL>(); publish(kr - 2); }
+    }
+    if (K >= 2) { wait_vmcnt<NL>(); publish(K - 2); }
+    wait_vmcnt<0>();
+    publish(K - 1);
+}
+
+// ---- far wave -------------------------------------------------------------------------------------------
+template <int MODE, int DIR>
+__device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds)
+{
+    const int T = P.T, B = P.B, K = P.K;
+    unsigned* const ctrl = P.ctrl;
+    const u64* const farg = P.farg;
+    const unsigned tag = P.tag;
+    const size_t Bs = (size_t)B;
+    const int lane = threadIdx.x & 63;
+    const int r = lane >> 2, ch = lane & 3;
+    const int c = P.c0 + sg * GS + ch;
+    const bool cvalid = c < P.c1;
+    float4* const far = (float4*)(lds + LDS_FAR);
+    for (int k = RING; k < K; ++k) {
+        const int prow = k * PB + r;
+        const bool rvalid = cvalid && prow < T;
+        const int nparts = (k - RING) / TPT + 1;
+        float aM = SEMICRF_NEG_INF, aS = 0.f;
+        int aK = 0x7fffffff;
+        if (rvalid) {
+            for (int part = 0; part < nparts; ++part) {
+                const u64* fp = farg + ((size_t)part * T + prow) * Bs + c;
+                u64 g0 = load_granule(fp);
+                int spins = 0;
+                while (true) {
+                    const bool ok = MODE == 0 ? (unsigned)(g0 >> 32) == tag : (unsigned)(g0 >> 48) == (tag & 0xffffu);
+                    if (ok) break;
+                    __builtin_amdgcn_s_sleep(4);
+                    if (spin_abort(ctrl, spins, SPIN_LIMIT, 3)) break;
+                    g0 = load_granule(fp);
+                }
+                if (MODE == 0) acc_push1(aM, aS, __uint_as_float((unsigned)g0));
+                else max_push(aM, aK, __uint_as_float((unsigned)g0), (int)((g0 >> 32) & 0xffffu));
+            }
+        }
+        const float val = MODE == 0 ? aM + flog2(aS) : aM;
+        far[(k & 7) * 64 + lane] = make_float4(val, __int_as_float(aK), __int_as_float(k + 1), 0.0f);   // one DS write: data + seq
+    }
+}
+
+// ---- ring waves -----------------------------------------------------------------------------------------
 template <int MODE, int DIR, bool GRAD>
-__device__ __forceinline__ void spine_role(const SweepParams& P, int sg, float* ring, float* dummy)
+__device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int ring_pos, char* lds)
 {
     // kernel arguments are copied into locals: lambdas that capture the struct by reference make the
     // compiler spill it to scratch and reload fields inside the step loops
@@ -195,121 +347,119 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, float* 
     unsigned* const ctrl = P.ctrl;
     u64* const ts = P.ts;
     u64* const ug = P.ug;
-    const u64* const farg = P.farg;
     float* const u_out = P.u_out;
     float* const last_out = P.last_out;
     int* const code = P.code;
-    const float* const vfwd = P.vfwd;
-    const float* const logZp = P.logZ;
-    const float* const goutp = P.gout;
     float* const dScore = P.dScore;
     float* const dNoise = P.dNoise;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int rw = __builtin_amdgcn_readfirstlane(ring_pos);                // position of the wave in the ring
     const int lane = threadIdx.x & 63;
-    const int r = lane >> 2, pr = lane & 3;
-    const int c = sg * GS + pr * 2;
-    const bool cvalid = c < B;
+    const int r = lane >> 2, ch = lane & 3;
+    const int c = P.c0 + sg * GS + ch;
+    const bool cvalid = c < P.c1;
+    const int cc = cvalid ? c : P.c0;
     const size_t Bs = (size_t)B;
-    const float* __restrict__ score = P.score;
-    const float* __restrict__ noise = P.noise;
     const unsigned tag = P.tag;
-    const long long stride = DIR == 0 ? (long long)B : -(long long)T * B;   // floats per +1 in j
     const bool trace = (dbg & 16u) && sg == 0 && lane == 0;
-    if (threadIdx.x == 0) __hip_atomic_store(ctrl + 64 + cu_key(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const float* rd_base = ring + pr * 4;                                   // + (j & 127) * 16 floats
-    float* wr_base = r == 0 ? ring + pr * 4 : dummy + lane * 4;             // writers: the four lanes of row 0
-    const int bp_addr = pr << 2;                                            // ds_bpermute byte address of lane pr
+    float* const ring = (float*)(lds + LDS_RING);
+    float* const dummy = (float*)(lds + LDS_DUMMY);
+    const float* rd_base = ring + ch * 2;                                   // + (j & 127) * 8 floats
+    float* wr_base = r == 0 ? ring + ch * 2 : dummy + lane * 2;             // writers: the four lanes of row 0
+    const int bp_addr = ch << 2;                                            // ds_bpermute byte address of lane ch
+    const int* const ready = (const int*)(lds + LDS_CTL);
+    int* const cons = (int*)(lds + LDS_CTL) + NRBUF;
+    const float4* const far = (const float4*)(lds + LDS_FAR);
+    float gz = 0.f, lzc = 0.f;
+    if (GRAD && cvalid) { gz = P.gout[c]; lzc = P.logZ[c]; }               // the only global loads of a ring wave
+    __builtin_amdgcn_s_setprio(1);
 
-    for (int k = wave; k < K; k += RING) {
+    for (int k = rw; k < K; k += RING) {
         u64* ev = ts + T + (size_t)k * 8;          // debug events of this block (8 slots)
         if (trace) ev[0] = __builtin_readcyclecounter();
         const int prow = k * PB + r;
         const bool rvalid = cvalid && prow < T;
-        const int frow = frame_of<DIR>(prow < T ? prow : T - 1, T);
+        const int prow_c = prow < T ? prow : T - 1;
+        const int frow = frame_of<DIR>(prow_c, T);
         const int own0 = k * PB;
-        const float* rowp = score + cell_index<DIR>(rvalid ? prow : 0, 0, T) * Bs + (cvalid ? c : 0);
+        const int slot = k % NRBUF;
 
-        // loads are unconditional (addresses clamped into the tensor) so that all 16 are issued back to back;
-        // cells with j >= prow are only ever applied AFTER this lane's row has been finalised, and invalid
-        // lanes never publish, so what they accumulate is never read.
-        auto load_block = [&](int b) -> SpineBlk {
-            SpineBlk o;
-            const int j0 = b * PB;
-#pragma unroll
-            for (int u = 0; u < PB; ++u) {
-                const int j = j0 + u < T ? j0 + u : T - 1;
-                o.v[u] = *(const float2*)(rowp + (long long)j * stride);
+        // ---- the row block's cells and constants, staged in LDS by the loader wave ----------------
+        {
+            int spins = 0;
+            while (lds_flag_load(ready + slot) != k + 1) {
+                __builtin_amdgcn_s_sleep(1);
+                if (spin_abort(ctrl, spins, SPIN_LIMIT_LDS, 7)) break;
             }
+        }
+        const char* tb = lds + LDS_TILES + slot * RING * TILE_BYTES + (r * RS + ch) * 4;
+        auto read_tile = [&](int i) -> SpineBlk {
+            SpineBlk o;
+#pragma unroll
+            for (int u = 0; u < PB; ++u) o.v[u] = *(const float*)(tb + i * TILE_BYTES + u * (PB * RS * 4));
             return o;
         };
-        SpineBlk A, Bk, C;
-        if (k >= 3) A = load_block(k - 3);
-        if (k >= 2) Bk = load_block(k - 2);
-        if (k >= 1) C = load_block(k - 1);
+        SpineBlk A = read_tile(0), Bk = read_tile(1), C = read_tile(2), D = read_tile(3);
+        const float* cst = (const float*)(lds + LDS_CONST + slot * NCONST * 256) + lane;
+        const float dcell = cst[0], nzl = cst[64], vfl = cst[128];
+        // first sub-diagonal cell of this lane's row: column r-1 of the own tile (last column of tile 2 for row 0)
+        const float s1own = *(const float*)(lds + LDS_TILES + (slot * RING + 3) * TILE_BYTES +
+                                            ((((r > 0 ? r - 1 : 0) * PB) + r) * RS + ch) * 4);
+        const float s1 = r == 0 ? C.v[PB - 1] : s1own;
+        if (lane == 0) lds_flag_store(cons + rw, k + 1);          // in-order DS queue: after the reads above
+
+        // GRAD stores: wave-uniform base (SGPR) + one per-lane byte offset
+        //   DIR 0: cell(prow, j) = ((own0 + r)*T + j)*B          DIR 1: cell(prow, j) = ((T-1-j)*T + (T-1-prow))*B
+        const unsigned bvoff = DIR == 0 ? (unsigned)(((size_t)(prow_c - own0) * T * Bs + cc) * 4)
+                                        : (unsigned)(((size_t)(T - 1 - prow_c) * Bs + cc) * 4);
+        auto col_off = [&](int j) -> size_t {
+            return DIR == 0 ? ((size_t)own0 * T + (size_t)j) * Bs : (size_t)(T - 1 - j) * T * Bs;
+        };
+        auto grad_store = [&](int j, float v) {
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(dScore + col_off(j)), 0, 0x7fffffff, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, bvoff, 0, 0);
+        };
 
         // ---- per-row constants ----------------------------------------------------------------
-        float sp[2] = {0.f, 0.f};   // LSE: softplus2(diag); MAX: diag
-        float nz[2] = {0.f, 0.f};   // MAX: noise between prow-1 and prow
-        float wl[2] = {0.f, 0.f};   // LSE: log2(2^s[prow][prow-1] + 2^n): first sub-diagonal cell with the skip folded in
+        float sp = 0.f;   // LSE: softplus2(diag); MAX: diag
+        float nz = 0.f;   // noise between prow-1 and prow
+        float wl = 0.f;   // LSE: log2(2^s[prow][prow-1] + 2^n): first sub-diagonal cell with the skip folded in
+        float draw = 0.f;
         if (rvalid) {
-            const float2 d = *(const float2*)(score + ((size_t)frow * T + frow) * Bs + c);
-            if (MODE == 0) { sp[0] = softplus2(d.x); sp[1] = softplus2(d.y); }
-            else { sp[0] = d.x; sp[1] = d.y; }
+            draw = dcell * LOG2E;
+            sp = MODE == 0 ? softplus2(dcell) : dcell;
             if (prow >= 1) {
-                const float2 n2 = *(const float2*)(noise + (size_t)gap_of<DIR>(prow, T) * Bs + c);
-                nz[0] = n2.x; nz[1] = n2.y;
+                nz = nzl;
                 if (MODE == 0) {
-                    const float2 s1 = *(const float2*)(rowp + (long long)(prow - 1) * stride);
-                    const float a0 = s1.x * LOG2E, b0 = n2.x * LOG2E, a1 = s1.y * LOG2E, b1 = n2.y * LOG2E;
-                    wl[0] = fmaxf(a0, b0) + flog2(1.0f + fexp2(-fabsf(a0 - b0)));
-                    wl[1] = fmaxf(a1, b1) + flog2(1.0f + fexp2(-fabsf(a1 - b1)));
+                    const float a0 = s1 * LOG2E, b0 = nz * LOG2E;
+                    wl = fmaxf(a0, b0) + flog2(1.0f + fexp2(-fabsf(a0 - b0)));
                 }
             }
         }
         // GRAD: marginal(prow, j) = gz * exp2(t + arow) with t = u[j] + cell*log2e, arow = (alpha[frame] - logZ)*log2e
-        float arow[2] = {0.f, 0.f}, gz[2] = {0.f, 0.f}, draw[2] = {0.f, 0.f};
-        float* const growp = GRAD ? dScore + (rowp - score) : nullptr;
-        if (GRAD && rvalid) {
-            const float2 vv = *(const float2*)(vfwd + (size_t)frow * Bs + c);
-            const float2 lz = *(const float2*)(logZp + c);
-            const float2 go = *(const float2*)(goutp + c);
-            arow[0] = (vv.x - lz.x) * LOG2E; arow[1] = (vv.y - lz.y) * LOG2E;
-            gz[0] = go.x; gz[1] = go.y;
-            const float2 d = *(const float2*)(score + ((size_t)frow * T + frow) * Bs + c);
-            draw[0] = d.x * LOG2E; draw[1] = d.y * LOG2E;
-        }
+        const float arow = (GRAD && rvalid) ? (vfl - lzc) * LOG2E : 0.f;
         if (trace) ev[1] = __builtin_readcyclecounter();
 
-        float aM[2] = {SEMICRF_NEG_INF, SEMICRF_NEG_INF}, aS[2] = {0.f, 0.f};
-        int aK[2] = {0x7fffffff, 0x7fffffff};
+        float aM = SEMICRF_NEG_INF, aS = 0.f;
+        int aK = 0x7fffffff;
 
-        // lazily rescaled LSE push of (p0,p1) into (aM,aS): one exp per chain, rare wave-uniform slow path
-        auto lse_push2 = [&](float p0, float p1) {
-            const float d0 = p0 - aM[0], d1 = p1 - aM[1];       // M = -inf -> +inf
-            if (__any(fmaxf(d0, d1) > RESCALE_THR)) {
-                if (d0 > RESCALE_THR) { aS[0] = aS[0] * fexp2(-d0) + 1.0f; aM[0] = p0; } else aS[0] += fexp2(d0);
-                if (d1 > RESCALE_THR) { aS[1] = aS[1] * fexp2(-d1) + 1.0f; aM[1] = p1; } else aS[1] += fexp2(d1);
-            } else {
-                aS[0] += fexp2(d0);
-                aS[1] += fexp2(d1);
-            }
-        };
-
-        // wait for position j in the ring and return this lane's pair
-        auto ring_get = [&](int j) -> float2 {
-            const float4* e = (const float4*)(rd_base + (j & 127) * 16);
-            float4 v = *e;
-            if (!__all(__float_as_int(v.z) == j + 1)) {
+        // wait for positions j .. j+3 in the ring and return this lane's chain (one check per four positions:
+        // a wave that lags behind its ring mate catches up at the cost of the pushes alone)
+        auto ring_get4 = [&](int j, float (&uo)[4]) {
+            const float2* e = (const float2*)(rd_base + (j & 127) * 8);       // j % 4 == 0: no wrap inside the group
+            float2 v0 = e[0], v1 = e[RS], v2 = e[2 * RS], v3 = e[3 * RS];
+            if (!__all(__float_as_int(v3.y) == j + 4)) {
                 int spins = 0;
                 while (true) {
                     __builtin_amdgcn_s_sleep(1);
                     asm volatile("" ::: "memory");           // force a fresh LDS read
-                    v = *e;
-                    if (__all(__float_as_int(v.z) == j + 1)) break;
+                    v3 = e[3 * RS];
+                    if (__all(__float_as_int(v3.y) == j + 4)) break;
                     if (spin_abort(ctrl, spins, SPIN_LIMIT_LDS, 2)) break;
                 }
+                asm volatile("" ::: "memory");
+                v0 = e[0]; v1 = e[RS]; v2 = e[2 * RS];       // published in order: all there once the last one is
             }
-            return make_float2(v.x, v.y);
+            uo[0] = v0.x; uo[1] = v1.x; uo[2] = v2.x; uo[3] = v3.x;
         };
 
         // ---------------- shadow phase: apply a block published by a ring mate ---------------------
@@ -317,225 +467,158 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, float* 
         auto shadow = [&](const SpineBlk& X, int b, bool last) {
             if (trace) ev[3 + (b - (k - 3))] = __builtin_readcyclecounter();
 #pragma unroll
-            for (int u = 0; u < PB; ++u) {
-                const int j = b * PB + u;
-                const float2 uv = ring_get(j);
-                if (MODE == 0) {
-                    float p0 = fmaf(X.v[u].x, LOG2E, uv.x), p1 = fmaf(X.v[u].y, LOG2E, uv.y);
-                    if (GRAD && rvalid && j < prow)
-                        *(float2*)(growp + (long long)j * stride) =
-                            make_float2(gz[0] * fexp2(p0 + arow[0]), gz[1] * fexp2(p1 + arow[1]));
-                    if (last && u == PB - 1 && r == 0) {
-                        if (GRAD && rvalid)       // noise marginal of the gap between prow-1 and prow
-                            *(float2*)(dNoise + (size_t)gap_of<DIR>(prow, T) * Bs + c) =
-                                make_float2(gz[0] * fexp2(uv.x + nz[0] * LOG2E + arow[0]),
-                                            gz[1] * fexp2(uv.y + nz[1] * LOG2E + arow[1]));
-                        p0 = uv.x + wl[0]; p1 = uv.y + wl[1];
+            for (int u4 = 0; u4 < PB; u4 += 4) {
+                float uq[4];
+                ring_get4(b * PB + u4, uq);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int u = u4 + q;
+                    const int j = b * PB + u;
+                    const float uv = uq[q];
+                    if (MODE == 0) {
+                        float p = fmaf(X.v[u], LOG2E, uv);
+                        if (GRAD && rvalid && j < prow) grad_store(j, gz * fexp2(p + arow));
+                        if (last && u == PB - 1 && r == 0) {
+                            if (GRAD && rvalid)       // noise marginal of the gap between prow-1 and prow
+                                dNoise[(size_t)gap_of<DIR>(prow, T) * Bs + c] = gz * fexp2(uv + nz * LOG2E + arow);
+                            p = uv + wl;
+                        }
+                        acc_push1(aM, aS, p);
+                    } else {
+                        const int key = frame_of<DIR>(j, T);
+                        if (last && u == PB - 1 && r == 0) max_push(aM, aK, uv + nz, -1);   // the skip candidate goes first
+                        max_push(aM, aK, uv + X.v[u], key);
                     }
-                    lse_push2(p0, p1);
-                } else {
-                    const int key = frame_of<DIR>(j, T);
-                    if (last && u == PB - 1 && r == 0) {         // the skip candidate goes first (key -1)
-                        max_push(aM[0], aK[0], uv.x + nz[0], -1);
-                        max_push(aM[1], aK[1], uv.y + nz[1], -1);
-                    }
-                    max_push(aM[0], aK[0], uv.x + X.v[u].x, key);
-                    max_push(aM[1], aK[1], uv.y + X.v[u].y, key);
                 }
             }
         };
 
         if (k >= 3) shadow(A, k - 3, false);
-        A = load_block(k);                               // own block: two blocks of lead
         if (k >= 2) shadow(Bk, k - 2, false);
-
-        // far-field partials of this block: request them one block ahead of the diagonal phase
-        const int nparts = k >= RING ? (k - RING) / TPT + 1 : 0;
-        u64 fg[FAR_PREFETCH][2];
-#pragma unroll
-        for (int part = 0; part < FAR_PREFETCH; ++part) {
-            fg[part][0] = 0; fg[part][1] = 0;
-            if (part < nparts && rvalid && !(dbg & 1u)) {
-                const u64* fp = farg + ((size_t)part * T + prow) * Bs + c;
-                fg[part][0] = load_granule(fp);
-                fg[part][1] = load_granule(fp + 1);
-            }
-        }
         if (k >= 1) shadow(C, k - 1, true);
 
         // ---------------- diagonal phase: finalise the 16 positions of block k ------------------------
+        __builtin_amdgcn_s_setprio(3);       // the dependent chain goes before everything else on this SIMD
         if (trace) ev[6] = __builtin_readcyclecounter();
-        if (nparts > 0 && !(dbg & 1u) && rvalid) {
-            for (int part = 0; part < nparts; ++part) {
-                const u64* fp = farg + ((size_t)part * T + prow) * Bs + c;
-                u64 g0 = 0, g1 = 0;
-#pragma unroll
-                for (int q = 0; q < FAR_PREFETCH; ++q) if (q == part) { g0 = fg[q][0]; g1 = fg[q][1]; }
+        if (k >= RING && !(dbg & 1u)) {
+            // combined far-field partial of this (row, chain), left in LDS by the far wave
+            const float4* fe = far + (k & 7) * 64 + lane;
+            float4 f = *fe;
+            if (!__all(__float_as_int(f.z) == k + 1)) {
                 int spins = 0;
                 while (true) {
-                    bool ok;
-                    if (MODE == 0) ok = (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag;
-                    else ok = (unsigned)(g0 >> 48) == (tag & 0xffffu) && (unsigned)(g1 >> 48) == (tag & 0xffffu);
-                    if (ok) break;
-                    __builtin_amdgcn_s_sleep(2);
-                    if (spin_abort(ctrl, spins, SPIN_LIMIT, 3)) break;
-                    g0 = load_granule(fp);
-                    g1 = load_granule(fp + 1);
+                    __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+                    f = *fe;
+                    if (__all(__float_as_int(f.z) == k + 1)) break;
+                    if (spin_abort(ctrl, spins, SPIN_LIMIT_LDS, 8)) break;
                 }
-                if (MODE == 0) {
-                    acc_push1(aM[0], aS[0], __uint_as_float((unsigned)g0));
-                    acc_push1(aM[1], aS[1], __uint_as_float((unsigned)g1));
-                } else {
-                    max_push(aM[0], aK[0], __uint_as_float((unsigned)g0), (int)((g0 >> 32) & 0xffffu));
-                    max_push(aM[1], aK[1], __uint_as_float((unsigned)g1), (int)((g1 >> 32) & 0xffffu));
-                }
+            }
+            if (rvalid) {
+                if (MODE == 0) acc_push1(aM, aS, f.x);
+                else max_push(aM, aK, f.x, __float_as_int(f.y));
             }
         }
 
-        float* const wr = wr_base + (own0 & 127) * 16;       // ring entry of position own0 (+16 floats per step)
-        int mykey[2] = {-1, -1};
+        float* const wr = wr_base + (own0 & 127) * 8;        // ring entry of position own0 (+8 floats per step)
+        int mykey = -1;
         if (MODE == 0) {
-            const float W[2] = {wl[0] + sp[0], wl[1] + sp[1]};
-            float Vp[2] = {aM[0] + flog2(aS[0]) + sp[0], aM[1] + flog2(aS[1]) + sp[1]};
-            float cv[2] = {prow == 0 ? sp[0] : Vp[0], prow == 0 ? sp[1] : Vp[1]};      // value of row 0 (lanes r == 0)
+            const float W = wl + sp;
+            float Vp = aM + flog2(aS) + sp;
+            float cv = prow == 0 ? sp : Vp;                  // value of row 0 (lanes r == 0)
 #pragma unroll
             for (int jj = 0; jj < PB; ++jj) {
                 const int j = own0 + jj;
                 // broadcast u[j] from the lanes of row jj to everybody
-                const float u0 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + (jj << 4), __float_as_int(cv[0])));
-                const float u1 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + (jj << 4), __float_as_int(cv[1])));
-                // publish it: data, then sequence number (in-order DS queue)
-                *(float4*)(wr + jj * 16) = make_float4(u0, u1, __int_as_float(j + 1), 0.0f);   // one DS write: data + seq
+                const float u = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + (jj << 4), __float_as_int(cv)));
+                *(float2*)(wr + jj * 8) = make_float2(u, __int_as_float(j + 1));    // one DS write: data + seq
                 // critical chain: value of row jj+1 = logaddexp2(Vp, u + W) (only its lanes matter)
-                const float t0 = u0 + W[0], t1 = u1 + W[1];
-                cv[0] = fmaxf(Vp[0], t0) + flog2(1.0f + fexp2(-fabsf(Vp[0] - t0)));
-                cv[1] = fmaxf(Vp[1], t1) + flog2(1.0f + fexp2(-fabsf(Vp[1] - t1)));
-                // generic push for the rows further down (branch-free exact-max form: the whole step stays one
-                // basic block so that the scheduler can overlap it with the critical chain), then refresh Vp
-                {
-                    const float p0 = fmaf(A.v[jj].x, LOG2E, u0), p1 = fmaf(A.v[jj].y, LOG2E, u1);
-                    if (GRAD) {
-                        if (rvalid && r > jj)
-                            *(float2*)(growp + (long long)j * stride) =
-                                make_float2(gz[0] * fexp2(p0 + arow[0]), gz[1] * fexp2(p1 + arow[1]));
-                        if (rvalid && r == jj + 1)
-                            *(float2*)(dNoise + (size_t)gap_of<DIR>(prow, T) * Bs + c) =
-                                make_float2(gz[0] * fexp2(u0 + nz[0] * LOG2E + arow[0]),
-                                            gz[1] * fexp2(u1 + nz[1] * LOG2E + arow[1]));
-                    }
-                    const float n0 = fmaxf(aM[0], p0), n1 = fmaxf(aM[1], p1);
-                    aS[0] = fmaf(aS[0], fexp2(aM[0] - n0), fexp2(p0 - n0));      // M = -inf: exp2(-inf) = 0, S = 0
-                    aS[1] = fmaf(aS[1], fexp2(aM[1] - n1), fexp2(p1 - n1));
-                    aM[0] = n0; aM[1] = n1;
+                const float t = u + W;
+                cv = fmaxf(Vp, t) + flog2(1.0f + fexp2(-fabsf(Vp - t)));
+                // generic push for the rows further down, then refresh Vp
+                const float p = fmaf(D.v[jj], LOG2E, u);
+                if (GRAD) {
+                    if (rvalid && r > jj) grad_store(j, gz * fexp2(p + arow));
+                    if (rvalid && r == jj + 1)
+                        dNoise[(size_t)gap_of<DIR>(prow, T) * Bs + c] = gz * fexp2(u + nz * LOG2E + arow);
                 }
-                Vp[0] = aM[0] + flog2(aS[0]) + sp[0];
-                Vp[1] = aM[1] + flog2(aS[1]) + sp[1];
+                acc_push1(aM, aS, p);
+                Vp = aM + flog2(aS) + sp;
             }
         } else {
             // (max,+): after the push of u[jj] the accumulator of row jj+1 is complete
-            float cv[2];
+            float cv;
             {
-                const float b0 = prow == 0 ? 0.0f : aM[0], b1 = prow == 0 ? 0.0f : aM[1];
-                cv[0] = sp[0] > 0.0f ? b0 + sp[0] : b0;
-                cv[1] = sp[1] > 0.0f ? b1 + sp[1] : b1;
-                if (r == 0) { mykey[0] = prow == 0 ? -1 : aK[0]; mykey[1] = prow == 0 ? -1 : aK[1]; }
+                const float b0 = prow == 0 ? 0.0f : aM;
+                cv = sp > 0.0f ? b0 + sp : b0;
+                if (r == 0) mykey = prow == 0 ? -1 : aK;
             }
 #pragma unroll
             for (int jj = 0; jj < PB; ++jj) {
                 const int j = own0 + jj;
-                const float u0 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + (jj << 4), __float_as_int(cv[0])));
-                const float u1 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + (jj << 4), __float_as_int(cv[1])));
-                *(float4*)(wr + jj * 16) = make_float4(u0, u1, __int_as_float(j + 1), 0.0f);
+                const float u = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + (jj << 4), __float_as_int(cv)));
+                *(float2*)(wr + jj * 8) = make_float2(u, __int_as_float(j + 1));
                 const int key = frame_of<DIR>(j < T ? j : T - 1, T);
-                if (r == jj + 1) {                               // the skip candidate goes first (key -1)
-                    max_push(aM[0], aK[0], u0 + nz[0], -1);
-                    max_push(aM[1], aK[1], u1 + nz[1], -1);
-                }
-                max_push(aM[0], aK[0], u0 + A.v[jj].x, key);
-                max_push(aM[1], aK[1], u1 + A.v[jj].y, key);
-                cv[0] = sp[0] > 0.0f ? aM[0] + sp[0] : aM[0];
-                cv[1] = sp[1] > 0.0f ? aM[1] + sp[1] : aM[1];
-                if (r == jj + 1) { mykey[0] = aK[0]; mykey[1] = aK[1]; }
+                if (r == jj + 1) max_push(aM, aK, u + nz, -1);                  // the skip candidate goes first (key -1)
+                max_push(aM, aK, u + D.v[jj], key);
+                cv = sp > 0.0f ? aM + sp : aM;
+                if (r == jj + 1) mykey = aK;
             }
         }
+        __builtin_amdgcn_s_setprio(1);
         if (trace) ev[7] = __builtin_readcyclecounter();
 
         // ---- once per block: publish the 16 finished positions to HBM -----------------------------
         if (rvalid) {
-            const float2 mine = *(const float2*)(rd_base + (prow & 127) * 16);
-            store_granule(ug + (size_t)prow * Bs + c, make_granule(tag, mine.x));
-            store_granule(ug + (size_t)prow * Bs + c + 1, make_granule(tag, mine.y));
+            const float mine = rd_base[(prow & 127) * 8];
+            store_granule(ug + (size_t)prow * Bs + c, make_granule(tag, mine));
             const float sc = MODE == 0 ? LN2 : 1.0f;
-            if (u_out) *(float2*)(u_out + (size_t)frow * Bs + c) = make_float2(mine.x * sc, mine.y * sc);
-            if (last_out && prow == T - 1) *(float2*)(last_out + c) = make_float2(mine.x * sc, mine.y * sc);
+            if (u_out) u_out[(size_t)frow * Bs + c] = mine * sc;
+            if (last_out && prow == T - 1) last_out[c] = mine * sc;
             if (GRAD)      // diagonal: gout * exp(alpha + beta - logZ + s - 2 softplus(s))
-                *(float2*)(dScore + ((size_t)frow * T + frow) * Bs + c) =
-                    make_float2(gz[0] * fexp2(arow[0] + mine.x + draw[0] - 2.0f * sp[0]),
-                                gz[1] * fexp2(arow[1] + mine.y + draw[1] - 2.0f * sp[1]));
-            if (MODE == 1) {
-                code[(size_t)c * T + frow] = (mykey[0] + 1) | (sp[0] > 0.0f ? 0x40000000 : 0);
-                code[(size_t)(c + 1) * T + frow] = (mykey[1] + 1) | (sp[1] > 0.0f ? 0x40000000 : 0);
-            }
+                dScore[((size_t)frow * T + frow) * Bs + c] = gz * fexp2(arow + mine + draw - 2.0f * sp);
+            if (MODE == 1) code[(size_t)c * T + frow] = (mykey + 1) | (sp > 0.0f ? 0x40000000 : 0);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// PANEL role
+// PANEL role (per wave)
 // ---------------------------------------------------------------------------------------------
-// Workgroup = 4 waves, position block k (16 positions), 32 chains.  lane = slot*8 + quad8:
-// quad8 selects 4 of the 32 chains, so 8 consecutive lanes read one 128-byte line.
-//   DIR 0: wave w owns positions 16k+4w+r (r<4); per tile a lane holds columns pj = 16m+slot+8h.
-//   DIR 1: wave w owns tile rows pj = 16m+4w+r; a lane holds positions pi = 16k+slot+8h.
-// Cells and u-granules of tile m+1 are requested before tile m is processed.
+// A wave owns rows pi = 16k + 4*q4 + rr (rr < 4) of position block k for 32 chains.  lane = slot*8 + q8:
+// q8 selects 4 of the 32 chains (8 consecutive lanes read one 128-byte line), slot selects the columns
+// pj = 16m + slot + 8h (h < 2) of tile m.  Cells and u-granules of tile m+1 are requested before tile m is
+// processed.  The same mapping serves both directions (only cell_index differs).
 template <int MODE, int DIR, bool GRAD>
-__device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int* s_task)
+__device__ __forceinline__ void panel_role(const SweepParams& P)
 {
     const int T = P.T, B = P.B;
+    const int c0 = P.c0, c1 = P.c1;
     const unsigned dbg = P.dbg;
     unsigned* const ctrl = P.ctrl;
     u64* const farg = P.farg;
     const int nTasks = P.nTasks, nPanelGroups = P.nPanelGroups;
-    const int maxAside = P.nSpine;
     const float* const vfwd = P.vfwd;
     const float* const logZp = P.logZ;
     const float* const goutp = P.gout;
     float* const dScore = P.dScore;
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
+    const int lane = threadIdx.x & 63;
     const int slot = lane >> 3, q8 = lane & 7;
     const size_t Bs = (size_t)B;
     const float* __restrict__ score = P.score;
     const unsigned tag = P.tag;
-    constexpr int NA = DIR == 0 ? 4 : 2;        // accumulators per chain: rows (DIR 0) or column halves (DIR 1)
-    constexpr int NU = DIR == 0 ? 2 : 4;        // u positions a lane needs per tile
-    constexpr int NL = DIR == 0 ? 2 : 1;        // u positions a lane LOADS per tile (DIR 1: position slot&3, shared by shuffles)
     const auto ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.ug, 0, (int)((size_t)T * Bs * 8), 0x00020000);
 
-    if (dbg & 128u) {
-        // power probe: burn ALU cycles for ~300 us without touching memory (is the spine slowed by clocks or by traffic?)
-        float a = (float)threadIdx.x, b = 1.0001f;
-        for (int i = 0; i < 20000; ++i) { a = fmaf(a, b, 0.5f); b = fmaf(b, 0.9999f, 0.0001f); }
-        if (a == 12345.678f) ctrl[5] = 1;
-        return;
-    }
     while (true) {
-        // ---- next task: (k, part, g), ordered so that a task only waits on spine progress below k-3 ----
-        __syncthreads();
-        if (tid == 0) {
-            int t = -1;
-            // leave the CU to the spine if one lives here (at most maxAside panels do so, the rest keep working)
-            if (!(dbg & 64u) && __hip_atomic_load(ctrl + 64 + cu_key(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u &&
-                atomicAdd(ctrl + 3, 1u) < (unsigned)maxAside) t = 0x7fffffff;
-            if (t < 0) t = (int)atomicAdd(ctrl + 2, 1u);
-            *s_task = t;
-        }
-        __syncthreads();
-        const int task = *s_task;
+        // ---- next task: (k, part, g, q4), ordered so that a task only waits on spine progress below k-3 ----
+        int task = 0;
+        if (lane == 0) task = (int)atomicAdd(ctrl + 2, 1u);
+        task = __builtin_amdgcn_readfirstlane(task);
         if (task >= nTasks) break;
-        const int g = task % nPanelGroups;
-        int tt = task / nPanelGroups;
+        const int q4 = task & 3;
+        const int t2 = task >> 2;
+        const int g = t2 % nPanelGroups;
+        int tt = t2 / nPanelGroups;
         int a = 0;
         while (tt >= TPT * (a + 1) * (a + 2) / 2) ++a;          // group a: blocks with a+1 parts
         tt -= TPT * a * (a + 1) / 2;
@@ -544,68 +627,91 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int
         const int k = RING + q;
         const int m0 = part * TPT;
         const int m1 = (m0 + TPT < q + 1) ? m0 + TPT : q + 1;   // tiles m0 .. m1-1 of the q+1 far tiles of block k
-        const int c = g * GP + q8 * 4;
-        const bool cvalid = c < B;
+        const int pbase = k * PB + q4 * 4;
+        if (pbase >= T) continue;                               // rows past the end (last block)
+        const int c = c0 + g * GP + q8 * 4;
+        const bool cvalid = c < c1;
+        const int cl = cvalid ? c : c0;                         // clamped chain for addresses
 
-        float aM[NA][4], aS[NA][4];
-        int aK[NA][4];
+        float aM[4][4], aS[4][4];
+        int aK[4][4];
 #pragma unroll
-        for (int ai = 0; ai < NA; ++ai)
+        for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { aM[ai][i] = SEMICRF_NEG_INF; aS[ai][i] = 0.f; aK[ai][i] = 0x7fffffff; }
+            for (int i = 0; i < 4; ++i) { aM[rr][i] = SEMICRF_NEG_INF; aS[rr][i] = 0.f; aK[rr][i] = 0x7fffffff; }
 
-        // GRAD (DIR 1): marginal(pi, pj) = gz * exp2(t + arow[h]), arow = (alpha[frame(pi)] - logZ) * log2e
-        float arow[2][4], gz[4];
+        // GRAD: marginal(pi, pj) = gz * exp2(t + arow[rr]), arow = (alpha[frame(pi)] - logZ) * log2e
+        float arow[4][4], gz[4];
         if (GRAD) {
             float lz[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const bool ok = c + i < B;
+                const bool ok = c + i < c1;
                 lz[i] = ok ? logZp[c + i] : 0.f;
                 gz[i] = ok ? goutp[c + i] : 0.f;
             }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int pi = k * PB + slot + 8 * h;
+            for (int rr = 0; rr < 4; ++rr) {
+                const int pi = pbase + rr;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float vv = (c + i < B && pi < T) ? vfwd[(size_t)frame_of<DIR>(pi, T) * Bs + c + i] : 0.f;
-                    arow[h][i] = (vv - lz[i]) * LOG2E;
+                    const float vv = (c + i < c1 && pi < T) ? vfwd[(size_t)frame_of<DIR>(pi, T) * Bs + c + i] : 0.f;
+                    arow[rr][i] = (vv - lz[i]) * LOG2E;
                 }
             }
         }
-        float4 x[2][4][2];    // [buffer][r][h] cells
-        v4u gq[2][NL][2];     // [buffer][loaded u position][chain pair] granules (2 granules per 16-byte load)
-        auto pi_of = [&](int rr, int h) { return DIR == 0 ? k * PB + wave * 4 + rr : k * PB + slot + 8 * h; };
-        auto pj_of = [&](int m, int rr, int h) { return DIR == 0 ? m * PB + slot + 8 * h : m * PB + wave * 4 + rr; };
-        auto pu_of = [&](int m, int ai) { return DIR == 0 ? m * PB + slot + 8 * ai : m * PB + wave * 4 + ai; };
+        float4 x[2][4][2];    // [buffer][rr][h] cells
+        v4u gq[2][2][2];      // [buffer][h][chain pair] granules (2 granules per 16-byte load)
+
+        // Buffer addressing: one VGPR byte offset per lane (constant over the task), everything that depends
+        // on (tile, rr, h) is wave-uniform and lives in the SGPR base / soffset -- no per-load 64-bit VALU math.
+        //   DIR 0: cell(pi, pj) = (pi*T + pj)*B: tile base at (pi_0, 16m), lane part slot*B, soffset ((pi_rr-pi_0)*T + 8h)*B
+        //   DIR 1: cell(pi, pj) = ((T-1-pj)*T + (T-1-pi))*B: tile base at (pi_3, 16m+15), lane part (7-slot)*T*B,
+        //          soffset ((1-h)*8*T + (pi_3-pi_rr))*B            (pi_rr = min(pbase+rr, T-1))
+        int pirow[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) pirow[rr] = pbase + rr < T ? pbase + rr : T - 1;
+        const unsigned voff = DIR == 0 ? (unsigned)((slot * B + cl) * 4)
+                                       : (unsigned)(((size_t)(7 - slot) * T * Bs + cl) * 4);
+        unsigned soff[4][2];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                soff[rr][h] = DIR == 0 ? (unsigned)((((size_t)(pirow[rr] - pirow[0]) * T + 8 * h) * Bs) * 4)
+                                       : (unsigned)((((size_t)(1 - h) * 8 * T + (pirow[3] - pirow[rr])) * Bs) * 4);
+        auto tile_off = [&](int m) -> size_t {       // element offset of the tile base
+            return DIR == 0 ? ((size_t)pirow[0] * T + (size_t)m * PB) * Bs
+                            : ((size_t)(T - 1 - (m * PB + 15)) * T + (size_t)(T - 1 - pirow[3])) * Bs;
+        };
+        const unsigned gvoff = (unsigned)((slot * B + cl) * 8);
 
         auto load_tile = [&](auto bufc, int m) {
             constexpr int buf = decltype(bufc)::value;
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(score + tile_off(m)), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int pi = pi_of(rr, h), pj = pj_of(m, rr, h);
-                    const size_t ci = cell_index<DIR>(pi < T ? pi : T - 1, pj, T);
-                    x[buf][rr][h] = *(const float4*)(score + ci * Bs + (cvalid ? c : 0));
+                    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff[rr][h], 0);
+                    x[buf][rr][h] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
+                                                __uint_as_float(v.w));
                 }
         };
         auto load_gran = [&](auto bufc, int m) {
             constexpr int buf = decltype(bufc)::value;
-            if (dbg & 32u) return;
+            if (SEMICRF_PANEL_PROBES && (dbg & 32u)) return;
 #pragma unroll
-            for (int ai = 0; ai < NL; ++ai) {
-                const int pu = DIR == 0 ? pu_of(m, ai) : m * PB + wave * 4 + (slot & 3);
-                const int off = (int)(((size_t)pu * Bs + (cvalid ? c : 0)) * 8);
-                gq[buf][ai][0] = __builtin_amdgcn_raw_buffer_load_b128(ursrc, off, 0, 16);        // sc1
-                gq[buf][ai][1] = __builtin_amdgcn_raw_buffer_load_b128(ursrc, off + 16, 0, 16);
+            for (int h = 0; h < 2; ++h) {
+                const unsigned so = (unsigned)((m * PB + 8 * h) * B * 8);
+                gq[buf][h][0] = __builtin_amdgcn_raw_buffer_load_b128(ursrc, gvoff, so, 16);        // sc1
+                gq[buf][h][1] = __builtin_amdgcn_raw_buffer_load_b128(ursrc, gvoff + 16, so, 16);
             }
         };
 
         auto process_tile = [&](auto bufc, int m) {
             constexpr int buf = decltype(bufc)::value;
-            if (dbg & 32u) {          // streaming probe: touch the data, nothing else
+            if (SEMICRF_PANEL_PROBES && (dbg & 32u)) {          // streaming probe: touch the data, nothing else
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
@@ -613,96 +719,90 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int
                         aS[0][0] += x[buf][rr][h].x + x[buf][rr][h].y + x[buf][rr][h].z + x[buf][rr][h].w;
                 return;
             }
-            // every granule carries its own tag: retry until the spine has published block m
-            if (!(dbg & 4u)) {
-                int spins = 0;
-                while (true) {
-                    bool ok = true;
-#pragma unroll
-                    for (int ai = 0; ai < NL; ++ai)
-#pragma unroll
-                        for (int hh = 0; hh < 2; ++hh)
-                            ok = ok && (gq[buf][ai][hh].y == tag || c + 2 * hh >= B) &&
-                                 (gq[buf][ai][hh].w == tag || c + 2 * hh + 1 >= B);
-                    if (__all(ok || !cvalid)) break;
-                    __builtin_amdgcn_s_sleep(16);
-                    if (spin_abort(ctrl, spins, SPIN_LIMIT, 5)) break;
+            // every granule carries its own tag: if some are missing, poll (probe loads into temporaries) until the
+            // spine has published block m, then fetch the tile's granules once more -- nothing is carried around the loop
+            if (!(SEMICRF_PANEL_PROBES && (dbg & 4u))) {
+                auto tags_ok = [&](const v4u& a0, const v4u& a1, const v4u& b0, const v4u& b1) {
+                    const bool v0 = c < c1, v1 = c + 1 < c1, v2 = c + 2 < c1, v3 = c + 3 < c1;
+                    const bool ok = (a0.y == tag || !v0) && (a0.w == tag || !v1) && (a1.y == tag || !v2) && (a1.w == tag || !v3) &&
+                                    (b0.y == tag || !v0) && (b0.w == tag || !v1) && (b1.y == tag || !v2) && (b1.w == tag || !v3);
+                    return __all(ok) != 0;
+                };
+                if (!tags_ok(gq[buf][0][0], gq[buf][0][1], gq[buf][1][0], gq[buf][1][1])) {
+                    int spins = 0;
+                    const unsigned so0 = (unsigned)((m * PB) * B * 8), so1 = (unsigned)((m * PB + 8) * B * 8);
+                    while (true) {
+                        __builtin_amdgcn_s_sleep(16);
+                        const v4u p00 = __builtin_amdgcn_raw_buffer_load_b128(ursrc, gvoff, so0, 16);
+                        const v4u p01 = __builtin_amdgcn_raw_buffer_load_b128(ursrc, gvoff + 16, so0, 16);
+                        const v4u p10 = __builtin_amdgcn_raw_buffer_load_b128(ursrc, gvoff, so1, 16);
+                        const v4u p11 = __builtin_amdgcn_raw_buffer_load_b128(ursrc, gvoff + 16, so1, 16);
+                        if (tags_ok(p00, p01, p10, p11)) break;
+                        if (spin_abort(ctrl, spins, SPIN_LIMIT, 5)) break;
+                    }
                     load_gran(bufc, m);
                 }
             }
-            float uv[NU][4];
-            if (DIR == 0) {
+            float uv[2][4];
 #pragma unroll
-                for (int ai = 0; ai < NL; ++ai) {
-                    uv[ai][0] = __uint_as_float(gq[buf][ai][0].x); uv[ai][1] = __uint_as_float(gq[buf][ai][0].z);
-                    uv[ai][2] = __uint_as_float(gq[buf][ai][1].x); uv[ai][3] = __uint_as_float(gq[buf][ai][1].z);
-                }
-            } else {
-                // position a lives in the lanes with slot == a (and a+4): fetch it from lane (a << 3) | q8
-                const float own[4] = {__uint_as_float(gq[buf][0][0].x), __uint_as_float(gq[buf][0][0].z),
-                                      __uint_as_float(gq[buf][0][1].x), __uint_as_float(gq[buf][0][1].z)};
-#pragma unroll
-                for (int ai = 0; ai < NU; ++ai)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) uv[ai][i] = __shfl(own[i], (ai << 3) | q8);
+            for (int h = 0; h < 2; ++h) {
+                uv[h][0] = __uint_as_float(gq[buf][h][0].x); uv[h][1] = __uint_as_float(gq[buf][h][0].z);
+                uv[h][2] = __uint_as_float(gq[buf][h][1].x); uv[h][3] = __uint_as_float(gq[buf][h][1].z);
             }
 
             if (MODE == 0) {
-                // t = u + cell*log2e; lazily rescaled accumulators: one exp per cell, rare rescale branch
-                float t[4][2][4];
-                float exc = 0.0f;
+                // t = u + cell*log2e; lazily rescaled accumulators: one exp per cell, rare rescale branch.
+                // One row at a time (scheduling fences in between) to bound the live registers.
+                const auto gs = __builtin_amdgcn_make_buffer_rsrc((void*)(GRAD ? dScore + tile_off(m) : nullptr), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
+                for (int rr = 0; rr < 4; ++rr) {
+                    float t[2][4];
+                    float exc = 0.0f;
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const float4 xv = x[buf][rr][h];
                         const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
-                        const int ai = DIR == 0 ? rr : h, ui = DIR == 0 ? h : rr;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            t[rr][h][i] = fmaf(xe[i], LOG2E, uv[ui][i]);
-                            exc = fmaxf(exc, t[rr][h][i] - (aM[ai][i] + RESCALE_THR));
+                            t[h][i] = fmaf(xe[i], LOG2E, uv[h][i]);
+                            exc = fmaxf(exc, t[h][i] - (aM[rr][i] + RESCALE_THR));
                         }
                     }
-                if (GRAD) {
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr)
+                    if (GRAD) {
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            const int pi = pi_of(rr, h), pj = pj_of(m, rr, h);
-                            if (cvalid && pi < T) {
-                                float* dst = dScore + cell_index<DIR>(pi, pj, T) * Bs + c;
-                                const float g0 = gz[0] * fexp2(t[rr][h][0] + arow[h][0]), g1 = gz[1] * fexp2(t[rr][h][1] + arow[h][1]);
-                                const float g2 = gz[2] * fexp2(t[rr][h][2] + arow[h][2]), g3 = gz[3] * fexp2(t[rr][h][3] + arow[h][3]);
-                                if (c + 3 < B) *(float4*)dst = make_float4(g0, g1, g2, g3);
-                                else *(float2*)dst = make_float2(g0, g1);            // B % 4 == 2: last pair only
+                            if (cvalid && pbase + rr < T) {
+                                v4u gv;
+                                gv.x = __float_as_uint(gz[0] * fexp2(t[h][0] + arow[rr][0]));
+                                gv.y = __float_as_uint(gz[1] * fexp2(t[h][1] + arow[rr][1]));
+                                gv.z = __float_as_uint(gz[2] * fexp2(t[h][2] + arow[rr][2]));
+                                gv.w = __float_as_uint(gz[3] * fexp2(t[h][3] + arow[rr][3]));
+                                if (c + 3 < c1) __builtin_amdgcn_raw_buffer_store_b128(gv, gs, voff, soff[rr][h], 0);
+                                else {                                  // ragged tail of the chain range
+                                    __builtin_amdgcn_raw_buffer_store_b32(gv.x, gs, voff, soff[rr][h], 0);
+                                    if (c + 1 < c1) __builtin_amdgcn_raw_buffer_store_b32(gv.y, gs, voff + 4, soff[rr][h], 0);
+                                    if (c + 2 < c1) __builtin_amdgcn_raw_buffer_store_b32(gv.z, gs, voff + 8, soff[rr][h], 0);
+                                }
                             }
                         }
-                }
-                if (__any(exc > 0.0f)) {
-                    // some accumulator's reference point is too low (always on the first tile): move it up
-#pragma unroll
-                    for (int ai = 0; ai < NA; ++ai)
+                    }
+                    if (__any(exc > 0.0f)) {
+                        // some accumulator's reference point is too low (always on the first tile): move it up
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            float mx = aM[ai][i];
-#pragma unroll
-                            for (int e = 0; e < (DIR == 0 ? 2 : 4); ++e)
-                                mx = fmaxf(mx, DIR == 0 ? t[ai][e][i] : t[e][ai][i]);
-                            if (mx > aM[ai][i] + RESCALE_THR) {
-                                aS[ai][i] = aS[ai][i] * fexp2(aM[ai][i] - mx);     // -inf - mx -> exp2 = 0, S = 0
-                                aM[ai][i] = mx;
+                            const float mx = fmaxf(aM[rr][i], fmaxf(t[0][i], t[1][i]));
+                            if (mx > aM[rr][i] + RESCALE_THR) {
+                                aS[rr][i] = aS[rr][i] * fexp2(aM[rr][i] - mx);     // -inf - mx -> exp2 = 0, S = 0
+                                aM[rr][i] = mx;
                             }
                         }
-                }
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int ai = DIR == 0 ? rr : h;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) aS[ai][i] += fexp2(t[rr][h][i] - aM[ai][i]);
                     }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) aS[rr][i] += fexp2(t[h][i] - aM[rr][i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             } else {
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr)
@@ -710,10 +810,9 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int
                     for (int h = 0; h < 2; ++h) {
                         const float4 xv = x[buf][rr][h];
                         const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
-                        const int ai = DIR == 0 ? rr : h, ui = DIR == 0 ? h : rr;
-                        const int key = frame_of<DIR>(pj_of(m, rr, h), T);
+                        const int key = frame_of<DIR>(m * PB + slot + 8 * h, T);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) max_push(aM[ai][i], aK[ai][i], uv[ui][i] + xe[i], key);
+                        for (int i = 0; i < 4; ++i) max_push(aM[rr][i], aK[rr][i], uv[h][i] + xe[i], key);
                     }
             }
         };
@@ -733,74 +832,51 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int
             }
         }
 
-        // ---- reduce the partials and hand them to the spine ------------------------------------------
-        u64* fbase = farg + (size_t)part * T * Bs;
-        if (DIR == 0) {
-            // across the 8 column slots of the wave (lane bits 3..5)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                    for (int off = 8; off < 64; off <<= 1) {
-                        const float oM = __shfl_xor(aM[rr][i], off);
-                        if (MODE == 0) {
-                            const float oS = __shfl_xor(aS[rr][i], off);
-                            acc_merge(aM[rr][i], aS[rr][i], oM, oS);
-                        } else {
-                            const int oK = __shfl_xor(aK[rr][i], off);
-                            max_push(aM[rr][i], aK[rr][i], oM, oK);
-                        }
-                    }
-                }
-            if (slot == 0 && cvalid) {
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int pi = k * PB + wave * 4 + rr;
-                    if (pi >= T) continue;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (c + i >= B) continue;
-                        u64 gr;
-                        if (MODE == 0) gr = make_granule(tag, aM[rr][i] + flog2(aS[rr][i]));
-                        else gr = ((u64)(((tag & 0xffffu) << 16) | ((unsigned)aK[rr][i] & 0xffffu)) << 32) |
-                                  (u64)__float_as_uint(aM[rr][i]);
-                        store_granule(fbase + (size_t)pi * Bs + c + i, gr);
-                    }
-                }
+        // ---- reduce over the 8 column slots (lane bits 3..5) as a reduce-scatter: each stage halves the
+        // accumulators a lane keeps, so 14 exchanges instead of 48; every lane ends with 2 of the 16 results
+        const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
+        auto xmerge = [&](float& kM, float& kS, int& kK, float sM, float sS, int sK, int off) {
+            const float oM = __shfl_xor(sM, off);
+            if (MODE == 0) {
+                const float oS = __shfl_xor(sS, off);
+                acc_merge(kM, kS, oM, oS);
+            } else {
+                const int oK = __shfl_xor(sK, off);
+                max_push(kM, kK, oM, oK);
             }
-        } else {
-            // across the 4 waves through LDS: lds[wave][h][slot][q8*4+i] x {M, S/K}
-            float* lm = lds;
-            float* ls = lds + 4 * 2 * 8 * 32;
+        };
+        float M1[2][4], S1[2][4];
+        int K1[2][4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+        for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int idx = ((wave * 2 + h) * 8 + slot) * 32 + q8 * 4 + i;
-                    lm[idx] = aM[h][i];
-                    ls[idx] = MODE == 0 ? aS[h][i] : __int_as_float(aK[h][i]);
-                }
-            __syncthreads();
-            // 16 positions x 32 chains = 512 results, 2 per thread
-            for (int e = tid; e < 2 * 8 * 32; e += 256) {
-                const int ch = e & 31, sl = (e >> 5) & 7, h = e >> 8;
-                float M = SEMICRF_NEG_INF, S = 0.f;
-                int Kk = 0x7fffffff;
+            for (int i = 0; i < 4; ++i) {
+                float kM = b5 ? aM[r2 + 2][i] : aM[r2][i], kS = b5 ? aS[r2 + 2][i] : aS[r2][i];
+                int kK = b5 ? aK[r2 + 2][i] : aK[r2][i];
+                xmerge(kM, kS, kK, b5 ? aM[r2][i] : aM[r2 + 2][i], b5 ? aS[r2][i] : aS[r2 + 2][i],
+                       b5 ? aK[r2][i] : aK[r2 + 2][i], 32);
+                M1[r2][i] = kM; S1[r2][i] = kS; K1[r2][i] = kK;
+            }
+        float M2[4], S2[4];
+        int K2[4];
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const int idx = ((w * 2 + h) * 8 + sl) * 32 + ch;
-                    if (MODE == 0) acc_merge(M, S, lm[idx], ls[idx]);
-                    else max_push(M, Kk, lm[idx], __float_as_int(ls[idx]));
-                }
-                const int pi = k * PB + sl + 8 * h;
-                const int cc = g * GP + ch;
-                if (pi < T && cc < B) {
-                    u64 gr;
-                    if (MODE == 0) gr = make_granule(tag, M + flog2(S));
-                    else gr = ((u64)(((tag & 0xffffu) << 16) | ((unsigned)Kk & 0xffffu)) << 32) | (u64)__float_as_uint(M);
-                    store_granule(fbase + (size_t)pi * Bs + cc, gr);
-                }
+        for (int i = 0; i < 4; ++i) {
+            float kM = b4 ? M1[1][i] : M1[0][i], kS = b4 ? S1[1][i] : S1[0][i];
+            int kK = b4 ? K1[1][i] : K1[0][i];
+            xmerge(kM, kS, kK, b4 ? M1[0][i] : M1[1][i], b4 ? S1[0][i] : S1[1][i], b4 ? K1[0][i] : K1[1][i], 16);
+            M2[i] = kM; S2[i] = kS; K2[i] = kK;
+        }
+        u64* fbase = farg + (size_t)part * T * Bs;
+        const int pi = pbase + (b5 ? 2 : 0) + (b4 ? 1 : 0);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float kM = b3 ? M2[2 + e] : M2[e], kS = b3 ? S2[2 + e] : S2[e];
+            int kK = b3 ? K2[2 + e] : K2[e];
+            xmerge(kM, kS, kK, b3 ? M2[e] : M2[2 + e], b3 ? S2[e] : S2[2 + e], b3 ? K2[e] : K2[2 + e], 8);
+            const int cc = c + (b3 ? 2 : 0) + e;
+            if (pi < T && cc < c1 && !(SEMICRF_PANEL_PROBES && (dbg & 32u))) {
+                const u64 gr = MODE == 0 ? make_granule(tag, kM + flog2(kS)) : make_granule_key(tag, kM, kK);
+                store_granule(fbase + (size_t)pi * Bs + cc, gr);
             }
         }
     }
@@ -809,26 +885,41 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, float* lds, int
 // ---------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------
+// Launched with enough dynamic LDS that only ONE workgroup fits a compute unit, so with grid <= #CUs every
+// workgroup is resident.  A SPINE workgroup (ticket < nSpine): waves 0-3 ring, wave 4 loader, wave 5 far wave,
+// waves 6.. panel waves (hybridPanelWaves of them); the other workgroups: `panelWaves` panel waves.
 template <int MODE, int DIR, bool GRAD>
-__global__ __launch_bounds__(256, 2) void persist_sweep_kernel(SweepParams P)
+__global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
 {
-    __shared__ __attribute__((aligned(16))) float s_ring[128 * 16];            // spine: ring of the last 128 published positions
-    __shared__ __attribute__((aligned(16))) float s_dummy[64 * 4 + 16 * 16];   // spine: sink of the non-writer lanes' stores
-    __shared__ float s_red[2 * 4 * 2 * 8 * 32];   // panel DIR 1 reduction
+    extern __shared__ __attribute__((aligned(16))) char s_dyn[];
     __shared__ int s_ticket;
-    __shared__ int s_task;
     if (threadIdx.x == 0) s_ticket = (int)atomicAdd(P.ctrl, 1u);
-    for (int i = threadIdx.x; i < 128 * 16; i += 256) s_ring[i] = 0.0f;      // sequence numbers start at 0
+    // flags and sequence numbers start at 0
+    for (int i = threadIdx.x; i < (LDS_DUMMY - LDS_FAR) / 4; i += NT) ((int*)(s_dyn + LDS_FAR))[i] = 0;
     __syncthreads();
     const int ticket = s_ticket;
+    const int wave = (int)(threadIdx.x >> 6);
     if (ticket < P.nSpine) {
-        if (!(P.dbg & 8u)) spine_role<MODE, DIR, GRAD>(P, ticket, s_ring, s_dummy);
+        // chain groups that share 32-byte sectors go to workgroups 8 tickets apart (same XCD, same L2)
+        int sg = ticket;
+        if ((P.nSpine & 7) == 0) sg = (ticket & 7) * (P.nSpine >> 3) + (ticket >> 3);
+        if (wave < RING) {
+            if (!(P.dbg & 8u)) spine_role<MODE, DIR, GRAD>(P, sg, wave, s_dyn);
+        } else if (wave == RING) {
+            if (!(P.dbg & 8u)) loader_role<DIR, GRAD>(P, sg, s_dyn);
+        } else if (wave == RING + 1) {
+            if (!(P.dbg & 9u)) far_role<MODE, DIR>(P, sg, s_dyn);
+        } else if (!(P.dbg & 2u) && wave - (RING + 2) < P.hybridPanelWaves) {
+            panel_role<MODE, DIR, GRAD>(P);
+        }
     } else {
-        if (!(P.dbg & 2u)) panel_role<MODE, DIR, GRAD>(P, s_red, &s_task);
+        if (!(P.dbg & 2u) && wave < P.panelWaves) panel_role<MODE, DIR, GRAD>(P);
     }
 }
 
-constexpr size_t CTRL_BYTES = (64 + 4096) * sizeof(unsigned);
+constexpr size_t CTRL_WORDS = 64;
+constexpr size_t CTRL_BYTES = MAX_CHUNKS * CTRL_WORDS * sizeof(unsigned);
+constexpr int LDS_DYN_BYTES = LDS_SPINE_BYTES > 84 * 1024 ? LDS_SPINE_BYTES : 84 * 1024;   // > half of the CU's 160 KB: one workgroup per CU
 
 static int max_parts(int T)
 {
@@ -842,10 +933,29 @@ __global__ __launch_bounds__(256) void zero_upper_kernel(float* __restrict__ dSc
     const int e = blockIdx.y;
     const size_t n = (size_t)(T - 1 - e) * B;                 // floats to clear in this row
     float* rowp = dScore + ((size_t)e * T + e + 1) * B;
-    const size_t n4 = ((uintptr_t)rowp & 15) == 0 ? n / 4 : 0;
+    const size_t lead = (4 - (((uintptr_t)rowp >> 2) & 3)) & 3;          // floats up to 16-byte alignment
+    const size_t head = lead < n ? lead : n;
+    const size_t n4 = (n - head) / 4;
+    float4* v = (float4*)(rowp + head);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
-        ((float4*)rowp)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) rowp[i] = 0.f;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) rowp[threadIdx.x] = 0.f;
+        const size_t tail0 = head + n4 * 4;
+        if (tail0 + threadIdx.x < n) rowp[tail0 + threadIdx.x] = 0.f;
+    }
+}
+
+static int device_cus()
+{
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0, v = 0;
+        ncu = 256;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+    }
+    return ncu;
 }
 
 size_t persist_workspace_bytes(int T, int B)
@@ -854,9 +964,13 @@ size_t persist_workspace_bytes(int T, int B)
            (size_t)(1 + max_parts(T)) * align_up((size_t)T * B * sizeof(u64));
 }
 
-// B even: the spine reads chain pairs; a panel lane reads 4 chains and masks the ones past B (B % 4 == 2: the
-// 16-byte loads are then only 8-byte aligned, which global memory accepts)
-bool persist_supported(int T, int B) { return (B % 2 == 0) && T >= 1 && T < 65535 && (long long)T * B * 8 < (1ll << 31); }
+// Even NBatch: the loader's 16-byte global->LDS loads and the panels' 16-byte loads need 8-byte aligned
+// addresses (4-byte aligned ones, i.e. odd NBatch, return wrong data); chains past the end of the range are masked.
+bool persist_supported(int T, int B)
+{
+    return B >= 2 && B % 2 == 0 && T >= 2 && T < 65535 && (long long)T * B * 64 < (1ll << 31) &&      // 32-bit buffer offsets
+           (B + GS - 1) / GS <= MAX_CHUNKS * 64;      // chain chunks of at most half the CUs' worth of rings
+}
 
 static unsigned next_tag()
 {
@@ -865,11 +979,23 @@ static unsigned next_tag()
     return (lo << 16) | lo;                                      // both 16-bit halves nonzero
 }
 
-// mode 0 = LSE, 1 = MAX.  ws must hold persist_workspace_bytes().  Enqueues a memset + one kernel.
 struct GradArgs {
     const float* vfwd; const float* logZ; const float* gout; float* dScore; float* dNoise;
 };
 
+template <int MODE, int DIR, bool GRAD>
+static void launch_one(const SweepParams& P, int grid, hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)persist_sweep_kernel<MODE, DIR, GRAD>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((persist_sweep_kernel<MODE, DIR, GRAD>), dim3(grid), dim3(NT), LDS_DYN_BYTES, stream, P);
+}
+
+// mode 0 = LSE, 1 = MAX.  ws must hold persist_workspace_bytes().  Enqueues a memset + one kernel per chain chunk.
 static int launch_persist_sweep_impl(int mode, int dir, const float* score, const float* noise, int T, int B,
                                      float* u_out, float* last_out, int* code, void* ws, hipStream_t stream,
                                      const GradArgs* grad)
@@ -878,13 +1004,10 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
     P.vfwd = nullptr; P.logZ = nullptr; P.gout = nullptr; P.dScore = nullptr; P.dNoise = nullptr;
     if (grad) { P.vfwd = grad->vfwd; P.logZ = grad->logZ; P.gout = grad->gout; P.dScore = grad->dScore; P.dNoise = grad->dNoise; }
     P.score = score; P.noise = noise; P.T = T; P.B = B; P.K = (T + PB - 1) / PB;
-    P.nSpine = (B + GS - 1) / GS;
-    P.nPanelGroups = (B + GP - 1) / GP;
     P.tag = next_tag();
     const char* dbg = getenv("SEMICRF_DEBUG_FLAGS");
     P.dbg = dbg ? (unsigned)atoi(dbg) : 0u;
     char* w = (char*)ws;
-    P.ctrl = (unsigned*)w;
     P.ts = (u64*)(w + CTRL_BYTES);
     const size_t ts_bytes = align_up((size_t)2 * T * sizeof(u64));
     P.ug = (u64*)(w + CTRL_BYTES + ts_bytes);
@@ -892,42 +1015,63 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
     P.u_out = u_out; P.last_out = last_out; P.code = code;
     const size_t zbytes = persist_workspace_bytes(T, B);
     if (hipMemsetAsync(ws, 0, zbytes, stream) != hipSuccess) return 1;
-    // panel tasks: block k = RING + q has q/TPT + 1 column parts
+    if (grad && T > 1) {
+        int gx = (int)(((size_t)T * B / 4 + 255) / 256);
+        if (gx > 8) gx = 8;
+        if (gx < 1) gx = 1;
+        hipLaunchKernelGGL(zero_upper_kernel, dim3(gx, T - 1), dim3(256), 0, stream, grad->dScore, T, B);
+    }
+    // panel tasks per chain group: block k = RING + q has q/TPT + 1 column parts, each split in 4 row quarters
     long long ntask = 0;
     for (int q = 0; q < P.K - RING; ++q) ntask += (q / TPT + 1);
-    P.nTasks = (int)(ntask * P.nPanelGroups);
-    // persistent panel workgroups: fill the chip at the kernel's occupancy (2 workgroups per CU)
-    int dev = 0, ncu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+    ntask *= 4;
+
+    // Chain chunks: at most a quarter of the CUs host spines in one launch (every workgroup must be resident
+    // and the panels need the rest of the chip).
+    const int ncu = device_cus();
+    const int nSpineTotal = (B + GS - 1) / GS;
+    const int maxSpine = ncu / 2 > 0 ? ncu / 2 : 1;
+    const int nchunks = (nSpineTotal + maxSpine - 1) / maxSpine;
+    if (nchunks > MAX_CHUNKS) return 1;
+    const int perChunk = (nSpineTotal + nchunks - 1) / nchunks;
+    for (int ci = 0; ci < nchunks; ++ci) {
+        P.c0 = ci * perChunk * GS;
+        P.c1 = P.c0 + perChunk * GS < B ? P.c0 + perChunk * GS : B;
+        if (P.c0 >= P.c1) break;
+        const int nb = P.c1 - P.c0;
+        P.nSpine = (nb + GS - 1) / GS;
+        P.nPanelGroups = (nb + GP - 1) / GP;
+        P.nTasks = (int)(ntask * P.nPanelGroups);
+        P.ctrl = (unsigned*)w + (size_t)ci * CTRL_WORDS;
+        // Panel waves.  Every CU streams (HBM bandwidth is limited per CU by the misses it can keep in flight):
+        // a spine workgroup carries NT/64 - RING panel waves, the other workgroups `panelWaves`.  More waves
+        // mean longer memory queues, and the spine's band loads and hand-offs wait in the same queues; the far
+        // field grows with T^2 and the spine's chain with T, so longer sequences get more panel waves, and
+        // the gradient sweep (which also stores a tile per tile loaded) a few more.
+        int nPanelWG = ncu - P.nSpine;
+        if (nPanelWG < 0) nPanelWG = 0;
+        float per_cu = (float)T / 1024.0f;
+        per_cu = per_cu < 0.75f ? 0.75f : (per_cu > 2.0f ? 2.0f : per_cu);
+        if (grad) per_cu *= 1.25f;
+        int hpw = 2;                                            // panel waves in a spine workgroup
+        if (const char* e = getenv("SEMICRF_HYBRID_PANEL_WAVES")) { const int v = atoi(e); if (v >= 0) hpw = v; }
+        if (hpw > NT / 64 - RING - 2) hpw = NT / 64 - RING - 2;
+        P.hybridPanelWaves = hpw;
+        int pw = NT / 64;
+        if (nPanelWG > 0)
+            pw = (int)((per_cu * 4.0f * (float)ncu - (float)(hpw * P.nSpine)) / (float)nPanelWG + 0.5f);
+        if (const char* e = getenv("SEMICRF_PANEL_WAVES")) { const int v = atoi(e); if (v > 0) pw = v; }   // tuning knob
+        if (pw < 1) pw = 1;
+        if (pw > NT / 64) pw = NT / 64;
+        P.panelWaves = pw;
+        if (P.nTasks == 0) nPanelWG = 0;
+        const int grid = P.nSpine + nPanelWG;
+        if (grad) launch_one<0, 1, true>(P, grid, stream);
+        else if (mode == 0 && dir == 0) launch_one<0, 0, false>(P, grid, stream);
+        else if (mode == 0 && dir == 1) launch_one<0, 1, false>(P, grid, stream);
+        else if (mode == 1 && dir == 0) launch_one<1, 0, false>(P, grid, stream);
+        else launch_one<1, 1, false>(P, grid, stream);
     }
-    // Panel workgroups.  More of them means more loads in flight than the ~8 MB that saturate HBM, i.e. only
-    // longer queues -- and the spine's band loads and hand-offs wait in the same queues.  Measured at T=1024,
-    // NBatch=352: forward 292 us with 1 panel workgroup per CU vs 336 us with 2; the gradient sweep (which also
-    // stores a tile per tile loaded) is best around 1.25 per CU.
-    // The far field grows with T^2 and the spine's chain with T, so longer sequences get more panel workgroups.
-    float per_cu = (float)T / 1024.0f;
-    per_cu = per_cu < 0.75f ? 0.75f : (per_cu > 2.0f ? 2.0f : per_cu);
-    if (grad) per_cu *= 1.25f;
-    int nPanelWG = (int)(per_cu * ncu);
-    if (nPanelWG > 2 * ncu - P.nSpine) nPanelWG = 2 * ncu - P.nSpine;
-    if (const char* e = getenv("SEMICRF_PANEL_WGS")) { const int v = atoi(e); if (v > 0) nPanelWG = v; }   // tuning knob
-    if (nPanelWG < ncu / 2) nPanelWG = ncu / 2;
-    if (nPanelWG > P.nTasks) nPanelWG = P.nTasks;
-    const int grid = P.nSpine + nPanelWG;
-    dim3 g(grid), b(256);
-    if (grad) {
-        if (T > 1) {
-            int gx = (int)(((size_t)T * B / 4 + 255) / 256);
-            if (gx > 8) gx = 8;
-            hipLaunchKernelGGL(zero_upper_kernel, dim3(gx, T - 1), dim3(256), 0, stream, grad->dScore, T, B);
-        }
-        hipLaunchKernelGGL((persist_sweep_kernel<0, 1, true>), g, b, 0, stream, P);
-    } else if (mode == 0 && dir == 0) hipLaunchKernelGGL((persist_sweep_kernel<0, 0, false>), g, b, 0, stream, P);
-    else if (mode == 0 && dir == 1) hipLaunchKernelGGL((persist_sweep_kernel<0, 1, false>), g, b, 0, stream, P);
-    else if (mode == 1 && dir == 0) hipLaunchKernelGGL((persist_sweep_kernel<1, 0, false>), g, b, 0, stream, P);
-    else hipLaunchKernelGGL((persist_sweep_kernel<1, 1, false>), g, b, 0, stream, P);
     return 0;
 }
 
