@@ -204,7 +204,7 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 struct SpineBlk { float v[PB]; };
 
 template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N)); }
 
 // LDS word accessors for the flags (every poll must be a fresh DS read)
 __device__ __forceinline__ int lds_flag_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -585,12 +585,100 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
 // ---------------------------------------------------------------------------------------------
 // PANEL role (per wave)
 // ---------------------------------------------------------------------------------------------
+constexpr int PNS = 3;                       // LDS stages per panel wave (tiles fetched ahead)
+constexpr int PSTAGE_BYTES = 12288;          // 8 KB of cells + 4 KB of u granules
+constexpr int PW_MAX = 4;                    // panel waves per workgroup (LDS: PW_MAX * PNS * PSTAGE_BYTES = 144 KB)
 // A wave owns rows pi = 16k + 4*q4 + rr (rr < 4) of position block k for 32 chains.  lane = slot*8 + q8:
 // q8 selects 4 of the 32 chains (8 consecutive lanes read one 128-byte line), slot selects the columns
 // pj = 16m + slot + 8h (h < 2) of tile m.  Cells and u-granules of tile m+1 are requested before tile m is
 // processed.  The same mapping serves both directions (only cell_index differs).
+// ---- panel helpers (free functions: a lambda that calls another lambda keeps its closure in scratch once
+// the body contains operations the optimiser treats as memory writes -- the global->LDS loads) ----------------
+struct PanelGeom {
+    int pirow[4];          // rows of the task, clamped to T-1
+    unsigned voff;         // per-lane byte offset of the PROCESSING mapping (also the gradient stores)
+    unsigned fvoff;        // per-lane byte offset of the FETCH mapping
+    unsigned gvoff;        // per-lane byte offset into the u granules
+};
+
+// element offset of the tile base
+template <int DIR>
+__device__ __forceinline__ size_t panel_tile_off(const PanelGeom& G, int m, int T, size_t Bs)
+{
+    return DIR == 0 ? ((size_t)G.pirow[0] * T + (size_t)m * PB) * Bs
+                    : ((size_t)(T - 1 - (m * PB + 15)) * T + (size_t)(T - 1 - G.pirow[3])) * Bs;
+}
+// wave-uniform byte offset of cell group (rr, h) in the processing mapping
+template <int DIR>
+__device__ __forceinline__ unsigned panel_soff(const PanelGeom& G, int rr, int h, int T, size_t Bs)
+{
+    return DIR == 0 ? (unsigned)((((size_t)(G.pirow[rr] - G.pirow[0]) * T + 8 * h) * Bs) * 4)
+                    : (unsigned)((((size_t)(1 - h) * 8 * T + (G.pirow[3] - G.pirow[rr])) * Bs) * 4);
+}
+// COHERENT = false: ordinary cached loads.  The granules are written once and re-read by every task of the
+// launch; device-scope (sc1) loads would fetch them through the fabric every time (a third of the far field's
+// own traffic).  A stale cache line can only show an OLD tag (8-byte granules are written atomically), which
+// sends the reader to the COHERENT retry below -- the tag keeps the protocol correct either way.
+template <bool COHERENT>
+__device__ __forceinline__ void panel_fetch_gran(__amdgpu_buffer_rsrc_t ursrc, char* stage, unsigned gvoff, int m, int B)
+{
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const unsigned so = (unsigned)((m * PB + 8 * h) * B * 8);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void_t*)(stage + 8192 + (h * 2 + hh) * 1024), 16, gvoff + 16 * hh, so, 0,
+                                                     COHERENT ? 16 : 0);        // 16 = sc1
+    }
+}
+// FETCH mapping (global -> LDS, 1 KB per instruction, lane-linear in LDS):
+//   DIR 0: instruction e = (rr, h) fetches what its lanes process (8 columns x 128 B of one matrix row);
+//   DIR 1: instruction e fetches columns pj = 16m + 2e + pjsub for the 4 rows pi (4 x 128 B contiguous per pj):
+//          lane = (pisub, pjsub, q8), same tile base, lane part ((1-pjsub)*T + (pi_3 - pi_pisub))*B, soffset (14-2e)*T*B.
+//          The processing lane reads its cells back from ((slot>>1) + 4h)*1024 + rr*256 + (slot&1)*128 + q8*16.
+template <int DIR>
+__device__ __forceinline__ void panel_fetch_cells(const float* score, const PanelGeom& G, char* stage, int m, int T, size_t Bs)
+{
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(score + panel_tile_off<DIR>(G, m, T, Bs)), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const unsigned so = DIR == 0 ? panel_soff<DIR>(G, e >> 1, e & 1, T, Bs) : (unsigned)(((size_t)(14 - 2 * e) * T * Bs) * 4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(stage + e * 1024), 16, G.fvoff, so, 0, 0);
+    }
+}
+__device__ __forceinline__ void panel_read_gran(unsigned addr, v4u& g00, v4u& g01, v4u& g10, v4u& g11)
+{
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
+                 "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(g00), "=&v"(g01), "=&v"(g10), "=&v"(g11)
+                 : "v"(addr));
+}
+template <int DIR>
+__device__ __forceinline__ void panel_read_cells(unsigned addr, v4u (&o)[8])
+{
+    constexpr int XR = DIR == 0 ? 2048 : 256, XH = DIR == 0 ? 1024 : 4096;      // LDS offset of (rr, h): rr*XR + h*XH
+    asm volatile("ds_read_b128 %0, %8 offset:%9\n\tds_read_b128 %1, %8 offset:%10\n\t"
+                 "ds_read_b128 %2, %8 offset:%11\n\tds_read_b128 %3, %8 offset:%12\n\t"
+                 "ds_read_b128 %4, %8 offset:%13\n\tds_read_b128 %5, %8 offset:%14\n\t"
+                 "ds_read_b128 %6, %8 offset:%15\n\tds_read_b128 %7, %8 offset:%16\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+                 : "v"(addr), "n"(0 * XR + 0 * XH), "n"(0 * XR + 1 * XH), "n"(1 * XR + 0 * XH), "n"(1 * XR + 1 * XH),
+                   "n"(2 * XR + 0 * XH), "n"(2 * XR + 1 * XH), "n"(3 * XR + 0 * XH), "n"(3 * XR + 1 * XH));
+}
+// wait until at most `younger` vector-memory operations are outstanding (rounded down to an encodable step)
+__device__ __forceinline__ void panel_wait_younger(int y)
+{
+    if (y >= 48) wait_vmcnt<48>();
+    else if (y >= 40) wait_vmcnt<40>();
+    else if (y >= 32) wait_vmcnt<32>();
+    else if (y >= 24) wait_vmcnt<24>();
+    else if (y >= 12) wait_vmcnt<12>();
+    else wait_vmcnt<0>();
+}
+
 template <int MODE, int DIR, bool GRAD>
-__device__ __forceinline__ void panel_role(const SweepParams& P)
+__device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int wslot)
 {
     const int T = P.T, B = P.B;
     const int c0 = P.c0, c1 = P.c1;
@@ -660,177 +748,153 @@ __device__ __forceinline__ void panel_role(const SweepParams& P)
                 }
             }
         }
-        float4 x[2][4][2];    // [buffer][rr][h] cells
-        v4u gq[2][2][2];      // [buffer][h][chain pair] granules (2 granules per 16-byte load)
-
+        // ---- addressing -----------------------------------------------------------------------------------
         // Buffer addressing: one VGPR byte offset per lane (constant over the task), everything that depends
         // on (tile, rr, h) is wave-uniform and lives in the SGPR base / soffset -- no per-load 64-bit VALU math.
         //   DIR 0: cell(pi, pj) = (pi*T + pj)*B: tile base at (pi_0, 16m), lane part slot*B, soffset ((pi_rr-pi_0)*T + 8h)*B
         //   DIR 1: cell(pi, pj) = ((T-1-pj)*T + (T-1-pi))*B: tile base at (pi_3, 16m+15), lane part (7-slot)*T*B,
         //          soffset ((1-h)*8*T + (pi_3-pi_rr))*B            (pi_rr = min(pbase+rr, T-1))
-        int pirow[4];
+        PanelGeom G;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) pirow[rr] = pbase + rr < T ? pbase + rr : T - 1;
-        const unsigned voff = DIR == 0 ? (unsigned)((slot * B + cl) * 4)
-                                       : (unsigned)(((size_t)(7 - slot) * T * Bs + cl) * 4);
-        unsigned soff[4][2];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                soff[rr][h] = DIR == 0 ? (unsigned)((((size_t)(pirow[rr] - pirow[0]) * T + 8 * h) * Bs) * 4)
-                                       : (unsigned)((((size_t)(1 - h) * 8 * T + (pirow[3] - pirow[rr])) * Bs) * 4);
-        auto tile_off = [&](int m) -> size_t {       // element offset of the tile base
-            return DIR == 0 ? ((size_t)pirow[0] * T + (size_t)m * PB) * Bs
-                            : ((size_t)(T - 1 - (m * PB + 15)) * T + (size_t)(T - 1 - pirow[3])) * Bs;
-        };
-        const unsigned gvoff = (unsigned)((slot * B + cl) * 8);
+        for (int rr = 0; rr < 4; ++rr) G.pirow[rr] = pbase + rr < T ? pbase + rr : T - 1;
+        G.voff = DIR == 0 ? (unsigned)((slot * B + cl) * 4) : (unsigned)(((size_t)(7 - slot) * T * Bs + cl) * 4);
+        {
+            const int f_pisub = lane >> 4, f_pjsub = (lane >> 3) & 1;
+            const int f_pirow = pbase + f_pisub < T ? pbase + f_pisub : T - 1;
+            G.fvoff = DIR == 0 ? G.voff : (unsigned)((((size_t)(1 - f_pjsub) * T + (G.pirow[3] - f_pirow)) * Bs + cl) * 4);
+        }
+        G.gvoff = (unsigned)((slot * B + cl) * 8);
+        char* const stage0 = lds + wslot * (PNS * PSTAGE_BYTES);
+        const unsigned rdbase = lds_addr(stage0) + (DIR == 0 ? (unsigned)lane * 16u
+                                                             : (unsigned)((slot >> 1) * 1024 + (slot & 1) * 128 + q8 * 16));
+        const unsigned grbase = lds_addr(stage0) + 8192u + (unsigned)lane * 16u;
+        const bool probe_stream = SEMICRF_PANEL_PROBES && (dbg & 32u);
+        const bool probe_nowait = SEMICRF_PANEL_PROBES && (dbg & 4u);
+        const int nst = GRAD ? 2 * (T - pbase < 4 ? T - pbase : 4) : 0;    // gradient stores per tile (a lower bound)
 
-        auto load_tile = [&](auto bufc, int m) {
-            constexpr int buf = decltype(bufc)::value;
-            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(score + tile_off(m)), 0, 0x7fffffff, 0x00020000);
+        // vector-memory operations issued so far in this task (a lower bound: the waits below may only under-count
+        // the operations younger than the fetch they wait for), and its value right after each stage's fetch
+        int issued = 0, mark0 = 0, mark1 = 0, mark2 = 0;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff[rr][h], 0);
-                    x[buf][rr][h] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
-                                                __uint_as_float(v.w));
-                }
-        };
-        auto load_gran = [&](auto bufc, int m) {
-            constexpr int buf = decltype(bufc)::value;
-            if (SEMICRF_PANEL_PROBES && (dbg & 32u)) return;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const unsigned so = (unsigned)((m * PB + 8 * h) * B * 8);
-                gq[buf][h][0] = __builtin_amdgcn_raw_buffer_load_b128(ursrc, gvoff, so, 16);        // sc1
-                gq[buf][h][1] = __builtin_amdgcn_raw_buffer_load_b128(ursrc, gvoff + 16, so, 16);
+        for (int i = 0; i < PNS; ++i)
+            if (m0 + i < m1) {
+                panel_fetch_cells<DIR>(score, G, stage0 + i * PSTAGE_BYTES, m0 + i, T, Bs);
+                if (!probe_stream) panel_fetch_gran<false>(ursrc, stage0 + i * PSTAGE_BYTES, G.gvoff, m0 + i, B);
+                issued += 12;
+                if (i == 0) mark0 = issued; else if (i == 1) mark1 = issued; else mark2 = issued;
             }
-        };
 
-        auto process_tile = [&](auto bufc, int m) {
-            constexpr int buf = decltype(bufc)::value;
-            if (SEMICRF_PANEL_PROBES && (dbg & 32u)) {          // streaming probe: touch the data, nothing else
+        for (int m = m0, s = 0; m < m1; ++m, s = (s + 1 == PNS ? 0 : s + 1)) {
+            char* const stage = stage0 + s * PSTAGE_BYTES;
+            // ---- wait for the stage, move it to registers ------------------------------------------------
+            panel_wait_younger(issued - (s == 0 ? mark0 : (s == 1 ? mark1 : mark2)));
+            v4u xo[8];
+            panel_read_cells<DIR>(rdbase + (unsigned)(s * PSTAGE_BYTES), xo);
+            if (probe_stream) {          // streaming probe: touch the data, nothing else
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-                        aS[0][0] += x[buf][rr][h].x + x[buf][rr][h].y + x[buf][rr][h].z + x[buf][rr][h].w;
-                return;
-            }
-            // every granule carries its own tag: if some are missing, poll (probe loads into temporaries) until the
-            // spine has published block m, then fetch the tile's granules once more -- nothing is carried around the loop
-            if (!(SEMICRF_PANEL_PROBES && (dbg & 4u))) {
-                auto tags_ok = [&](const v4u& a0, const v4u& a1, const v4u& b0, const v4u& b1) {
+                for (int e = 0; e < 8; ++e)
+                    aS[0][0] += __uint_as_float(xo[e].x) + __uint_as_float(xo[e].y) + __uint_as_float(xo[e].z) + __uint_as_float(xo[e].w);
+            } else {
+                v4u g00, g01, g10, g11;      // [h][chain pair] granules (2 granules per 16 bytes)
+                panel_read_gran(grbase + (unsigned)(s * PSTAGE_BYTES), g00, g01, g10, g11);
+                // every granule carries its own tag: if some are missing, fetch them again until the spine has
+                // published block m
+                if (!probe_nowait) {
                     const bool v0 = c < c1, v1 = c + 1 < c1, v2 = c + 2 < c1, v3 = c + 3 < c1;
-                    const bool ok = (a0.y == tag || !v0) && (a0.w == tag || !v1) && (a1.y == tag || !v2) && (a1.w == tag || !v3) &&
-                                    (b0.y == tag || !v0) && (b0.w == tag || !v1) && (b1.y == tag || !v2) && (b1.w == tag || !v3);
-                    return __all(ok) != 0;
-                };
-                if (!tags_ok(gq[buf][0][0], gq[buf][0][1], gq[buf][1][0], gq[buf][1][1])) {
                     int spins = 0;
-                    const unsigned so0 = (unsigned)((m * PB) * B * 8), so1 = (unsigned)((m * PB + 8) * B * 8);
                     while (true) {
+                        const bool ok = (g00.y == tag || !v0) && (g00.w == tag || !v1) && (g01.y == tag || !v2) &&
+                                        (g01.w == tag || !v3) && (g10.y == tag || !v0) && (g10.w == tag || !v1) &&
+                                        (g11.y == tag || !v2) && (g11.w == tag || !v3);
+                        if (__all(ok)) break;
                         __builtin_amdgcn_s_sleep(16);
-                        const v4u p00 = __builtin_amdgcn_raw_buffer_load_b128(ursrc, gvoff, so0, 16);
-                        const v4u p01 = __builtin_amdgcn_raw_buffer_load_b128(ursrc, gvoff + 16, so0, 16);
-                        const v4u p10 = __builtin_amdgcn_raw_buffer_load_b128(ursrc, gvoff, so1, 16);
-                        const v4u p11 = __builtin_amdgcn_raw_buffer_load_b128(ursrc, gvoff + 16, so1, 16);
-                        if (tags_ok(p00, p01, p10, p11)) break;
                         if (spin_abort(ctrl, spins, SPIN_LIMIT, 5)) break;
+                        panel_fetch_gran<true>(ursrc, stage, G.gvoff, m, B);
+                        wait_vmcnt<0>();
+                        panel_read_gran(grbase + (unsigned)(s * PSTAGE_BYTES), g00, g01, g10, g11);
                     }
-                    load_gran(bufc, m);
                 }
-            }
-            float uv[2][4];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                uv[h][0] = __uint_as_float(gq[buf][h][0].x); uv[h][1] = __uint_as_float(gq[buf][h][0].z);
-                uv[h][2] = __uint_as_float(gq[buf][h][1].x); uv[h][3] = __uint_as_float(gq[buf][h][1].z);
-            }
+                const float uv[2][4] = {{__uint_as_float(g00.x), __uint_as_float(g00.z), __uint_as_float(g01.x), __uint_as_float(g01.z)},
+                                        {__uint_as_float(g10.x), __uint_as_float(g10.z), __uint_as_float(g11.x), __uint_as_float(g11.z)}};
 
-            if (MODE == 0) {
-                // t = u + cell*log2e; lazily rescaled accumulators: one exp per cell, rare rescale branch.
-                // One row at a time (scheduling fences in between) to bound the live registers.
-                const auto gs = __builtin_amdgcn_make_buffer_rsrc((void*)(GRAD ? dScore + tile_off(m) : nullptr), 0, 0x7fffffff, 0x00020000);
+                if (MODE == 0) {
+                    // t = u + cell*log2e; lazily rescaled accumulators: one exp per cell, rare rescale branch.
+                    // One row at a time (scheduling fences in between) to bound the live registers.
+                    const auto gs = __builtin_amdgcn_make_buffer_rsrc((void*)(GRAD ? dScore + panel_tile_off<DIR>(G, m, T, Bs) : nullptr), 0,
+                                                                      0x7fffffff, 0x00020000);
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    float t[2][4];
-                    float exc = 0.0f;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const float4 xv = x[buf][rr][h];
-                        const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            t[h][i] = fmaf(xe[i], LOG2E, uv[h][i]);
-                            exc = fmaxf(exc, t[h][i] - (aM[rr][i] + RESCALE_THR));
-                        }
-                    }
-                    if (GRAD) {
+                    for (int rr = 0; rr < 4; ++rr) {
+                        float t[2][4];
+                        float exc = 0.0f;
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            if (cvalid && pbase + rr < T) {
-                                v4u gv;
-                                gv.x = __float_as_uint(gz[0] * fexp2(t[h][0] + arow[rr][0]));
-                                gv.y = __float_as_uint(gz[1] * fexp2(t[h][1] + arow[rr][1]));
-                                gv.z = __float_as_uint(gz[2] * fexp2(t[h][2] + arow[rr][2]));
-                                gv.w = __float_as_uint(gz[3] * fexp2(t[h][3] + arow[rr][3]));
-                                if (c + 3 < c1) __builtin_amdgcn_raw_buffer_store_b128(gv, gs, voff, soff[rr][h], 0);
-                                else {                                  // ragged tail of the chain range
-                                    __builtin_amdgcn_raw_buffer_store_b32(gv.x, gs, voff, soff[rr][h], 0);
-                                    if (c + 1 < c1) __builtin_amdgcn_raw_buffer_store_b32(gv.y, gs, voff + 4, soff[rr][h], 0);
-                                    if (c + 2 < c1) __builtin_amdgcn_raw_buffer_store_b32(gv.z, gs, voff + 8, soff[rr][h], 0);
+                            const v4u xv = xo[rr * 2 + h];
+                            const float xe[4] = {__uint_as_float(xv.x), __uint_as_float(xv.y), __uint_as_float(xv.z), __uint_as_float(xv.w)};
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                t[h][i] = fmaf(xe[i], LOG2E, uv[h][i]);
+                                exc = fmaxf(exc, t[h][i] - (aM[rr][i] + RESCALE_THR));
+                            }
+                        }
+                        if (GRAD) {
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                if (cvalid && pbase + rr < T) {
+                                    const unsigned so = panel_soff<DIR>(G, rr, h, T, Bs);
+                                    v4u gv;
+                                    gv.x = __float_as_uint(gz[0] * fexp2(t[h][0] + arow[rr][0]));
+                                    gv.y = __float_as_uint(gz[1] * fexp2(t[h][1] + arow[rr][1]));
+                                    gv.z = __float_as_uint(gz[2] * fexp2(t[h][2] + arow[rr][2]));
+                                    gv.w = __float_as_uint(gz[3] * fexp2(t[h][3] + arow[rr][3]));
+                                    if (c + 3 < c1) __builtin_amdgcn_raw_buffer_store_b128(gv, gs, G.voff, so, 0);
+                                    else {                                  // ragged tail of the chain range
+                                        __builtin_amdgcn_raw_buffer_store_b32(gv.x, gs, G.voff, so, 0);
+                                        if (c + 1 < c1) __builtin_amdgcn_raw_buffer_store_b32(gv.y, gs, G.voff + 4, so, 0);
+                                        if (c + 2 < c1) __builtin_amdgcn_raw_buffer_store_b32(gv.z, gs, G.voff + 8, so, 0);
+                                    }
                                 }
                             }
                         }
-                    }
-                    if (__any(exc > 0.0f)) {
-                        // some accumulator's reference point is too low (always on the first tile): move it up
+                        if (__any(exc > 0.0f)) {
+                            // some accumulator's reference point is too low (always on the first tile): move it up
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float mx = fmaxf(aM[rr][i], fmaxf(t[0][i], t[1][i]));
-                            if (mx > aM[rr][i] + RESCALE_THR) {
-                                aS[rr][i] = aS[rr][i] * fexp2(aM[rr][i] - mx);     // -inf - mx -> exp2 = 0, S = 0
-                                aM[rr][i] = mx;
+                            for (int i = 0; i < 4; ++i) {
+                                const float mx = fmaxf(aM[rr][i], fmaxf(t[0][i], t[1][i]));
+                                if (mx > aM[rr][i] + RESCALE_THR) {
+                                    aS[rr][i] = aS[rr][i] * fexp2(aM[rr][i] - mx);     // -inf - mx -> exp2 = 0, S = 0
+                                    aM[rr][i] = mx;
+                                }
                             }
                         }
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) aS[rr][i] += fexp2(t[h][i] - aM[rr][i]);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
+                    issued += nst;
+                } else {
 #pragma unroll
-                    for (int h = 0; h < 2; ++h)
+                    for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) aS[rr][i] += fexp2(t[h][i] - aM[rr][i]);
-                    __builtin_amdgcn_sched_barrier(0);
+                        for (int h = 0; h < 2; ++h) {
+                            const v4u xv = xo[rr * 2 + h];
+                            const float xe[4] = {__uint_as_float(xv.x), __uint_as_float(xv.y), __uint_as_float(xv.z), __uint_as_float(xv.w)};
+                            const int key = frame_of<DIR>(m * PB + slot + 8 * h, T);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) max_push(aM[rr][i], aK[rr][i], uv[h][i] + xe[i], key);
+                        }
                 }
-            } else {
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const float4 xv = x[buf][rr][h];
-                        const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
-                        const int key = frame_of<DIR>(m * PB + slot + 8 * h, T);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) max_push(aM[rr][i], aK[rr][i], uv[h][i] + xe[i], key);
-                    }
             }
-        };
-
-        {
-            int m = m0;
-            load_tile(IC<0>{}, m);
-            load_gran(IC<0>{}, m);
-            while (m < m1) {
-                if (m + 1 < m1) { load_tile(IC<1>{}, m + 1); load_gran(IC<1>{}, m + 1); }
-                process_tile(IC<0>{}, m);
-                ++m;
-                if (m >= m1) break;
-                if (m + 1 < m1) { load_tile(IC<0>{}, m + 1); load_gran(IC<0>{}, m + 1); }
-                process_tile(IC<1>{}, m);
-                ++m;
+            // ---- refill the stage PNS tiles ahead ----------------------------------------------------------
+            if (m + PNS < m1) {
+                panel_fetch_cells<DIR>(score, G, stage, m + PNS, T, Bs);
+                if (!probe_stream) panel_fetch_gran<false>(ursrc, stage, G.gvoff, m + PNS, B);
+                issued += 12;
+                if (s == 0) mark0 = issued; else if (s == 1) mark1 = issued; else mark2 = issued;
             }
         }
+        wait_vmcnt<0>();      // nothing of this task is in flight when its stages are reused
 
         // ---- reduce over the 8 column slots (lane bits 3..5) as a reduce-scatter: each stage halves the
         // accumulators a lane keeps, so 14 exchanges instead of 48; every lane ends with 2 of the 16 results
@@ -909,17 +973,16 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
             if (!(P.dbg & 8u)) loader_role<DIR, GRAD>(P, sg, s_dyn);
         } else if (wave == RING + 1) {
             if (!(P.dbg & 9u)) far_role<MODE, DIR>(P, sg, s_dyn);
-        } else if (!(P.dbg & 2u) && wave - (RING + 2) < P.hybridPanelWaves) {
-            panel_role<MODE, DIR, GRAD>(P);
         }
     } else {
-        if (!(P.dbg & 2u) && wave < P.panelWaves) panel_role<MODE, DIR, GRAD>(P);
+        if (!(P.dbg & 2u) && wave < P.panelWaves) panel_role<MODE, DIR, GRAD>(P, s_dyn, wave);
     }
 }
 
 constexpr size_t CTRL_WORDS = 64;
 constexpr size_t CTRL_BYTES = MAX_CHUNKS * CTRL_WORDS * sizeof(unsigned);
-constexpr int LDS_DYN_BYTES = LDS_SPINE_BYTES > 84 * 1024 ? LDS_SPINE_BYTES : 84 * 1024;   // > half of the CU's 160 KB: one workgroup per CU
+constexpr int LDS_PANEL_BYTES = PW_MAX * PNS * PSTAGE_BYTES;
+constexpr int LDS_DYN_BYTES = LDS_SPINE_BYTES > LDS_PANEL_BYTES ? LDS_SPINE_BYTES : LDS_PANEL_BYTES;   // > half of the CU's 160 KB: one workgroup per CU
 
 static int max_parts(int T)
 {
@@ -1053,16 +1116,12 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         float per_cu = (float)T / 1024.0f;
         per_cu = per_cu < 0.75f ? 0.75f : (per_cu > 2.0f ? 2.0f : per_cu);
         if (grad) per_cu *= 1.25f;
-        int hpw = 2;                                            // panel waves in a spine workgroup
-        if (const char* e = getenv("SEMICRF_HYBRID_PANEL_WAVES")) { const int v = atoi(e); if (v >= 0) hpw = v; }
-        if (hpw > NT / 64 - RING - 2) hpw = NT / 64 - RING - 2;
-        P.hybridPanelWaves = hpw;
-        int pw = NT / 64;
-        if (nPanelWG > 0)
-            pw = (int)((per_cu * 4.0f * (float)ncu - (float)(hpw * P.nSpine)) / (float)nPanelWG + 0.5f);
+        P.hybridPanelWaves = 0;
+        int pw = PW_MAX;
         if (const char* e = getenv("SEMICRF_PANEL_WAVES")) { const int v = atoi(e); if (v > 0) pw = v; }   // tuning knob
         if (pw < 1) pw = 1;
-        if (pw > NT / 64) pw = NT / 64;
+        if (pw > PW_MAX) pw = PW_MAX;
+        (void)per_cu;
         P.panelWaves = pw;
         if (P.nTasks == 0) nPanelWG = 0;
         const int grid = P.nSpine + nPanelWG;
