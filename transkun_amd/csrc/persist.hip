@@ -43,7 +43,10 @@ constexpr int RING = 4;            // waves per ring; band = RING-1 off-diagonal
 constexpr int RS = 4;              // chains per ring (one per lane)
 constexpr int GS = RS;              // chains per spine workgroup
 constexpr int GP = 32;             // chains per panel task (4 per lane)
-constexpr int TPT = 16;            // tiles (column blocks) per panel task
+#ifndef SEMICRF_TPT
+#define SEMICRF_TPT 16
+#endif
+constexpr int TPT = SEMICRF_TPT;   // tiles (column blocks) per panel task
 constexpr int NT = 512;            // threads per workgroup (8 waves, 2 per SIMD)
 constexpr int MAX_CHUNKS = 16;     // chain chunks (launches) per call
 constexpr float LOG2E = 1.4426950408889634f;
@@ -187,7 +190,10 @@ __device__ __forceinline__ bool spin_abort(unsigned* ctrl, int& spins, int limit
 //     next broadcast simply reads the lanes of the next row,
 //   * row jj+1 receives its last term through logaddexp2(Vp, u + W) where Vp (everything but that term)
 //     is refreshed one step ahead by the (M,S) push that runs beside it.
-constexpr int NRBUF = 6;                              // row-block buffers between the loader and the ring
+#ifndef SEMICRF_NRBUF
+#define SEMICRF_NRBUF 3
+#endif
+constexpr int NRBUF = SEMICRF_NRBUF;                  // row-block buffers between the loader and the ring
 constexpr int TILE_BYTES = PB * PB * RS * 4;          // 4096: [column u][row r][chain] floats
 constexpr int NCONST = 3;                             // per-row constants: diagonal cell, noise, alpha (GRAD)
 constexpr int LDS_TILES = 0;
@@ -364,7 +370,6 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
     float* const ring = (float*)(lds + LDS_RING);
     float* const dummy = (float*)(lds + LDS_DUMMY);
     const float* rd_base = ring + ch * 2;                                   // + (j & 127) * 8 floats
-    float* wr_base = r == 0 ? ring + ch * 2 : dummy + lane * 2;             // writers: the four lanes of row 0
     const int bp_addr = ch << 2;                                            // ds_bpermute byte address of lane ch
     const int* const ready = (const int*)(lds + LDS_CTL);
     int* const cons = (int*)(lds + LDS_CTL) + NRBUF;
@@ -520,7 +525,8 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
             }
         }
 
-        float* const wr = wr_base + (own0 & 127) * 8;        // ring entry of position own0 (+8 floats per step)
+        // ring entry of position own0 (+8 floats per step); writers: the four lanes of row 0, the other lanes' stores go to a sink
+        float* const wr = r == 0 ? ring + ch * 2 + (own0 & 127) * 8 : dummy + lane * 2;
         int mykey = -1;
         if (MODE == 0) {
             const float W = wl + sp;
@@ -585,9 +591,19 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
 // ---------------------------------------------------------------------------------------------
 // PANEL role (per wave)
 // ---------------------------------------------------------------------------------------------
+#ifndef SEMICRF_CELL_AUX
+#define SEMICRF_CELL_AUX 2      // nt: every cell is read once -- keep the stream from evicting the (re-read) u granules from L2
+#endif
 constexpr int PNS = 3;                       // LDS stages per panel wave (tiles fetched ahead)
 constexpr int PSTAGE_BYTES = 12288;          // 8 KB of cells + 4 KB of u granules
 constexpr int PW_MAX = 4;                    // panel waves per workgroup (LDS: PW_MAX * PNS * PSTAGE_BYTES = 144 KB)
+constexpr int LDS_PANEL_BYTES = PW_MAX * PNS * PSTAGE_BYTES;
+constexpr int LDS_HYBRID_PANEL = (LDS_SPINE_BYTES + 1023) / 1024 * 1024;     // stages of a spine workgroup's panel waves
+constexpr int HPW_MAX = (160 * 1024 - 512 - LDS_HYBRID_PANEL) / (PNS * PSTAGE_BYTES) < NT / 64 - RING - 2
+                            ? (160 * 1024 - 512 - LDS_HYBRID_PANEL) / (PNS * PSTAGE_BYTES) : NT / 64 - RING - 2;
+constexpr int LDS_HYBRID_BYTES = LDS_HYBRID_PANEL + (HPW_MAX > 0 ? HPW_MAX : 0) * PNS * PSTAGE_BYTES;
+constexpr int LDS_DYN_MAX2 = LDS_SPINE_BYTES > LDS_PANEL_BYTES ? LDS_SPINE_BYTES : LDS_PANEL_BYTES;
+constexpr int LDS_DYN_BYTES = LDS_HYBRID_BYTES > LDS_DYN_MAX2 ? LDS_HYBRID_BYTES : LDS_DYN_MAX2;   // > half of the CU's 160 KB: one workgroup per CU
 // A wave owns rows pi = 16k + 4*q4 + rr (rr < 4) of position block k for 32 chains.  lane = slot*8 + q8:
 // q8 selects 4 of the 32 chains (8 consecutive lanes read one 128-byte line), slot selects the columns
 // pj = 16m + slot + 8h (h < 2) of tile m.  Cells and u-granules of tile m+1 are requested before tile m is
@@ -643,7 +659,7 @@ __device__ __forceinline__ void panel_fetch_cells(const float* score, const Pane
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const unsigned so = DIR == 0 ? panel_soff<DIR>(G, e >> 1, e & 1, T, Bs) : (unsigned)(((size_t)(14 - 2 * e) * T * Bs) * 4);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(stage + e * 1024), 16, G.fvoff, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(stage + e * 1024), 16, G.fvoff, so, 0, SEMICRF_CELL_AUX);
     }
 }
 __device__ __forceinline__ void panel_read_gran(unsigned addr, v4u& g00, v4u& g01, v4u& g10, v4u& g11)
@@ -973,6 +989,9 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
             if (!(P.dbg & 8u)) loader_role<DIR, GRAD>(P, sg, s_dyn);
         } else if (wave == RING + 1) {
             if (!(P.dbg & 9u)) far_role<MODE, DIR>(P, sg, s_dyn);
+        } else if (!(P.dbg & 2u) && wave - (RING + 2) < P.hybridPanelWaves) {
+            // spare waves stream tiles like the panel workgroups do (their stages lie behind the spine's LDS)
+            panel_role<MODE, DIR, GRAD>(P, s_dyn + LDS_HYBRID_PANEL, wave - (RING + 2));
         }
     } else {
         if (!(P.dbg & 2u) && wave < P.panelWaves) panel_role<MODE, DIR, GRAD>(P, s_dyn, wave);
@@ -981,8 +1000,6 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
 
 constexpr size_t CTRL_WORDS = 64;
 constexpr size_t CTRL_BYTES = MAX_CHUNKS * CTRL_WORDS * sizeof(unsigned);
-constexpr int LDS_PANEL_BYTES = PW_MAX * PNS * PSTAGE_BYTES;
-constexpr int LDS_DYN_BYTES = LDS_SPINE_BYTES > LDS_PANEL_BYTES ? LDS_SPINE_BYTES : LDS_PANEL_BYTES;   // > half of the CU's 160 KB: one workgroup per CU
 
 static int max_parts(int T)
 {
@@ -1116,7 +1133,11 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         float per_cu = (float)T / 1024.0f;
         per_cu = per_cu < 0.75f ? 0.75f : (per_cu > 2.0f ? 2.0f : per_cu);
         if (grad) per_cu *= 1.25f;
-        P.hybridPanelWaves = 0;
+        // long sequences are bound by the far field: the spine workgroups' spare waves then stream tiles too
+        // (at T = 1024 they only slow the ring down: 233 vs 250 us; at T = 2048 they win: 701 vs 788 us)
+        int hpw = (HPW_MAX > 0 && T >= 1536) ? HPW_MAX : 0;
+        if (const char* e = getenv("SEMICRF_HYBRID_PANEL_WAVES")) { const int v = atoi(e); if (v >= 0 && v <= HPW_MAX) hpw = v; }
+        P.hybridPanelWaves = hpw;
         int pw = PW_MAX;
         if (const char* e = getenv("SEMICRF_PANEL_WAVES")) { const int v = atoi(e); if (v > 0) pw = v; }   // tuning knob
         if (pw < 1) pw = 1;
