@@ -69,12 +69,13 @@ struct SweepParams {
     int nTasks;            // panel tasks (k ascending, then column part, then chain group, then row quarter)
     int panelWaves;        // waves per non-spine workgroup that work as panels (the rest exit at once)
     int hybridPanelWaves;  // panel waves of a spine workgroup (0..2)
+    int zeroWaves;         // GRAD: waves per panel workgroup that write the zero upper triangle of dScore (0: separate kernel)
     unsigned tag;          // nonzero launch epoch
     unsigned dbg;          // SEMICRF_DEBUG_FLAGS (timing experiments only; results are wrong when set):
                            // 1 spine ignores far partials, 2 panels exit at once, 4 panels do not wait for u,
                            // 8 spine exits at once, 16 spine 0 records per-block timestamps,
                            // 32 panels only stream their cells (no granules, no math)
-    unsigned* ctrl;        // [0] ticket, [1] error, [2] panel task queue head
+    unsigned* ctrl;        // [0] ticket, [1] error, [2] panel task queue head, [3] zero-fill row queue head
     u64* ts;               // [2T] debug timestamps of spine 0, ring 0 (dbg & 16)
     u64* ug;               // [T][B] granules of u (position-major: index p*B + c)
     u64* farg;             // [parts][T][B] granules of far-field partials (part = column range of TPT tiles)
@@ -591,6 +592,9 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
 // ---------------------------------------------------------------------------------------------
 // PANEL role (per wave)
 // ---------------------------------------------------------------------------------------------
+#ifndef SEMICRF_GRAD_AUX
+#define SEMICRF_GRAD_AUX 2      // nt: the gradient is written once
+#endif
 #ifndef SEMICRF_CELL_AUX
 #define SEMICRF_CELL_AUX 2      // nt: every cell is read once -- keep the stream from evicting the (re-read) u granules from L2
 #endif
@@ -862,7 +866,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                                     gv.y = __float_as_uint(gz[1] * fexp2(t[h][1] + arow[rr][1]));
                                     gv.z = __float_as_uint(gz[2] * fexp2(t[h][2] + arow[rr][2]));
                                     gv.w = __float_as_uint(gz[3] * fexp2(t[h][3] + arow[rr][3]));
-                                    if (c + 3 < c1) __builtin_amdgcn_raw_buffer_store_b128(gv, gs, G.voff, so, 0);
+                                    if (c + 3 < c1) __builtin_amdgcn_raw_buffer_store_b128(gv, gs, G.voff, so, SEMICRF_GRAD_AUX);
                                     else {                                  // ragged tail of the chain range
                                         __builtin_amdgcn_raw_buffer_store_b32(gv.x, gs, G.voff, so, 0);
                                         if (c + 1 < c1) __builtin_amdgcn_raw_buffer_store_b32(gv.y, gs, G.voff + 4, so, 0);
@@ -963,6 +967,44 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
 }
 
 // ---------------------------------------------------------------------------------------------
+// ZERO role (GRAD): the dense gradient's upper triangle (begin > end) is exact zeros.  Spare waves of the panel
+// workgroups write it while the sweep runs (row e: columns e+1..T-1, contiguous over all chains); rows are handed
+// out in pairs (e, T-2-e) of equal total length.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void zero_row(float* __restrict__ dScore, int e, int T, int B, int lane)
+{
+    const size_t n = (size_t)(T - 1 - e) * B;                 // floats to clear in this row
+    float* rowp = dScore + ((size_t)e * T + e + 1) * B;
+    const size_t lead = (4 - (((uintptr_t)rowp >> 2) & 3)) & 3;          // floats up to 16-byte alignment
+    const size_t head = lead < n ? lead : n;
+    const size_t n4 = (n - head) / 4;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4* v = (f32x4*)(rowp + head);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = lane; i < n4; i += 64) __builtin_nontemporal_store(z, v + i);
+    if ((size_t)lane < head) rowp[lane] = 0.f;
+    const size_t tail0 = head + n4 * 4;
+    if (tail0 + lane < n) rowp[tail0 + lane] = 0.f;
+}
+__device__ __forceinline__ void zero_role(const SweepParams& P)
+{
+    const int T = P.T, B = P.B;
+    float* const dScore = P.dScore;
+    unsigned* const ctrl = P.ctrl;
+    const int lane = threadIdx.x & 63;
+    const int npairs = T / 2;                                  // rows 0 .. T-2 in pairs (e, T-2-e)
+    while (true) {
+        int p = 0;
+        if (lane == 0) p = (int)atomicAdd(ctrl + 3, 1u);
+        p = __builtin_amdgcn_readfirstlane(p);
+        if (p >= npairs) break;
+        const int e2 = T - 2 - p;
+        if (p <= e2) zero_row(dScore, p, T, B, lane);
+        if (p < e2) zero_row(dScore, e2, T, B, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------
 // Launched with enough dynamic LDS that only ONE workgroup fits a compute unit, so with grid <= #CUs every
@@ -995,6 +1037,7 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
         }
     } else {
         if (!(P.dbg & 2u) && wave < P.panelWaves) panel_role<MODE, DIR, GRAD>(P, s_dyn, wave);
+        else if (GRAD && wave - P.panelWaves >= 0 && wave - P.panelWaves < P.zeroWaves) zero_role(P);
     }
 }
 
@@ -1095,12 +1138,6 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
     P.u_out = u_out; P.last_out = last_out; P.code = code;
     const size_t zbytes = persist_workspace_bytes(T, B);
     if (hipMemsetAsync(ws, 0, zbytes, stream) != hipSuccess) return 1;
-    if (grad && T > 1) {
-        int gx = (int)(((size_t)T * B / 4 + 255) / 256);
-        if (gx > 8) gx = 8;
-        if (gx < 1) gx = 1;
-        hipLaunchKernelGGL(zero_upper_kernel, dim3(gx, T - 1), dim3(256), 0, stream, grad->dScore, T, B);
-    }
     // panel tasks per chain group: block k = RING + q has q/TPT + 1 column parts, each split in 4 row quarters
     long long ntask = 0;
     for (int q = 0; q < P.K - RING; ++q) ntask += (q / TPT + 1);
@@ -1144,6 +1181,22 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         if (pw > PW_MAX) pw = PW_MAX;
         (void)per_cu;
         P.panelWaves = pw;
+        // the zero upper triangle of the gradient: by spare waves of the first chunk's panel workgroups, or (no
+        // panel workgroups: short sequences) by its own kernel
+        int zw = 0;
+        if (grad && ci == 0) {
+            zw = 2;
+            if (const char* e = getenv("SEMICRF_ZERO_WAVES")) { const int v = atoi(e); if (v >= 0) zw = v; }
+            if (zw > NT / 64 - pw) zw = NT / 64 - pw;
+            if (nPanelWG <= 0 || P.nTasks == 0) zw = 0;
+            if (zw == 0 && T > 1) {
+                int gx = (int)(((size_t)T * B / 4 + 255) / 256);
+                if (gx > 8) gx = 8;
+                if (gx < 1) gx = 1;
+                hipLaunchKernelGGL(zero_upper_kernel, dim3(gx, T - 1), dim3(256), 0, stream, grad->dScore, T, B);
+            }
+        }
+        P.zeroWaves = zw;
         if (P.nTasks == 0) nPanelWG = 0;
         const int grid = P.nSpine + nPanelWG;
         if (grad) launch_one<0, 1, true>(P, grid, stream);
