@@ -39,7 +39,10 @@
 namespace semicrf {
 
 constexpr int PB = 16;             // positions per block
-constexpr int RING = 4;            // waves per ring; band = RING-1 off-diagonal blocks + the diagonal block
+#ifndef SEMICRF_RING
+#define SEMICRF_RING 4
+#endif
+constexpr int RING = SEMICRF_RING;            // waves per ring; band = RING-1 off-diagonal blocks + the diagonal block
 constexpr int RS = 4;              // chains per ring (one per lane)
 constexpr int GS = RS;              // chains per spine workgroup
 constexpr int GP = 32;             // chains per panel task (4 per lane)
@@ -192,7 +195,7 @@ __device__ __forceinline__ bool spin_abort(unsigned* ctrl, int& spins, int limit
 //   * row jj+1 receives its last term through logaddexp2(Vp, u + W) where Vp (everything but that term)
 //     is refreshed one step ahead by the (M,S) push that runs beside it.
 #ifndef SEMICRF_NRBUF
-#define SEMICRF_NRBUF 3
+#define SEMICRF_NRBUF 4
 #endif
 constexpr int NRBUF = SEMICRF_NRBUF;                  // row-block buffers between the loader and the ring
 constexpr int TILE_BYTES = PB * PB * RS * 4;          // 4096: [column u][row r][chain] floats
@@ -200,8 +203,11 @@ constexpr int NCONST = 3;                             // per-row constants: diag
 constexpr int LDS_TILES = 0;
 constexpr int LDS_CONST = LDS_TILES + NRBUF * RING * TILE_BYTES;       // [NRBUF][NCONST][64] floats
 constexpr int LDS_FAR = LDS_CONST + NRBUF * NCONST * 256;              // [8][64] x {value, key, seq, pad}
-constexpr int LDS_RING = LDS_FAR + 8 * 64 * 16;                        // [128][RS] x {u, seq}
-constexpr int LDS_CTL = LDS_RING + 128 * RS * 8;                       // ready[NRBUF], cons[RING] (ints)
+constexpr int NFAR = 8;                               // far-partial entries (blocks) between the far wave and the ring (>= RING)
+constexpr int NPOS = 128;                             // positions kept in the LDS ring (>= the band, RING blocks)
+static_assert(NFAR >= RING && NPOS >= RING * PB && RING + 2 <= NT / 64, "ring geometry");
+constexpr int LDS_RING = LDS_FAR + NFAR * 64 * 16;                     // [NPOS][RS] x {u, seq}
+constexpr int LDS_CTL = LDS_RING + NPOS * RS * 8;                       // ready[NRBUF], cons[RING] (ints)
 constexpr int LDS_DUMMY = LDS_CTL + 256;                               // sink of the non-writer lanes' ring stores
 constexpr int LDS_SPINE_BYTES = LDS_DUMMY + (64 * 2 + PB * 8) * 4;
 
@@ -254,6 +260,8 @@ __device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* 
     int* const ready = (int*)(lds + LDS_CTL);
     int* const cons = ready + NRBUF;
     constexpr int NL = RING * 4 + 2 + (GRAD ? 1 : 0);            // loads per row block (exactly, the waits count them)
+    constexpr int LDEPTH = 3 * NL <= 63 ? 3 : 2;
+    static_assert(2 * NL <= 63, "loader pipeline");
 
     auto issue = [&](int kr) {
         const int slot = kr % NRBUF;
@@ -295,9 +303,11 @@ __device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* 
             }
         }
         issue(kr);
-        if (kr >= 2) { wait_vmcnt<2 * NL>(); publish(kr - 2); }
+        // LDEPTH row blocks in flight (the counter holds 63 operations)
+        if (LDEPTH == 3) { if (kr >= 2) { wait_vmcnt<2 * NL>(); publish(kr - 2); } }
+        else { if (kr >= 1) { wait_vmcnt<NL>(); publish(kr - 1); } }
     }
-    if (K >= 2) { wait_vmcnt<NL>(); publish(K - 2); }
+    if (LDEPTH == 3 && K >= 2) { wait_vmcnt<NL>(); publish(K - 2); }
     wait_vmcnt<0>();
     publish(K - 1);
 }
@@ -339,7 +349,7 @@ __device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds
             }
         }
         const float val = MODE == 0 ? aM + flog2(aS) : aM;
-        far[(k & 7) * 64 + lane] = make_float4(val, __int_as_float(aK), __int_as_float(k + 1), 0.0f);   // one DS write: data + seq
+        far[(k % NFAR) * 64 + lane] = make_float4(val, __int_as_float(aK), __int_as_float(k + 1), 0.0f);   // one DS write: data + seq
     }
 }
 
@@ -370,7 +380,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
     const bool trace = (dbg & 16u) && sg == 0 && lane == 0;
     float* const ring = (float*)(lds + LDS_RING);
     float* const dummy = (float*)(lds + LDS_DUMMY);
-    const float* rd_base = ring + ch * 2;                                   // + (j & 127) * 8 floats
+    const float* rd_base = ring + ch * 2;                                   // + (j % NPOS) * 8 floats
     const int bp_addr = ch << 2;                                            // ds_bpermute byte address of lane ch
     const int* const ready = (const int*)(lds + LDS_CTL);
     int* const cons = (int*)(lds + LDS_CTL) + NRBUF;
@@ -404,13 +414,15 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
             for (int u = 0; u < PB; ++u) o.v[u] = *(const float*)(tb + i * TILE_BYTES + u * (PB * RS * 4));
             return o;
         };
-        SpineBlk A = read_tile(0), Bk = read_tile(1), C = read_tile(2), D = read_tile(3);
+        SpineBlk X[RING];        // X[i]: columns of block k - (RING-1) + i (the last one is the own block)
+#pragma unroll
+        for (int i = 0; i < RING; ++i) X[i] = read_tile(i);
         const float* cst = (const float*)(lds + LDS_CONST + slot * NCONST * 256) + lane;
         const float dcell = cst[0], nzl = cst[64], vfl = cst[128];
-        // first sub-diagonal cell of this lane's row: column r-1 of the own tile (last column of tile 2 for row 0)
-        const float s1own = *(const float*)(lds + LDS_TILES + (slot * RING + 3) * TILE_BYTES +
+        // first sub-diagonal cell of this lane's row: column r-1 of the own tile (last column of the previous tile for row 0)
+        const float s1own = *(const float*)(lds + LDS_TILES + (slot * RING + RING - 1) * TILE_BYTES +
                                             ((((r > 0 ? r - 1 : 0) * PB) + r) * RS + ch) * 4);
-        const float s1 = r == 0 ? C.v[PB - 1] : s1own;
+        const float s1 = r == 0 ? X[RING - 2].v[PB - 1] : s1own;
         if (lane == 0) lds_flag_store(cons + rw, k + 1);          // in-order DS queue: after the reads above
 
         // GRAD stores: wave-uniform base (SGPR) + one per-lane byte offset
@@ -451,7 +463,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
         // wait for positions j .. j+3 in the ring and return this lane's chain (one check per four positions:
         // a wave that lags behind its ring mate catches up at the cost of the pushes alone)
         auto ring_get4 = [&](int j, float (&uo)[4]) {
-            const float2* e = (const float2*)(rd_base + (j & 127) * 8);       // j % 4 == 0: no wrap inside the group
+            const float2* e = (const float2*)(rd_base + (j % NPOS) * 8);       // j % 4 == 0: no wrap inside the group
             float2 v0 = e[0], v1 = e[RS], v2 = e[2 * RS], v3 = e[3 * RS];
             if (!__all(__float_as_int(v3.y) == j + 4)) {
                 int spins = 0;
@@ -471,7 +483,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
         // ---------------- shadow phase: apply a block published by a ring mate ---------------------
         // `last`: block k-1, whose final column own0-1 is the first sub-diagonal cell of row 0 (skip folded in)
         auto shadow = [&](const SpineBlk& X, int b, bool last) {
-            if (trace) ev[3 + (b - (k - 3))] = __builtin_readcyclecounter();
+            if (trace && b >= k - 3) ev[3 + (b - (k - 3))] = __builtin_readcyclecounter();
 #pragma unroll
             for (int u4 = 0; u4 < PB; u4 += 4) {
                 float uq[4];
@@ -499,16 +511,16 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
             }
         };
 
-        if (k >= 3) shadow(A, k - 3, false);
-        if (k >= 2) shadow(Bk, k - 2, false);
-        if (k >= 1) shadow(C, k - 1, true);
+#pragma unroll
+        for (int i = 0; i < RING - 1; ++i)
+            if (k - (RING - 1) + i >= 0) shadow(X[i], k - (RING - 1) + i, i == RING - 2);
 
         // ---------------- diagonal phase: finalise the 16 positions of block k ------------------------
         __builtin_amdgcn_s_setprio(3);       // the dependent chain goes before everything else on this SIMD
         if (trace) ev[6] = __builtin_readcyclecounter();
         if (k >= RING && !(dbg & 1u)) {
             // combined far-field partial of this (row, chain), left in LDS by the far wave
-            const float4* fe = far + (k & 7) * 64 + lane;
+            const float4* fe = far + (k % NFAR) * 64 + lane;
             float4 f = *fe;
             if (!__all(__float_as_int(f.z) == k + 1)) {
                 int spins = 0;
@@ -527,7 +539,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
         }
 
         // ring entry of position own0 (+8 floats per step); writers: the four lanes of row 0, the other lanes' stores go to a sink
-        float* const wr = r == 0 ? ring + ch * 2 + (own0 & 127) * 8 : dummy + lane * 2;
+        float* const wr = r == 0 ? ring + ch * 2 + (own0 % NPOS) * 8 : dummy + lane * 2;
         int mykey = -1;
         if (MODE == 0) {
             const float W = wl + sp;
@@ -543,7 +555,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
                 const float t = u + W;
                 cv = fmaxf(Vp, t) + flog2(1.0f + fexp2(-fabsf(Vp - t)));
                 // generic push for the rows further down, then refresh Vp
-                const float p = fmaf(D.v[jj], LOG2E, u);
+                const float p = fmaf(X[RING - 1].v[jj], LOG2E, u);
                 if (GRAD) {
                     if (rvalid && r > jj) grad_store(j, gz * fexp2(p + arow));
                     if (rvalid && r == jj + 1)
@@ -567,7 +579,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
                 *(float2*)(wr + jj * 8) = make_float2(u, __int_as_float(j + 1));
                 const int key = frame_of<DIR>(j < T ? j : T - 1, T);
                 if (r == jj + 1) max_push(aM, aK, u + nz, -1);                  // the skip candidate goes first (key -1)
-                max_push(aM, aK, u + D.v[jj], key);
+                max_push(aM, aK, u + X[RING - 1].v[jj], key);
                 cv = sp > 0.0f ? aM + sp : aM;
                 if (r == jj + 1) mykey = aK;
             }
@@ -577,7 +589,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
 
         // ---- once per block: publish the 16 finished positions to HBM -----------------------------
         if (rvalid) {
-            const float mine = rd_base[(prow & 127) * 8];
+            const float mine = rd_base[(prow % NPOS) * 8];
             store_granule(ug + (size_t)prow * Bs + c, make_granule(tag, mine));
             const float sc = MODE == 0 ? LN2 : 1.0f;
             if (u_out) u_out[(size_t)frow * Bs + c] = mine * sc;
