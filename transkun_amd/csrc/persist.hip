@@ -7,27 +7,27 @@
 // frames ascending (DIR 0) or descending (DIR 1); cell(p,j) is score[end][begin] of the two frames.
 //
 // Work decomposition (positions in blocks of 16, workgroups of 8 waves, ONE workgroup per compute unit):
-//   * SPINE workgroup, one per 8 chains: two rings of four waves, a ring serves 4 chains; wave w of a ring
-//     owns position blocks k = w, w+4, ...; a lane is (row r of the block, ONE chain).  Every wave applies
-//     each newly finished u[j] to its own block's rows (band = the current block and the next three); the
-//     owner of the current block finalises one position per step and publishes it through LDS to its ring
-//     mates; once per block it publishes 16 positions to HBM for the panels.  The T-step dependent chain
-//     never leaves one CU.  A lone wave issues one plain instruction per ~4.5 cycles and one transcendental
-//     per ~16, so the step is kept at ~22 instructions with 4 transcendentals (one chain per lane: with two
-//     chains per lane the step simply costs twice as much).  Band cells are prefetched 16..32 steps ahead
-//     in registers.
-//   * PANEL waves (every wave pulls its own tasks, no workgroup-level synchronisation): a task is
-//     (position block k >= 4, column part of <= 16 tiles, 32 chains, 4 of the 16 rows).  The wave streams the
-//     far field -- cells (p in its rows, j < 16(k-3)) -- tile by tile as the spine publishes u, keeps the
-//     partial accumulators in registers and hands ONE number per (position, chain, part) to the spine.
+//   * SPINE workgroup, one per 4 chains: a ring of four waves, wave w owns position blocks k = w, w+4, ...;
+//     a lane is (row r of the block, ONE chain).  Every wave applies each newly finished u[j] to its own
+//     block's rows (band = the current block and the next three); the owner of the current block finalises
+//     one position per step and publishes it through LDS to its ring mates; once per block it publishes 16
+//     positions to HBM for the panels.  The T-step dependent chain never leaves one CU.  A lone wave issues
+//     one plain instruction per ~4.5 cycles and one transcendental per ~16, so the step is kept at ~24
+//     instructions with 4 transcendentals.  The ring waves never wait for memory: a LOADER wave stages the
+//     band cells in LDS with asynchronous global->LDS loads several blocks ahead, and a FAR wave collects the
+//     panels' partial results into LDS (see the SPINE section).
+//   * PANEL waves (four per panel workgroup; every wave pulls its own tasks, no workgroup-level
+//     synchronisation): a task is (position block k >= 4, column part of <= 16 tiles, 32 chains, 4 of the 16
+//     rows).  The wave streams the far field -- cells (p in its rows, j < 16(k-3)) -- tile by tile through
+//     three LDS stages filled by asynchronous global->LDS loads (it counts its own outstanding loads), keeps
+//     the partial accumulators in registers and hands ONE number per (position, chain, part) to the spine.
 //   * Hand-offs are 8-byte {tag, value} granules written with relaxed agent-scope atomic stores and
 //     polled with relaxed agent-scope atomic loads (data is the flag; no fences, placement independent).
 //     Roles are drawn from an atomic ticket so that a workgroup only ever waits on lower tickets; every
 //     spin is bounded and raises the error word instead of hanging.
 //
-// HBM traffic: every lower-triangle cell is read exactly once (128-byte lines in the panels, 16-byte
-// segments -- two rings share a 32-byte sector -- in the band).  Algorithmic bytes per sweep:
-// 4*B*(T(T+1)/2 + T-1).
+// HBM traffic: every lower-triangle cell is read exactly once (128-byte lines, non-temporal, in the panels;
+// 16-byte segments in the band).  Algorithmic bytes per sweep: 4*B*(T(T+1)/2 + T-1).
 #include <atomic>
 #include <stdlib.h>
 #include "common.h"
