@@ -21,8 +21,9 @@
 //     rows).  The wave streams the far field -- cells (p in its rows, j < 16(k-3)) -- tile by tile through
 //     three LDS stages filled by asynchronous global->LDS loads (it counts its own outstanding loads), keeps
 //     the partial accumulators in registers and hands ONE number per (position, chain, part) to the spine.
-//   * Hand-offs are 8-byte {tag, value} granules written with relaxed agent-scope atomic stores and
-//     polled with relaxed agent-scope atomic loads (data is the flag; no fences, placement independent).
+//   * Hand-offs carry their own flag -- u: a float that reads U_EMPTY until published; far-field partials: 8-byte
+//     {tag, value} granules -- written with relaxed agent-scope atomic stores and polled with tagged loads
+//     (no fences, placement independent).
 //     Roles are drawn from an atomic ticket so that a workgroup only ever waits on lower tickets; every
 //     spin is bounded and raises the error word instead of hanging.
 //
@@ -57,6 +58,7 @@ constexpr float LN2 = 0.6931471805599453f;
 constexpr int SPIN_LIMIT = 1 << 20;       // global-memory polls (with s_sleep): ~0.3 s
 constexpr int SPIN_LIMIT_LDS = 1 << 24;   // LDS polls (s_sleep 1): ~0.5 s
 constexpr float RESCALE_THR = 64.0f;
+constexpr unsigned U_EMPTY = 0xffffffffu;  // not-yet-published u (a NaN pattern the spine never stores): the value is its own flag
 
 typedef unsigned long long u64;
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -80,7 +82,7 @@ struct SweepParams {
                            // 32 panels only stream their cells (no granules, no math)
     unsigned* ctrl;        // [0] ticket, [1] error, [2] panel task queue head, [3] zero-fill row queue head
     u64* ts;               // [2T] debug timestamps of spine 0, ring 0 (dbg & 16)
-    u64* ug;               // [T][B] granules of u (position-major: index p*B + c)
+    unsigned* ug;          // [T][B] u as float bits (position-major: index p*B + c); U_EMPTY until the spine publishes it
     u64* farg;             // [parts][T][B] granules of far-field partials (part = column range of TPT tiles)
     float* u_out;          // [T][B] by FRAME (natural-log units for LSE) or nullptr
     float* last_out;       // [B] value at the last position (logZ for DIR 0) or nullptr
@@ -363,7 +365,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
     const unsigned dbg = P.dbg;
     unsigned* const ctrl = P.ctrl;
     u64* const ts = P.ts;
-    u64* const ug = P.ug;
+    unsigned* const ug = P.ug;
     float* const u_out = P.u_out;
     float* const last_out = P.last_out;
     int* const code = P.code;
@@ -376,7 +378,6 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
     const bool cvalid = c < P.c1;
     const int cc = cvalid ? c : P.c0;
     const size_t Bs = (size_t)B;
-    const unsigned tag = P.tag;
     const bool trace = (dbg & 16u) && sg == 0 && lane == 0;
     float* const ring = (float*)(lds + LDS_RING);
     float* const dummy = (float*)(lds + LDS_DUMMY);
@@ -590,7 +591,11 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
         // ---- once per block: publish the 16 finished positions to HBM -----------------------------
         if (rvalid) {
             const float mine = rd_base[(prow % NPOS) * 8];
-            store_granule(ug + (size_t)prow * Bs + c, make_granule(tag, mine));
+            {
+                unsigned ub = __float_as_uint(mine);
+                if (ub == U_EMPTY) ub = 0x7fc00000u;            // keep the one reserved pattern free (NaN input scores)
+                __hip_atomic_store(ug + (size_t)prow * Bs + c, ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             const float sc = MODE == 0 ? LN2 : 1.0f;
             if (u_out) u_out[(size_t)frow * Bs + c] = mine * sc;
             if (last_out && prow == T - 1) last_out[c] = mine * sc;
@@ -611,7 +616,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
 #define SEMICRF_CELL_AUX 2      // nt: every cell is read once -- keep the stream from evicting the (re-read) u granules from L2
 #endif
 constexpr int PNS = 3;                       // LDS stages per panel wave (tiles fetched ahead)
-constexpr int PSTAGE_BYTES = 12288;          // 8 KB of cells + 4 KB of u granules
+constexpr int PSTAGE_BYTES = 10240;          // 8 KB of cells + 2 KB of u values
 constexpr int PW_MAX = 4;                    // panel waves per workgroup (LDS: PW_MAX * PNS * PSTAGE_BYTES = 144 KB)
 constexpr int LDS_PANEL_BYTES = PW_MAX * PNS * PSTAGE_BYTES;
 constexpr int LDS_HYBRID_PANEL = (LDS_SPINE_BYTES + 1023) / 1024 * 1024;     // stages of a spine workgroup's panel waves
@@ -622,7 +627,7 @@ constexpr int LDS_DYN_MAX2 = LDS_SPINE_BYTES > LDS_PANEL_BYTES ? LDS_SPINE_BYTES
 constexpr int LDS_DYN_BYTES = LDS_HYBRID_BYTES > LDS_DYN_MAX2 ? LDS_HYBRID_BYTES : LDS_DYN_MAX2;   // > half of the CU's 160 KB: one workgroup per CU
 // A wave owns rows pi = 16k + 4*q4 + rr (rr < 4) of position block k for 32 chains.  lane = slot*8 + q8:
 // q8 selects 4 of the 32 chains (8 consecutive lanes read one 128-byte line), slot selects the columns
-// pj = 16m + slot + 8h (h < 2) of tile m.  Cells and u-granules of tile m+1 are requested before tile m is
+// pj = 16m + slot + 8h (h < 2) of tile m.  Cells and u values of the next tiles are requested before tile m is
 // processed.  The same mapping serves both directions (only cell_index differs).
 // ---- panel helpers (free functions: a lambda that calls another lambda keeps its closure in scratch once
 // the body contains operations the optimiser treats as memory writes -- the global->LDS loads) ----------------
@@ -630,7 +635,7 @@ struct PanelGeom {
     int pirow[4];          // rows of the task, clamped to T-1
     unsigned voff;         // per-lane byte offset of the PROCESSING mapping (also the gradient stores)
     unsigned fvoff;        // per-lane byte offset of the FETCH mapping
-    unsigned gvoff;        // per-lane byte offset into the u granules
+    unsigned gvoff;        // per-lane byte offset into the u values
 };
 
 // element offset of the tile base
@@ -647,20 +652,18 @@ __device__ __forceinline__ unsigned panel_soff(const PanelGeom& G, int rr, int h
     return DIR == 0 ? (unsigned)((((size_t)(G.pirow[rr] - G.pirow[0]) * T + 8 * h) * Bs) * 4)
                     : (unsigned)((((size_t)(1 - h) * 8 * T + (G.pirow[3] - G.pirow[rr])) * Bs) * 4);
 }
-// COHERENT = false: ordinary cached loads.  The granules are written once and re-read by every task of the
-// launch; device-scope (sc1) loads would fetch them through the fabric every time (a third of the far field's
-// own traffic).  A stale cache line can only show an OLD tag (8-byte granules are written atomically), which
-// sends the reader to the COHERENT retry below -- the tag keeps the protocol correct either way.
+// u of a tile's 16 columns (2 KB: the value is its own flag, U_EMPTY until published).
+// COHERENT = false: ordinary cached loads.  u is written once and re-read by every task of the launch;
+// device-scope (sc1) loads would fetch it through the fabric every time.  A stale cache line can only show
+// U_EMPTY (the launch's fill, visible since the kernel boundary; 4-byte values are written atomically), which
+// sends the reader to the COHERENT retry.
 template <bool COHERENT>
 __device__ __forceinline__ void panel_fetch_gran(__amdgpu_buffer_rsrc_t ursrc, char* stage, unsigned gvoff, int m, int B)
 {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const unsigned so = (unsigned)((m * PB + 8 * h) * B * 8);
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void_t*)(stage + 8192 + (h * 2 + hh) * 1024), 16, gvoff + 16 * hh, so, 0,
-                                                     COHERENT ? 16 : 0);        // 16 = sc1
+    for (int h = 0; h < 2; ++h) {       // positions 16m + 8h + slot, 4 chains (16 bytes) per lane
+        const unsigned so = (unsigned)((m * PB + 8 * h) * B * 4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void_t*)(stage + 8192 + h * 1024), 16, gvoff, so, 0, COHERENT ? 16 : 0);   // 16 = sc1
     }
 }
 // FETCH mapping (global -> LDS, 1 KB per instruction, lane-linear in LDS):
@@ -678,11 +681,10 @@ __device__ __forceinline__ void panel_fetch_cells(const float* score, const Pane
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(stage + e * 1024), 16, G.fvoff, so, 0, SEMICRF_CELL_AUX);
     }
 }
-__device__ __forceinline__ void panel_read_gran(unsigned addr, v4u& g00, v4u& g01, v4u& g10, v4u& g11)
+__device__ __forceinline__ void panel_read_gran(unsigned addr, v4u& g0, v4u& g1)
 {
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
-                 "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(g00), "=&v"(g01), "=&v"(g10), "=&v"(g11)
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(g0), "=&v"(g1)
                  : "v"(addr));
 }
 template <int DIR>
@@ -701,11 +703,11 @@ __device__ __forceinline__ void panel_read_cells(unsigned addr, v4u (&o)[8])
 // wait until at most `younger` vector-memory operations are outstanding (rounded down to an encodable step)
 __device__ __forceinline__ void panel_wait_younger(int y)
 {
-    if (y >= 48) wait_vmcnt<48>();
-    else if (y >= 40) wait_vmcnt<40>();
-    else if (y >= 32) wait_vmcnt<32>();
-    else if (y >= 24) wait_vmcnt<24>();
-    else if (y >= 12) wait_vmcnt<12>();
+    if (y >= 44) wait_vmcnt<44>();
+    else if (y >= 36) wait_vmcnt<36>();
+    else if (y >= 28) wait_vmcnt<28>();
+    else if (y >= 20) wait_vmcnt<20>();
+    else if (y >= 10) wait_vmcnt<10>();
     else wait_vmcnt<0>();
 }
 
@@ -727,7 +729,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
     const size_t Bs = (size_t)B;
     const float* __restrict__ score = P.score;
     const unsigned tag = P.tag;
-    const auto ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.ug, 0, (int)((size_t)T * Bs * 8), 0x00020000);
+    const auto ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.ug, 0, (int)((size_t)T * Bs * 4), 0x00020000);
 
     while (true) {
         // ---- next task: (k, part, g, q4), ordered so that a task only waits on spine progress below k-3 ----
@@ -795,7 +797,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
             const int f_pirow = pbase + f_pisub < T ? pbase + f_pisub : T - 1;
             G.fvoff = DIR == 0 ? G.voff : (unsigned)((((size_t)(1 - f_pjsub) * T + (G.pirow[3] - f_pirow)) * Bs + cl) * 4);
         }
-        G.gvoff = (unsigned)((slot * B + cl) * 8);
+        G.gvoff = (unsigned)((slot * B + cl) * 4);
         char* const stage0 = lds + wslot * (PNS * PSTAGE_BYTES);
         const unsigned rdbase = lds_addr(stage0) + (DIR == 0 ? (unsigned)lane * 16u
                                                              : (unsigned)((slot >> 1) * 1024 + (slot & 1) * 128 + q8 * 16));
@@ -812,7 +814,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
             if (m0 + i < m1) {
                 panel_fetch_cells<DIR>(score, G, stage0 + i * PSTAGE_BYTES, m0 + i, T, Bs);
                 if (!probe_stream) panel_fetch_gran<false>(ursrc, stage0 + i * PSTAGE_BYTES, G.gvoff, m0 + i, B);
-                issued += 12;
+                issued += 10;
                 if (i == 0) mark0 = issued; else if (i == 1) mark1 = issued; else mark2 = issued;
             }
 
@@ -827,27 +829,27 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                 for (int e = 0; e < 8; ++e)
                     aS[0][0] += __uint_as_float(xo[e].x) + __uint_as_float(xo[e].y) + __uint_as_float(xo[e].z) + __uint_as_float(xo[e].w);
             } else {
-                v4u g00, g01, g10, g11;      // [h][chain pair] granules (2 granules per 16 bytes)
-                panel_read_gran(grbase + (unsigned)(s * PSTAGE_BYTES), g00, g01, g10, g11);
-                // every granule carries its own tag: if some are missing, fetch them again until the spine has
-                // published block m
+                v4u g0, g1;      // [h]: u of 4 chains at position 16m + 8h + slot
+                panel_read_gran(grbase + (unsigned)(s * PSTAGE_BYTES), g0, g1);
+                // a value that has not been published yet reads as U_EMPTY (from the launch's memset, possibly out of a
+                // stale cache line): fetch again with device-scope loads until the spine has published block m
                 if (!probe_nowait) {
                     const bool v0 = c < c1, v1 = c + 1 < c1, v2 = c + 2 < c1, v3 = c + 3 < c1;
                     int spins = 0;
                     while (true) {
-                        const bool ok = (g00.y == tag || !v0) && (g00.w == tag || !v1) && (g01.y == tag || !v2) &&
-                                        (g01.w == tag || !v3) && (g10.y == tag || !v0) && (g10.w == tag || !v1) &&
-                                        (g11.y == tag || !v2) && (g11.w == tag || !v3);
+                        const bool ok = (g0.x != U_EMPTY || !v0) && (g0.y != U_EMPTY || !v1) && (g0.z != U_EMPTY || !v2) &&
+                                        (g0.w != U_EMPTY || !v3) && (g1.x != U_EMPTY || !v0) && (g1.y != U_EMPTY || !v1) &&
+                                        (g1.z != U_EMPTY || !v2) && (g1.w != U_EMPTY || !v3);
                         if (__all(ok)) break;
                         __builtin_amdgcn_s_sleep(16);
                         if (spin_abort(ctrl, spins, SPIN_LIMIT, 5)) break;
                         panel_fetch_gran<true>(ursrc, stage, G.gvoff, m, B);
                         wait_vmcnt<0>();
-                        panel_read_gran(grbase + (unsigned)(s * PSTAGE_BYTES), g00, g01, g10, g11);
+                        panel_read_gran(grbase + (unsigned)(s * PSTAGE_BYTES), g0, g1);
                     }
                 }
-                const float uv[2][4] = {{__uint_as_float(g00.x), __uint_as_float(g00.z), __uint_as_float(g01.x), __uint_as_float(g01.z)},
-                                        {__uint_as_float(g10.x), __uint_as_float(g10.z), __uint_as_float(g11.x), __uint_as_float(g11.z)}};
+                const float uv[2][4] = {{__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z), __uint_as_float(g0.w)},
+                                        {__uint_as_float(g1.x), __uint_as_float(g1.y), __uint_as_float(g1.z), __uint_as_float(g1.w)}};
 
                 if (MODE == 0) {
                     // t = u + cell*log2e; lazily rescaled accumulators: one exp per cell, rare rescale branch.
@@ -922,7 +924,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
             if (m + PNS < m1) {
                 panel_fetch_cells<DIR>(score, G, stage, m + PNS, T, Bs);
                 if (!probe_stream) panel_fetch_gran<false>(ursrc, stage, G.gvoff, m + PNS, B);
-                issued += 12;
+                issued += 10;
                 if (s == 0) mark0 = issued; else if (s == 1) mark1 = issued; else mark2 = issued;
             }
         }
@@ -1095,8 +1097,8 @@ static int device_cus()
 
 size_t persist_workspace_bytes(int T, int B)
 {
-    return CTRL_BYTES + align_up((size_t)2 * T * sizeof(u64)) +
-           (size_t)(1 + max_parts(T)) * align_up((size_t)T * B * sizeof(u64));
+    return CTRL_BYTES + align_up((size_t)2 * T * sizeof(u64)) + (size_t)max_parts(T) * align_up((size_t)T * B * sizeof(u64)) +
+           align_up((size_t)T * B * sizeof(unsigned));
 }
 
 // Even NBatch: the loader's 16-byte global->LDS loads and the panels' 16-byte loads need 8-byte aligned
@@ -1145,11 +1147,13 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
     char* w = (char*)ws;
     P.ts = (u64*)(w + CTRL_BYTES);
     const size_t ts_bytes = align_up((size_t)2 * T * sizeof(u64));
-    P.ug = (u64*)(w + CTRL_BYTES + ts_bytes);
-    P.farg = (u64*)(w + CTRL_BYTES + ts_bytes + align_up((size_t)T * B * sizeof(u64)));
+    P.farg = (u64*)(w + CTRL_BYTES + ts_bytes);
+    const size_t ug_off = CTRL_BYTES + ts_bytes + (size_t)max_parts(T) * align_up((size_t)T * B * sizeof(u64));
+    P.ug = (unsigned*)(w + ug_off);
     P.u_out = u_out; P.last_out = last_out; P.code = code;
-    const size_t zbytes = persist_workspace_bytes(T, B);
-    if (hipMemsetAsync(ws, 0, zbytes, stream) != hipSuccess) return 1;
+    // control words and far-field granules start at 0, u at U_EMPTY (two fills: the patterns differ)
+    if (hipMemsetAsync(ws, 0, ug_off, stream) != hipSuccess) return 1;
+    if (hipMemsetAsync(w + ug_off, 0xff, align_up((size_t)T * B * sizeof(unsigned)), stream) != hipSuccess) return 1;
     // panel tasks per chain group: block k = RING + q has q/TPT + 1 column parts, each split in 4 row quarters
     long long ntask = 0;
     for (int q = 0; q < P.K - RING; ++q) ntask += (q / TPT + 1);
