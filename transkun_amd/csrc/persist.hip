@@ -454,6 +454,14 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
                 }
             }
         }
+        // LSE: W = wl + sp of every row of the block, in every lane (the value chain is carried redundantly)
+        float Wb[PB];
+        if (MODE == 0) {
+#pragma unroll
+            for (int jj = 1; jj < PB; ++jj)
+                Wb[jj] = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + (jj << 4), __float_as_int(wl + sp)));
+            Wb[0] = 0.0f;
+        }
         // GRAD: marginal(prow, j) = gz * exp2(t + arow) with t = u[j] + cell*log2e, arow = (alpha[frame] - logZ)*log2e
         const float arow = (GRAD && rvalid) ? (vfl - lzc) * LOG2E : 0.f;
         if (trace) ev[1] = __builtin_readcyclecounter();
@@ -543,19 +551,24 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
         float* const wr = r == 0 ? ring + ch * 2 + (own0 % NPOS) * 8 : dummy + lane * 2;
         int mykey = -1;
         if (MODE == 0) {
-            const float W = wl + sp;
+            // Every lane carries the value chain of its chain redundantly, so the dependent chain u[j] -> u[j+1]
+            // = logaddexp2(VpB, u[j] + W[j+1]) contains no cross-lane step: W of every row was broadcast at the
+            // start of the iteration, and VpB (row j+1's sum of everything but its last term) is broadcast one
+            // step ahead, right after the push of u[j-1].
             float Vp = aM + flog2(aS) + sp;
-            float cv = prow == 0 ? sp : Vp;                  // value of row 0 (lanes r == 0)
+            float ucur = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(prow == 0 ? sp : Vp)));   // row 0
+            float VpB = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + (1 << 4), __float_as_int(Vp)));           // row 1
 #pragma unroll
             for (int jj = 0; jj < PB; ++jj) {
                 const int j = own0 + jj;
-                // broadcast u[j] from the lanes of row jj to everybody
-                const float u = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + (jj << 4), __float_as_int(cv)));
+                const float u = ucur;
                 *(float2*)(wr + jj * 8) = make_float2(u, __int_as_float(j + 1));    // one DS write: data + seq
-                // critical chain: value of row jj+1 = logaddexp2(Vp, u + W) (only its lanes matter)
-                const float t = u + W;
-                cv = fmaxf(Vp, t) + flog2(1.0f + fexp2(-fabsf(Vp - t)));
-                // generic push for the rows further down, then refresh Vp
+                // critical chain: value of row jj+1
+                if (jj + 1 < PB) {
+                    const float t = u + Wb[jj + 1 < PB ? jj + 1 : 0];
+                    ucur = fmaxf(VpB, t) + flog2(1.0f + fexp2(-fabsf(VpB - t)));
+                }
+                // push for the rows further down, refresh Vp, send row jj+2's ahead
                 const float p = fmaf(X[RING - 1].v[jj], LOG2E, u);
                 if (GRAD) {
                     if (rvalid && r > jj) grad_store(j, gz * fexp2(p + arow));
@@ -564,6 +577,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
                 }
                 acc_push1(aM, aS, p);
                 Vp = aM + flog2(aS) + sp;
+                if (jj + 2 < PB) VpB = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + ((jj + 2) << 4), __float_as_int(Vp)));
             }
         } else {
             // (max,+): after the push of u[jj] the accumulator of row jj+1 is complete
