@@ -149,6 +149,16 @@ __device__ __forceinline__ void acc_merge(float& M, float& S, float M2, float S2
         S += S2 * fexp2(M2 - M);
     }
 }
+// (max, key) push for candidates that arrive in position order within one accumulator: frames ascend with the
+// positions in DIR 0 (the first maximum stays) and descend in DIR 1 (a later equal candidate has the smaller
+// frame and wins) -- one compare instead of the general three (the reference keeps the smallest frame index)
+template <int DIR>
+__device__ __forceinline__ void max_push_seq(float& best, int& key, float t, int k)
+{
+    const bool take = DIR == 0 ? t > best : t >= best;
+    best = take ? t : best;
+    key = take ? k : key;
+}
 // softplus in log2 units: log2(1 + 2^(x*log2e)), linear above the reference's threshold (20)
 __device__ __forceinline__ float softplus2(float x)
 {
@@ -930,7 +940,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                             const float xe[4] = {__uint_as_float(xv.x), __uint_as_float(xv.y), __uint_as_float(xv.z), __uint_as_float(xv.w)};
                             const int key = frame_of<DIR>(m * PB + slot + 8 * h, T);
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) max_push(aM[rr][i], aK[rr][i], uv[h][i] + xe[i], key);
+                            for (int i = 0; i < 4; ++i) max_push_seq<DIR>(aM[rr][i], aK[rr][i], uv[h][i] + xe[i], key);
                         }
                 }
             }
