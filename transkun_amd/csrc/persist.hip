@@ -1060,9 +1060,10 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
     const int ticket = s_ticket;
     const int wave = (int)(threadIdx.x >> 6);
     if (ticket < P.nSpine) {
-        // chain groups that share 32-byte sectors go to workgroups 8 tickets apart (same XCD, same L2)
-        int sg = ticket;
-        if ((P.nSpine & 7) == 0) sg = (ticket & 7) * (P.nSpine >> 3) + (ticket >> 3);
+        // chain group = ticket: neighbouring groups read neighbouring 16-byte pieces of the same sectors, and
+        // measured fetch traffic is 3x lower this way than with groups spread 8 tickets apart (0.13 vs 0.36 GB for
+        // the band at T=1024, NBatch=352)
+        const int sg = ticket;
         if (wave < RING) {
             if (!(P.dbg & 8u)) spine_role<MODE, DIR, GRAD>(P, sg, wave, s_dyn);
         } else if (wave == RING) {
