@@ -1211,9 +1211,9 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         float per_cu = (float)T / 1024.0f;
         per_cu = per_cu < 0.75f ? 0.75f : (per_cu > 2.0f ? 2.0f : per_cu);
         if (grad) per_cu *= 1.25f;
-        // long sequences are bound by the far field: the spine workgroups' spare waves then stream tiles too
-        // (at T = 1024 they only slow the ring down: 233 vs 250 us; at T = 2048 they win: 701 vs 788 us)
-        int hpw = (HPW_MAX > 0 && T >= 1536) ? HPW_MAX : 0;
+        // the spine workgroups' two spare waves stream tiles too: both for long sequences (bound by the far field:
+        // 701 vs 788 us at T = 2048), one at T = 1024 (213 vs 217 us; two slow the ring down more than they add)
+        int hpw = HPW_MAX > 0 ? (T >= 1536 ? HPW_MAX : 1) : 0;
         if (const char* e = getenv("SEMICRF_HYBRID_PANEL_WAVES")) { const int v = atoi(e); if (v >= 0 && v <= HPW_MAX) hpw = v; }
         P.hybridPanelWaves = hpw;
         int pw = PW_MAX;
