@@ -58,6 +58,7 @@ constexpr float LN2 = 0.6931471805599453f;
 constexpr int SPIN_LIMIT = 1 << 20;       // global-memory polls (with s_sleep): ~0.3 s
 constexpr int SPIN_LIMIT_LDS = 1 << 24;   // LDS polls (s_sleep 1): ~0.5 s
 constexpr float RESCALE_THR = 64.0f;
+constexpr unsigned CTRL_INIT = 0xffffffffu;  // initial value of every workspace word (one 0xff fill per launch)
 constexpr unsigned U_EMPTY = 0xffffffffu;  // not-yet-published u (a NaN pattern the spine never stores): the value is its own flag
 
 typedef unsigned long long u64;
@@ -183,7 +184,7 @@ __device__ __forceinline__ bool spin_abort(unsigned* ctrl, int& spins, int limit
     ++spins;
     if (spins > limit) { set_error(ctrl, code); return true; }
     if ((spins & 255) == 0 &&
-        __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
+        __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != CTRL_INIT) return true;
     return false;
 }
 
@@ -758,7 +759,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
     while (true) {
         // ---- next task: (k, part, g, q4), ordered so that a task only waits on spine progress below k-3 ----
         int task = 0;
-        if (lane == 0) task = (int)atomicAdd(ctrl + 2, 1u);
+        if (lane == 0) task = (int)(atomicAdd(ctrl + 2, 1u) + 1u);        // counters start at 0xffffffff (one 0xff fill)
         task = __builtin_amdgcn_readfirstlane(task);
         if (task >= nTasks) break;
         const int q4 = task & 3;
@@ -1033,7 +1034,7 @@ __device__ __forceinline__ void zero_role(const SweepParams& P)
     const int npairs = T / 2;                                  // rows 0 .. T-2 in pairs (e, T-2-e)
     while (true) {
         int p = 0;
-        if (lane == 0) p = (int)atomicAdd(ctrl + 3, 1u);
+        if (lane == 0) p = (int)(atomicAdd(ctrl + 3, 1u) + 1u);
         p = __builtin_amdgcn_readfirstlane(p);
         if (p >= npairs) break;
         const int e2 = T - 2 - p;
@@ -1053,7 +1054,7 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
 {
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];
     __shared__ int s_ticket;
-    if (threadIdx.x == 0) s_ticket = (int)atomicAdd(P.ctrl, 1u);
+    if (threadIdx.x == 0) s_ticket = (int)(atomicAdd(P.ctrl, 1u) + 1u);
     // flags and sequence numbers start at 0
     for (int i = threadIdx.x; i < (LDS_DUMMY - LDS_FAR) / 4; i += NT) ((int*)(s_dyn + LDS_FAR))[i] = 0;
     __syncthreads();
@@ -1137,7 +1138,7 @@ bool persist_supported(int T, int B)
 static unsigned next_tag()
 {
     static std::atomic<unsigned> counter{0};
-    const unsigned lo = (counter.fetch_add(1) % 65535u) + 1u;   // 1..65535
+    const unsigned lo = (counter.fetch_add(1) % 65534u) + 1u;   // 1..65534: never the workspace's fill pattern 0xffff
     return (lo << 16) | lo;                                      // both 16-bit halves nonzero
 }
 
@@ -1176,9 +1177,9 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
     const size_t ug_off = CTRL_BYTES + ts_bytes + (size_t)max_parts(T) * align_up((size_t)T * B * sizeof(u64));
     P.ug = (unsigned*)(w + ug_off);
     P.u_out = u_out; P.last_out = last_out; P.code = code;
-    // control words and far-field granules start at 0, u at U_EMPTY (two fills: the patterns differ)
-    if (hipMemsetAsync(ws, 0, ug_off, stream) != hipSuccess) return 1;
-    if (hipMemsetAsync(w + ug_off, 0xff, align_up((size_t)T * B * sizeof(unsigned)), stream) != hipSuccess) return 1;
+    // ONE fill: every word of the workspace starts as 0xffffffff -- u reads U_EMPTY, far-field granules carry a tag no
+    // launch uses, the counters return 0 after their first increment, the error word reads CTRL_INIT
+    if (hipMemsetAsync(ws, 0xff, persist_workspace_bytes(T, B), stream) != hipSuccess) return 1;
     // panel tasks per chain group: block k = RING + q has q/TPT + 1 column parts, each split in 4 row quarters
     long long ntask = 0;
     for (int q = 0; q < P.K - RING; ++q) ntask += (q / TPT + 1);
