@@ -32,5 +32,6 @@ K = (a.T + 15) // 16
 ev = ws[CT + a.T * 8:CT + a.T * 8 + K * 64].view(torch.int64).cpu().numpy().reshape(K, 8)
 t0 = ev[0, 0]
 print("  per-block events (cycles since start): iter_start, consts_done, loads_issued, shadow0, shadow1, shadow2, diag_start, diag_end")
+print('  diag_start by block (us at 2.4 GHz):', [round((ev[k,6]-t0)/2400,1) for k in range(0,K,4)])
 for k in list(range(0, 12)) + list(range(32, 38)):
     print(f"   k={k:3d} wave={k%4}: " + " ".join(f"{(x - t0) if x not in (0, -1) else 0:9d}" for x in ev[k]))

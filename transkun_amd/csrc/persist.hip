@@ -353,7 +353,7 @@ __device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds
                 while (true) {
                     const bool ok = MODE == 0 ? (unsigned)(g0 >> 32) == tag : (unsigned)(g0 >> 48) == (tag & 0xffffu);
                     if (ok) break;
-                    __builtin_amdgcn_s_sleep(4);
+                    __builtin_amdgcn_s_sleep(1);
                     if (spin_abort(ctrl, spins, SPIN_LIMIT, 3)) break;
                     g0 = load_granule(fp);
                 }
@@ -866,7 +866,13 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                                         (g0.w != U_EMPTY || !v3) && (g1.x != U_EMPTY || !v0) && (g1.y != U_EMPTY || !v1) &&
                                         (g1.z != U_EMPTY || !v2) && (g1.w != U_EMPTY || !v3);
                         if (__all(ok)) break;
-                        __builtin_amdgcn_s_sleep(16);
+                        // The task's newest tile (m == q) is on the spine's critical path: poll tightly.  Waves blocked
+                        // further ahead advance one tile per spine block; the forward sweeps want them prompt as well
+                        // (lazy: 240 us, prompt: 212 us), the bandwidth-bound gradient sweep wants the fabric quiet
+                        // (prompt: 505-525 us, lazy: 465-472 us).
+                        if (m == q) __builtin_amdgcn_s_sleep(2);
+                        else if (GRAD) __builtin_amdgcn_s_sleep(127);
+                        else __builtin_amdgcn_s_sleep(16);
                         if (spin_abort(ctrl, spins, SPIN_LIMIT, 5)) break;
                         panel_fetch_gran<true>(ursrc, stage, G.gvoff, m, B);
                         wait_vmcnt<0>();
