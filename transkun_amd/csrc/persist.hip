@@ -874,6 +874,11 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                         else if (GRAD) __builtin_amdgcn_s_sleep(127);
                         else __builtin_amdgcn_s_sleep(16);
                         if (spin_abort(ctrl, spins, SPIN_LIMIT, 5)) break;
+                        // light probe first: one word per lane -- the block's last position for the first of the lane's four
+                        // chains (a ring publishes its 16 positions x 4 chains with one store instruction); only when every
+                        // ring of the tile shows a value is the 2 KB tile fetched again
+                        const unsigned pw = __builtin_amdgcn_raw_buffer_load_b32(ursrc, (unsigned)(cl * 4), (unsigned)((m * PB + PB - 1) * B * 4), 16);
+                        if (!__all(pw != U_EMPTY || !cvalid)) continue;
                         panel_fetch_gran<true>(ursrc, stage, G.gvoff, m, B);
                         wait_vmcnt<0>();
                         panel_read_gran(grbase + (unsigned)(s * PSTAGE_BYTES), g0, g1);
