@@ -210,6 +210,7 @@ __device__ __forceinline__ bool spin_abort(unsigned* ctrl, int& spins, int limit
 #ifndef SEMICRF_NRBUF
 #define SEMICRF_NRBUF 4
 #endif
+constexpr int NLOADER = RING >= 5 ? 2 : 1;          // loader waves per ring (a row block is RING tiles)
 constexpr int NRBUF = SEMICRF_NRBUF;                  // row-block buffers between the loader and the ring
 constexpr int TILE_BYTES = PB * PB * RS * 4;          // 4096: [column u][row r][chain] floats
 constexpr int NCONST = 3;                             // per-row constants: diagonal cell, noise, alpha (GRAD)
@@ -218,7 +219,7 @@ constexpr int LDS_CONST = LDS_TILES + NRBUF * RING * TILE_BYTES;       // [NRBUF
 constexpr int LDS_FAR = LDS_CONST + NRBUF * NCONST * 256;              // [8][64] x {value, key, seq, pad}
 constexpr int NFAR = 8;                               // far-partial entries (blocks) between the far wave and the ring (>= RING)
 constexpr int NPOS = 128;                             // positions kept in the LDS ring (>= the band, RING blocks)
-static_assert(NFAR >= RING && NPOS >= RING * PB && RING + 2 <= NT / 64, "ring geometry");
+static_assert(NFAR >= RING && NPOS >= RING * PB && RING + NLOADER + 1 <= NT / 64, "ring geometry");
 constexpr int LDS_RING = LDS_FAR + NFAR * 64 * 16;                     // [NPOS][RS] x {u, seq}
 constexpr int LDS_CTL = LDS_RING + NPOS * RS * 8;                       // ready[NRBUF], cons[RING] (ints)
 constexpr int LDS_DUMMY = LDS_CTL + 256;                               // sink of the non-writer lanes' ring stores
@@ -254,7 +255,7 @@ __device__ __forceinline__ void lds_flag_store_asm(int* p, int v)
 
 // ---- loader wave ---------------------------------------------------------------------------------------
 template <int DIR, bool GRAD>
-__device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* lds)
+__device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* lds, int lid)
 {
     const int T = P.T, B = P.B, K = P.K;
     unsigned* const ctrl = P.ctrl;
@@ -305,7 +306,10 @@ __device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* 
         if (lane == 0) lds_flag_store_asm(ready + kr % NRBUF, kr + 1);
     };
 
-    for (int kr = 0; kr < K; ++kr) {
+    // NLOADER loader waves take the row blocks round-robin (lid = this wave's index); each keeps LDEPTH of its own
+    // row blocks in flight (the counter holds 63 operations)
+    int prev2 = -1, prev1 = -1;                    // row blocks issued by this wave and not yet published (oldest first)
+    for (int kr = lid; kr < K; kr += NLOADER) {
         if (kr >= NRBUF) {
             // the buffer's previous row block (kr - NRBUF) must have been read by its ring wave
             const int w = (kr - NRBUF) % RING;
@@ -316,13 +320,17 @@ __device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* 
             }
         }
         issue(kr);
-        // LDEPTH row blocks in flight (the counter holds 63 operations)
-        if (LDEPTH == 3) { if (kr >= 2) { wait_vmcnt<2 * NL>(); publish(kr - 2); } }
-        else { if (kr >= 1) { wait_vmcnt<NL>(); publish(kr - 1); } }
+        if (LDEPTH == 3) {
+            if (prev2 >= 0) { wait_vmcnt<2 * NL>(); publish(prev2); }
+            prev2 = prev1; prev1 = kr;
+        } else {
+            if (prev1 >= 0) { wait_vmcnt<NL>(); publish(prev1); }
+            prev1 = kr;
+        }
     }
-    if (LDEPTH == 3 && K >= 2) { wait_vmcnt<NL>(); publish(K - 2); }
+    if (LDEPTH == 3 && prev2 >= 0) { wait_vmcnt<NL>(); publish(prev2); }
     wait_vmcnt<0>();
-    publish(K - 1);
+    if (prev1 >= 0) publish(prev1);
 }
 
 // ---- far wave -------------------------------------------------------------------------------------------
@@ -645,8 +653,8 @@ constexpr int PSTAGE_BYTES = 10240;          // 8 KB of cells + 2 KB of u values
 constexpr int PW_MAX = 4;                    // panel waves per workgroup (LDS: PW_MAX * PNS * PSTAGE_BYTES = 144 KB)
 constexpr int LDS_PANEL_BYTES = PW_MAX * PNS * PSTAGE_BYTES;
 constexpr int LDS_HYBRID_PANEL = (LDS_SPINE_BYTES + 1023) / 1024 * 1024;     // stages of a spine workgroup's panel waves
-constexpr int HPW_MAX = (160 * 1024 - 512 - LDS_HYBRID_PANEL) / (PNS * PSTAGE_BYTES) < NT / 64 - RING - 2
-                            ? (160 * 1024 - 512 - LDS_HYBRID_PANEL) / (PNS * PSTAGE_BYTES) : NT / 64 - RING - 2;
+constexpr int HPW_MAX = (160 * 1024 - 512 - LDS_HYBRID_PANEL) / (PNS * PSTAGE_BYTES) < NT / 64 - RING - NLOADER - 1
+                            ? (160 * 1024 - 512 - LDS_HYBRID_PANEL) / (PNS * PSTAGE_BYTES) : NT / 64 - RING - NLOADER - 1;
 constexpr int LDS_HYBRID_BYTES = LDS_HYBRID_PANEL + (HPW_MAX > 0 ? HPW_MAX : 0) * PNS * PSTAGE_BYTES;
 constexpr int LDS_DYN_MAX2 = LDS_SPINE_BYTES > LDS_PANEL_BYTES ? LDS_SPINE_BYTES : LDS_PANEL_BYTES;
 constexpr int LDS_DYN_BYTES = LDS_HYBRID_BYTES > LDS_DYN_MAX2 ? LDS_HYBRID_BYTES : LDS_DYN_MAX2;   // > half of the CU's 160 KB: one workgroup per CU
@@ -1078,13 +1086,13 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
         const int sg = ticket;
         if (wave < RING) {
             if (!(P.dbg & 8u)) spine_role<MODE, DIR, GRAD>(P, sg, wave, s_dyn);
-        } else if (wave == RING) {
-            if (!(P.dbg & 8u)) loader_role<DIR, GRAD>(P, sg, s_dyn);
-        } else if (wave == RING + 1) {
+        } else if (wave < RING + NLOADER) {
+            if (!(P.dbg & 8u)) loader_role<DIR, GRAD>(P, sg, s_dyn, wave - RING);
+        } else if (wave == RING + NLOADER) {
             if (!(P.dbg & 9u)) far_role<MODE, DIR>(P, sg, s_dyn);
-        } else if (!(P.dbg & 2u) && wave - (RING + 2) < P.hybridPanelWaves) {
+        } else if (!(P.dbg & 2u) && wave - (RING + NLOADER + 1) >= 0 && wave - (RING + NLOADER + 1) < P.hybridPanelWaves) {
             // spare waves stream tiles like the panel workgroups do (their stages lie behind the spine's LDS)
-            panel_role<MODE, DIR, GRAD>(P, s_dyn + LDS_HYBRID_PANEL, wave - (RING + 2));
+            panel_role<MODE, DIR, GRAD>(P, s_dyn + LDS_HYBRID_PANEL, wave - (RING + NLOADER + 1));
         }
     } else {
         if (!(P.dbg & 2u) && wave < P.panelWaves) panel_role<MODE, DIR, GRAD>(P, s_dyn, wave);
