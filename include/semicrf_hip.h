@@ -137,6 +137,20 @@ int interval_score_fwd(const float* q, const float* k, const float* diag, int C,
                        int64_t ldq, int64_t ldk, int64_t ldd, float qscale, int length_scaling,
                        int full_square, float* S, float* noise_out, semicrf_stream_t stream);
 
+/*
+ * Backward of interval_score_fwd.  Replaces: the autograd of LayersTransformer.py:410-433 (scale, einsum,
+ * length scaling, diag_embed).  dS is [T][T][C] (the CRF's gradient layout; only e >= b is read: the counterpart of
+ * interval_score_fwd with full_square == 0):
+ *   dq[c,e,:] = qscale * sum_{b<=e} dS[e,b,c] len(e-b) k[c,b,:]
+ *   dk[c,b,:] = qscale * sum_{e>=b} dS[e,b,c] len(e-b) q[c,e,:]
+ *   ddiag[c,t] = dS[t,t,c]
+ * dq/dk: [C][T][D] with row strides lddq/lddk; ddiag: [C][T] with stride lddd.  Any output may be NULL.
+ * Requires D % 32 == 0 and D <= 256 (SEMICRF_EINVAL otherwise; the Python mirror then differentiates with torch).
+ */
+int interval_score_bwd(const float* dS, const float* q, const float* k, int C, int T, int D, int64_t ldq,
+                       int64_t ldk, float qscale, int length_scaling, float* dq, float* dk, float* ddiag,
+                       int64_t lddq, int64_t lddk, int64_t lddd, semicrf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

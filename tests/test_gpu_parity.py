@@ -279,6 +279,31 @@ def test_scorer(gpu, impl, oracle, name):
     assert rel_err(m.map[0].bias.grad.cpu().numpy(), g["dbias"]) < 1e-3
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,P,T,D,ls", [(1, 5, 70, 64, "linear"), (2, 9, 97, 256, "linear"), (1, 3, 33, 32, "sqrt"),
+                                         (1, 8, 64, 128, "none"), (3, 11, 130, 96, "linear")])
+def test_scorer_backward_kernel(gpu, N, P, T, D, ls):
+    """interval_score_bwd (MFMA, dS in the CRF layout) against the plain-torch differentiation of the same formula:
+    dq, dk, ddiag for a dense cotangent (the upper triangle must be ignored)."""
+    from transkun_amd import _lib, synth
+    from transkun_amd.scorer import _IntervalScore
+    _lib.set_impl(0)
+    C = N * P
+    q = synth.hash_normal(C * T * D, 51, gpu).view(N, P, T, D).contiguous()
+    k = synth.hash_normal(C * T * D, 52, gpu).view(N, P, T, D).contiguous()
+    dg = synth.hash_normal(C * T, 53, gpu).view(N, P, T).contiguous()
+    qa, ka, da = (x.clone().requires_grad_() for x in (q, k, dg))
+    S, b = _IntervalScore.apply(qa, ka, da, N, P, T, D, _lib.LEN_MODES[ls], False)
+    cot = synth.hash_normal(T * T * C, 54, gpu).view(T, T, N, P)          # dense: e < b entries must not contribute
+    S.backward(cot)
+    ref = _IntervalScore._backward_torch(cot, q.view(C, T, D), k.view(C, T, D), N, P, T, D, _lib.LEN_MODES[ls], False)
+    for got, want, name in ((qa.grad, ref[0], "dq"), (ka.grad, ref[1], "dk"), (da.grad, ref[2], "ddiag")):
+        scale = float(want.abs().max()) + 1e-30
+        err = float((got - want).abs().max()) / scale
+        assert err < 2e-5, (name, err)
+    assert _lib.device_status() == 0
+
+
 # ---- the persistent blocked kernels against the oracle over a grid of shapes -------------------
 
 PERSIST_SHAPES = [(1, 4), (2, 4), (15, 8), (16, 4), (17, 12), (33, 16), (48, 20), (63, 36), (64, 32), (65, 4),

@@ -35,6 +35,10 @@ void launch_interval_score_naive(const float* q, const float* k, const float* di
                                  float* S, hipStream_t stream);
 
 bool interval_score_mfma_supported(int C, int T, int D);
+bool interval_score_bwd_supported(int C, int T, int D);
+void launch_interval_score_bwd(const float* dS, const float* q, const float* k, int C, int T, int D, long long ldq,
+                               long long ldk, float qscale, int mode, float* dq, float* dk, float* ddiag,
+                               long long lddq, long long lddk, long long lddd, hipStream_t stream);
 void launch_interval_score_mfma(const float* q, const float* k, const float* diag, int C, int T, int D,
                                 long long ldq, long long ldk, long long ldd, float qscale, int mode, int full,
                                 float* S, hipStream_t stream);
@@ -227,6 +231,22 @@ int interval_score_fwd(const float* q, const float* k, const float* diag, int C,
         }
     }
     SEMICRF_CHECK_LAUNCH("interval_score_fwd");
+    return SEMICRF_OK;
+}
+
+int interval_score_bwd(const float* dS, const float* q, const float* k, int C, int T, int D, int64_t ldq, int64_t ldk,
+                       float qscale, int length_scaling, float* dq, float* dk, float* ddiag, int64_t lddq,
+                       int64_t lddk, int64_t lddd, semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(C >= 1 && T >= 1 && D >= 1, "C=%d T=%d D=%d must be >= 1", C, T, D);
+    SEMICRF_CHECK_ARG(dS && q && k, "dS/q/k must be non-NULL");
+    SEMICRF_CHECK_ARG(ldq >= D && ldk >= D && (!dq || lddq >= D) && (!dk || lddk >= D) && (!ddiag || lddd >= 1),
+                      "bad leading dimensions");
+    SEMICRF_CHECK_ARG(length_scaling >= 0 && length_scaling <= 2, "bad length_scaling %d", length_scaling);
+    SEMICRF_CHECK_ARG(interval_score_bwd_supported(C, T, D), "interval_score_bwd needs D %% 32 == 0 and D <= 256 (D=%d)", D);
+    launch_interval_score_bwd(dS, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, ddiag, lddq, lddk, lddd,
+                              (hipStream_t)stream);
+    SEMICRF_CHECK_LAUNCH("interval_score_bwd");
     return SEMICRF_OK;
 }
 

@@ -1,0 +1,200 @@
+// scorer_bwd.hip -- backward of the scaled-inner-product interval scores on the CDNA4 matrix cores
+// (the autograd of LayersTransformer.py:406-441 after the Linear map).
+//
+//   S[e,b,c] = qscale * <q[c,e,:], k[c,b,:]> * len(|e-b|)  (+ diag[c,e] when e == b),   dS given as [T][T][C], e >= b
+//   G[e,b,c] = dS[e,b,c] * qscale * len(|e-b|) for e >= b, 0 above the diagonal (at e == b: len(0) = 0 unless scaling is off)
+//   dq[c,e,:] = sum_{b<=e} G[e,b,c] k[c,b,:]     dk[c,b,:] = sum_{e>=b} G[e,b,c] q[c,e,:]     ddiag[c,t] = dS[t,t,c]
+//
+// One kernel, two instantiations: ROWS_E (dq: a workgroup owns 32 end frames and walks the begin tiles to the
+// left of the diagonal) and its transpose (dk: owns 32 begin frames, walks the end tiles below).  A workgroup
+// is 8 waves = 8 chains; per step the 32x32x8-chain block of dS is read as 32-byte runs, scaled and transposed
+// through LDS into per-chain [e][b] tiles (double buffered), and each wave accumulates its chain's 32 x D
+// result with exact-fp32 v_mfma_f32_32x32x2_f32 (A = the G tile from LDS, B = the rows of k or q straight from
+// global memory, 128-byte runs).  Every output element is written once (no atomics): results are deterministic.
+#include "common.h"
+
+namespace semicrf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BT = 32;            // tile edge (frames)
+constexpr int BC = 8;             // chains per workgroup (one per wave)
+constexpr int BPAD = BT + 1;      // LDS row pitch: conflict-free transposed reads
+constexpr int BND_MAX = 8;        // D / 32 <= 8
+
+__device__ __forceinline__ float len_scale_bwd(int len, int mode)
+{
+    if (mode == SEMICRF_LEN_LINEAR) return (float)len;
+    if (mode == SEMICRF_LEN_SQRT) return sqrtf((float)len);
+    return 1.0f;
+}
+
+template <bool ROWS_E, int ND>
+__global__ __launch_bounds__(64 * BC) void interval_score_bwd_kernel(
+    const float* __restrict__ dS, const float* __restrict__ other, float* __restrict__ out, int C, int T,
+    long long ldo, long long ldout, float qscale, int mode)
+{
+    extern __shared__ __attribute__((aligned(16))) float g_lds[];     // [buffer][chain][e][b], 2 x 8 x 32 x 33 floats
+    auto G = [&](int buf, int ch) -> float* { return g_lds + (buf * BC + ch) * (BT * BPAD); };
+    const int nt = (T + BT - 1) / BT;
+    const int rt = blockIdx.x;                     // row tile (end frames for dq, begin frames for dk)
+    const int cg = blockIdx.y * BC;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int col = lane & 31, half = lane >> 5;
+    const int c = cg + wave < C ? cg + wave : C - 1;
+    // dq walks the begin tiles 0 .. rt, dk the end tiles rt .. nt-1
+    const int nstep = ROWS_E ? rt + 1 : nt - rt;
+    auto tile_of = [&](int s) { return ROWS_E ? s : rt + s; };
+
+    // stage the (e-tile, b-tile) block of dS for 8 chains: 1024 cells x 32 bytes, two float4 per cell
+    const bool vec = (C % 4 == 0) && (((uintptr_t)dS & 15) == 0);      // uniform: 16-byte loads are aligned
+    auto stage = [&](int buf, int ct) __attribute__((always_inline)) {
+        const int e0 = (ROWS_E ? rt : ct) * BT, b0 = (ROWS_E ? ct : rt) * BT;
+        constexpr int NS = (BT * BT * 2) / (64 * BC);
+        float4 sv[NS];
+#pragma unroll
+        for (int it = 0; it < NS; ++it) {
+            const int idx = tid + it * 64 * BC;
+            const int cell = idx >> 1, quad = idx & 1;
+            const int el = cell >> 5, bl = cell & 31;
+            const int e = e0 + el, b = b0 + bl;
+            const int cc = cg + quad * 4;
+            sv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < T && b <= e) {          // e == b: len(0) = 0 unless length scaling is off
+                const float* src = dS + ((size_t)e * T + b) * C + cc;
+                if (vec) {
+                    if (cc < C) sv[it] = *(const float4*)src;
+                } else {
+                    if (cc + 0 < C) sv[it].x = src[0];
+                    if (cc + 1 < C) sv[it].y = src[1];
+                    if (cc + 2 < C) sv[it].z = src[2];
+                    if (cc + 3 < C) sv[it].w = src[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NS; ++it) {
+            const int idx = tid + it * 64 * BC;
+            const int cell = idx >> 1, quad = idx & 1;
+            const int el = cell >> 5, bl = cell & 31;
+            const int d = (e0 + el) - (b0 + bl);
+            const float sc = d >= 0 ? qscale * len_scale_bwd(d, mode) : 0.0f;
+            G(buf, quad * 4 + 0)[el * BPAD + bl] = sv[it].x * sc;
+            G(buf, quad * 4 + 1)[el * BPAD + bl] = sv[it].y * sc;
+            G(buf, quad * 4 + 2)[el * BPAD + bl] = sv[it].z * sc;
+            G(buf, quad * 4 + 3)[el * BPAD + bl] = sv[it].w * sc;
+        }
+    };
+
+    f32x16 acc[ND];
+#pragma unroll
+    for (int n = 0; n < ND; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[n][i] = 0.0f;
+
+    stage(0, tile_of(0));
+    __syncthreads();
+    for (int s = 0, buf = 0; s < nstep; ++s, buf ^= 1) {
+        const int ct = tile_of(s);
+        if (s + 1 < nstep) stage(buf ^ 1, tile_of(s + 1));      // the next block lands while this one is multiplied
+        // A operand: 32 rows x 32 contraction steps of this wave's chain; lane = (row, contraction parity)
+        float a[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kk = 2 * i + half;
+            a[i] = ROWS_E ? G(buf, wave)[col * BPAD + kk] : G(buf, wave)[kk * BPAD + col];
+        }
+        // B operand: rows kk of the other factor (k for dq, q for dk) of the walked tile, 32 columns per block
+        const int r0 = ct * BT;
+        const float* ob = other + (size_t)c * T * ldo;
+        // (scheduling fences keep the 16 loads of the next block together and ahead of this block's 16 matrix
+        // instructions: left alone the compiler pairs every load with an immediate wait)
+        float bv[2][16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rr = r0 + 2 * i + half;
+            bv[0][i] = ob[(size_t)(rr < T ? rr : T - 1) * ldo + col];            // rows >= T meet G == 0
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < ND; ++n) {
+            if (n + 1 < ND) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int rr = r0 + 2 * i + half;
+                    bv[(n + 1) & 1][i] = ob[(size_t)(rr < T ? rr : T - 1) * ldo + (n + 1) * 32 + col];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[n & 1][i], acc[n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    // C/D layout of 32x32: col j = lane & 31, row i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    if (cg + wave < C) {
+        float* ob = out + (size_t)c * T * ldout;
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rt * BT + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < T) ob[(size_t)row * ldout + n * 32 + col] = acc[n][r];
+            }
+    }
+}
+
+// ddiag[c][t] = dS[t][t][c]
+__global__ __launch_bounds__(256) void interval_score_bwd_diag_kernel(const float* __restrict__ dS, float* __restrict__ ddiag,
+                                                                       int C, int T, long long ldd)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)T * C) return;
+    const int t = (int)(i / C), c = (int)(i % C);
+    ddiag[(size_t)c * T * ldd + (size_t)t * ldd] = dS[((size_t)t * T + t) * C + c];
+}
+
+bool interval_score_bwd_supported(int C, int T, int D) { return D % 32 == 0 && D >= 32 && D <= 32 * BND_MAX && T >= 1 && C >= 1; }
+
+template <bool ROWS_E>
+static void launch_bwd_pass(const float* dS, const float* other, float* out, int C, int T, int D, long long ldo,
+                            long long ldout, float qscale, int mode, hipStream_t stream)
+{
+    const dim3 grid((T + BT - 1) / BT, (C + BC - 1) / BC), block(64 * BC);
+    const size_t lds = (size_t)2 * BC * BT * BPAD * sizeof(float);
+    switch (D / 32) {
+#define SEMICRF_BWD_CASE(N)                                                                                             \
+    case N: {                                                                                                           \
+        static bool attr_set = false;                                                                                   \
+        if (!attr_set) {                                                                                                \
+            (void)hipFuncSetAttribute((const void*)interval_score_bwd_kernel<ROWS_E, N>,                                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+            attr_set = true;                                                                                            \
+        }                                                                                                               \
+        hipLaunchKernelGGL((interval_score_bwd_kernel<ROWS_E, N>), grid, block, lds, stream, dS, other, out, C, T, ldo, \
+                           ldout, qscale, mode);                                                                        \
+        break;                                                                                                          \
+    }
+        SEMICRF_BWD_CASE(1) SEMICRF_BWD_CASE(2) SEMICRF_BWD_CASE(3) SEMICRF_BWD_CASE(4)
+        SEMICRF_BWD_CASE(5) SEMICRF_BWD_CASE(6) SEMICRF_BWD_CASE(7) SEMICRF_BWD_CASE(8)
+#undef SEMICRF_BWD_CASE
+    }
+}
+
+void launch_interval_score_bwd(const float* dS, const float* q, const float* k, int C, int T, int D, long long ldq,
+                               long long ldk, float qscale, int mode, float* dq, float* dk, float* ddiag,
+                               long long lddq, long long lddk, long long lddd, hipStream_t stream)
+{
+    if (dq) launch_bwd_pass<true>(dS, k, dq, C, T, D, ldk, lddq, qscale, mode, stream);
+    if (dk) launch_bwd_pass<false>(dS, q, dk, C, T, D, ldq, lddk, qscale, mode, stream);
+    if (ddiag) {
+        const size_t n = (size_t)T * C;
+        hipLaunchKernelGGL(interval_score_bwd_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dS, ddiag,
+                           C, T, lddd);
+    }
+}
+
+}  // namespace semicrf

@@ -34,8 +34,8 @@ def _interval_score_raw(q, k, diag, T: int, C: int, D: int, qscale: float, mode:
 
 
 class _IntervalScore(torch.autograd.Function):
-    """S = lenscale * (q*qscale) k^T + diag, chain-minor layout.  Backward is plain torch for now
-    (SURVEY 8(f) rank 1 replaces it with the fused loss-gradient kernel)."""
+    """S = lenscale * (q*qscale) k^T + diag, chain-minor layout; forward and backward are HIP kernels
+    (the backward falls back to torch for contraction sizes the kernel does not take)."""
 
     @staticmethod
     def forward(ctx, q, k, diag, N, P, T, D, mode, full_square):
@@ -45,13 +45,33 @@ class _IntervalScore(torch.autograd.Function):
         qscale = 1.0 / math.sqrt(D)
         S, noise = _interval_score_raw(q3, k3, d2, T, C, D, qscale, mode, full_square)
         ctx.save_for_backward(q3, k3)
-        ctx.meta = (N, P, T, D, mode)
+        ctx.meta = (N, P, T, D, mode, bool(full_square))
         return S.view(T, T, N, P), noise.view(max(T - 1, 0), N, P)
 
     @staticmethod
     def backward(ctx, dS, dnoise):
         q, k = ctx.saved_tensors
-        N, P, T, D, mode = ctx.meta
+        N, P, T, D, mode, full = ctx.meta
+        C = N * P
+        qs = 1.0 / math.sqrt(D)
+        if D % 32 == 0 and D <= 256 and dS.is_cuda and not full:
+            # HIP kernel: dq/dk from dS in its native [T,T,C] layout on the matrix cores (exact fp32)
+            lib = _lib.load()
+            g = dS.reshape(T, T, C)
+            if not g.is_contiguous():
+                g = g.contiguous()
+            dq = torch.empty(C, T, D, dtype=torch.float32, device=g.device)
+            dk = torch.empty(C, T, D, dtype=torch.float32, device=g.device)
+            dd = torch.empty(C, T, dtype=torch.float32, device=g.device)
+            rc = lib.interval_score_bwd(_lib.ptr(g), _lib.ptr(q), _lib.ptr(k), C, T, D, q.stride(-2), k.stride(-2), qs, mode,
+                                        _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dd), D, D, 1, _lib.stream_of(g))
+            _lib.check(rc, "interval_score_bwd")
+            return (dq.view(N, P, T, D), dk.view(N, P, T, D), dd.view(N, P, T), None, None, None, None, None, None)
+        return _IntervalScore._backward_torch(dS, q, k, N, P, T, D, mode, full)
+
+    @staticmethod
+    def _backward_torch(dS, q, k, N, P, T, D, mode, full=False):
+        """Plain-torch differentiation (any D; also the reference the HIP backward is tested against)."""
         C = N * P
         g = dS.reshape(T, T, C).permute(2, 0, 1)                     # [C, e, b]
         t = torch.arange(T, device=g.device)
@@ -61,6 +81,8 @@ class _IntervalScore(torch.autograd.Function):
         elif mode == 2:
             ln = torch.ones_like(ln)
         gl = g * ln
+        if not full:
+            gl = torch.tril(gl)                                       # only e >= b was produced by the forward
         qs = 1.0 / math.sqrt(D)
         dq = torch.bmm(gl, k) * qs                                    # [C,T,D]
         dk = torch.bmm(gl.transpose(1, 2), q) * qs
