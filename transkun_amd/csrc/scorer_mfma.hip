@@ -28,7 +28,9 @@ __device__ __forceinline__ float len_scale_mfma(int len, int mode)
 }
 
 // tile list: blockIdx.x enumerates (et, bt) with bt <= et (or the full square), blockIdx.y the chain group
-template <bool ALIGNED>
+// NCH = chunks of 32 contraction values per half-wave (D / 64) when known at compile time (<= 4), else 0: with a
+// compile-time trip count the two-stage load/multiply pipeline unrolls without branches and every wait is exact
+template <bool ALIGNED, int NCH>
 __global__ __launch_bounds__(256) void interval_score_mfma_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ diag, int C, int T, int D,
     long long ldq, long long ldk, long long ldd, float qscale, int mode, int full, float* __restrict__ S)
@@ -89,12 +91,28 @@ __global__ __launch_bounds__(256) void interval_score_mfma_kernel(
         };
         float4 qa0[8], ka0[8], qa1[8], ka1[8];
         load_chunk(qa0, ka0, 0);
-        for (int d0 = 0; d0 < Dh; d0 += 64) {
-            if (d0 + 32 < Dh) load_chunk(qa1, ka1, d0 + 32);
-            mma_chunk(qa0, ka0);
-            if (d0 + 32 >= Dh) break;
-            if (d0 + 64 < Dh) load_chunk(qa0, ka0, d0 + 64);
-            mma_chunk(qa1, ka1);
+        if (NCH > 0) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                if (ch & 1) {
+                    if (ch + 1 < NCH) load_chunk(qa0, ka0, (ch + 1) * 32);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_chunk(qa1, ka1);
+                } else {
+                    if (ch + 1 < NCH) load_chunk(qa1, ka1, (ch + 1) * 32);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_chunk(qa0, ka0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            for (int d0 = 0; d0 < Dh; d0 += 64) {
+                if (d0 + 32 < Dh) load_chunk(qa1, ka1, d0 + 32);
+                mma_chunk(qa0, ka0);
+                if (d0 + 32 >= Dh) break;
+                if (d0 + 64 < Dh) load_chunk(qa0, ka0, d0 + 64);
+                mma_chunk(qa1, ka1);
+            }
         }
         // C/D layout of 32x32: col j = lane & 31, row i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
         const int bj = lane & 31;
@@ -134,21 +152,31 @@ void launch_interval_score_mfma(const float* q, const float* k, const float* dia
     const int nt = (T + ST - 1) / ST;
     const int ntiles = full ? nt * nt : nt * (nt + 1) / 2;
     const size_t lds = (size_t)ST * ST * SPAD * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)interval_score_mfma_kernel<true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)interval_score_mfma_kernel<false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
     const bool aligned = ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ldq % 4 == 0 && ldk % 4 == 0;
-    if (aligned)
-        hipLaunchKernelGGL(interval_score_mfma_kernel<true>, dim3(ntiles, (C + SC - 1) / SC), dim3(256), lds, stream, q,
-                           k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S);
-    else
-        hipLaunchKernelGGL(interval_score_mfma_kernel<false>, dim3(ntiles, (C + SC - 1) / SC), dim3(256), lds, stream, q,
-                           k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S);
+    const int nch = (D / 64 <= 4) ? D / 64 : 0;
+    const dim3 grid(ntiles, (C + SC - 1) / SC), block(256);
+#define SEMICRF_FWD_LAUNCH(A, N)                                                                                        \
+    do {                                                                                                                \
+        static bool attr_set = false;                                                                                   \
+        if (!attr_set) {                                                                                                \
+            (void)hipFuncSetAttribute((const void*)interval_score_mfma_kernel<A, N>,                                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+            attr_set = true;                                                                                            \
+        }                                                                                                               \
+        hipLaunchKernelGGL((interval_score_mfma_kernel<A, N>), grid, block, lds, stream, q, k, diag, C, T, D, ldq, ldk, \
+                           ldd, qscale, mode, full, S);                                                                 \
+    } while (0)
+#define SEMICRF_FWD_DISPATCH(A)                                                                                         \
+    switch (nch) {                                                                                                      \
+    case 1: SEMICRF_FWD_LAUNCH(A, 1); break;                                                                            \
+    case 2: SEMICRF_FWD_LAUNCH(A, 2); break;                                                                            \
+    case 3: SEMICRF_FWD_LAUNCH(A, 3); break;                                                                            \
+    case 4: SEMICRF_FWD_LAUNCH(A, 4); break;                                                                            \
+    default: SEMICRF_FWD_LAUNCH(A, 0); break;                                                                           \
+    }
+    if (aligned) { SEMICRF_FWD_DISPATCH(true) } else { SEMICRF_FWD_DISPATCH(false) }
+#undef SEMICRF_FWD_DISPATCH
+#undef SEMICRF_FWD_LAUNCH
 }
 
 }  // namespace semicrf
