@@ -347,6 +347,7 @@ __device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds
     const int c = P.c0 + sg * GS + ch;
     const bool cvalid = c < P.c1;
     float4* const far = (float4*)(lds + LDS_FAR);
+    const bool cbase_is_first = sg == 0;
     for (int k = RING; k < K; ++k) {
         const int prow = k * PB + r;
         const bool rvalid = cvalid && prow < T;
@@ -354,23 +355,36 @@ __device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds
         float aM = SEMICRF_NEG_INF, aS = 0.f;
         int aK = 0x7fffffff;
         if (rvalid) {
-            for (int part = 0; part < nparts; ++part) {
-                const u64* fp = farg + ((size_t)part * T + prow) * Bs + c;
-                u64 g0 = load_granule(fp);
+            // all parts are requested together (they complete in any order); the poll repeats for the missing ones
+            for (int p0 = 0; p0 < nparts; p0 += 4) {
+                const int np = nparts - p0 < 4 ? nparts - p0 : 4;
+                u64 gq[4];
+                bool have[4] = {false, false, false, false};
                 int spins = 0;
                 while (true) {
-                    const bool ok = MODE == 0 ? (unsigned)(g0 >> 32) == tag : (unsigned)(g0 >> 48) == (tag & 0xffffu);
-                    if (ok) break;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (i < np && !have[i]) gq[i] = load_granule(farg + ((size_t)(p0 + i) * T + prow) * Bs + c);
+                    bool all = true;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (i < np && !have[i]) {
+                            const bool ok = MODE == 0 ? (unsigned)(gq[i] >> 32) == tag : (unsigned)(gq[i] >> 48) == (tag & 0xffffu);
+                            if (ok) {
+                                have[i] = true;
+                                if (MODE == 0) acc_push1(aM, aS, __uint_as_float((unsigned)gq[i]));
+                                else max_push(aM, aK, __uint_as_float((unsigned)gq[i]), (int)((gq[i] >> 32) & 0xffffu));
+                            } else all = false;
+                        }
+                    if (all) break;
                     __builtin_amdgcn_s_sleep(1);
                     if (spin_abort(ctrl, spins, SPIN_LIMIT, 3)) break;
-                    g0 = load_granule(fp);
                 }
-                if (MODE == 0) acc_push1(aM, aS, __uint_as_float((unsigned)g0));
-                else max_push(aM, aK, __uint_as_float((unsigned)g0), (int)((g0 >> 32) & 0xffffu));
             }
         }
         const float val = MODE == 0 ? aM + flog2(aS) : aM;
         far[(k % NFAR) * 64 + lane] = make_float4(val, __int_as_float(aK), __int_as_float(k + 1), 0.0f);   // one DS write: data + seq
+        if (SEMICRF_PANEL_PROBES && (P.dbg & 16u) && cbase_is_first && lane == 0) P.ts[128 + k] = __builtin_amdgcn_s_memrealtime();   // chain probe
     }
 }
 
@@ -567,6 +581,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
         }
 
         // ring entry of position own0 (+8 floats per step); writers: the four lanes of row 0, the other lanes' stores go to a sink
+        if (SEMICRF_PANEL_PROBES && trace) ts[64 + k] = __builtin_amdgcn_s_memrealtime();            // chain probe: far partial in hand
         float* const wr = r == 0 ? ring + ch * 2 + (own0 % NPOS) * 8 : dummy + lane * 2;
         int mykey = -1;
         if (MODE == 0) {
@@ -636,6 +651,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
                 dScore[((size_t)frow * T + frow) * Bs + c] = gz * fexp2(arow + mine + draw - 2.0f * sp);
             if (MODE == 1) code[(size_t)c * T + frow] = (mykey + 1) | (sp > 0.0f ? 0x40000000 : 0);
         }
+        if (SEMICRF_PANEL_PROBES && trace) ts[k] = __builtin_amdgcn_s_memrealtime();                 // chain probe: u published
     }
 }
 
@@ -882,16 +898,20 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                         else if (GRAD) __builtin_amdgcn_s_sleep(127);
                         else __builtin_amdgcn_s_sleep(16);
                         if (spin_abort(ctrl, spins, SPIN_LIMIT, 5)) break;
-                        // light probe first: one word per lane -- the block's last position for the first of the lane's four
-                        // chains (a ring publishes its 16 positions x 4 chains with one store instruction); only when every
-                        // ring of the tile shows a value is the 2 KB tile fetched again
+                        // One round trip per poll: the 2 KB tile is fetched again together with a light probe -- one word per
+                        // lane, the block's last position for the first of the lane's four chains (a ring publishes its
+                        // 16 positions x 4 chains with one store instruction).  The LDS copy is only read back and checked
+                        // when every ring of the tile shows a value in the probe; urgent polls (the task's newest tile)
+                        // fetch the tile with every probe, lazy ones only after a successful probe.
+                        if (m == q) panel_fetch_gran<true>(ursrc, stage, G.gvoff, m, B);
                         const unsigned pw = __builtin_amdgcn_raw_buffer_load_b32(ursrc, (unsigned)(cl * 4), (unsigned)((m * PB + PB - 1) * B * 4), 16);
                         if (!__all(pw != U_EMPTY || !cvalid)) continue;
-                        panel_fetch_gran<true>(ursrc, stage, G.gvoff, m, B);
+                        if (m != q) panel_fetch_gran<true>(ursrc, stage, G.gvoff, m, B);
                         wait_vmcnt<0>();
                         panel_read_gran(grbase + (unsigned)(s * PSTAGE_BYTES), g0, g1);
                     }
                 }
+                if (SEMICRF_PANEL_PROBES && (dbg & 16u) && g == 0 && q4 == 0 && m == q && lane == 0) P.ts[192 + k] = __builtin_amdgcn_s_memrealtime();   // chain probe: newest tile's u seen
                 const float uv[2][4] = {{__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z), __uint_as_float(g0.w)},
                                         {__uint_as_float(g1.x), __uint_as_float(g1.y), __uint_as_float(g1.z), __uint_as_float(g1.w)}};
 
@@ -1021,6 +1041,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                 store_granule(fbase + (size_t)pi * Bs + cc, gr);
             }
         }
+        if (SEMICRF_PANEL_PROBES && (dbg & 16u) && g == 0 && q4 == 0 && m1 == q + 1 && lane == 0) P.ts[256 + k] = __builtin_amdgcn_s_memrealtime();     // chain probe: partial stored
     }
 }
 
