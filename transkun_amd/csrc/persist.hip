@@ -858,6 +858,10 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
         // vector-memory operations issued so far in this task (a lower bound: the waits below may only under-count
         // the operations younger than the fetch they wait for), and its value right after each stage's fetch
         int issued = 0, mark0 = 0, mark1 = 0, mark2 = 0;
+        // A task that has met an unpublished u runs at the spine's frontier: the u copies it prefetched three tiles ahead
+        // are stale by construction.  From then on it fetches the NEXT tile's u again (device scope) while it works on
+        // the current tile, so that a published value is found on the first look instead of two round trips later.
+        bool frontier = false;
 #pragma unroll
         for (int i = 0; i < PNS; ++i)
             if (m0 + i < m1) {
@@ -890,6 +894,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                                         (g0.w != U_EMPTY || !v3) && (g1.x != U_EMPTY || !v0) && (g1.y != U_EMPTY || !v1) &&
                                         (g1.z != U_EMPTY || !v2) && (g1.w != U_EMPTY || !v3);
                         if (__all(ok)) break;
+                        frontier = true;
                         // The task's newest tile (m == q) is on the spine's critical path: poll tightly.  Waves blocked
                         // further ahead advance one tile per spine block; the forward sweeps want them prompt as well
                         // (lazy: 240 us, prompt: 212 us), the bandwidth-bound gradient sweep wants the fabric quiet
@@ -910,6 +915,12 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                         wait_vmcnt<0>();
                         panel_read_gran(grbase + (unsigned)(s * PSTAGE_BYTES), g0, g1);
                     }
+                }
+                if (frontier && m + 1 < m1) {
+                    const int sn = s + 1 == PNS ? 0 : s + 1;
+                    panel_fetch_gran<true>(ursrc, stage0 + sn * PSTAGE_BYTES, G.gvoff, m + 1, B);
+                    issued += 2;
+                    if (sn == 0) mark0 = issued; else if (sn == 1) mark1 = issued; else mark2 = issued;
                 }
                 if (SEMICRF_PANEL_PROBES && (dbg & 16u) && g == 0 && q4 == 0 && m == q && lane == 0) P.ts[192 + k] = __builtin_amdgcn_s_memrealtime();   // chain probe: newest tile's u seen
                 const float uv[2][4] = {{__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z), __uint_as_float(g0.w)},
