@@ -75,6 +75,7 @@ struct SweepParams {
     int nTasks;            // panel tasks (k ascending, then column part, then chain group, then row quarter)
     int panelWaves;        // waves per non-spine workgroup that work as panels (the rest exit at once)
     int hybridPanelWaves;  // panel waves of a spine workgroup (0..2)
+    int hybridStart;       // ... which start once the ring has reached this row block
     int zeroWaves;         // GRAD: waves per panel workgroup that write the zero upper triangle of dScore (0: separate kernel)
     unsigned tag;          // nonzero launch epoch
     unsigned dbg;          // SEMICRF_DEBUG_FLAGS (timing experiments only; results are wrong when set):
@@ -1123,7 +1124,17 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
         } else if (wave == RING + NLOADER) {
             if (!(P.dbg & 9u)) far_role<MODE, DIR>(P, sg, s_dyn);
         } else if (!(P.dbg & 2u) && wave - (RING + NLOADER + 1) >= 0 && wave - (RING + NLOADER + 1) < P.hybridPanelWaves) {
-            // spare waves stream tiles like the panel workgroups do (their stages lie behind the spine's LDS)
+            // Spare waves stream tiles like the panel workgroups do (their stages lie behind the spine's LDS) -- but only
+            // once the sweep is bound by the far field: during the first blocks the ring sets the pace and a streaming
+            // wave on its CU only slows it down.  They wait until the ring has taken row block hybridStart.
+            {
+                const int* cons = (const int*)(s_dyn + LDS_CTL) + NRBUF;
+                int spins = 0;
+                while (lds_flag_load(cons + (P.hybridStart % RING)) < P.hybridStart + 1 && P.hybridStart < P.K) {
+                    __builtin_amdgcn_s_sleep(127);
+                    if (spin_abort(P.ctrl, spins, SPIN_LIMIT_LDS, 10)) break;
+                }
+            }
             panel_role<MODE, DIR, GRAD>(P, s_dyn + LDS_HYBRID_PANEL, wave - (RING + NLOADER + 1));
         }
     } else {
@@ -1263,10 +1274,17 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         float per_cu = (float)T / 1024.0f;
         per_cu = per_cu < 0.75f ? 0.75f : (per_cu > 2.0f ? 2.0f : per_cu);
         if (grad) per_cu *= 1.25f;
-        // the spine workgroups' two spare waves stream tiles too: both for long sequences (bound by the far field:
-        // 701 vs 788 us at T = 2048), one at T = 1024 (213 vs 217 us; two slow the ring down more than they add)
-        int hpw = HPW_MAX > 0 ? (T >= 1536 ? HPW_MAX : 1) : 0;
+        // The spine workgroups' two spare waves stream tiles too, from row block hybridStart on: while the ring sets
+        // the pace (the first third of the blocks) a streaming wave on its CU only slows it down; afterwards the sweep is
+        // bound by the far field and every CU helps.  Forward, T=1024: 205 us (start at 24-32) vs 214 (from the start)
+        // vs 217 (never); T=691, NBatch=360: 158 vs 177 vs 173; T=2048: 651 vs 677 (from the start) vs 788 (never).
+        // The gradient sweep is bandwidth-bound almost from the start.
+        int hpw = HPW_MAX > 0 ? HPW_MAX : 0;
         if (const char* e = getenv("SEMICRF_HYBRID_PANEL_WAVES")) { const int v = atoi(e); if (v >= 0 && v <= HPW_MAX) hpw = v; }
+        int hstart = grad ? 12 : P.K * 3 / 8;
+        hstart = hstart < 8 ? 8 : (hstart > 32 ? 32 : hstart);
+        if (const char* e = getenv("SEMICRF_HYBRID_START")) { const int v = atoi(e); if (v >= 0) hstart = v; }
+        P.hybridStart = hstart;
         P.hybridPanelWaves = hpw;
         int pw = PW_MAX;
         if (const char* e = getenv("SEMICRF_PANEL_WAVES")) { const int v = atoi(e); if (v > 0) pw = v; }   // tuning knob
