@@ -151,6 +151,27 @@ int interval_score_bwd(const float* dS, const float* q, const float* k, int C, i
                        int64_t ldk, float qscale, int length_scaling, float* dq, float* dk, float* ddiag,
                        int64_t lddq, int64_t lddk, int64_t lddd, semicrf_stream_t stream);
 
+/*
+ * Backward-direction values only (the beta half of forward_backward, NeuralSemiCRFInterval.py:386-414, without the
+ * marginals): beta[t][c] by frame, natural log.  Workspace: semicrf_workspace_bytes(SEMICRF_OP_LOGZ_FWD, T, B).
+ * Used by interval_score_bwd_fused, which rebuilds the marginals tile by tile instead of reading a dense gradient.
+ */
+int semicrf_beta(const float* score, const float* noise, int T, int B, float* beta, void* ws, size_t ws_bytes,
+                 semicrf_stream_t stream);
+
+/*
+ * Loss gradient fused into the scorer backward: interval_score_bwd with the cotangent
+ *   dS[e,b,c] = gout[c] * marginal[e,b,c]      (marginal as in NeuralSemiCRFInterval.py:424-440, e >= b)
+ * built on the fly from S (= score [T][T][C]), alpha (= v of semicrf_logz_fwd), beta (semicrf_beta) and logZ --
+ * the dense [T][T][C] gradient of ComputeLogZFasterGrad.backward (:469-472) is never written or read.
+ * Outputs as interval_score_bwd.  The evalPath part of logProb's gradient (one-hot on the path cells) is sparse and
+ * is added by the caller (transkun_amd/fused.py).
+ */
+int interval_score_bwd_fused(const float* S, const float* alpha, const float* beta, const float* logZ,
+                             const float* gout, const float* q, const float* k, int C, int T, int D, int64_t ldq,
+                             int64_t ldk, float qscale, int length_scaling, float* dq, float* dk, float* ddiag,
+                             int64_t lddq, int64_t lddk, int64_t lddd, semicrf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -304,6 +304,41 @@ def test_scorer_backward_kernel(gpu, N, P, T, D, ls):
     assert _lib.device_status() == 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,P,T,D,ls", [(1, 6, 70, 64, "linear"), (2, 5, 130, 256, "linear"), (1, 4, 48, 32, "none"), (1, 10, 97, 128, "sqrt")])
+def test_fused_scorer_crf(gpu, N, P, T, D, ls):
+    """scorer_crf_logprob (loss gradient fused into the scorer backward: no dense dS) against the unfused route
+    scorer -> NeuralSemiCRFInterval.logProb: same log-probabilities, same gradients of ctx and of the Linear map."""
+    from transkun_amd import CRF, _lib, synth
+    from transkun_amd.fused import scorer_crf_logprob
+    from transkun_amd.scorer import ScaledInnerProductIntervalScorer
+    _lib.set_impl(0)
+    m = ScaledInnerProductIntervalScorer(D, 1, lengthScaling=ls).to(gpu)
+    with torch.no_grad():
+        m.map[0].weight.mul_(0.3)          # keep the interval scores (x |e-b|) in a numerically tame range
+    ctx0 = synth.hash_normal(N * P * T * D, 61, gpu).view(N, P, T, D) * 0.5
+    iv = synth.synthetic_intervals(T, N * P, seed=7)
+    gout = synth.hash_normal(N * P, 62, gpu)
+
+    def run(fused):
+        m.zero_grad()
+        ctx = ctx0.clone().requires_grad_()
+        if fused:
+            lp = scorer_crf_logprob(m, ctx, iv)
+        else:
+            S, b = m(ctx)
+            lp = CRF.NeuralSemiCRFInterval(S.flatten(-2, -1), b.flatten(-2, -1)).logProb(iv)
+        (lp * gout).sum().backward()
+        return lp.detach(), ctx.grad.clone(), m.map[0].weight.grad.clone(), m.map[0].bias.grad.clone()
+
+    a, b = run(True), run(False)
+    for x, y, name in zip(a, b, ("logp", "dctx", "dW", "dbias")):
+        scale = float(y.abs().max()) + 1e-30
+        err = float((x - y).abs().max()) / scale
+        assert err < 2e-4, (name, err)
+    assert _lib.device_status() == 0
+
+
 # ---- the persistent blocked kernels against the oracle over a grid of shapes -------------------
 
 PERSIST_SHAPES = [(1, 4), (2, 4), (15, 8), (16, 4), (17, 12), (33, 16), (48, 20), (63, 36), (64, 32), (65, 4),

@@ -36,6 +36,10 @@ void launch_interval_score_naive(const float* q, const float* k, const float* di
 
 bool interval_score_mfma_supported(int C, int T, int D);
 bool interval_score_bwd_supported(int C, int T, int D);
+void launch_interval_score_bwd_fused(const float* S, const float* alpha, const float* beta, const float* logZ,
+                                     const float* gout, const float* q, const float* k, int C, int T, int D,
+                                     long long ldq, long long ldk, float qscale, int mode, float* dq, float* dk,
+                                     float* ddiag, long long lddq, long long lddk, long long lddd, hipStream_t stream);
 void launch_interval_score_bwd(const float* dS, const float* q, const float* k, int C, int T, int D, long long ldq,
                                long long ldk, float qscale, int mode, float* dq, float* dk, float* ddiag,
                                long long lddq, long long lddk, long long lddd, hipStream_t stream);
@@ -160,6 +164,27 @@ int semicrf_logz_bwd(const float* score, const float* noise, const float* v, con
     return SEMICRF_OK;
 }
 
+int semicrf_beta(const float* score, const float* noise, int T, int B, float* beta, void* ws, size_t ws_bytes,
+                 semicrf_stream_t stream)
+{
+    if (int rc = check_common(score, noise, T, B)) return rc;
+    SEMICRF_CHECK_ARG(beta, "beta must be non-NULL");
+    Carver cv(ws, ws_bytes);
+    const bool fast = use_persist(T, B);
+    void* pws = fast ? cv.take<char>(persist_workspace_bytes(T, B)) : nullptr;
+    if (!cv.ok || (fast && !ws)) { set_error("workspace too small for beta"); return SEMICRF_EWORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    if (fast) {
+        if (launch_persist_sweep(0, 1, score, noise, T, B, beta, nullptr, nullptr, pws, st)) {
+            set_error("hipMemsetAsync failed"); return SEMICRF_ELAUNCH;
+        }
+    } else {
+        launch_rowseq_sweep(0, 1, score, noise, T, B, beta, nullptr, nullptr, st);
+    }
+    SEMICRF_CHECK_LAUNCH("semicrf_beta");
+    return SEMICRF_OK;
+}
+
 int semicrf_viterbi(const float* score, const float* noise, int T, int B, const int32_t* start, int forward,
                     int32_t* pairs, int64_t cap, int32_t* offsets, void* ws, size_t ws_bytes,
                     semicrf_stream_t stream)
@@ -247,6 +272,23 @@ int interval_score_bwd(const float* dS, const float* q, const float* k, int C, i
     launch_interval_score_bwd(dS, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, ddiag, lddq, lddk, lddd,
                               (hipStream_t)stream);
     SEMICRF_CHECK_LAUNCH("interval_score_bwd");
+    return SEMICRF_OK;
+}
+
+int interval_score_bwd_fused(const float* S, const float* alpha, const float* beta, const float* logZ,
+                             const float* gout, const float* q, const float* k, int C, int T, int D, int64_t ldq,
+                             int64_t ldk, float qscale, int length_scaling, float* dq, float* dk, float* ddiag,
+                             int64_t lddq, int64_t lddk, int64_t lddd, semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(C >= 1 && T >= 1 && D >= 1, "C=%d T=%d D=%d must be >= 1", C, T, D);
+    SEMICRF_CHECK_ARG(S && alpha && beta && logZ && gout && q && k, "S/alpha/beta/logZ/gout/q/k must be non-NULL");
+    SEMICRF_CHECK_ARG(ldq >= D && ldk >= D && (!dq || lddq >= D) && (!dk || lddk >= D) && (!ddiag || lddd >= 1),
+                      "bad leading dimensions");
+    SEMICRF_CHECK_ARG(length_scaling >= 0 && length_scaling <= 2, "bad length_scaling %d", length_scaling);
+    SEMICRF_CHECK_ARG(interval_score_bwd_supported(C, T, D), "interval_score_bwd_fused needs D %% 32 == 0 and D <= 256 (D=%d)", D);
+    launch_interval_score_bwd_fused(S, alpha, beta, logZ, gout, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk,
+                                    ddiag, lddq, lddk, lddd, (hipStream_t)stream);
+    SEMICRF_CHECK_LAUNCH("interval_score_bwd_fused");
     return SEMICRF_OK;
 }
 

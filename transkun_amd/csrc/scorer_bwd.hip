@@ -29,10 +29,29 @@ __device__ __forceinline__ float len_scale_bwd(int len, int mode)
     return 1.0f;
 }
 
-template <bool ROWS_E, int ND>
+// FUSED: dS is not read; the cotangent is built on the fly from the CRF's own quantities (the dense
+// [T][T][C] gradient is never written):  dS[e,b,c] = gout[c] * marginal[e,b,c],
+//   marginal = exp(alpha[b,c] + beta[e,c] + S[e,b,c] - logZ[c])                       (e > b)
+//            = exp(alpha[t,c] + beta[t,c] + S[t,t,c] - 2 softplus(S[t,t,c]) - logZ[c])  (e == b == t)
+// (NeuralSemiCRFInterval.py:424-447); `dS` then points at S itself.
+struct FusedArgs {
+    const float* alpha;   // [T][C] by frame
+    const float* beta;    // [T][C] by frame
+    const float* logZ;    // [C]
+    const float* gout;    // [C]
+};
+
+__device__ __forceinline__ float marginal_of(float s, float a, float b, float lz, bool diag)
+{
+    float x = a + b + s - lz;
+    if (diag) x -= 2.0f * softplus_f(s);
+    return __expf(x);
+}
+
+template <bool ROWS_E, int ND, bool FUSED>
 __global__ __launch_bounds__(64 * BC) void interval_score_bwd_kernel(
     const float* __restrict__ dS, const float* __restrict__ other, float* __restrict__ out, int C, int T,
-    long long ldo, long long ldout, float qscale, int mode)
+    long long ldo, long long ldout, float qscale, int mode, FusedArgs F)
 {
     extern __shared__ __attribute__((aligned(16))) float g_lds[];     // [buffer][chain][e][b], 2 x 8 x 32 x 33 floats
     auto G = [&](int buf, int ch) -> float* { return g_lds + (buf * BC + ch) * (BT * BPAD); };
@@ -70,6 +89,26 @@ __global__ __launch_bounds__(64 * BC) void interval_score_bwd_kernel(
                     if (cc + 1 < C) sv[it].y = src[1];
                     if (cc + 2 < C) sv[it].z = src[2];
                     if (cc + 3 < C) sv[it].w = src[3];
+                }
+            }
+        }
+        if (FUSED) {
+#pragma unroll
+            for (int it = 0; it < NS; ++it) {
+                const int idx = tid + it * 64 * BC;
+                const int cell = idx >> 1, quad = idx & 1;
+                const int el = cell >> 5, bl = cell & 31;
+                const int e = e0 + el, b = b0 + bl;
+                const int cc = cg + quad * 4;
+                if (e < T && b <= e) {
+                    float sx[4] = {sv[it].x, sv[it].y, sv[it].z, sv[it].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (cc + i < C)
+                            sx[i] = F.gout[cc + i] * marginal_of(sx[i], F.alpha[(size_t)b * C + cc + i], F.beta[(size_t)e * C + cc + i],
+                                                                 F.logZ[cc + i], e == b);
+                    }
+                    sv[it] = make_float4(sx[0], sx[1], sx[2], sx[3]);
                 }
             }
         }
@@ -157,11 +196,22 @@ __global__ __launch_bounds__(256) void interval_score_bwd_diag_kernel(const floa
     ddiag[(size_t)c * T * ldd + (size_t)t * ldd] = dS[((size_t)t * T + t) * C + c];
 }
 
+// FUSED ddiag[c][t] = gout[c] * marginal[t,t,c]
+__global__ __launch_bounds__(256) void interval_score_bwd_diag_fused_kernel(const float* __restrict__ S, FusedArgs F,
+                                                                             float* __restrict__ ddiag, int C, int T, long long ldd)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)T * C) return;
+    const int t = (int)(i / C), c = (int)(i % C);
+    const float s = S[((size_t)t * T + t) * C + c];
+    ddiag[((size_t)c * T + t) * ldd] = F.gout[c] * marginal_of(s, F.alpha[(size_t)t * C + c], F.beta[(size_t)t * C + c], F.logZ[c], true);
+}
+
 bool interval_score_bwd_supported(int C, int T, int D) { return D % 32 == 0 && D >= 32 && D <= 32 * BND_MAX && T >= 1 && C >= 1; }
 
-template <bool ROWS_E>
+template <bool ROWS_E, bool FUSED>
 static void launch_bwd_pass(const float* dS, const float* other, float* out, int C, int T, int D, long long ldo,
-                            long long ldout, float qscale, int mode, hipStream_t stream)
+                            long long ldout, float qscale, int mode, FusedArgs F, hipStream_t stream)
 {
     const dim3 grid((T + BT - 1) / BT, (C + BC - 1) / BC), block(64 * BC);
     const size_t lds = (size_t)2 * BC * BT * BPAD * sizeof(float);
@@ -170,12 +220,12 @@ static void launch_bwd_pass(const float* dS, const float* other, float* out, int
     case N: {                                                                                                           \
         static bool attr_set = false;                                                                                   \
         if (!attr_set) {                                                                                                \
-            (void)hipFuncSetAttribute((const void*)interval_score_bwd_kernel<ROWS_E, N>,                                \
+            (void)hipFuncSetAttribute((const void*)interval_score_bwd_kernel<ROWS_E, N, FUSED>,                                \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
             attr_set = true;                                                                                            \
         }                                                                                                               \
-        hipLaunchKernelGGL((interval_score_bwd_kernel<ROWS_E, N>), grid, block, lds, stream, dS, other, out, C, T, ldo, \
-                           ldout, qscale, mode);                                                                        \
+        hipLaunchKernelGGL((interval_score_bwd_kernel<ROWS_E, N, FUSED>), grid, block, lds, stream, dS, other, out, C, T,  \
+                           ldo, ldout, qscale, mode, F);                                                                        \
         break;                                                                                                          \
     }
         SEMICRF_BWD_CASE(1) SEMICRF_BWD_CASE(2) SEMICRF_BWD_CASE(3) SEMICRF_BWD_CASE(4)
@@ -188,12 +238,28 @@ void launch_interval_score_bwd(const float* dS, const float* q, const float* k, 
                                long long ldk, float qscale, int mode, float* dq, float* dk, float* ddiag,
                                long long lddq, long long lddk, long long lddd, hipStream_t stream)
 {
-    if (dq) launch_bwd_pass<true>(dS, k, dq, C, T, D, ldk, lddq, qscale, mode, stream);
-    if (dk) launch_bwd_pass<false>(dS, q, dk, C, T, D, ldq, lddk, qscale, mode, stream);
+    const FusedArgs F{nullptr, nullptr, nullptr, nullptr};
+    if (dq) launch_bwd_pass<true, false>(dS, k, dq, C, T, D, ldk, lddq, qscale, mode, F, stream);
+    if (dk) launch_bwd_pass<false, false>(dS, q, dk, C, T, D, ldq, lddk, qscale, mode, F, stream);
     if (ddiag) {
         const size_t n = (size_t)T * C;
         hipLaunchKernelGGL(interval_score_bwd_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dS, ddiag,
                            C, T, lddd);
+    }
+}
+
+void launch_interval_score_bwd_fused(const float* S, const float* alpha, const float* beta, const float* logZ,
+                                     const float* gout, const float* q, const float* k, int C, int T, int D,
+                                     long long ldq, long long ldk, float qscale, int mode, float* dq, float* dk,
+                                     float* ddiag, long long lddq, long long lddk, long long lddd, hipStream_t stream)
+{
+    const FusedArgs F{alpha, beta, logZ, gout};
+    if (dq) launch_bwd_pass<true, true>(S, k, dq, C, T, D, ldk, lddq, qscale, mode, F, stream);
+    if (dk) launch_bwd_pass<false, true>(S, q, dk, C, T, D, ldq, lddk, qscale, mode, F, stream);
+    if (ddiag) {
+        const size_t n = (size_t)T * C;
+        hipLaunchKernelGGL(interval_score_bwd_diag_fused_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, S, F,
+                           ddiag, C, T, lddd);
     }
 }
 

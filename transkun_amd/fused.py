@@ -1,0 +1,113 @@
+"""Scorer + CRF log-probability as ONE autograd node (the loss gradient fused into the scorer
+backward).
+
+The reference's training step (ModelTransformer.py:256-266 after :102-105/:222) is
+
+    S, noise = scorer(ctx)                       # [T,T,N,P]
+    crf = NeuralSemiCRFInterval(S.flatten(-2), noise.flatten(-2))
+    logp = crf.logProb(intervals)                # dense d(logp)/dS [T,T,NBatch] in the backward
+
+and its backward materialises the dense gradient of S (ComputeLogZFasterGrad.backward,
+NeuralSemiCRFInterval.py:469-472: 1.48 GB at T=1024, NBatch=352), which the scorer's backward then reads twice.
+Here the backward runs the beta sweep only (`semicrf_beta`) and `interval_score_bwd_fused` rebuilds the marginals
+tile by tile inside the two matrix products that produce dq and dk -- the dense gradient never exists.  The
+one-hot part of logProb's gradient (the path cells of evalPath, :540-548) is a few thousand rows and is added with
+index_put.
+
+Opt-in: `scorer_crf_logprob(scorer, ctx, intervals)` replaces the three lines above; results and gradients are the
+same as the unfused route (tests/test_gpu_parity.py::test_fused_scorer_crf).
+"""
+from __future__ import annotations
+
+import importlib
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .scorer import ScaledInnerProductIntervalScorer, _interval_score_raw
+
+_nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
+
+
+def _beta_raw(score, noise):
+    T, B = score.shape[0], score.shape[2]
+    lib = _lib.load()
+    beta = torch.empty(T, B, dtype=torch.float32, device=score.device)
+    ws = _lib.workspace(_lib.OP_LOGZ_FWD, T, B, score.device)
+    rc = lib.semicrf_beta(_lib.ptr(score), _lib.ptr(noise), T, B, _lib.ptr(beta), _lib.ptr(ws), ws.numel(),
+                          _lib.stream_of(score))
+    _lib.check(rc, "semicrf_beta")
+    return beta
+
+
+class _ScorerCRFLogProb(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, diag, pairs, offsets, N, P, T, D, mode):
+        C = N * P
+        q3, k3, d2 = q.reshape(C, T, D), k.reshape(C, T, D), diag.reshape(C, T)
+        qs = 1.0 / math.sqrt(D)
+        S, noise = _interval_score_raw(q3, k3, d2, T, C, D, qs, mode, False)
+        logz, v = _nsci._logz_fwd_raw(S, noise, True)
+        path = _nsci._eval_path_raw(S, noise, pairs, offsets)
+        ctx.save_for_backward(q3, k3, S, noise, v, logz, pairs, offsets)
+        ctx.meta = (N, P, T, D, mode, getattr(pairs, "_semicrf_K", pairs.shape[0]))
+        return path - logz
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, S, noise, v, logz, pairs, offsets = ctx.saved_tensors
+        N, P, T, D, mode, K = ctx.meta
+        C = N * P
+        qs = 1.0 / math.sqrt(D)
+        g = g.reshape(C).to(torch.float32).contiguous()
+        lib = _lib.load()
+        beta = _beta_raw(S, noise)
+        gneg = (-g).contiguous()                                   # d logProb / d logZ = -1
+        dq = torch.empty(C, T, D, dtype=torch.float32, device=S.device)
+        dk = torch.empty(C, T, D, dtype=torch.float32, device=S.device)
+        dd = torch.empty(C, T, dtype=torch.float32, device=S.device)
+        rc = lib.interval_score_bwd_fused(_lib.ptr(S), _lib.ptr(v), _lib.ptr(beta), _lib.ptr(logz), _lib.ptr(gneg), _lib.ptr(q),
+                                          _lib.ptr(k), C, T, D, q.stride(-2), k.stride(-2), qs, mode, _lib.ptr(dq),
+                                          _lib.ptr(dk), _lib.ptr(dd), D, D, 1, _lib.stream_of(S))
+        _lib.check(rc, "interval_score_bwd_fused")
+        if K > 0:
+            # + g on the path cells: dq[c,e] += g qs len(e-b) k[c,b], dk[c,b] += g qs len(e-b) q[c,e], ddiag[c,t] += g (b == e)
+            pr = pairs[:K].long()
+            b, e = pr[:, 0], pr[:, 1]
+            counts = (offsets[1:] - offsets[:-1]).long()
+            cid = torch.repeat_interleave(torch.arange(C, device=S.device), counts)
+            ln = (e - b).to(torch.float32)
+            if mode == 1:
+                ln = ln.sqrt()
+            elif mode == 2:
+                ln = torch.ones_like(ln)
+            w = (g[cid] * qs * ln)[:, None]
+            dq.index_put_((cid, e), w * k[cid, b], accumulate=True)
+            dk.index_put_((cid, b), w * q[cid, e], accumulate=True)
+            single = b == e
+            dd.index_put_((cid[single], e[single]), g[cid[single]], accumulate=True)
+        return (dq.view(N, P, T, D), dk.view(N, P, T, D), dd.view(N, P, T), None, None, None, None, None, None, None)
+
+
+def scorer_crf_logprob(scorer: ScaledInnerProductIntervalScorer, ctx: torch.Tensor, intervals) -> torch.Tensor:
+    """log p(intervals | ctx) per chain, [N*P], differentiable w.r.t. ctx and the scorer's parameters.
+
+    ctx: [N, P, T, size] on the GPU; intervals: List (len N*P, chain index n*P + p) of Lists of (begin, end).
+    Equivalent to NeuralSemiCRFInterval(*[x.flatten(-2) for x in scorer(ctx)]).logProb(intervals)."""
+    assert ctx.dim() == 4
+    N, P, T, _ = ctx.shape
+    D = scorer.size * scorer.expansionFactor
+    _lib.require_gpu(ctx, "ctx")
+    if D % 32 != 0 or D > 256:
+        S, b = scorer(ctx)                      # contraction sizes the fused kernel does not take: unfused route
+        return _nsci.NeuralSemiCRFInterval(S.flatten(-2, -1), b.flatten(-2, -1)).logProb(intervals)
+    lin = scorer.map[0]
+    W, bias = lin.weight, lin.bias
+    x = ctx.float()
+    q = F.linear(x, W[:D], bias[:D])
+    k = F.linear(x, W[D:2 * D], bias[D:2 * D])
+    diag = F.linear(x, W[2 * D:2 * D + 1], bias[2 * D:2 * D + 1]).squeeze(-1)
+    pairs, offsets = _nsci.pack_intervals(intervals, T, N * P, ctx.device)
+    return _ScorerCRFLogProb.apply(q, k, diag, pairs, offsets, N, P, T, D, _lib.LEN_MODES[scorer.lengthScaling])
