@@ -93,22 +93,41 @@ __global__ __launch_bounds__(64 * BC) void interval_score_bwd_kernel(
             }
         }
         if (FUSED) {
+            // this thread's four chains are the same in every iteration (cc depends on tid only): logZ and gout once
+            const int ccq = cg + (tid & 1) * 4;
+            float lz[4], gz[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lz[i] = ccq + i < C ? F.logZ[ccq + i] : 0.f;
+                gz[i] = ccq + i < C ? F.gout[ccq + i] : 0.f;
+            }
+            float4 av[NS], bw[NS];
 #pragma unroll
             for (int it = 0; it < NS; ++it) {
                 const int idx = tid + it * 64 * BC;
-                const int cell = idx >> 1, quad = idx & 1;
+                const int cell = idx >> 1;
+                const int el = cell >> 5, bl = cell & 31;
+                const int e = e0 + el < T ? e0 + el : T - 1, b = b0 + bl < T ? b0 + bl : T - 1;
+                const float* ap = F.alpha + (size_t)b * C + ccq;
+                const float* bp = F.beta + (size_t)e * C + ccq;
+                if (vec && ccq < C) { av[it] = *(const float4*)ap; bw[it] = *(const float4*)bp; }
+                else {
+                    av[it] = make_float4(ccq < C ? ap[0] : 0.f, ccq + 1 < C ? ap[1] : 0.f, ccq + 2 < C ? ap[2] : 0.f, ccq + 3 < C ? ap[3] : 0.f);
+                    bw[it] = make_float4(ccq < C ? bp[0] : 0.f, ccq + 1 < C ? bp[1] : 0.f, ccq + 2 < C ? bp[2] : 0.f, ccq + 3 < C ? bp[3] : 0.f);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NS; ++it) {
+                const int idx = tid + it * 64 * BC;
+                const int cell = idx >> 1;
                 const int el = cell >> 5, bl = cell & 31;
                 const int e = e0 + el, b = b0 + bl;
-                const int cc = cg + quad * 4;
                 if (e < T && b <= e) {
-                    float sx[4] = {sv[it].x, sv[it].y, sv[it].z, sv[it].w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (cc + i < C)
-                            sx[i] = F.gout[cc + i] * marginal_of(sx[i], F.alpha[(size_t)b * C + cc + i], F.beta[(size_t)e * C + cc + i],
-                                                                 F.logZ[cc + i], e == b);
-                    }
-                    sv[it] = make_float4(sx[0], sx[1], sx[2], sx[3]);
+                    const bool dg = e == b;
+                    sv[it].x = gz[0] * marginal_of(sv[it].x, av[it].x, bw[it].x, lz[0], dg);
+                    sv[it].y = gz[1] * marginal_of(sv[it].y, av[it].y, bw[it].y, lz[1], dg);
+                    sv[it].z = gz[2] * marginal_of(sv[it].z, av[it].z, bw[it].z, lz[2], dg);
+                    sv[it].w = gz[3] * marginal_of(sv[it].w, av[it].w, bw[it].w, lz[3], dg);
                 }
             }
         }
