@@ -211,7 +211,10 @@ __device__ __forceinline__ bool spin_abort(unsigned* ctrl, int& spins, int limit
 #ifndef SEMICRF_NRBUF
 #define SEMICRF_NRBUF 4
 #endif
-constexpr int NLOADER = RING >= 5 ? 2 : 1;          // loader waves per ring (a row block is RING tiles)
+#ifndef SEMICRF_NLOADER
+#define SEMICRF_NLOADER (RING >= 5 ? 2 : 1)
+#endif
+constexpr int NLOADER = SEMICRF_NLOADER;          // loader waves per ring (a row block is RING tiles)
 constexpr int NRBUF = SEMICRF_NRBUF;                  // row-block buffers between the loader and the ring
 constexpr int TILE_BYTES = PB * PB * RS * 4;          // 4096: [column u][row r][chain] floats
 constexpr int NCONST = 3;                             // per-row constants: diagonal cell, noise, alpha (GRAD)
