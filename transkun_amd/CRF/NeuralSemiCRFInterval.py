@@ -96,7 +96,21 @@ def unpack_intervals(pairs_host: torch.Tensor, offsets_host: torch.Tensor) -> In
 _DEBUG_WS = []      # test/diagnostic hook: when non-None-appendable and env SEMICRF_DEBUG_KEEP_WS is set, keeps workspaces
 
 
+def _odd_pad(score) -> bool:
+    """The persistent kernels take even NBatch (16-byte global->LDS loads at 8-byte aligned chain offsets).  An odd
+    NBatch is run with one all-zero ghost chain appended (one extra pass over the tensor) instead of on the ~100x
+    slower row-sequential kernels; the ghost chain's outputs are dropped."""
+    return score.shape[2] % 2 == 1 and score.shape[0] >= 2 and _lib.get_impl() == 0
+
+
+def _pad1(t):
+    return torch.nn.functional.pad(t, (0, 1))
+
+
 def _logz_fwd_raw(score, noise, want_v: bool):
+    if _odd_pad(score):
+        logz, v = _logz_fwd_raw(_pad1(score), _pad1(noise), want_v)
+        return logz[:-1].contiguous(), (v[:, :-1].contiguous() if v is not None else None)
     T, B = score.shape[0], score.shape[2]
     lib = _lib.load()
     logz = torch.empty(B, dtype=torch.float32, device=score.device)
@@ -111,6 +125,9 @@ def _logz_fwd_raw(score, noise, want_v: bool):
 
 
 def _logz_bwd_raw(score, noise, v, logz, gout, want_q: bool = False):
+    if _odd_pad(score):
+        ds, dn, q = _logz_bwd_raw(_pad1(score), _pad1(noise), _pad1(v), _pad1(logz), _pad1(gout), want_q)
+        return ds[:, :, :-1].contiguous(), dn[:, :-1].contiguous(), (q[:, :-1].contiguous() if q is not None else None)
     T, B = score.shape[0], score.shape[2]
     lib = _lib.load()
     dscore = torch.empty_like(score)
@@ -228,6 +245,10 @@ class _LogProb(torch.autograd.Function):
 
 def _viterbi_raw(score_c, noise_c, start, forward: bool):
     """Enqueue the Viterbi sweep + on-device backtrack; returns device tensors (pairs [cap,2], offsets [B+1])."""
+    if _odd_pad(score_c):
+        st = _pad1(start) if start is not None else None
+        pairs, offsets = _viterbi_raw(_pad1(score_c), _pad1(noise_c), st, forward)
+        return pairs, offsets[:-1]        # the ghost chain is last: its intervals lie behind offsets[B]
     T, B = score_c.shape[0], score_c.shape[2]
     dev = score_c.device
     cap = B * 2 * T
