@@ -339,6 +339,30 @@ def test_fused_scorer_crf(gpu, N, P, T, D, ls):
     assert _lib.device_status() == 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,B,n", [(333, 46, 12), (1024, 352, 4)])
+def test_repeatable_bits(gpu, T, B, n):
+    """Every reduction order is fixed by the task decomposition, not by timing: repeated launches give bit-identical
+    logZ, alpha, gradient and decoded intervals (a race in the hand-off protocol would show up here)."""
+    import hashlib
+    from transkun_amd import _lib, synth
+    import importlib
+    nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
+    _lib.set_impl(0)
+    s, nz = synth.crf_inputs(T, B, 77, gpu)
+    g = synth.hash_normal(B, 5, gpu)
+    dig = lambda t: hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()
+    ref = None
+    for _ in range(n):
+        lz, v = nsci._logz_fwd_raw(s, nz, True)
+        ds, dn, q = nsci._logz_bwd_raw(s, nz, v, lz, g, True)
+        pairs, offs = nsci._viterbi_raw(s, nz, None, False)
+        cur = (dig(lz), dig(v), dig(ds), dig(dn), dig(q), dig(offs), dig(pairs[:int(offs[-1])]))
+        ref = ref or cur
+        assert cur == ref
+    assert _lib.device_status() == 0
+
+
 # ---- the persistent blocked kernels against the oracle over a grid of shapes -------------------
 
 PERSIST_SHAPES = [(1, 4), (2, 4), (15, 8), (16, 4), (17, 12), (33, 16), (48, 20), (63, 36), (64, 32), (65, 4),
