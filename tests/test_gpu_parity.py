@@ -280,6 +280,34 @@ def test_scorer(gpu, impl, oracle, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 8, 32, 128])
+@pytest.mark.parametrize("C,T,D,mode,full", [(5, 70, 64, 0, False), (37, 300, 128, 1, False), (33, 257, 256, 0, True),
+                                              (8, 128, 64, 2, False), (64, 384, 256, 0, False), (3, 31, 64, 0, True)])
+def test_scorer_forward_kernels(gpu, variant, C, T, D, mode, full, monkeypatch):
+    """Every forward kernel of the interval scorer (register-load, LDS-staged, streaming, 128x128 shared-operand) against
+    an fp64 einsum of the same definition (LayersTransformer.py:406-441)."""
+    from transkun_amd import synth
+    from transkun_amd.scorer import _interval_score_raw
+    monkeypatch.setenv("SEMICRF_SCORE_VARIANT", str(variant))
+    q = synth.hash_normal(C * T * D, 71, "cpu").view(C, T, D).to(gpu)
+    k = synth.hash_normal(C * T * D, 72, "cpu").view(C, T, D).to(gpu)
+    dg = synth.hash_normal(C * T, 73, "cpu").view(C, T).to(gpu)
+    qs = 1.0 / D ** 0.5
+    S, _ = _interval_score_raw(q, k, dg, T, C, D, qs, mode, full)
+    t = torch.arange(T, device=gpu)
+    ln = (t[:, None] - t[None, :]).abs().double()
+    ln = ln if mode == 0 else (ln.sqrt() if mode == 1 else torch.ones_like(ln))
+    ref = torch.einsum("ced,cbd->ebc", q.double(), k.double()) * qs * ln[:, :, None]
+    ref[t, t, :] += dg.double().t()
+    if not full:
+        keep = torch.ones(T, T, device=gpu).tril()[:, :, None].double()
+        ref = ref * keep
+        assert float((S.double() * (1 - keep)).abs().max()) == 0.0
+    err = float((S.double() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 2e-6, err
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,P,T,D,ls", [(1, 5, 70, 64, "linear"), (2, 9, 97, 256, "linear"), (1, 3, 33, 32, "sqrt"),
                                          (1, 8, 64, 128, "none"), (3, 11, 130, 96, "linear")])
 def test_scorer_backward_kernel(gpu, N, P, T, D, ls):

@@ -12,6 +12,12 @@
 // segments), lower triangle only unless the caller asks for the full square.
 #include "common.h"
 
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
 namespace semicrf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -27,29 +33,26 @@ __device__ __forceinline__ float len_scale_mfma(int len, int mode)
     return 1.0f;
 }
 
-// tile list: blockIdx.x enumerates (et, bt) with bt <= et (or the full square), blockIdx.y the chain group
+// Work list (XCD-aware): workgroups are dispatched round-robin over the 8 XCDs, each with its own 4 MB L2, and the
+// operands are heavy (a 32-row tile of q or k for 16 chains is 512 KB at D=256) while HBM delivers only ~10 B/clk/CU --
+// a third of what the matrix pipe consumes with 32x32 tiles.  So the host orders the tiles such that the workgroups
+// resident on ONE XCD at a time work on a band of SBAND tile rows of one chain group, column by column: the band's q
+// tiles stay in that L2 and each k tile is fetched once for the SBAND workgroups that use it back to back.
+// work[blockIdx.x] = {et | bt << 16, chain group} (et < 0: padding).
 // NCH = chunks of 32 contraction values per half-wave (D / 64) when known at compile time (<= 4), else 0: with a
 // compile-time trip count the two-stage load/multiply pipeline unrolls without branches and every wait is exact
 template <bool ALIGNED, int NCH>
 __global__ __launch_bounds__(256) void interval_score_mfma_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ diag, int C, int T, int D,
-    long long ldq, long long ldk, long long ldd, float qscale, int mode, int full, float* __restrict__ S)
+    long long ldq, long long ldk, long long ldd, float qscale, int mode, int full, float* __restrict__ S,
+    const int2* __restrict__ work)
 {
     extern __shared__ __attribute__((aligned(16))) float tile[];   // [ST*ST][SPAD]
-    const int nt = (T + ST - 1) / ST;
-    int et, bt;
-    if (full) {
-        et = blockIdx.x / nt; bt = blockIdx.x % nt;
-    } else {
-        // invert t = et*(et+1)/2 + bt
-        int t = blockIdx.x;
-        et = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-        while (et * (et + 1) / 2 > t) --et;
-        while ((et + 1) * (et + 2) / 2 <= t) ++et;
-        bt = t - et * (et + 1) / 2;
-    }
+    const int2 wk = work[blockIdx.x];
+    if (wk.x < 0) return;
+    const int et = wk.x & 0xffff, bt = wk.x >> 16;
     const int e0 = et * ST, b0 = bt * ST;
-    const int cg = blockIdx.y * SC;
+    const int cg = wk.y * SC;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = lane & 31, half = lane >> 5;
     const int Dh = D >> 1;                                  // d range of this half-wave: [half*Dh, half*Dh + Dh)
@@ -145,16 +148,794 @@ __global__ __launch_bounds__(256) void interval_score_mfma_kernel(
 
 bool interval_score_mfma_supported(int C, int T, int D) { return D % 64 == 0 && T >= 1 && C >= 1; }
 
-void launch_interval_score_mfma(const float* q, const float* k, const float* diag, int C, int T, int D,
+constexpr int NXCD = 8;
+
+// builds (once per shape) the device-resident work list described above
+static const int2* score_work_list(int nt, int ngroups, int full, int band, int* grid_out)
+{
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int, int>, std::pair<int2*, int>> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_tuple(dev, nt, ngroups, full, band);
+    auto it = cache.find(key);
+    if (it != cache.end()) { *grid_out = it->second.second; return it->second.first; }
+    // units: (chain group, pair of bands p and nb-1-p) -- equal work per unit in the triangle
+    const int nb = (nt + band - 1) / band;
+    std::vector<std::vector<int2>> per(NXCD);
+    int u = 0;
+    auto add_band = [&](std::vector<int2>& out, int g, int j) {
+        const int r0 = j * band, r1 = (r0 + band < nt) ? r0 + band : nt;
+        const int ncol = full ? nt : r1;                 // columns 0 .. r1-1 (bt <= et)
+        for (int bt = 0; bt < ncol; ++bt)
+            for (int et = r0; et < r1; ++et)
+                if (full || bt <= et) out.push_back(make_int2(et | (bt << 16), g));
+    };
+    for (int g = 0; g < ngroups; ++g)
+        for (int p = 0; p < (nb + 1) / 2; ++p, ++u) {
+            std::vector<int2>& out = per[u % NXCD];
+            add_band(out, g, p);
+            if (nb - 1 - p != p) add_band(out, g, nb - 1 - p);
+        }
+    size_t longest = 0;
+    for (auto& v : per) longest = v.size() > longest ? v.size() : longest;
+    std::vector<int2> flat(longest * NXCD, make_int2(-1, 0));
+    for (int x = 0; x < NXCD; ++x)
+        for (size_t i = 0; i < per[x].size(); ++i) flat[i * NXCD + x] = per[x][i];
+    int2* d = nullptr;
+    if (hipMalloc((void**)&d, flat.size() * sizeof(int2)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, flat.data(), flat.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    cache[key] = std::make_pair(d, (int)flat.size());
+    *grid_out = (int)flat.size();
+    return d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-staged variant (16-byte aligned rows, D % 32 == 0)
+// ---------------------------------------------------------------------------------------------
+// With one matrix row per lane a register load touches 64 different 128-byte lines and the CU's L1 looks them up one
+// per clock: the operand loads, not the matrix pipe, set the pace of the kernel above (28 % of the fp32 MFMA rate).
+// Here every wave copies its operands with `buffer_load ... lds`: one instruction moves 8 rows x 128 contiguous bytes
+// (8 full lines), 8 instructions one chunk (32 rows x 32 contraction values of q and of k = 8 KB) into a wave-private
+// LDS stage.  The 16-byte segments of a row are XOR-swizzled by the LOADING lanes ((row >> 1) & 7) so that the
+// row-per-lane ds_read_b128 of the MFMA operands is bank-conflict free without padding.  Three stages per wave plus
+// the register double buffer keep two chunks in flight; the loads of chunk i+3 are issued between the matrix
+// instructions of chunk i.  LDS reads/writes in the main loop are asm: the compiler would order every DS operation it
+// sees after ALL outstanding LDS-DMA (s_waitcnt vmcnt(0)).
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+constexpr int ZNS = 3;                    // LDS stages per wave
+constexpr int ZSTAGE = 8192;              // bytes per stage: q chunk (4 KB) + k chunk (4 KB)
+constexpr int ZCH = 32;                   // contraction values per chunk
+
+template <int V>
+struct ZIC { static constexpr int value = V; };
+
+__device__ __forceinline__ unsigned z_lds_addr(const void* p)
+{
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+template <int ZSC>
+__global__ __launch_bounds__(256) void interval_score_lds_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ diag, int C, int T, int D,
+    long long ldq, long long ldk, long long ldd, float qscale, int mode, int full, float* __restrict__ S,
+    const int2* __restrict__ work)
+{
+    constexpr int ZPAD = ZSC + 1;
+    extern __shared__ __attribute__((aligned(16))) char zlds[];    // [4 waves][ZNS][ZSTAGE] | out tile [ST*ST][ZPAD] floats
+    const int2 wk = work[blockIdx.x];
+    if (wk.x < 0) return;
+    const int et = wk.x & 0xffff, bt = wk.x >> 16;
+    const int e0 = et * ST, b0 = bt * ST;
+    const int cg = wk.y * ZSC;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int row = lane & 31, half = lane >> 5;
+    float* const tile = (float*)(zlds + 4 * ZNS * ZSTAGE);
+    char* const stage0 = zlds + wave * (ZNS * ZSTAGE);
+    const unsigned stage0_addr = z_lds_addr(stage0);
+    const int nchunk = D / ZCH;
+    const int rounds = ZSC / 4;
+    const int total = rounds * nchunk;
+
+    // loading lanes: piece j (0..3) covers rows 8j .. 8j+7, lane = (row within the piece, 16-byte position)
+    unsigned voq[4], vok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int lr = 8 * j + (lane >> 3);
+        const int seg = (lane & 7) ^ ((lr >> 1) & 7);
+        const int er = e0 + lr < T ? e0 + lr : T - 1;          // clamped rows (masked at the write)
+        const int br = b0 + lr < T ? b0 + lr : T - 1;
+        voq[j] = (unsigned)(((size_t)er * ldq + seg * 4) * 4);
+        vok[j] = (unsigned)(((size_t)br * ldk + seg * 4) * 4);
+    }
+    // reading lanes: lane = (row, half); segment 4*half + m of the row, m = 0..3
+    unsigned rd[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) rd[m] = (unsigned)(row * 128 + (((4 * half + m) ^ ((row >> 1) & 7)) * 16));
+
+    // requests run ZNS chunks ahead of the multiplications; both walk (round, chunk of the chain, stage) with counters
+    // (no divisions in the loop)
+    int nx_i = 0, nx_ch = 0, nx_round = 0, nx_stage = 0;
+    const float* nx_q = q + (size_t)(cg + wave < C ? cg + wave : C - 1) * T * ldq;
+    const float* nx_k = k + (size_t)(cg + wave < C ? cg + wave : C - 1) * T * ldk;
+    // one 1 KB piece of the next chunk: p < 4 -> q rows 8p.., else k rows 8(p-4)..
+    auto issue_piece = [&](int p) {
+        char* dst = stage0 + nx_stage * ZSTAGE + p * 1024;
+        if (p < 4) {
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)nx_q, 0, 0x7fffffff, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)dst, 16, voq[p & 3], nx_ch * (ZCH * 4), 0, 0);
+        } else {
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)nx_k, 0, 0x7fffffff, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)dst, 16, vok[p & 3], nx_ch * (ZCH * 4), 0, 0);
+        }
+    };
+    auto advance_next = [&]() {
+        ++nx_i;
+        nx_stage = nx_stage + 1 == ZNS ? 0 : nx_stage + 1;
+        if (++nx_ch == nchunk) {
+            nx_ch = 0;
+            ++nx_round;
+            const int ci = wave + 4 * nx_round;
+            const int c = cg + ci < C ? cg + ci : C - 1;
+            nx_q = q + (size_t)c * T * ldq;
+            nx_k = k + (size_t)c * T * ldk;
+        }
+    };
+    auto read_chunk = [&](int stage, v4f (&qa)[4], v4f (&ka)[4]) {
+        const unsigned sb = stage0_addr + (unsigned)(stage * ZSTAGE);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const unsigned a = sb + rd[m];
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096" : "=&v"(qa[m]), "=&v"(ka[m]) : "v"(a));
+        }
+    };
+    auto wait_reads = [&](v4f (&qa)[4], v4f (&ka)[4]) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]), "+v"(ka[0]), "+v"(ka[1]), "+v"(ka[2]), "+v"(ka[3]));
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    v4f qa0[4], ka0[4], qa1[4], ka1[4];
+
+    // prologue: chunks 0 .. ZNS-1 requested, chunk 0 in registers
+    for (int i = 0; i < ZNS && i < total; ++i) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) issue_piece(p);
+        advance_next();
+    }
+    if (total > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (total > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    read_chunk(0, qa0, ka0);
+    wait_reads(qa0, ka0);
+
+    int cur_ch = 0, cur_round = 0, rd_stage = 1;      // chunk i within its chain; stage of chunk i+1
+    // step i: chunk i is in registers (cur), chunk i+1 is read into the other set, chunk i+ZNS is requested
+    auto step = [&](int i, v4f (&qc)[4], v4f (&kc)[4], v4f (&qn)[4], v4f (&kn)[4]) {
+        const bool have_next = i + 1 < total;
+        if (have_next) {
+            if (i + 2 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // chunk i+1 landed, i+2 may be in flight
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            read_chunk(rd_stage, qn, kn);
+            rd_stage = rd_stage + 1 == ZNS ? 0 : rd_stage + 1;
+        }
+        const bool more = nx_i < total;                           // its stage (that of chunk i) was read out during step i-1
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[m].x, kc[m].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[m].y, kc[m].y, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) issue_piece(2 * m);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[m].z, kc[m].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[m].w, kc[m].w, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) issue_piece(2 * m + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) advance_next();
+        if (have_next) wait_reads(qn, kn);
+        if (++cur_ch == nchunk) {
+            // the chain's 32x32 block: scale, park it in the out tile (C/D layout: col = lane & 31,
+            // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+            const int ci = wave + 4 * cur_round;
+            cur_ch = 0;
+            ++cur_round;
+            const int bj = row;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ei = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int e = e0 + ei, b = b0 + bj;
+                const int len = e > b ? e - b : b - e;
+                const float v = acc[r] * qscale * len_scale_mfma(len, mode);
+                const unsigned a = z_lds_addr(tile + (ei * ST + bj) * ZPAD + ci);
+                asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
+                acc[r] = 0.0f;
+            }
+        }
+    };
+    for (int i = 0; i < total; i += 2) {
+        step(i, qa0, ka0, qa1, ka1);
+        if (i + 1 < total) step(i + 1, qa1, ka1, qa0, ka0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // write out: ZSC/4 threads per cell (4 chains each), chain axis contiguous; the diagonal term joins here
+    constexpr int nq = ZSC / 4;
+    for (int idx = threadIdx.x; idx < ST * ST * nq; idx += 256) {
+        const int cell = idx / nq, qd = idx % nq;
+        const int ei = cell / ST, bj = cell % ST;
+        const int e = e0 + ei, b = b0 + bj;
+        if (e >= T || b >= T || (!full && b > e)) continue;
+        float* dst = S + ((size_t)e * T + b) * C + cg + qd * 4;
+        const float* src = tile + cell * ZPAD + qd * 4;
+        float v[4] = {src[0], src[1], src[2], src[3]};
+        if (e == b) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (cg + qd * 4 + i < C) v[i] += diag[((size_t)(cg + qd * 4 + i) * T + e) * ldd];
+        }
+        if (cg + qd * 4 + 3 < C && (C & 3) == 0) {
+            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (cg + qd * 4 + i < C) dst[i] = v[i];
+        }
+    }
+}
+
+template <int ZSC>
+static int launch_score_lds(const float* q, const float* k, const float* diag, int C, int T, int D, long long ldq,
+                            long long ldk, long long ldd, float qscale, int mode, int full, float* S, int band,
+                            hipStream_t stream)
+{
+    const int nt = (T + ST - 1) / ST;
+    const size_t lds = (size_t)4 * ZNS * ZSTAGE + (size_t)ST * ST * (ZSC + 1) * sizeof(float);
+    int ngrid = 0;
+    const int2* work = score_work_list(nt, (C + ZSC - 1) / ZSC, full ? 1 : 0, band, &ngrid);
+    if (!work) return 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)interval_score_lds_kernel<ZSC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((interval_score_lds_kernel<ZSC>), dim3(ngrid), dim3(256), lds, stream, q, k, diag, C, T, D, ldq, ldk, ldd,
+                       qscale, mode, full, S, work);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Streaming variant: persistent, barrier-free, no output tile
+// ---------------------------------------------------------------------------------------------
+// Counters of the kernel above (T=1024, C=352, D=256: 1.85 ms) say the matrix pipe is busy a third of the time: 19 % of
+// it no workgroup is resident at all (133 KB of LDS: the next workgroup starts only when the previous one has drained
+// its stores), and inside a workgroup a third of the cycles are issue stalls (instructions placed between two matrix
+// instructions on the SAME accumulator lose the back-to-back forwarding) and a quarter are pipeline fill, barrier and
+// write-out.  Here
+//   * a wave owns FOUR ADJACENT chains of one 32x32 tile: it multiplies them one after the other, keeps the finished
+//     blocks in registers and writes each cell's four chains as one 16-byte piece straight from registers -- the
+//     eight waves of a workgroup cover 32 adjacent chains of the same tile, i.e. whole 128-byte lines, which L2 merges;
+//     no output tile in LDS, no barrier, waves never wait for each other;
+//   * workgroups are persistent (one per CU, 8 waves = 2 per SIMD) and walk their XCD's part of the work list; the
+//     operand stream (two 8 KB LDS stages per wave + the register double buffer) runs on across chains and tiles;
+//   * consecutive matrix instructions alternate between two accumulators (summed at the end of a chain).
+constexpr int YW = 8;                      // waves per workgroup
+constexpr int YNS = 2;                     // LDS stages per wave
+constexpr int YG = 4 * YW;                 // chains per workgroup item
+
+__global__ __launch_bounds__(64 * YW) void interval_score_stream_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ diag, int C, int T, int D,
+    long long ldq, long long ldk, long long ldd, float qscale, int mode, int full, float* __restrict__ S,
+    const int2* __restrict__ work, int nlist)
+{
+    extern __shared__ __attribute__((aligned(16))) char ylds[];    // [YW waves][YNS][ZSTAGE]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int row = lane & 31, half = lane >> 5;
+    char* const stage0 = ylds + wave * (YNS * ZSTAGE);
+    const unsigned stage0_addr = z_lds_addr(stage0);
+    const int nchunk = D / ZCH;                                     // even (D % 64 == 0)
+    const int xcd = blockIdx.x % NXCD, slot0 = blockIdx.x / NXCD, nslots = gridDim.x / NXCD;
+    const int nper = nlist / NXCD;                                  // entries per XCD (the tail may be padding)
+
+    // reading lanes: lane = (row, half); segment 4*half + m of the row, m = 0..3
+    unsigned rd[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) rd[m] = (unsigned)(row * 128 + (((4 * half + m) ^ ((row >> 1) & 7)) * 16));
+
+    // ---- request side: (item, chain of the quad, chunk) walked with counters ---------------------------------
+    int nx_item = slot0;                       // index into this XCD's list
+    int nx_j = 0, nx_ch = 0, nx_stage = 0;
+    bool nx_valid = false;
+    unsigned voq[4], vok[4];
+    const float* nx_q = q;
+    const float* nx_k = k;
+    int nx_c4 = 0;
+    auto set_chain = [&]() {
+        const int c = nx_c4 + nx_j < C ? nx_c4 + nx_j : C - 1;
+        nx_q = q + (size_t)c * T * ldq;
+        nx_k = k + (size_t)c * T * ldk;
+    };
+    auto set_item = [&]() {
+        nx_valid = false;
+        if (nx_item < nper) {
+            const int2 wk = work[(size_t)nx_item * NXCD + xcd];
+            if (wk.x >= 0) {
+                nx_valid = true;
+                const int e0 = (wk.x & 0xffff) * ST, b0 = (wk.x >> 16) * ST;
+                nx_c4 = wk.y * YG + wave * 4;
+                // loading lanes: piece j (0..3) covers rows 8j .. 8j+7, lane = (row within the piece, 16-byte position)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int lr = 8 * j + (lane >> 3);
+                    const int seg = (lane & 7) ^ ((lr >> 1) & 7);
+                    const int er = e0 + lr < T ? e0 + lr : T - 1;          // clamped rows (masked at the write)
+                    const int br = b0 + lr < T ? b0 + lr : T - 1;
+                    voq[j] = (unsigned)(((size_t)er * ldq + seg * 4) * 4);
+                    vok[j] = (unsigned)(((size_t)br * ldk + seg * 4) * 4);
+                }
+                nx_j = 0;
+                nx_ch = 0;
+                set_chain();
+            }
+        }
+    };
+    // one 1 KB piece of the next chunk: p < 4 -> q rows 8p.., else k rows 8(p-4)..
+    auto issue_piece = [&](int p) {
+        char* dst = stage0 + nx_stage * ZSTAGE + p * 1024;
+        if (p < 4) {
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)nx_q, 0, 0x7fffffff, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)dst, 16, voq[p & 3], nx_ch * (ZCH * 4), 0, 0);
+        } else {
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)nx_k, 0, 0x7fffffff, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)dst, 16, vok[p & 3], nx_ch * (ZCH * 4), 0, 0);
+        }
+    };
+    auto advance_next = [&]() {
+        nx_stage ^= 1;
+        if (++nx_ch == nchunk) {
+            nx_ch = 0;
+            if (++nx_j == 4) {
+                nx_item += nslots;
+                set_item();
+            } else {
+                set_chain();
+            }
+        }
+    };
+    auto read_chunk = [&](int stage, v4f (&qa)[4], v4f (&ka)[4]) {
+        const unsigned sb = stage0_addr + (unsigned)(stage * ZSTAGE);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const unsigned a = sb + rd[m];
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096" : "=&v"(qa[m]), "=&v"(ka[m]) : "v"(a));
+        }
+    };
+    auto wait_reads = [&](v4f (&qa)[4], v4f (&ka)[4]) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]), "+v"(ka[0]), "+v"(ka[1]), "+v"(ka[2]), "+v"(ka[3]));
+    };
+
+    set_item();
+    if (!nx_valid) return;
+    // the compute side's view of the current item
+    int cur_item = nx_item;
+    int2 cur_wk = work[(size_t)cur_item * NXCD + xcd];
+
+    f32x16 accA, accB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accA[r] = 0.0f; accB[r] = 0.0f; }
+    float hold[3][16];
+    v4f qa0[4], ka0[4], qa1[4], ka1[4];
+
+    // prologue: chunk 0 requested and read into registers, chunk 1 requested
+#pragma unroll
+    for (int p = 0; p < 8; ++p) issue_piece(p);
+    advance_next();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    read_chunk(0, qa0, ka0);
+    wait_reads(qa0, ka0);
+    if (nx_valid) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) issue_piece(p);
+        advance_next();
+    }
+    bool have_next = true;                     // a chunk after the current one exists (requested into stage rd_stage)
+    int rd_stage = 1;
+
+    // step: the current chunk is in registers (qc, kc); the next one (in flight since the previous step) is awaited and
+    // read into the other set; the one after it is requested between the matrix instructions
+    auto step = [&](v4f (&qc)[4], v4f (&kc)[4], v4f (&qn)[4], v4f (&kn)[4], bool last_of_stream) {
+        if (!last_of_stream) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // the chunk after the next goes into the stage of the current one (which is in registers); all of it is
+            // requested NOW so that every piece has the whole step to arrive
+            if (nx_valid) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) issue_piece(p);
+                advance_next();
+            }
+            read_chunk(rd_stage, qn, kn);
+            rd_stage ^= 1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            accA = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[m].x, kc[m].x, accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[m].y, kc[m].y, accB, 0, 0, 0);
+            accA = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[m].z, kc[m].z, accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[m].w, kc[m].w, accB, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!last_of_stream) wait_reads(qn, kn);
+    };
+
+    while (true) {
+        // is there an item after this one (for this workgroup)?  the request side knows: it is at most two chunks ahead
+        const int e0 = (cur_wk.x & 0xffff) * ST, b0 = (cur_wk.x >> 16) * ST;
+        const int c4 = cur_wk.y * YG + wave * 4;
+        int nxt_item = cur_item + nslots;
+        bool nxt_ok = false;
+        int2 nxt_wk = make_int2(-1, 0);
+        if (nxt_item < nper) {
+            nxt_wk = work[(size_t)nxt_item * NXCD + xcd];
+            nxt_ok = nxt_wk.x >= 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            for (int ch = 0; ch < nchunk; ch += 2) {
+                step(qa0, ka0, qa1, ka1, false);
+                step(qa1, ka1, qa0, ka0, !nxt_ok && j == 3 && ch + 2 == nchunk);
+            }
+            if (j < 3) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { hold[j][r] = accA[r] + accB[r]; accA[r] = 0.0f; accB[r] = 0.0f; }
+            }
+        }
+        // ---- write the item's four chains: one 16-byte piece per cell (C/D layout: col = lane & 31,
+        //      row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) ----
+        {
+            const int bj = row, b = b0 + bj;
+            const bool vec = (C & 3) == 0 && c4 + 3 < C;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ei = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int e = e0 + ei;
+                const int len = e > b ? e - b : b - e;
+                const float sc = qscale * len_scale_mfma(len, mode);
+                float v[4] = {hold[0][r] * sc, hold[1][r] * sc, hold[2][r] * sc, (accA[r] + accB[r]) * sc};
+                accA[r] = 0.0f; accB[r] = 0.0f;
+                if (e < T && b < T && (full || b <= e) && c4 < C) {
+                    if (e == b) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (c4 + i < C) v[i] += diag[((size_t)(c4 + i) * T + e) * ldd];
+                    }
+                    float* dst = S + ((size_t)e * T + b) * C + c4;
+                    if (vec) {
+                        *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (c4 + i < C) dst[i] = v[i];
+                    }
+                }
+            }
+        }
+        if (!nxt_ok) break;
+        cur_item = nxt_item;
+        cur_wk = nxt_wk;
+    }
+}
+
+static int launch_score_stream(const float* q, const float* k, const float* diag, int C, int T, int D, long long ldq,
+                               long long ldk, long long ldd, float qscale, int mode, int full, float* S, int band,
+                               hipStream_t stream)
+{
+    const int nt = (T + ST - 1) / ST;
+    const size_t lds = (size_t)YW * YNS * ZSTAGE;
+    int nlist = 0;
+    const int2* work = score_work_list(nt, (C + YG - 1) / YG, full ? 1 : 0, band, &nlist);
+    if (!work) return 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)interval_score_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    int ncu = 256, dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+        ncu = v;
+    int grid = ncu / NXCD * NXCD;                       // one persistent workgroup per CU, a whole number per XCD
+    if (grid < NXCD) grid = NXCD;
+    if (grid > nlist) grid = nlist;                     // nlist is a multiple of NXCD
+    hipLaunchKernelGGL(interval_score_stream_kernel, dim3(grid), dim3(64 * YW), lds, stream, q, k, diag, C, T, D, ldq, ldk, ldd,
+                       qscale, mode, full, S, work, nlist);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 128x128 variant: operands shared by the whole workgroup through LDS
+// ---------------------------------------------------------------------------------------------
+// Counters of the streaming kernel (1.8 ms): the L1 waits on L2 80 % of the time and delivers 15 B/clk/CU -- its miss
+// queue holds about 8 KB and an L2 round trip is ~600 cycles, so that IS what a CU can pull, whatever the access
+// pattern.  32x32 tiles need 32 B/clk/CU to keep the fp32 matrix pipe busy (8 flop per operand byte).  Hence the
+// classic answer: the eight waves of a workgroup multiply ONE chain's 128x128 tile together (wave = 32 rows x 64
+// columns, two accumulators), the q and k chunks (128 rows x 32 contraction values each, 32 KB per stage, swizzled as
+// above) are fetched once per workgroup: 32 flop per byte, 8 B/clk/CU at full rate.  A workgroup item is one tile for
+// FOUR adjacent chains: finished blocks stay in registers and every cell leaves as one 16-byte piece.  The eight
+// workgroups that cover the 32 chains of a 128-byte output line run side by side on the same XCD (persistent
+// workgroups, static schedule: slot % 8 = chain quad), so its L2 assembles whole lines.  One s_barrier per chunk (no
+// fence: the prefetch stays in flight); the matrix instructions of a wave alternate between its two accumulators.
+constexpr int XT = 128;                    // tile edge
+constexpr int XNS = 3;                     // LDS stages
+constexpr int XSTAGE = 2 * XT * 128;       // bytes per stage: q chunk (16 KB) + k chunk (16 KB)
+constexpr int XW = 8;                      // waves per workgroup
+
+__global__ __launch_bounds__(64 * XW) void interval_score_tile_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ diag, int C, int T, int D,
+    long long ldq, long long ldk, long long ldd, float qscale, int mode, int full, float* __restrict__ S,
+    int ntiles, int nquadp)
+{
+    extern __shared__ __attribute__((aligned(16))) char xlds[];    // [XNS][XSTAGE]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int row = lane & 31, half = lane >> 5;
+    const int wer = wave >> 1, wh = wave & 1;                       // this wave: rows 32*wer.., columns 64*wh.. of the tile
+    const unsigned lds0 = z_lds_addr(xlds);
+    const int nchunk = D / ZCH;
+    const int nxt = (T + XT - 1) / XT;                              // tiles per edge
+    const int xcd = blockIdx.x % NXCD, slot0 = blockIdx.x / NXCD, nslots = gridDim.x / NXCD;
+    const long long nitems = (long long)ntiles * nquadp;            // nquadp: chain quads, padded to a multiple of 8
+
+    // entry u of this XCD's list -> global item n: 8 consecutive entries = the 8 quads of one 128-byte line group
+    auto item_of = [&](int u, int& et, int& bt, int& c4) -> bool {
+        const long long n = (long long)(u >> 3) * (8 * NXCD) + xcd * 8 + (u & 7);
+        if (n >= nitems) return false;
+        const int t = (int)(n / nquadp);
+        c4 = (int)(n % nquadp) * 4;
+        if (full) {
+            et = t / nxt; bt = t % nxt;
+        } else {
+            et = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            while (et * (et + 1) / 2 > t) --et;
+            while ((et + 1) * (et + 2) / 2 <= t) ++et;
+            bt = t - et * (et + 1) / 2;
+        }
+        return true;
+    };
+
+    // reading lanes: lane = (row, half); segment 4*half + m of the row
+    unsigned rdq[4], rdk[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const unsigned sw = (unsigned)((((4 * half + m) ^ ((row >> 1) & 7)) * 16));
+        rdq[m] = (unsigned)((32 * wer + row) * 128) + sw;
+        rdk[m] = (unsigned)(XT * 128 + (64 * wh + row) * 128) + sw;        // second column block: + 32 rows = + 4096 bytes
+    }
+
+    // ---- request side (identical in all waves): (entry, chain of the quad, chunk, stage) ----------------------
+    int nx_u = slot0, nx_j = 0, nx_ch = 0, nx_stage = 0, nx_c4 = 0;
+    bool nx_valid = false;
+    unsigned voq[2], vok[2];
+    const float* nx_q = q;
+    const float* nx_k = k;
+    auto set_chain = [&]() {
+        const int c = nx_c4 + nx_j < C ? nx_c4 + nx_j : C - 1;
+        nx_q = q + (size_t)c * T * ldq;
+        nx_k = k + (size_t)c * T * ldk;
+    };
+    auto set_item = [&]() {
+        int et, bt;
+        nx_valid = item_of(nx_u, et, bt, nx_c4);
+        if (nx_valid) {
+            // loading lanes: this wave's pieces 2*wave, 2*wave+1 (8 rows x 128 bytes each) of the q and of the k chunk
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int lr = 8 * (2 * wave + j) + (lane >> 3);
+                const int seg = (lane & 7) ^ ((lr >> 1) & 7);
+                const int er = et * XT + lr < T ? et * XT + lr : T - 1;       // clamped rows (masked at the write)
+                const int br = bt * XT + lr < T ? bt * XT + lr : T - 1;
+                voq[j] = (unsigned)(((size_t)er * ldq + seg * 4) * 4);
+                vok[j] = (unsigned)(((size_t)br * ldk + seg * 4) * 4);
+            }
+            nx_j = 0;
+            nx_ch = 0;
+            set_chain();
+        }
+    };
+    auto issue_chunk = [&]() {
+        char* dst = xlds + nx_stage * XSTAGE + (2 * wave) * 1024;
+        const auto rq = __builtin_amdgcn_make_buffer_rsrc((void*)nx_q, 0, 0x7fffffff, 0x00020000);
+        const auto rk = __builtin_amdgcn_make_buffer_rsrc((void*)nx_k, 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void_t*)dst, 16, voq[0], nx_ch * (ZCH * 4), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void_t*)(dst + 1024), 16, voq[1], nx_ch * (ZCH * 4), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_t*)(dst + XT * 128), 16, vok[0], nx_ch * (ZCH * 4), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_t*)(dst + XT * 128 + 1024), 16, vok[1], nx_ch * (ZCH * 4), 0, 0);
+        // advance
+        nx_stage = nx_stage + 1 == XNS ? 0 : nx_stage + 1;
+        if (++nx_ch == nchunk) {
+            nx_ch = 0;
+            if (++nx_j == 4) {
+                nx_u += nslots;
+                set_item();
+            } else {
+                set_chain();
+            }
+        }
+    };
+
+    set_item();
+    if (!nx_valid) return;                      // uniform over the workgroup
+    int cur_u = slot0;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    float hold[3][2][16];
+
+    // prologue: XNS-1 chunks requested
+    int inflight = 0;                           // chunks requested and not yet consumed
+#pragma unroll
+    for (int i = 0; i < XNS - 1; ++i)
+        if (nx_valid) { issue_chunk(); ++inflight; }
+    int rd_stage = 0;
+
+    while (true) {
+        int et, bt, c4;
+        (void)item_of(cur_u, et, bt, c4);
+        const bool diag_tile = !full && et == bt;
+        // sub-blocks of this wave that lie entirely above the diagonal are not multiplied (nor written)
+        const bool on0 = !diag_tile || 2 * wh <= wer, on1 = !diag_tile || 2 * wh + 1 <= wer;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            for (int ch = 0; ch < nchunk; ++ch) {
+                // this wave's pieces of the current chunk have landed (younger requests may stay in flight) ...
+                if (inflight >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // ... and so have everybody's; everybody is also done reading the previous chunk
+                __builtin_amdgcn_s_barrier();
+                --inflight;
+                if (nx_valid) { issue_chunk(); ++inflight; }        // into the stage of the previous chunk
+                v4f qa[4], ka0[4], ka1[4];
+                const unsigned sb = lds0 + (unsigned)(rd_stage * XSTAGE);
+                rd_stage = rd_stage + 1 == XNS ? 0 : rd_stage + 1;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %4 offset:4096"
+                                 : "=&v"(qa[m]), "=&v"(ka0[m]), "=&v"(ka1[m])
+                                 : "v"(sb + rdq[m]), "v"(sb + rdk[m]));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]), "+v"(ka0[0]), "+v"(ka0[1]), "+v"(ka0[2]),
+                               "+v"(ka0[3]), "+v"(ka1[0]), "+v"(ka1[1]), "+v"(ka1[2]), "+v"(ka1[3]));
+                __builtin_amdgcn_sched_barrier(0);
+                if (on0 && on1) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[m].x, ka0[m].x, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[m].x, ka1[m].x, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[m].y, ka0[m].y, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[m].y, ka1[m].y, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[m].z, ka0[m].z, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[m].z, ka1[m].z, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[m].w, ka0[m].w, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[m].w, ka1[m].w, acc1, 0, 0, 0);
+                    }
+                } else if (on0) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[m].x, ka0[m].x, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[m].y, ka0[m].y, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[m].z, ka0[m].z, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[m].w, ka0[m].w, acc0, 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (j < 3) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    hold[j][0][r] = acc0[r]; hold[j][1][r] = acc1[r];
+                    acc0[r] = 0.0f; acc1[r] = 0.0f;
+                }
+            }
+        }
+        // ---- write the item's four chains: one 16-byte piece per cell (C/D layout: col = lane & 31,
+        //      row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) ----
+        {
+            const bool vec = (C & 3) == 0 && c4 + 3 < C;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int b = bt * XT + 64 * wh + 32 * t + row;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int e = et * XT + 32 * wer + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int len = e > b ? e - b : b - e;
+                    const float sc = qscale * len_scale_mfma(len, mode);
+                    const float last = t == 0 ? acc0[r] : acc1[r];
+                    float v[4] = {hold[0][t][r] * sc, hold[1][t][r] * sc, hold[2][t][r] * sc, last * sc};
+                    if (e < T && b < T && (full || b <= e) && c4 < C) {
+                        if (e == b) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (c4 + i < C) v[i] += diag[((size_t)(c4 + i) * T + e) * ldd];
+                        }
+                        float* dst = S + ((size_t)e * T + b) * C + c4;
+                        if (vec) {
+                            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (c4 + i < C) dst[i] = v[i];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+        }
+        cur_u += nslots;
+        int e2, b2, c2;
+        if (!item_of(cur_u, e2, b2, c2)) break;
+    }
+}
+
+static int launch_score_tile(const float* q, const float* k, const float* diag, int C, int T, int D, long long ldq,
+                             long long ldk, long long ldd, float qscale, int mode, int full, float* S, hipStream_t stream)
+{
+    const int nxt = (T + XT - 1) / XT;
+    const int ntiles = full ? nxt * nxt : nxt * (nxt + 1) / 2;
+    const int nquadp = ((C + 3) / 4 + 7) / 8 * 8;
+    const size_t lds = (size_t)XNS * XSTAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)interval_score_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    int ncu = 256, dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+        ncu = v;
+    int grid = ncu / (8 * NXCD) * (8 * NXCD);           // one persistent workgroup per CU; per XCD a multiple of 8 slots
+    if (grid < 8 * NXCD) grid = 8 * NXCD;
+    const long long nitems = (long long)ntiles * nquadp;
+    const long long need = (nitems + 8 * NXCD - 1) / (8 * NXCD) * (8 * NXCD);
+    if (grid > need) grid = (int)need;
+    hipLaunchKernelGGL(interval_score_tile_kernel, dim3(grid), dim3(64 * XW), lds, stream, q, k, diag, C, T, D, ldq, ldk, ldd,
+                       qscale, mode, full, S, ntiles, nquadp);
+    return 0;
+}
+
+int launch_interval_score_mfma(const float* q, const float* k, const float* diag, int C, int T, int D,
                                 long long ldq, long long ldk, long long ldd, float qscale, int mode, int full,
                                 float* S, hipStream_t stream)
 {
     const int nt = (T + ST - 1) / ST;
-    const int ntiles = full ? nt * nt : nt * (nt + 1) / 2;
     const size_t lds = (size_t)ST * ST * SPAD * sizeof(float);
     const bool aligned = ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ldq % 4 == 0 && ldk % 4 == 0;
     const int nch = (D / 64 <= 4) ? D / 64 : 0;
-    const dim3 grid(ntiles, (C + SC - 1) / SC), block(256);
+    int band = 4;
+    if (const char* e = getenv("SEMICRF_SCORE_BAND")) { const int v = atoi(e); if (v >= 1 && v <= 64) band = v; }   // tuning knob
+    // 16-byte aligned rows: the LDS-staged kernel (T*ld*4 < 2^31: 32-bit buffer offsets)
+    if (aligned && D % ZCH == 0 && (long long)T * ldq * 4 < (1ll << 31) && (long long)T * ldk * 4 < (1ll << 31)) {
+        int variant = T >= 256 ? 128 : 32;
+        if (const char* e = getenv("SEMICRF_SCORE_VARIANT")) variant = atoi(e);      // tuning knob: 0 = register-load kernel
+        if (variant == 128)
+            return launch_score_tile(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream);
+        if (variant == 32 && D % 64 == 0)
+            return launch_score_stream(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, band, stream);
+        if (variant == 8) return launch_score_lds<8>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, band, stream);
+        if (variant == 4) return launch_score_lds<4>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, band, stream);
+    }
+    int ngrid = 0;
+    const int2* work = score_work_list(nt, (C + SC - 1) / SC, full ? 1 : 0, band, &ngrid);
+    if (!work) return 1;
+    const dim3 grid(ngrid), block(256);
 #define SEMICRF_FWD_LAUNCH(A, N)                                                                                        \
     do {                                                                                                                \
         static bool attr_set = false;                                                                                   \
@@ -164,7 +945,7 @@ void launch_interval_score_mfma(const float* q, const float* k, const float* dia
             attr_set = true;                                                                                            \
         }                                                                                                               \
         hipLaunchKernelGGL((interval_score_mfma_kernel<A, N>), grid, block, lds, stream, q, k, diag, C, T, D, ldq, ldk, \
-                           ldd, qscale, mode, full, S);                                                                 \
+                           ldd, qscale, mode, full, S, work);                                                           \
     } while (0)
 #define SEMICRF_FWD_DISPATCH(A)                                                                                         \
     switch (nch) {                                                                                                      \
@@ -177,6 +958,7 @@ void launch_interval_score_mfma(const float* q, const float* k, const float* dia
     if (aligned) { SEMICRF_FWD_DISPATCH(true) } else { SEMICRF_FWD_DISPATCH(false) }
 #undef SEMICRF_FWD_DISPATCH
 #undef SEMICRF_FWD_LAUNCH
+    return 0;
 }
 
 }  // namespace semicrf
