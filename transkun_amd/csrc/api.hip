@@ -43,6 +43,7 @@ void launch_interval_score_bwd_fused(const float* S, const float* alpha, const f
 void launch_interval_score_bwd(const float* dS, const float* q, const float* k, int C, int T, int D, long long ldq,
                                long long ldk, float qscale, int mode, float* dq, float* dk, float* ddiag,
                                long long lddq, long long lddk, long long lddd, hipStream_t stream);
+void launch_zero_upper(float* X, int T, int B, hipStream_t stream);
 int launch_interval_score_mfma(const float* q, const float* k, const float* diag, int C, int T, int D,
                                 long long ldq, long long ldk, long long ldd, float qscale, int mode, int full,
                                 float* S, hipStream_t stream);
@@ -245,6 +246,7 @@ int interval_score_fwd(const float* q, const float* k, const float* diag, int C,
     SEMICRF_CHECK_ARG(ldq >= D && ldk >= D && ldd >= 1, "bad leading dimensions");
     SEMICRF_CHECK_ARG(length_scaling >= 0 && length_scaling <= 2, "bad length_scaling %d", length_scaling);
     hipStream_t st = (hipStream_t)stream;
+    if (!full_square) launch_zero_upper(S, T, C, st);          // begin > end: defined (zero), half the bytes of a full fill
     if (g_impl.load() == 0 && interval_score_mfma_supported(C, T, D)) {
         if (launch_interval_score_mfma(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, length_scaling, full_square, S, st) != 0) {
             set_error("interval_score_fwd: work list allocation failed");

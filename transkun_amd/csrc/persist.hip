@@ -1174,6 +1174,16 @@ __global__ __launch_bounds__(256) void zero_upper_kernel(float* __restrict__ dSc
     }
 }
 
+// exact zeros above the diagonal (begin > end) of a [T][T][B] tensor
+void launch_zero_upper(float* X, int T, int B, hipStream_t stream)
+{
+    if (T < 2) return;
+    int gx = (int)(((size_t)T * B / 4 + 255) / 256);
+    if (gx > 8) gx = 8;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(zero_upper_kernel, dim3(gx, T - 1), dim3(256), 0, stream, X, T, B);
+}
+
 static int device_cus()
 {
     static int ncu = 0;
@@ -1304,10 +1314,7 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
             if (zw > NT / 64 - pw) zw = NT / 64 - pw;
             if (nPanelWG <= 0 || P.nTasks == 0) zw = 0;
             if (zw == 0 && T > 1) {
-                int gx = (int)(((size_t)T * B / 4 + 255) / 256);
-                if (gx > 8) gx = 8;
-                if (gx < 1) gx = 1;
-                hipLaunchKernelGGL(zero_upper_kernel, dim3(gx, T - 1), dim3(256), 0, stream, grad->dScore, T, B);
+                launch_zero_upper(grad->dScore, T, B, stream);
             }
         }
         P.zeroWaves = zw;

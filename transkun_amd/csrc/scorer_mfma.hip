@@ -192,234 +192,33 @@ static const int2* score_work_list(int nt, int ngroups, int full, int band, int*
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS-staged variant (16-byte aligned rows, D % 32 == 0)
+// LDS-staged operands (16-byte aligned rows, D % 64 == 0)
 // ---------------------------------------------------------------------------------------------
 // With one matrix row per lane a register load touches 64 different 128-byte lines and the CU's L1 looks them up one
 // per clock: the operand loads, not the matrix pipe, set the pace of the kernel above (28 % of the fp32 MFMA rate).
-// Here every wave copies its operands with `buffer_load ... lds`: one instruction moves 8 rows x 128 contiguous bytes
-// (8 full lines), 8 instructions one chunk (32 rows x 32 contraction values of q and of k = 8 KB) into a wave-private
-// LDS stage.  The 16-byte segments of a row are XOR-swizzled by the LOADING lanes ((row >> 1) & 7) so that the
-// row-per-lane ds_read_b128 of the MFMA operands is bank-conflict free without padding.  Three stages per wave plus
-// the register double buffer keep two chunks in flight; the loads of chunk i+3 are issued between the matrix
-// instructions of chunk i.  LDS reads/writes in the main loop are asm: the compiler would order every DS operation it
-// sees after ALL outstanding LDS-DMA (s_waitcnt vmcnt(0)).
+// The kernels below copy operands with `buffer_load ... lds`: one instruction moves 8 rows x 128 contiguous bytes
+// (8 full lines), a chunk is 32 contraction values of every row.  The 16-byte segments of a row are XOR-swizzled by
+// the LOADING lanes ((row >> 1) & 7) so that the row-per-lane ds_read_b128 of the MFMA operands is bank-conflict free
+// without padding.  LDS reads in the main loops are asm: the compiler would order every DS operation it sees after ALL
+// outstanding LDS-DMA (s_waitcnt vmcnt(0)).
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-constexpr int ZNS = 3;                    // LDS stages per wave
 constexpr int ZSTAGE = 8192;              // bytes per stage: q chunk (4 KB) + k chunk (4 KB)
 constexpr int ZCH = 32;                   // contraction values per chunk
-
-template <int V>
-struct ZIC { static constexpr int value = V; };
 
 __device__ __forceinline__ unsigned z_lds_addr(const void* p)
 {
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
 
-template <int ZSC>
-__global__ __launch_bounds__(256) void interval_score_lds_kernel(
-    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ diag, int C, int T, int D,
-    long long ldq, long long ldk, long long ldd, float qscale, int mode, int full, float* __restrict__ S,
-    const int2* __restrict__ work)
-{
-    constexpr int ZPAD = ZSC + 1;
-    extern __shared__ __attribute__((aligned(16))) char zlds[];    // [4 waves][ZNS][ZSTAGE] | out tile [ST*ST][ZPAD] floats
-    const int2 wk = work[blockIdx.x];
-    if (wk.x < 0) return;
-    const int et = wk.x & 0xffff, bt = wk.x >> 16;
-    const int e0 = et * ST, b0 = bt * ST;
-    const int cg = wk.y * ZSC;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int row = lane & 31, half = lane >> 5;
-    float* const tile = (float*)(zlds + 4 * ZNS * ZSTAGE);
-    char* const stage0 = zlds + wave * (ZNS * ZSTAGE);
-    const unsigned stage0_addr = z_lds_addr(stage0);
-    const int nchunk = D / ZCH;
-    const int rounds = ZSC / 4;
-    const int total = rounds * nchunk;
-
-    // loading lanes: piece j (0..3) covers rows 8j .. 8j+7, lane = (row within the piece, 16-byte position)
-    unsigned voq[4], vok[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int lr = 8 * j + (lane >> 3);
-        const int seg = (lane & 7) ^ ((lr >> 1) & 7);
-        const int er = e0 + lr < T ? e0 + lr : T - 1;          // clamped rows (masked at the write)
-        const int br = b0 + lr < T ? b0 + lr : T - 1;
-        voq[j] = (unsigned)(((size_t)er * ldq + seg * 4) * 4);
-        vok[j] = (unsigned)(((size_t)br * ldk + seg * 4) * 4);
-    }
-    // reading lanes: lane = (row, half); segment 4*half + m of the row, m = 0..3
-    unsigned rd[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) rd[m] = (unsigned)(row * 128 + (((4 * half + m) ^ ((row >> 1) & 7)) * 16));
-
-    // requests run ZNS chunks ahead of the multiplications; both walk (round, chunk of the chain, stage) with counters
-    // (no divisions in the loop)
-    int nx_i = 0, nx_ch = 0, nx_round = 0, nx_stage = 0;
-    const float* nx_q = q + (size_t)(cg + wave < C ? cg + wave : C - 1) * T * ldq;
-    const float* nx_k = k + (size_t)(cg + wave < C ? cg + wave : C - 1) * T * ldk;
-    // one 1 KB piece of the next chunk: p < 4 -> q rows 8p.., else k rows 8(p-4)..
-    auto issue_piece = [&](int p) {
-        char* dst = stage0 + nx_stage * ZSTAGE + p * 1024;
-        if (p < 4) {
-            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)nx_q, 0, 0x7fffffff, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)dst, 16, voq[p & 3], nx_ch * (ZCH * 4), 0, 0);
-        } else {
-            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)nx_k, 0, 0x7fffffff, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)dst, 16, vok[p & 3], nx_ch * (ZCH * 4), 0, 0);
-        }
-    };
-    auto advance_next = [&]() {
-        ++nx_i;
-        nx_stage = nx_stage + 1 == ZNS ? 0 : nx_stage + 1;
-        if (++nx_ch == nchunk) {
-            nx_ch = 0;
-            ++nx_round;
-            const int ci = wave + 4 * nx_round;
-            const int c = cg + ci < C ? cg + ci : C - 1;
-            nx_q = q + (size_t)c * T * ldq;
-            nx_k = k + (size_t)c * T * ldk;
-        }
-    };
-    auto read_chunk = [&](int stage, v4f (&qa)[4], v4f (&ka)[4]) {
-        const unsigned sb = stage0_addr + (unsigned)(stage * ZSTAGE);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const unsigned a = sb + rd[m];
-            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096" : "=&v"(qa[m]), "=&v"(ka[m]) : "v"(a));
-        }
-    };
-    auto wait_reads = [&](v4f (&qa)[4], v4f (&ka)[4]) {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]), "+v"(ka[0]), "+v"(ka[1]), "+v"(ka[2]), "+v"(ka[3]));
-    };
-
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    v4f qa0[4], ka0[4], qa1[4], ka1[4];
-
-    // prologue: chunks 0 .. ZNS-1 requested, chunk 0 in registers
-    for (int i = 0; i < ZNS && i < total; ++i) {
-#pragma unroll
-        for (int p = 0; p < 8; ++p) issue_piece(p);
-        advance_next();
-    }
-    if (total > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (total > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    read_chunk(0, qa0, ka0);
-    wait_reads(qa0, ka0);
-
-    int cur_ch = 0, cur_round = 0, rd_stage = 1;      // chunk i within its chain; stage of chunk i+1
-    // step i: chunk i is in registers (cur), chunk i+1 is read into the other set, chunk i+ZNS is requested
-    auto step = [&](int i, v4f (&qc)[4], v4f (&kc)[4], v4f (&qn)[4], v4f (&kn)[4]) {
-        const bool have_next = i + 1 < total;
-        if (have_next) {
-            if (i + 2 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // chunk i+1 landed, i+2 may be in flight
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            read_chunk(rd_stage, qn, kn);
-            rd_stage = rd_stage + 1 == ZNS ? 0 : rd_stage + 1;
-        }
-        const bool more = nx_i < total;                           // its stage (that of chunk i) was read out during step i-1
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[m].x, kc[m].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[m].y, kc[m].y, acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) issue_piece(2 * m);
-            __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[m].z, kc[m].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[m].w, kc[m].w, acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) issue_piece(2 * m + 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (more) advance_next();
-        if (have_next) wait_reads(qn, kn);
-        if (++cur_ch == nchunk) {
-            // the chain's 32x32 block: scale, park it in the out tile (C/D layout: col = lane & 31,
-            // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
-            const int ci = wave + 4 * cur_round;
-            cur_ch = 0;
-            ++cur_round;
-            const int bj = row;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ei = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int e = e0 + ei, b = b0 + bj;
-                const int len = e > b ? e - b : b - e;
-                const float v = acc[r] * qscale * len_scale_mfma(len, mode);
-                const unsigned a = z_lds_addr(tile + (ei * ST + bj) * ZPAD + ci);
-                asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
-                acc[r] = 0.0f;
-            }
-        }
-    };
-    for (int i = 0; i < total; i += 2) {
-        step(i, qa0, ka0, qa1, ka1);
-        if (i + 1 < total) step(i + 1, qa1, ka1, qa0, ka0);
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // write out: ZSC/4 threads per cell (4 chains each), chain axis contiguous; the diagonal term joins here
-    constexpr int nq = ZSC / 4;
-    for (int idx = threadIdx.x; idx < ST * ST * nq; idx += 256) {
-        const int cell = idx / nq, qd = idx % nq;
-        const int ei = cell / ST, bj = cell % ST;
-        const int e = e0 + ei, b = b0 + bj;
-        if (e >= T || b >= T || (!full && b > e)) continue;
-        float* dst = S + ((size_t)e * T + b) * C + cg + qd * 4;
-        const float* src = tile + cell * ZPAD + qd * 4;
-        float v[4] = {src[0], src[1], src[2], src[3]};
-        if (e == b) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (cg + qd * 4 + i < C) v[i] += diag[((size_t)(cg + qd * 4 + i) * T + e) * ldd];
-        }
-        if (cg + qd * 4 + 3 < C && (C & 3) == 0) {
-            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (cg + qd * 4 + i < C) dst[i] = v[i];
-        }
-    }
-}
-
-template <int ZSC>
-static int launch_score_lds(const float* q, const float* k, const float* diag, int C, int T, int D, long long ldq,
-                            long long ldk, long long ldd, float qscale, int mode, int full, float* S, int band,
-                            hipStream_t stream)
-{
-    const int nt = (T + ST - 1) / ST;
-    const size_t lds = (size_t)4 * ZNS * ZSTAGE + (size_t)ST * ST * (ZSC + 1) * sizeof(float);
-    int ngrid = 0;
-    const int2* work = score_work_list(nt, (C + ZSC - 1) / ZSC, full ? 1 : 0, band, &ngrid);
-    if (!work) return 1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)interval_score_lds_kernel<ZSC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((interval_score_lds_kernel<ZSC>), dim3(ngrid), dim3(256), lds, stream, q, k, diag, C, T, D, ldq, ldk, ldd,
-                       qscale, mode, full, S, work);
-    return 0;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Streaming variant: persistent, barrier-free, no output tile
 // ---------------------------------------------------------------------------------------------
-// Counters of the kernel above (T=1024, C=352, D=256: 1.85 ms) say the matrix pipe is busy a third of the time: 19 % of
-// it no workgroup is resident at all (133 KB of LDS: the next workgroup starts only when the previous one has drained
-// its stores), and inside a workgroup a third of the cycles are issue stalls (instructions placed between two matrix
-// instructions on the SAME accumulator lose the back-to-back forwarding) and a quarter are pipeline fill, barrier and
-// write-out.  Here
+// A first LDS-staged version kept the output tile of the kernel above (one workgroup per 32x32 tile and 8 chains, 1.85 ms
+// at T=1024, C=352, D=256): 19 % of the time no workgroup was resident (133 KB of LDS: the next one starts only when the
+// previous one has drained its stores) and a quarter of a workgroup's cycles were pipeline fill, barrier and write-out.
+// Here
 //   * a wave owns FOUR ADJACENT chains of one 32x32 tile: it multiplies them one after the other, keeps the finished
 //     blocks in registers and writes each cell's four chains as one 16-byte piece straight from registers -- the
 //     eight waves of a workgroup cover 32 adjacent chains of the same tile, i.e. whole 128-byte lines, which L2 merges;
@@ -673,23 +472,30 @@ static int launch_score_stream(const float* q, const float* k, const float* diag
 // workgroups that cover the 32 chains of a 128-byte output line run side by side on the same XCD (persistent
 // workgroups, static schedule: slot % 8 = chain quad), so its L2 assembles whole lines.  One s_barrier per chunk (no
 // fence: the prefetch stays in flight); the matrix instructions of a wave alternate between its two accumulators.
-constexpr int XT = 128;                    // tile edge
+constexpr int XTB = 128;                   // tile columns (begin positions)
 constexpr int XNS = 3;                     // LDS stages
-constexpr int XSTAGE = 2 * XT * 128;       // bytes per stage: q chunk (16 KB) + k chunk (16 KB)
-constexpr int XW = 8;                      // waves per workgroup
 
-__global__ __launch_bounds__(64 * XW) void interval_score_tile_kernel(
+// XTE = tile rows (end positions): 128 -> 8 waves, one workgroup per CU; 64 -> 4 waves, two (independent) workgroups
+// per CU whose barriers and operand reads fall into each other's matrix phases (24 instead of 32 flop per byte).
+template <int XTE>
+__global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ diag, int C, int T, int D,
     long long ldq, long long ldk, long long ldd, float qscale, int mode, int full, float* __restrict__ S,
     int ntiles, int nquadp)
 {
+    constexpr int XW = XTE / 16;                   // waves: (row block of 32, column half of 64)
+    constexpr int KP = 16 / XW;                    // k pieces (8 rows x 128 bytes) per wave and chunk; q pieces: 2
+    constexpr int XSTAGE = (XTE + XTB) * 128;      // bytes per stage: q chunk | k chunk
     extern __shared__ __attribute__((aligned(16))) char xlds[];    // [XNS][XSTAGE]
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int row = lane & 31, half = lane >> 5;
     const int wer = wave >> 1, wh = wave & 1;                       // this wave: rows 32*wer.., columns 64*wh.. of the tile
     const unsigned lds0 = z_lds_addr(xlds);
+    const int dbg = mode >> 8;       // timing ablations (SEMICRF_SCORE_DEBUG; results are wrong when set): 1 no matrix
+                                     // instructions, 2 no operand requests, 4 no stores, 8 no LDS reads
+    mode &= 0xff;
     const int nchunk = D / ZCH;
-    const int nxt = (T + XT - 1) / XT;                              // tiles per edge
+    const int nbt = (T + XTB - 1) / XTB;                            // column tiles
     const int xcd = blockIdx.x % NXCD, slot0 = blockIdx.x / NXCD, nslots = gridDim.x / NXCD;
     const long long nitems = (long long)ntiles * nquadp;            // nquadp: chain quads, padded to a multiple of 8
 
@@ -700,12 +506,21 @@ __global__ __launch_bounds__(64 * XW) void interval_score_tile_kernel(
         const int t = (int)(n / nquadp);
         c4 = (int)(n % nquadp) * 4;
         if (full) {
-            et = t / nxt; bt = t % nxt;
-        } else {
+            et = t / nbt; bt = t % nbt;
+        } else if (XTE == XTB) {
+            // row et holds et+1 tiles
             et = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
             while (et * (et + 1) / 2 > t) --et;
             while ((et + 1) * (et + 2) / 2 <= t) ++et;
             bt = t - et * (et + 1) / 2;
+        } else {
+            // rows 2p and 2p+1 hold p+1 tiles each; p(p+1) tiles lie before the pair
+            int pp = (int)((sqrtf(4.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            while (pp * (pp + 1) > t) --pp;
+            while ((pp + 1) * (pp + 2) <= t) ++pp;
+            const int r = t - pp * (pp + 1);
+            et = r < pp + 1 ? 2 * pp : 2 * pp + 1;
+            bt = r < pp + 1 ? r : r - (pp + 1);
         }
         return true;
     };
@@ -716,13 +531,13 @@ __global__ __launch_bounds__(64 * XW) void interval_score_tile_kernel(
     for (int m = 0; m < 4; ++m) {
         const unsigned sw = (unsigned)((((4 * half + m) ^ ((row >> 1) & 7)) * 16));
         rdq[m] = (unsigned)((32 * wer + row) * 128) + sw;
-        rdk[m] = (unsigned)(XT * 128 + (64 * wh + row) * 128) + sw;        // second column block: + 32 rows = + 4096 bytes
+        rdk[m] = (unsigned)(XTE * 128 + (64 * wh + row) * 128) + sw;       // second column block: + 32 rows = + 4096 bytes
     }
 
     // ---- request side (identical in all waves): (entry, chain of the quad, chunk, stage) ----------------------
     int nx_u = slot0, nx_j = 0, nx_ch = 0, nx_stage = 0, nx_c4 = 0;
     bool nx_valid = false;
-    unsigned voq[2], vok[2];
+    unsigned voq[2], vok[4];      // (a [KP] array captured by the lambdas below trips the host compiler)
     const float* nx_q = q;
     const float* nx_k = k;
     auto set_chain = [&]() {
@@ -734,14 +549,19 @@ __global__ __launch_bounds__(64 * XW) void interval_score_tile_kernel(
         int et, bt;
         nx_valid = item_of(nx_u, et, bt, nx_c4);
         if (nx_valid) {
-            // loading lanes: this wave's pieces 2*wave, 2*wave+1 (8 rows x 128 bytes each) of the q and of the k chunk
+            // loading lanes: a piece is 8 rows x 128 bytes; this wave's q pieces 2*wave.. and k pieces KP*wave..
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int lr = 8 * (2 * wave + j) + (lane >> 3);
                 const int seg = (lane & 7) ^ ((lr >> 1) & 7);
-                const int er = et * XT + lr < T ? et * XT + lr : T - 1;       // clamped rows (masked at the write)
-                const int br = bt * XT + lr < T ? bt * XT + lr : T - 1;
+                const int er = et * XTE + lr < T ? et * XTE + lr : T - 1;     // clamped rows (masked at the write)
                 voq[j] = (unsigned)(((size_t)er * ldq + seg * 4) * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                const int lr = 8 * (KP * wave + j) + (lane >> 3);
+                const int seg = (lane & 7) ^ ((lr >> 1) & 7);
+                const int br = bt * XTB + lr < T ? bt * XTB + lr : T - 1;
                 vok[j] = (unsigned)(((size_t)br * ldk + seg * 4) * 4);
             }
             nx_j = 0;
@@ -750,14 +570,20 @@ __global__ __launch_bounds__(64 * XW) void interval_score_tile_kernel(
         }
     };
     auto issue_chunk = [&]() {
-        char* dst = xlds + nx_stage * XSTAGE + (2 * wave) * 1024;
+        if (!(dbg & 2)) {
+        char* dq = xlds + nx_stage * XSTAGE + (2 * wave) * 1024;
+        char* dk = xlds + nx_stage * XSTAGE + XTE * 128 + (KP * wave) * 1024;
         const auto rq = __builtin_amdgcn_make_buffer_rsrc((void*)nx_q, 0, 0x7fffffff, 0x00020000);
         const auto rk = __builtin_amdgcn_make_buffer_rsrc((void*)nx_k, 0, 0x7fffffff, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void_t*)dst, 16, voq[0], nx_ch * (ZCH * 4), 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void_t*)(dst + 1024), 16, voq[1], nx_ch * (ZCH * 4), 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_t*)(dst + XT * 128), 16, vok[0], nx_ch * (ZCH * 4), 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_t*)(dst + XT * 128 + 1024), 16, vok[1], nx_ch * (ZCH * 4), 0, 0);
-        // advance
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void_t*)dq, 16, voq[0], nx_ch * (ZCH * 4), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void_t*)(dq + 1024), 16, voq[1], nx_ch * (ZCH * 4), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_t*)dk, 16, vok[0], nx_ch * (ZCH * 4), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_t*)(dk + 1024), 16, vok[1], nx_ch * (ZCH * 4), 0, 0);
+        if (KP == 4) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_t*)(dk + 2048), 16, vok[KP - 2], nx_ch * (ZCH * 4), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_t*)(dk + 3072), 16, vok[KP - 1], nx_ch * (ZCH * 4), 0, 0);
+        }
+        }
         nx_stage = nx_stage + 1 == XNS ? 0 : nx_stage + 1;
         if (++nx_ch == nchunk) {
             nx_ch = 0;
@@ -789,22 +615,31 @@ __global__ __launch_bounds__(64 * XW) void interval_score_tile_kernel(
     while (true) {
         int et, bt, c4;
         (void)item_of(cur_u, et, bt, c4);
-        const bool diag_tile = !full && et == bt;
-        // sub-blocks of this wave that lie entirely above the diagonal are not multiplied (nor written)
-        const bool on0 = !diag_tile || 2 * wh <= wer, on1 = !diag_tile || 2 * wh + 1 <= wer;
+        // 32x32 blocks of this wave that lie entirely above the diagonal are not multiplied (nor written)
+        const int erow = et * (XTE / 32) + wer, bcol = bt * (XTB / 32) + 2 * wh;
+        const bool on0 = full || bcol <= erow, on1 = full || bcol + 1 <= erow;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             for (int ch = 0; ch < nchunk; ++ch) {
-                // this wave's pieces of the current chunk have landed (younger requests may stay in flight) ...
-                if (inflight >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                // ... and so have everybody's; everybody is also done reading the previous chunk
+                // this wave's pieces of the current chunk have landed (a younger request may stay in flight) ...
+                if (inflight >= 2) {
+                    if (KP == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                // ... and so have everybody's; everybody is also done reading the previous chunk (no fence: the
+                // prefetch stays in flight)
                 __builtin_amdgcn_s_barrier();
                 --inflight;
                 if (nx_valid) { issue_chunk(); ++inflight; }        // into the stage of the previous chunk
                 v4f qa[4], ka0[4], ka1[4];
                 const unsigned sb = lds0 + (unsigned)(rd_stage * XSTAGE);
                 rd_stage = rd_stage + 1 == XNS ? 0 : rd_stage + 1;
+                if (dbg & 8) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) { qa[m] = (v4f)(1.0f); ka0[m] = (v4f)(1.0f); ka1[m] = (v4f)(1.0f); }
+                } else
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %4 offset:4096"
@@ -815,7 +650,10 @@ __global__ __launch_bounds__(64 * XW) void interval_score_tile_kernel(
                              : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]), "+v"(ka0[0]), "+v"(ka0[1]), "+v"(ka0[2]),
                                "+v"(ka0[3]), "+v"(ka1[0]), "+v"(ka1[1]), "+v"(ka1[2]), "+v"(ka1[3]));
                 __builtin_amdgcn_sched_barrier(0);
-                if (on0 && on1) {
+                if (dbg & 1) {
+                    acc0[0] += qa[0].x + qa[1].y + qa[2].z + qa[3].w + ka0[0].x + ka0[3].w;
+                    acc1[0] += ka1[0].x + ka1[3].w;
+                } else if (on0 && on1) {
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
                         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[m].x, ka0[m].x, acc0, 0, 0, 0);
@@ -852,15 +690,15 @@ __global__ __launch_bounds__(64 * XW) void interval_score_tile_kernel(
             const bool vec = (C & 3) == 0 && c4 + 3 < C;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const int b = bt * XT + 64 * wh + 32 * t + row;
+                const int b = bt * XTB + 64 * wh + 32 * t + row;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int e = et * XT + 32 * wer + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int e = et * XTE + 32 * wer + (r & 3) + 8 * (r >> 2) + 4 * half;
                     const int len = e > b ? e - b : b - e;
                     const float sc = qscale * len_scale_mfma(len, mode);
                     const float last = t == 0 ? acc0[r] : acc1[r];
                     float v[4] = {hold[0][t][r] * sc, hold[1][t][r] * sc, hold[2][t][r] * sc, last * sc};
-                    if (e < T && b < T && (full || b <= e) && c4 < C) {
+                    if (e < T && b < T && (full || b <= e) && c4 < C && !(dbg & 4)) {
                         if (e == b) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
@@ -886,28 +724,35 @@ __global__ __launch_bounds__(64 * XW) void interval_score_tile_kernel(
     }
 }
 
+template <int XTE>
 static int launch_score_tile(const float* q, const float* k, const float* diag, int C, int T, int D, long long ldq,
                              long long ldk, long long ldd, float qscale, int mode, int full, float* S, hipStream_t stream)
 {
-    const int nxt = (T + XT - 1) / XT;
-    const int ntiles = full ? nxt * nxt : nxt * (nxt + 1) / 2;
+    const int net = (T + XTE - 1) / XTE, nbt = (T + XTB - 1) / XTB;
+    int ntiles = 0;
+    if (full) ntiles = net * nbt;
+    else
+        for (int et = 0; et < net; ++et) ntiles += (et * XTE + XTE - 1) / XTB + 1 < nbt ? (et * XTE + XTE - 1) / XTB + 1 : nbt;
     const int nquadp = ((C + 3) / 4 + 7) / 8 * 8;
-    const size_t lds = (size_t)XNS * XSTAGE;
+    const size_t lds = (size_t)XNS * (XTE + XTB) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)interval_score_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)interval_score_tile_kernel<XTE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     int ncu = 256, dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
         ncu = v;
-    int grid = ncu / (8 * NXCD) * (8 * NXCD);           // one persistent workgroup per CU; per XCD a multiple of 8 slots
+    // persistent workgroups (128 / XTE per CU); per XCD a multiple of 8 slots
+    int grid = ncu * (128 / XTE) / (8 * NXCD) * (8 * NXCD);
     if (grid < 8 * NXCD) grid = 8 * NXCD;
     const long long nitems = (long long)ntiles * nquadp;
     const long long need = (nitems + 8 * NXCD - 1) / (8 * NXCD) * (8 * NXCD);
     if (grid > need) grid = (int)need;
-    hipLaunchKernelGGL(interval_score_tile_kernel, dim3(grid), dim3(64 * XW), lds, stream, q, k, diag, C, T, D, ldq, ldk, ldd,
-                       qscale, mode, full, S, ntiles, nquadp);
+    int dbg = 0;
+    if (const char* e = getenv("SEMICRF_SCORE_DEBUG")) dbg = atoi(e) & 0xff;
+    hipLaunchKernelGGL(interval_score_tile_kernel<XTE>, dim3(grid), dim3(XTE * 4), lds, stream, q, k, diag, C, T, D, ldq, ldk, ldd,
+                       qscale, mode | (dbg << 8), full, S, ntiles, nquadp);
     return 0;
 }
 
@@ -922,15 +767,16 @@ int launch_interval_score_mfma(const float* q, const float* k, const float* diag
     int band = 4;
     if (const char* e = getenv("SEMICRF_SCORE_BAND")) { const int v = atoi(e); if (v >= 1 && v <= 64) band = v; }   // tuning knob
     // 16-byte aligned rows: the LDS-staged kernel (T*ld*4 < 2^31: 32-bit buffer offsets)
-    if (aligned && D % ZCH == 0 && (long long)T * ldq * 4 < (1ll << 31) && (long long)T * ldk * 4 < (1ll << 31)) {
-        int variant = T >= 256 ? 128 : 32;
+    if (aligned && D % 64 == 0 && (long long)T * ldq * 4 < (1ll << 31) && (long long)T * ldk * 4 < (1ll << 31)) {
+        // 64-row tiles when they waste less of the last tile row (e.g. T=691: 704 vs 768 rows) -- measured 779 vs 814 us
+        int variant = T < 256 ? 32 : ((T + 63) / 64 * 64 < (T + 127) / 128 * 128 ? 64 : 128);
         if (const char* e = getenv("SEMICRF_SCORE_VARIANT")) variant = atoi(e);      // tuning knob: 0 = register-load kernel
         if (variant == 128)
-            return launch_score_tile(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream);
-        if (variant == 32 && D % 64 == 0)
+            return launch_score_tile<128>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream);
+        if (variant == 64)
+            return launch_score_tile<64>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream);
+        if (variant == 32)
             return launch_score_stream(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, band, stream);
-        if (variant == 8) return launch_score_lds<8>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, band, stream);
-        if (variant == 4) return launch_score_lds<4>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, band, stream);
     }
     int ngrid = 0;
     const int2* work = score_work_list(nt, (C + SC - 1) / SC, full ? 1 : 0, band, &ngrid);

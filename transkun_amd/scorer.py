@@ -23,8 +23,8 @@ def _interval_score_raw(q, k, diag, T: int, C: int, D: int, qscale: float, mode:
     lib = _lib.load()
     dev = q.device
     assert q.stride(-1) == 1 and k.stride(-1) == 1
-    # when only the lower triangle is written the rest must still be defined: zero-fill
-    S = (torch.empty if full_square else torch.zeros)(T, T, C, dtype=torch.float32, device=dev)
+    # full_square=False: the library computes e >= b and zero-fills the rest itself (half the bytes of torch.zeros)
+    S = torch.empty(T, T, C, dtype=torch.float32, device=dev)
     noise = torch.empty(max(T - 1, 0), C, dtype=torch.float32, device=dev)
     rc = lib.interval_score_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(diag), C, T, D, q.stride(-2), k.stride(-2),
                                 diag.stride(-1), qscale, mode, 1 if full_square else 0, _lib.ptr(S),
