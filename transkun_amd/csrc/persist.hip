@@ -670,7 +670,10 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
 #endif
 constexpr int PNS = 3;                       // LDS stages per panel wave (tiles fetched ahead)
 constexpr int PSTAGE_BYTES = 10240;          // 8 KB of cells + 2 KB of u values
-constexpr int PW_MAX = 4;                    // panel waves per workgroup (LDS: PW_MAX * PNS * PSTAGE_BYTES = 144 KB)
+#ifndef SEMICRF_PW_MAX
+#define SEMICRF_PW_MAX 4
+#endif
+constexpr int PW_MAX = SEMICRF_PW_MAX;       // panel waves per workgroup (LDS: PW_MAX * PNS * PSTAGE_BYTES = 120 KB)
 constexpr int LDS_PANEL_BYTES = PW_MAX * PNS * PSTAGE_BYTES;
 constexpr int LDS_HYBRID_PANEL = (LDS_SPINE_BYTES + 1023) / 1024 * 1024;     // stages of a spine workgroup's panel waves
 constexpr int HPW_MAX = (160 * 1024 - 512 - LDS_HYBRID_PANEL) / (PNS * PSTAGE_BYTES) < NT / 64 - RING - NLOADER - 1
