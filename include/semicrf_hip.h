@@ -153,6 +153,18 @@ int interval_score_bwd(const float* dS, const float* q, const float* k, int C, i
                        int64_t lddq, int64_t lddk, int64_t lddd, semicrf_stream_t stream);
 
 /*
+ * The same with a workspace: the cotangent is first repacked into per-chain matrices (scaled, zero above the diagonal)
+ * and dq/dk become two batched triangular GEMMs with LDS-shared operands (scorer_bwd_gemm.hip), about 1.7x faster at
+ * T=1024, C=352, D=256.  interval_score_bwd_workspace_bytes returns 0 when the packed path does not apply (D not in
+ * {64, 128, 256}, T < 64); with ws == NULL, too few bytes or q/k rows that are not 16-byte aligned the call runs
+ * exactly interval_score_bwd.
+ */
+size_t interval_score_bwd_workspace_bytes(int C, int T, int D);
+int interval_score_bwd_ws(const float* dS, const float* q, const float* k, int C, int T, int D, int64_t ldq,
+                          int64_t ldk, float qscale, int length_scaling, float* dq, float* dk, float* ddiag,
+                          int64_t lddq, int64_t lddk, int64_t lddd, void* ws, size_t ws_bytes, semicrf_stream_t stream);
+
+/*
  * Backward-direction values only (the beta half of forward_backward, NeuralSemiCRFInterval.py:386-414, without the
  * marginals): beta[t][c] by frame, natural log.  Workspace: semicrf_workspace_bytes(SEMICRF_OP_LOGZ_FWD, T, B).
  * Used by interval_score_bwd_fused, which rebuilds the marginals tile by tile instead of reading a dense gradient.

@@ -333,6 +333,44 @@ def test_scorer_backward_kernel(gpu, N, P, T, D, ls):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("C,T,D,mode", [(5, 70, 64, 0), (37, 300, 128, 1), (33, 257, 256, 0), (8, 128, 64, 2), (64, 384, 256, 0),
+                                         (3, 64, 256, 0), (40, 691, 256, 0)])
+def test_scorer_backward_packed(gpu, C, T, D, mode):
+    """interval_score_bwd_ws (repacked cotangent + two tiled GEMMs) against the direct kernels and an fp64 reference of the
+    same definition (the autograd of LayersTransformer.py:410-433)."""
+    from transkun_amd import _lib, synth
+    _lib.set_impl(0)
+    lib = _lib.load()
+    q = synth.hash_normal(C * T * D, 81, gpu).view(C, T, D).contiguous()
+    k = synth.hash_normal(C * T * D, 82, gpu).view(C, T, D).contiguous()
+    dS = synth.hash_normal(T * T * C, 83, gpu).view(T, T, C).contiguous()       # dense: e < b entries must not contribute
+    qs = 1.0 / D ** 0.5
+    nws = int(lib.interval_score_bwd_workspace_bytes(C, T, D))
+    assert nws > 0
+    ws = torch.full((nws,), 0xFF, dtype=torch.uint8, device=gpu)                # NaN patterns: every byte read must have been written
+    outs = []
+    for use_ws in (True, False):
+        dq = torch.full((C, T, D), float("nan"), device=gpu)
+        dk = torch.full((C, T, D), float("nan"), device=gpu)
+        dd = torch.full((C, T), float("nan"), device=gpu)
+        rc = lib.interval_score_bwd_ws(_lib.ptr(dS), _lib.ptr(q), _lib.ptr(k), C, T, D, D, D, qs, mode, _lib.ptr(dq), _lib.ptr(dk),
+                                       _lib.ptr(dd), D, D, 1, _lib.ptr(ws) if use_ws else None, nws if use_ws else 0,
+                                       _lib.stream_of(dS))
+        _lib.check(rc, "interval_score_bwd_ws")
+        outs.append((dq, dk, dd))
+    t = torch.arange(T, device=gpu)
+    ln = (t[:, None] - t[None, :]).double()
+    ln = ln if mode == 0 else (ln.clamp_min(0).sqrt() if mode == 1 else torch.ones_like(ln))
+    G = torch.tril(dS.double().permute(2, 0, 1) * ln) * qs                                   # [C, e, b]
+    ref = (torch.bmm(G, k.double()), torch.bmm(G.transpose(1, 2), q.double()), torch.diagonal(dS, dim1=0, dim2=1).double())
+    for name, got_ws, got_direct, want in zip(("dq", "dk", "ddiag"), outs[0], outs[1], ref):
+        scale = float(want.abs().max()) + 1e-30
+        assert float((got_ws.double() - want).abs().max()) / scale < 2e-6, name
+        assert float((got_direct.double() - want).abs().max()) / scale < 2e-6, name
+    assert _lib.device_status() == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,P,T,D,ls", [(1, 6, 70, 64, "linear"), (2, 5, 130, 256, "linear"), (1, 4, 48, 32, "none"), (1, 10, 97, 128, "sqrt")])
 def test_fused_scorer_crf(gpu, N, P, T, D, ls):
     """scorer_crf_logprob (loss gradient fused into the scorer backward: no dense dS) against the unfused route

@@ -33,3 +33,12 @@ for (C, T, D) in ((352, 1024, 256), (360, 691, 256), (90, 691, 256)):
     ms = e0.elapsed_time(e1) / 5
     fl = 2 * 2.0 * C * (T * (T + 1) / 2) * D
     print(f"interval_score_bwd C={C} T={T} D={D}: {ms:.2f} ms  {fl/ms/1e9:.1f} TFLOP/s")
+    nws = int(lib.interval_score_bwd_workspace_bytes(C, T, D))
+    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)
+    f = lambda: _lib.check(lib.interval_score_bwd_ws(_lib.ptr(dS), _lib.ptr(q), _lib.ptr(k), C, T, D, D, D, 1.0 / 16, 0, _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dd), D, D, 1, _lib.ptr(ws), nws, _lib.stream_of(dS)), "bwd_ws")
+    for _ in range(2): f()
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(5): f()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    print(f"interval_score_bwd_ws (repack + 2 GEMMs) C={C} T={T} D={D}: {ms:.2f} ms  {fl/ms/1e9:.1f} TFLOP/s")

@@ -1,0 +1,391 @@
+// scorer_bwd_gemm.hip -- backward of the interval scores as two batched triangular GEMMs on a repacked cotangent
+// (the autograd of LayersTransformer.py:406-441 after the Linear map; same definition as scorer_bwd.hip).
+//
+//   G[e,b,c] = dS[e,b,c] * qscale * len(e-b) for e >= b, 0 otherwise
+//   dq[c,e,:] = sum_b G[e,b,c] k[c,b,:]           dk[c,b,:] = sum_e G[e,b,c] q[c,e,:]
+//
+// scorer_bwd.hip multiplies straight out of the CRF's chain-minor gradient layout: a 32-row tile of 8 chains per
+// workgroup, the k/q rows of every chain re-read by every row tile -- 16 B/clk/CU of operands at full matrix rate,
+// which is what a CU's L1 can deliver at best (see scorer_mfma.hip), and the kernel ends up at a quarter of the fp32
+// MFMA rate.  Here the cotangent is repacked ONCE into per-chain matrices Gt[c][e][b] (scaled, zero above the
+// diagonal; whole 128-byte lines in, 128-byte rows out), and both products become ordinary tiled GEMMs of one chain
+// at a time: a persistent workgroup of 8 waves owns a 128 x D output tile (wave = 32 rows x D/2 columns), the
+// operand chunks (32 contraction values: 16 KB of Gt + 32 rows of k or q) arrive by `buffer_load ... lds`, three
+// stages deep, one s_barrier per chunk: 6 B/clk/CU.  dq reads Gt rows along the contraction (ds_read_b128, swizzled as
+// in scorer_mfma.hip); dk needs the transpose, which is just a different walk of the same LDS stage (ds_read_b32 with
+// consecutive lanes on consecutive b): no second copy.  The triangular structure shows up as the contraction range
+// of an output tile (dq: b < 128 (i+1); dk: e >= 128 i); items are dealt longest first.
+#include "common.h"
+
+#include <type_traits>
+
+namespace semicrf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+constexpr int GM = 128;            // rows of an output tile
+constexpr int GK = 32;             // contraction values per chunk
+constexpr int GNS = 3;             // LDS stages
+constexpr int GA_BYTES = GM * GK * 4;      // 16 KB: the Gt part of a stage
+
+__device__ __forceinline__ float len_scale_pack(int len, int mode)
+{
+    if (mode == SEMICRF_LEN_LINEAR) return (float)len;
+    if (mode == SEMICRF_LEN_SQRT) return sqrtf((float)len);
+    return 1.0f;
+}
+
+__device__ __forceinline__ unsigned g_lds_addr(const void* p)
+{
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// repack: dS [T][T][C] -> Gt [C][Tp][Tp] (Tp = T rounded up to 32), scaled; zero for b > e and for e >= T
+// ---------------------------------------------------------------------------------------------
+// One block = 8 end frames x 32 begin frames x 32 chains (whole 128-byte lines in; 128-byte rows out).  Only the
+// b tiles up to the end of the row's 128-aligned diagonal block are written: the GEMMs read nothing beyond.
+constexpr int PK_CH = 32, PK_E = 8, PK_B = 32;
+constexpr int PK_ROW = PK_B + 4;                   // LDS row pitch (floats): 16-byte aligned rows
+constexpr int PK_CHS = PK_E * PK_ROW + 4;          // chain pitch
+
+__global__ __launch_bounds__(256) void score_bwd_pack_kernel(const float* __restrict__ dS, float* __restrict__ Gt, int C,
+                                                             int T, int Tp, float qscale, int mode)
+{
+    __shared__ __attribute__((aligned(16))) float L[PK_CH * PK_CHS];
+    const int b0 = blockIdx.x * PK_B, e0 = blockIdx.y * PK_E, cg = blockIdx.z * PK_CH;
+    if (b0 >= (e0 / GM + 1) * GM) return;
+    const int tid = threadIdx.x;
+    const bool vec = (C % 4 == 0) && (((uintptr_t)dS & 15) == 0);
+#pragma unroll
+    for (int it = 0; it < (PK_E * PK_B * PK_CH / 4) / 256; ++it) {
+        const int idx = tid + it * 256;
+        const int quad = idx & 7, cell = idx >> 3;
+        const int bl = cell & 31, el = cell >> 5;
+        const int e = e0 + el, b = b0 + bl, c4 = cg + quad * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < T && b <= e && c4 < C) {
+            const float* src = dS + ((size_t)e * T + b) * C + c4;
+            if (vec) {
+                v = *(const float4*)src;
+            } else {
+                v.x = src[0];
+                if (c4 + 1 < C) v.y = src[1];
+                if (c4 + 2 < C) v.z = src[2];
+                if (c4 + 3 < C) v.w = src[3];
+            }
+            const float sc = qscale * len_scale_pack(e - b, mode);
+            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        }
+        float* dst = L + (quad * 4) * PK_CHS + el * PK_ROW + bl;
+        dst[0] = v.x; dst[PK_CHS] = v.y; dst[2 * PK_CHS] = v.z; dst[3 * PK_CHS] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < (PK_E * PK_B * PK_CH / 4) / 256; ++it) {
+        const int idx = tid + it * 256;
+        const int j4 = idx & 7, rowid = idx >> 3;
+        const int el = rowid & 7, ch = rowid >> 3;
+        const int c = cg + ch;
+        if (c < C) {
+            const float4 v = *(const float4*)(L + ch * PK_CHS + el * PK_ROW + 4 * j4);
+            *(float4*)(Gt + ((size_t)c * Tp + e0 + el) * Tp + b0 + 4 * j4) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEMM: out[c][m][:] = sum_k A[m][k] other[c][k][:]   with A = Gt (dq: m = e, k = b) or Gt^T (dk: m = b, k = e)
+// ---------------------------------------------------------------------------------------------
+// AT: A is read transposed (dk).  NW: 32-column blocks per wave (D = 64 NW; NW in {1, 2, 4}).
+template <bool AT, int NW>
+__global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __restrict__ Gt, int Tp,
+                                                                const float* __restrict__ other, long long ldo,
+                                                                float* __restrict__ out, long long ldout, int C, int T)
+{
+    constexpr int D = 64 * NW;
+    constexpr int GB_BYTES = GK * D * 4;               // the k/q part of a stage: 32 rows
+    constexpr int GSTAGE = GA_BYTES + GB_BYTES;
+    constexpr int RPP = 4 / NW;                        // k/q rows per 1 KB piece
+    constexpr int NLOAD = 2 + NW;                      // pieces per wave and chunk
+    extern __shared__ __attribute__((aligned(16))) char glds[];    // [GNS][GSTAGE]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;           // this wave: rows 32*wm.., columns 32*NW*wn.. of the tile
+    const unsigned lds0 = g_lds_addr(glds);
+    const int nm = (T + GM - 1) / GM;                  // output tiles per chain
+    const long long nitems = (long long)nm * C;
+    const int nkt = Tp / GK;                           // chunks of the whole contraction axis
+
+    // item n: tiles dealt longest first (dq: the last row tile has the longest contraction range, dk: the first)
+    auto item_of = [&](long long n, int& c, int& mi, int& kbeg, int& nk) -> bool {
+        if (n >= nitems) return false;
+        const int r = (int)(n / C);
+        c = (int)(n % C);
+        mi = AT ? r : nm - 1 - r;
+        if (AT) {
+            kbeg = mi * (GM / GK);
+            nk = nkt - kbeg;
+        } else {
+            kbeg = 0;
+            nk = (mi + 1) * (GM / GK) < nkt ? (mi + 1) * (GM / GK) : nkt;
+        }
+        return true;
+    };
+
+    // ---- LDS read addresses (bytes within a stage) ----------------------------------------------------------
+    // contraction order inside a chunk: matrix instruction (mm, comp) takes k = 4 mm + comp from lanes 0-31 and
+    // k = 16 + 4 mm + comp from lanes 32-63 -- the same permutation for both operands
+    unsigned rdA[4];                                   // !AT: one 16-byte segment per mm (row = m, swizzled)
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm) {
+        const int row = 32 * wm + l31;
+        rdA[mm] = (unsigned)(row * 128 + (((4 * half + mm) ^ ((row >> 1) & 7)) * 16));
+    }
+    const unsigned rdAT = (unsigned)(half * 16 * (GM * 4) + (32 * wm + l31) * 4);        // AT: stage rows = k, 512 bytes each
+    const unsigned rdB = (unsigned)(GA_BYTES + half * 16 * (D * 4) + (32 * NW * wn + l31) * 4);
+
+    // ---- request side (identical in all waves) --------------------------------------------------------------
+    long long nx_n = blockIdx.x;
+    int nx_c = 0, nx_mi = 0, nx_kbeg = 0, nx_nk = 0, nx_j = 0, nx_stage = 0;
+    bool nx_valid = item_of(nx_n, nx_c, nx_mi, nx_kbeg, nx_nk);
+    if (!nx_valid) return;                             // uniform
+    // per-lane byte offsets of this wave's pieces (relative to the chain slab, without the chunk)
+    unsigned voA[2], voB[4];                           // (dependent array bounds captured by lambdas trip the host compiler)
+    auto set_offsets = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int p = 2 * wave + j;                // Gt piece 0..15
+            if (!AT) {
+                const int row = 8 * p + (lane >> 3);   // m within the tile; 128 contiguous bytes along k
+                const int seg = (lane & 7) ^ ((row >> 1) & 7);
+                voA[j] = (unsigned)((((size_t)(nx_mi * GM + row)) * Tp + seg * 4) * 4);
+            } else {
+                const int row = 2 * p + (lane >> 5);   // k within the chunk; 512 contiguous bytes along m
+                voA[j] = (unsigned)(((size_t)row * Tp + nx_mi * GM + (lane & 31) * 4) * 4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int p = NW * wave + j;               // k/q piece 0 .. 8 NW - 1
+            const int row = p * RPP + lane / (16 * NW);
+            voB[j] = (unsigned)(((size_t)row * ldo + (lane % (16 * NW)) * 4) * 4);
+        }
+    };
+    set_offsets();
+    auto issue_chunk = [&]() {
+        const int k0 = (nx_kbeg + nx_j) * GK;
+        // bounds-checked buffers over the chain's slab: rows past the end read as zero
+        const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)(Gt + (size_t)nx_c * Tp * Tp), 0, (int)((size_t)Tp * Tp * 4), 0x00020000);
+        const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)(other + (size_t)nx_c * T * ldo), 0, (int)((size_t)T * ldo * 4), 0x00020000);
+        char* da = glds + nx_stage * GSTAGE + (2 * wave) * 1024;
+        char* db = glds + nx_stage * GSTAGE + GA_BYTES + (NW * wave) * 1024;
+        const unsigned sa = AT ? (unsigned)((size_t)k0 * Tp * 4) : (unsigned)(k0 * 4);      // always inside the slab
+        // the k/q rows of the last chunk may lie past T: their offset goes into the per-lane part, which is what the
+        // buffer's range check looks at (the scalar offset is not checked); such rows keep the stage's old contents
+        // and meet Gt == 0 (the stages are cleared once at the start so that they never hold a NaN pattern)
+        const unsigned kb = (unsigned)((size_t)k0 * ldo * 4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)da, 16, voA[0], sa, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(da + 1024), 16, voA[1], sa, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)db, 16, voB[0] + kb, 0, 0, 0);
+        if (NW >= 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(db + 1024), 16, voB[1] + kb, 0, 0, 0);
+        if (NW >= 4) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(db + 2048), 16, voB[2] + kb, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(db + 3072), 16, voB[3] + kb, 0, 0, 0);
+        }
+        nx_stage = nx_stage + 1 == GNS ? 0 : nx_stage + 1;
+        if (++nx_j == nx_nk) {
+            nx_j = 0;
+            nx_n += gridDim.x;
+            nx_valid = item_of(nx_n, nx_c, nx_mi, nx_kbeg, nx_nk);
+            if (nx_valid) set_offsets();
+        }
+    };
+
+    // clear the stages once (see issue_chunk)
+    for (int i = threadIdx.x; i < GNS * GSTAGE / 16; i += 512) ((float4*)glds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < NW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    int inflight = 0;
+#pragma unroll
+    for (int i = 0; i < GNS - 1; ++i)
+        if (nx_valid) { issue_chunk(); ++inflight; }
+    int rd_stage = 0;
+
+    long long cur_n = blockIdx.x;
+    while (true) {
+        int c, mi, kbeg, nk;
+        if (!item_of(cur_n, c, mi, kbeg, nk)) break;
+        for (int j = 0; j < nk; ++j) {
+            // this wave's pieces of the current chunk have landed (a younger request may stay in flight) ...
+            if (inflight >= 2) {
+                if (NLOAD == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else if (NLOAD == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            // ... and so have everybody's; everybody is also done reading the previous chunk
+            __builtin_amdgcn_s_barrier();
+            --inflight;
+            if (nx_valid) { issue_chunk(); ++inflight; }
+            const unsigned sb = lds0 + (unsigned)(rd_stage * GSTAGE);
+            rd_stage = rd_stage + 1 == GNS ? 0 : rd_stage + 1;
+            // four groups of four contraction pairs; the operands of group g+1 are read while group g multiplies
+            // (the registers an asm read returns must not be touched before the wait that is tied to them: no copies)
+            v4f a4[2];                         // !AT: four consecutive contraction values of the row
+            float a1[2][4];                    // AT: one value per read
+            float bq[2][4][4];
+            auto read_group = [&](auto mmc, v4f& av4, float (&av)[4], float (&bv)[4][4]) {
+                constexpr int mm = decltype(mmc)::value;
+                if (!AT) {
+                    const unsigned addr = sb + rdA[mm];
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(av4) : "v"(addr));
+                } else {
+                    static_for<0, 4>([&](auto cc) {
+                        constexpr int comp = decltype(cc)::value;
+                        float& dst = av[comp];                       // (asm operands alone do not capture)
+                        const unsigned addr = sb + rdAT;
+                        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"((4 * mm + comp) * (GM * 4)));
+                    });
+                }
+                static_for<0, 4>([&](auto cc) {
+                    constexpr int comp = decltype(cc)::value;
+                    static_for<0, NW>([&](auto tc) {
+                        constexpr int t = decltype(tc)::value;
+                        float& dst = bv[comp][t];
+                        const unsigned addr = sb + rdB;
+                        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"((4 * mm + comp) * (D * 4) + t * 128));
+                    });
+                });
+            };
+            auto wait_group = [&](v4f& av4, float (&av)[4], float (&bv)[4][4]) {
+                if (!AT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av4));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]));
+#pragma unroll
+                for (int comp = 0; comp < 4; ++comp)
+#pragma unroll
+                    for (int t = 0; t < NW; ++t) asm volatile("" : "+v"(bv[comp][t]));
+            };
+            auto mul_group = [&](const v4f& av4, const float (&av)[4], const float (&bv)[4][4]) {
+#pragma unroll
+                for (int comp = 0; comp < 4; ++comp)
+#pragma unroll
+                    for (int t = 0; t < NW; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(AT ? av[comp] : av4[comp], bv[comp][t], acc[t], 0, 0, 0);
+            };
+            read_group(std::integral_constant<int, 0>{}, a4[0], a1[0], bq[0]);
+            wait_group(a4[0], a1[0], bq[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            read_group(std::integral_constant<int, 1>{}, a4[1], a1[1], bq[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mul_group(a4[0], a1[0], bq[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_group(a4[1], a1[1], bq[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            read_group(std::integral_constant<int, 2>{}, a4[0], a1[0], bq[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            mul_group(a4[1], a1[1], bq[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_group(a4[0], a1[0], bq[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            read_group(std::integral_constant<int, 3>{}, a4[1], a1[1], bq[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mul_group(a4[0], a1[0], bq[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_group(a4[1], a1[1], bq[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mul_group(a4[1], a1[1], bq[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- the item's 128 x D block (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) ----
+        {
+            float* ob = out + (size_t)c * T * ldout;
+#pragma unroll
+            for (int t = 0; t < NW; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mi * GM + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (m < T) ob[(size_t)m * ldout + 32 * NW * wn + 32 * t + l31] = acc[t][r];
+                    acc[t][r] = 0.0f;
+                }
+        }
+        cur_n += gridDim.x;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int round_up32(int T) { return (T + 31) / 32 * 32; }
+
+// 0: the packed path does not apply (the caller uses the direct kernels)
+size_t interval_score_bwd_ws_bytes(int C, int T, int D)
+{
+    if (!(D == 64 || D == 128 || D == 256) || T < 64 || C < 1) return 0;
+    const size_t Tp = (size_t)round_up32(T);
+    if (Tp * Tp * 4 >= (1ull << 31)) return 0;                 // 32-bit buffer offsets inside a chain's slab
+    return (size_t)C * Tp * Tp * sizeof(float) + 4096;         // + slack for the transposed walk of the last tile
+}
+
+template <bool AT, int NW>
+static void launch_gemm(const float* Gt, int Tp, const float* other, long long ldo, float* out, long long ldout, int C,
+                        int T, hipStream_t stream)
+{
+    const size_t lds = (size_t)GNS * (GA_BYTES + GK * 64 * NW * 4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)score_bwd_gemm_kernel<AT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    int ncu = 256, dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+        ncu = v;
+    const long long nitems = (long long)((T + GM - 1) / GM) * C;
+    const int grid = nitems < ncu ? (int)nitems : ncu;
+    hipLaunchKernelGGL((score_bwd_gemm_kernel<AT, NW>), dim3(grid), dim3(512), lds, stream, Gt, Tp, other, ldo, out, ldout, C, T);
+}
+
+// true when the packed path ran (q/k rows must be 16-byte aligned for the LDS loads)
+bool launch_interval_score_bwd_packed(const float* dS, const float* q, const float* k, int C, int T, int D, long long ldq,
+                                      long long ldk, float qscale, int mode, float* dq, float* dk, long long lddq,
+                                      long long lddk, void* ws, size_t ws_bytes, hipStream_t stream)
+{
+    const size_t need = interval_score_bwd_ws_bytes(C, T, D);
+    if (need == 0 || !ws || ws_bytes < need) return false;
+    if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ldq % 4 || ldk % 4 || ((uintptr_t)ws & 15)) return false;
+    if ((long long)T * ldq * 4 >= (1ll << 31) || (long long)T * ldk * 4 >= (1ll << 31)) return false;
+    const int Tp = round_up32(T);
+    float* Gt = (float*)ws;
+    hipLaunchKernelGGL(score_bwd_pack_kernel, dim3(Tp / PK_B, Tp / PK_E, (C + PK_CH - 1) / PK_CH), dim3(256), 0, stream, dS, Gt, C,
+                       T, Tp, qscale, mode);
+#define SEMICRF_GEMM_DISPATCH(AT_, OTHER, LDO, OUT, LDOUT)                                                              \
+    switch (D) {                                                                                                        \
+    case 64: launch_gemm<AT_, 1>(Gt, Tp, OTHER, LDO, OUT, LDOUT, C, T, stream); break;                                  \
+    case 128: launch_gemm<AT_, 2>(Gt, Tp, OTHER, LDO, OUT, LDOUT, C, T, stream); break;                                 \
+    default: launch_gemm<AT_, 4>(Gt, Tp, OTHER, LDO, OUT, LDOUT, C, T, stream); break;                                  \
+    }
+    if (dq) { SEMICRF_GEMM_DISPATCH(false, k, ldk, dq, lddq) }
+    if (dk) { SEMICRF_GEMM_DISPATCH(true, q, ldq, dk, lddk) }
+#undef SEMICRF_GEMM_DISPATCH
+    return true;
+}
+
+}  // namespace semicrf

@@ -63,9 +63,14 @@ class _IntervalScore(torch.autograd.Function):
             dq = torch.empty(C, T, D, dtype=torch.float32, device=g.device)
             dk = torch.empty(C, T, D, dtype=torch.float32, device=g.device)
             dd = torch.empty(C, T, dtype=torch.float32, device=g.device)
-            rc = lib.interval_score_bwd(_lib.ptr(g), _lib.ptr(q), _lib.ptr(k), C, T, D, q.stride(-2), k.stride(-2), qs, mode,
-                                        _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dd), D, D, 1, _lib.stream_of(g))
-            _lib.check(rc, "interval_score_bwd")
+            # with a workspace the library repacks dS per chain and runs two LDS-tiled GEMMs (scorer_bwd_gemm.hip);
+            # 0 bytes: shapes it does not take -- the direct kernels run
+            nws = int(lib.interval_score_bwd_workspace_bytes(C, T, D))
+            ws = torch.empty(nws, dtype=torch.uint8, device=g.device) if nws > 0 else None
+            rc = lib.interval_score_bwd_ws(_lib.ptr(g), _lib.ptr(q), _lib.ptr(k), C, T, D, q.stride(-2), k.stride(-2), qs, mode,
+                                           _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dd), D, D, 1, _lib.ptr(ws), nws,
+                                           _lib.stream_of(g))
+            _lib.check(rc, "interval_score_bwd_ws")
             return (dq.view(N, P, T, D), dk.view(N, P, T, D), dd.view(N, P, T), None, None, None, None, None, None)
         return _IntervalScore._backward_torch(dS, q, k, N, P, T, D, mode, full)
 
