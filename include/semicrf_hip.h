@@ -185,6 +185,17 @@ int interval_score_bwd_fused(const float* S, const float* alpha, const float* be
                              int64_t ldk, float qscale, int length_scaling, float* dq, float* dk, float* ddiag,
                              int64_t lddq, int64_t lddk, int64_t lddd, semicrf_stream_t stream);
 
+/*
+ * interval_score_bwd_fused on the packed path (workspace as interval_score_bwd_ws): the repack kernel evaluates the
+ * marginals while it builds the per-chain matrices, the two GEMMs are the same.  Falls back to
+ * interval_score_bwd_fused exactly like interval_score_bwd_ws falls back to interval_score_bwd.
+ */
+int interval_score_bwd_fused_ws(const float* S, const float* alpha, const float* beta, const float* logZ,
+                                const float* gout, const float* q, const float* k, int C, int T, int D, int64_t ldq,
+                                int64_t ldk, float qscale, int length_scaling, float* dq, float* dk, float* ddiag,
+                                int64_t lddq, int64_t lddk, int64_t lddd, void* ws, size_t ws_bytes,
+                                semicrf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

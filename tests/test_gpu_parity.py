@@ -371,7 +371,8 @@ def test_scorer_backward_packed(gpu, C, T, D, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,P,T,D,ls", [(1, 6, 70, 64, "linear"), (2, 5, 130, 256, "linear"), (1, 4, 48, 32, "none"), (1, 10, 97, 128, "sqrt")])
+@pytest.mark.parametrize("N,P,T,D,ls", [(1, 6, 70, 64, "linear"), (2, 5, 130, 256, "linear"), (1, 4, 48, 32, "none"), (1, 10, 97, 128, "sqrt"),
+                                         (1, 34, 260, 128, "linear")])
 def test_fused_scorer_crf(gpu, N, P, T, D, ls):
     """scorer_crf_logprob (loss gradient fused into the scorer backward: no dense dS) against the unfused route
     scorer -> NeuralSemiCRFInterval.logProb: same log-probabilities, same gradients of ctx and of the Linear map."""

@@ -47,7 +47,8 @@ void launch_zero_upper(float* X, int T, int B, hipStream_t stream);
 size_t interval_score_bwd_ws_bytes(int C, int T, int D);
 bool launch_interval_score_bwd_packed(const float* dS, const float* q, const float* k, int C, int T, int D, long long ldq,
                                       long long ldk, float qscale, int mode, float* dq, float* dk, long long lddq,
-                                      long long lddk, void* ws, size_t ws_bytes, hipStream_t stream);
+                                      long long lddk, void* ws, size_t ws_bytes, hipStream_t stream,
+                                      const float* const* fused);
 int launch_interval_score_mfma(const float* q, const float* k, const float* diag, int C, int T, int D,
                                 long long ldq, long long ldk, long long ldd, float qscale, int mode, int full,
                                 float* S, hipStream_t stream);
@@ -298,7 +299,7 @@ int interval_score_bwd_ws(const float* dS, const float* q, const float* k, int C
     SEMICRF_CHECK_ARG(interval_score_bwd_supported(C, T, D), "interval_score_bwd needs D %% 32 == 0 and D <= 256 (D=%d)", D);
     hipStream_t st = (hipStream_t)stream;
     if (g_impl.load() == 0 && (dq || dk) &&
-        launch_interval_score_bwd_packed(dS, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, lddq, lddk, ws, ws_bytes, st)) {
+        launch_interval_score_bwd_packed(dS, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, lddq, lddk, ws, ws_bytes, st, nullptr)) {
         if (ddiag) launch_interval_score_bwd(dS, q, k, C, T, D, ldq, ldk, qscale, length_scaling, nullptr, nullptr, ddiag, lddq, lddk, lddd, st);
     } else {
         launch_interval_score_bwd(dS, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, ddiag, lddq, lddk, lddd, st);
@@ -321,6 +322,31 @@ int interval_score_bwd_fused(const float* S, const float* alpha, const float* be
     launch_interval_score_bwd_fused(S, alpha, beta, logZ, gout, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk,
                                     ddiag, lddq, lddk, lddd, (hipStream_t)stream);
     SEMICRF_CHECK_LAUNCH("interval_score_bwd_fused");
+    return SEMICRF_OK;
+}
+
+int interval_score_bwd_fused_ws(const float* S, const float* alpha, const float* beta, const float* logZ,
+                                const float* gout, const float* q, const float* k, int C, int T, int D, int64_t ldq,
+                                int64_t ldk, float qscale, int length_scaling, float* dq, float* dk, float* ddiag,
+                                int64_t lddq, int64_t lddk, int64_t lddd, void* ws, size_t ws_bytes, semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(C >= 1 && T >= 1 && D >= 1, "C=%d T=%d D=%d must be >= 1", C, T, D);
+    SEMICRF_CHECK_ARG(S && alpha && beta && logZ && gout && q && k, "S/alpha/beta/logZ/gout/q/k must be non-NULL");
+    SEMICRF_CHECK_ARG(ldq >= D && ldk >= D && (!dq || lddq >= D) && (!dk || lddk >= D) && (!ddiag || lddd >= 1),
+                      "bad leading dimensions");
+    SEMICRF_CHECK_ARG(length_scaling >= 0 && length_scaling <= 2, "bad length_scaling %d", length_scaling);
+    SEMICRF_CHECK_ARG(interval_score_bwd_supported(C, T, D), "interval_score_bwd_fused needs D %% 32 == 0 and D <= 256 (D=%d)", D);
+    hipStream_t st = (hipStream_t)stream;
+    const float* fused[4] = {alpha, beta, logZ, gout};
+    if (g_impl.load() == 0 && (dq || dk) &&
+        launch_interval_score_bwd_packed(S, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, lddq, lddk, ws, ws_bytes, st, fused)) {
+        if (ddiag) launch_interval_score_bwd_fused(S, alpha, beta, logZ, gout, q, k, C, T, D, ldq, ldk, qscale, length_scaling, nullptr,
+                                                   nullptr, ddiag, lddq, lddk, lddd, st);
+    } else {
+        launch_interval_score_bwd_fused(S, alpha, beta, logZ, gout, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, ddiag, lddq,
+                                        lddk, lddd, st);
+    }
+    SEMICRF_CHECK_LAUNCH("interval_score_bwd_fused_ws");
     return SEMICRF_OK;
 }
 

@@ -60,14 +60,36 @@ constexpr int PK_CH = 32, PK_E = 8, PK_B = 32;
 constexpr int PK_ROW = PK_B + 4;                   // LDS row pitch (floats): 16-byte aligned rows
 constexpr int PK_CHS = PK_E * PK_ROW + 4;          // chain pitch
 
+// FUSED: the cotangent is built on the fly from the CRF's own quantities (the dense [T][T][C]
+// gradient of ComputeLogZFasterGrad.backward is never written):  dS[e,b,c] = gout[c] * marginal[e,b,c],
+//   marginal = exp(alpha[b,c] + beta[e,c] + S[e,b,c] - logZ[c])                         (e > b)
+//            = exp(alpha[t,c] + beta[t,c] + S[t,t,c] - 2 softplus(S[t,t,c]) - logZ[c])  (e == b == t)
+// (NeuralSemiCRFInterval.py:424-447); `dS` then points at S itself.
+struct PackFused {
+    const float* alpha;   // [T][C] by frame
+    const float* beta;    // [T][C] by frame
+    const float* logZ;    // [C]
+    const float* gout;    // [C]
+};
+
+template <bool FUSED>
 __global__ __launch_bounds__(256) void score_bwd_pack_kernel(const float* __restrict__ dS, float* __restrict__ Gt, int C,
-                                                             int T, int Tp, float qscale, int mode)
+                                                             int T, int Tp, float qscale, int mode, PackFused F)
 {
     __shared__ __attribute__((aligned(16))) float L[PK_CH * PK_CHS];
     const int b0 = blockIdx.x * PK_B, e0 = blockIdx.y * PK_E, cg = blockIdx.z * PK_CH;
     if (b0 >= (e0 / GM + 1) * GM) return;
     const int tid = threadIdx.x;
-    const bool vec = (C % 4 == 0) && (((uintptr_t)dS & 15) == 0);
+    const bool vec = (C % 4 == 0) && (((uintptr_t)dS & 15) == 0) &&
+                     (!FUSED || ((((uintptr_t)F.alpha | (uintptr_t)F.beta) & 15) == 0));
+    // this thread's four chains are the same in every iteration (the quad depends on tid only)
+    float lz[4] = {0.f, 0.f, 0.f, 0.f}, gz[4] = {0.f, 0.f, 0.f, 0.f};
+    if (FUSED) {
+        const int cq = cg + (tid & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (cq + i < C) { lz[i] = F.logZ[cq + i]; gz[i] = F.gout[cq + i]; }
+    }
 #pragma unroll
     for (int it = 0; it < (PK_E * PK_B * PK_CH / 4) / 256; ++it) {
         const int idx = tid + it * 256;
@@ -84,6 +106,28 @@ __global__ __launch_bounds__(256) void score_bwd_pack_kernel(const float* __rest
                 if (c4 + 1 < C) v.y = src[1];
                 if (c4 + 2 < C) v.z = src[2];
                 if (c4 + 3 < C) v.w = src[3];
+            }
+            if (FUSED) {
+                float al[4] = {0.f, 0.f, 0.f, 0.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
+                const float* ap = F.alpha + (size_t)b * C + c4;
+                const float* bp = F.beta + (size_t)e * C + c4;
+                if (vec) {
+                    const float4 a4 = *(const float4*)ap, b4 = *(const float4*)bp;
+                    al[0] = a4.x; al[1] = a4.y; al[2] = a4.z; al[3] = a4.w;
+                    be[0] = b4.x; be[1] = b4.y; be[2] = b4.z; be[3] = b4.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (c4 + i < C) { al[i] = ap[i]; be[i] = bp[i]; }
+                }
+                float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float x = al[i] + be[i] + vv[i] - lz[i];
+                    if (e == b) x -= 2.0f * softplus_f(vv[i]);
+                    vv[i] = gz[i] * __expf(x);
+                }
+                v = make_float4(vv[0], vv[1], vv[2], vv[3]);
             }
             const float sc = qscale * len_scale_pack(e - b, mode);
             v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
@@ -364,9 +408,11 @@ static void launch_gemm(const float* Gt, int Tp, const float* other, long long l
 }
 
 // true when the packed path ran (q/k rows must be 16-byte aligned for the LDS loads)
+// fused != nullptr: {alpha, beta, logZ, gout} and dS is the score tensor itself
 bool launch_interval_score_bwd_packed(const float* dS, const float* q, const float* k, int C, int T, int D, long long ldq,
                                       long long ldk, float qscale, int mode, float* dq, float* dk, long long lddq,
-                                      long long lddk, void* ws, size_t ws_bytes, hipStream_t stream)
+                                      long long lddk, void* ws, size_t ws_bytes, hipStream_t stream,
+                                      const float* const* fused)
 {
     const size_t need = interval_score_bwd_ws_bytes(C, T, D);
     if (need == 0 || !ws || ws_bytes < need) return false;
@@ -374,8 +420,14 @@ bool launch_interval_score_bwd_packed(const float* dS, const float* q, const flo
     if ((long long)T * ldq * 4 >= (1ll << 31) || (long long)T * ldk * 4 >= (1ll << 31)) return false;
     const int Tp = round_up32(T);
     float* Gt = (float*)ws;
-    hipLaunchKernelGGL(score_bwd_pack_kernel, dim3(Tp / PK_B, Tp / PK_E, (C + PK_CH - 1) / PK_CH), dim3(256), 0, stream, dS, Gt, C,
-                       T, Tp, qscale, mode);
+    const dim3 pgrid(Tp / PK_B, Tp / PK_E, (C + PK_CH - 1) / PK_CH);
+    if (fused) {
+        const PackFused F{fused[0], fused[1], fused[2], fused[3]};
+        hipLaunchKernelGGL(score_bwd_pack_kernel<true>, pgrid, dim3(256), 0, stream, dS, Gt, C, T, Tp, qscale, mode, F);
+    } else {
+        const PackFused F{nullptr, nullptr, nullptr, nullptr};
+        hipLaunchKernelGGL(score_bwd_pack_kernel<false>, pgrid, dim3(256), 0, stream, dS, Gt, C, T, Tp, qscale, mode, F);
+    }
 #define SEMICRF_GEMM_DISPATCH(AT_, OTHER, LDO, OUT, LDOUT)                                                              \
     switch (D) {                                                                                                        \
     case 64: launch_gemm<AT_, 1>(Gt, Tp, OTHER, LDO, OUT, LDOUT, C, T, stream); break;                                  \
