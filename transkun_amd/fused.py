@@ -9,8 +9,9 @@ The reference's training step (ModelTransformer.py:256-266 after :102-105/:222) 
 
 and its backward materialises the dense gradient of S (ComputeLogZFasterGrad.backward,
 NeuralSemiCRFInterval.py:469-472: 1.48 GB at T=1024, NBatch=352), which the scorer's backward then reads twice.
-Here the backward runs the beta sweep only (`semicrf_beta`) and `interval_score_bwd_fused` rebuilds the marginals
-tile by tile inside the two matrix products that produce dq and dk -- the dense gradient never exists.  The
+Here the backward runs the beta sweep only (`semicrf_beta`) and `interval_score_bwd_fused_ws` evaluates the marginals
+while it repacks the cotangent per chain for the two GEMMs that produce dq and dk -- the dense gradient in the CRF's
+layout never exists (without a workspace: rebuilt tile by tile inside the direct kernels).  The
 one-hot part of logProb's gradient (the path cells of evalPath, :540-548) is a few thousand rows and is added with
 index_put.
 
@@ -68,10 +69,14 @@ class _ScorerCRFLogProb(torch.autograd.Function):
         dq = torch.empty(C, T, D, dtype=torch.float32, device=S.device)
         dk = torch.empty(C, T, D, dtype=torch.float32, device=S.device)
         dd = torch.empty(C, T, dtype=torch.float32, device=S.device)
-        rc = lib.interval_score_bwd_fused(_lib.ptr(S), _lib.ptr(v), _lib.ptr(beta), _lib.ptr(logz), _lib.ptr(gneg), _lib.ptr(q),
-                                          _lib.ptr(k), C, T, D, q.stride(-2), k.stride(-2), qs, mode, _lib.ptr(dq),
-                                          _lib.ptr(dk), _lib.ptr(dd), D, D, 1, _lib.stream_of(S))
-        _lib.check(rc, "interval_score_bwd_fused")
+        # with a workspace: marginals evaluated by the repack kernel + two tiled GEMMs (scorer_bwd_gemm.hip)
+        nws = int(lib.interval_score_bwd_workspace_bytes(C, T, D))
+        ws = torch.empty(nws, dtype=torch.uint8, device=S.device) if nws > 0 else None
+        rc = lib.interval_score_bwd_fused_ws(_lib.ptr(S), _lib.ptr(v), _lib.ptr(beta), _lib.ptr(logz), _lib.ptr(gneg), _lib.ptr(q),
+                                             _lib.ptr(k), C, T, D, q.stride(-2), k.stride(-2), qs, mode, _lib.ptr(dq),
+                                             _lib.ptr(dk), _lib.ptr(dd), D, D, 1, _lib.ptr(ws), nws, _lib.stream_of(S))
+        _lib.check(rc, "interval_score_bwd_fused_ws")
+        del ws
         if K > 0:
             # + g on the path cells: dq[c,e] += g qs len(e-b) k[c,b], dk[c,b] += g qs len(e-b) q[c,e], ddiag[c,t] += g (b == e)
             pr = pairs[:K].long()
