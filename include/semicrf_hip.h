@@ -186,6 +186,17 @@ int interval_score_bwd_fused(const float* S, const float* alpha, const float* be
                              int64_t lddq, int64_t lddk, int64_t lddd, semicrf_stream_t stream);
 
 /*
+ * The evalPath half of logProb's gradient (one-hot on the path cells, NeuralSemiCRFInterval.py:540-548) pushed through
+ * the scorer, ADDED to dq/dk/ddiag: for every interval (b, e) of chain c (pairs/offsets as in semicrf_eval_path)
+ *   dq[c,e,:] += w k[c,b,:],  dk[c,b,:] += w q[c,e,:],  w = gout[c] qscale len(e-b);  ddiag[c,e] += gout[c] if b == e.
+ * Completes interval_score_bwd_fused[_ws] to the gradient of logProb = evalPath - logZ.
+ */
+int interval_score_path_bwd(const float* gout, const int32_t* pairs, int64_t K, const int32_t* offsets, const float* q,
+                            const float* k, int C, int T, int D, int64_t ldq, int64_t ldk, float qscale, int length_scaling,
+                            float* dq, float* dk, float* ddiag, int64_t lddq, int64_t lddk, int64_t lddd,
+                            semicrf_stream_t stream);
+
+/*
  * interval_score_bwd_fused on the packed path (workspace as interval_score_bwd_ws): the repack kernel evaluates the
  * marginals while it builds the per-chain matrices, the two GEMMs are the same.  Falls back to
  * interval_score_bwd_fused exactly like interval_score_bwd_ws falls back to interval_score_bwd.

@@ -44,6 +44,10 @@ void launch_interval_score_bwd(const float* dS, const float* q, const float* k, 
                                long long ldk, float qscale, int mode, float* dq, float* dk, float* ddiag,
                                long long lddq, long long lddk, long long lddd, hipStream_t stream);
 void launch_zero_upper(float* X, int T, int B, hipStream_t stream);
+void launch_interval_score_path_bwd(const float* gout, const int* pairs, int K, const int* offsets, const float* q,
+                                    const float* k, int C, int T, int D, long long ldq, long long ldk, float qscale, int mode,
+                                    float* dq, float* dk, float* ddiag, long long lddq, long long lddk, long long lddd,
+                                    hipStream_t stream);
 size_t interval_score_bwd_ws_bytes(int C, int T, int D);
 bool launch_interval_score_bwd_packed(const float* dS, const float* q, const float* k, int C, int T, int D, long long ldq,
                                       long long ldk, float qscale, int mode, float* dq, float* dk, long long lddq,
@@ -347,6 +351,23 @@ int interval_score_bwd_fused_ws(const float* S, const float* alpha, const float*
                                         lddk, lddd, st);
     }
     SEMICRF_CHECK_LAUNCH("interval_score_bwd_fused_ws");
+    return SEMICRF_OK;
+}
+
+int interval_score_path_bwd(const float* gout, const int32_t* pairs, int64_t K, const int32_t* offsets, const float* q,
+                            const float* k, int C, int T, int D, int64_t ldq, int64_t ldk, float qscale, int length_scaling,
+                            float* dq, float* dk, float* ddiag, int64_t lddq, int64_t lddk, int64_t lddd,
+                            semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(C >= 1 && T >= 1 && D >= 1, "C=%d T=%d D=%d must be >= 1", C, T, D);
+    SEMICRF_CHECK_ARG(gout && offsets && q && k, "gout/offsets/q/k must be non-NULL");
+    SEMICRF_CHECK_ARG(K >= 0 && K < (1ll << 31) && (K == 0 || pairs), "bad interval count");
+    SEMICRF_CHECK_ARG(ldq >= D && ldk >= D && (!dq || lddq >= D) && (!dk || lddk >= D) && (!ddiag || lddd >= 1),
+                      "bad leading dimensions");
+    SEMICRF_CHECK_ARG(length_scaling >= 0 && length_scaling <= 2, "bad length_scaling %d", length_scaling);
+    launch_interval_score_path_bwd(gout, pairs, (int)K, offsets, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, ddiag,
+                                   lddq, lddk, lddd, (hipStream_t)stream);
+    SEMICRF_CHECK_LAUNCH("interval_score_path_bwd");
     return SEMICRF_OK;
 }
 

@@ -226,6 +226,44 @@ __global__ __launch_bounds__(256) void interval_score_bwd_diag_fused_kernel(cons
     ddiag[((size_t)c * T + t) * ldd] = F.gout[c] * marginal_of(s, F.alpha[(size_t)t * C + c], F.beta[(size_t)t * C + c], F.logZ[c], true);
 }
 
+// The evalPath part of logProb's gradient pushed through the scorer: every interval (b, e) of chain c contributes
+// w = gout[c] * qscale * len(e-b) to d S[e,b,c], i.e.  dq[c,e,:] += w k[c,b,:],  dk[c,b,:] += w q[c,e,:],
+// ddiag[c,e] += gout[c] when b == e.  One wave per interval; atomics keep duplicate intervals (a caller error) exact.
+__global__ __launch_bounds__(256) void interval_score_path_bwd_kernel(
+    const float* __restrict__ gout, const int* __restrict__ pairs, int K, const int* __restrict__ offsets,
+    const float* __restrict__ q, const float* __restrict__ k, int C, int T, int D, long long ldq, long long ldk, float qscale,
+    int mode, float* dq, float* dk, float* ddiag, long long lddq, long long lddk, long long lddd)
+{
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= K) return;
+    int lo = 0, hi = C;                       // chain of interval i: largest c with offsets[c] <= i
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    const int c = lo;
+    const int b = pairs[2 * i], e = pairs[2 * i + 1];
+    const float g = gout[c];
+    const float w = g * qscale * len_scale_bwd(e - b, mode);
+    const float* qe = q + ((size_t)c * T + e) * ldq;
+    const float* kb = k + ((size_t)c * T + b) * ldk;
+    for (int d = lane; d < D; d += 64) {
+        if (dq) atomicAdd(dq + ((size_t)c * T + e) * lddq + d, w * kb[d]);
+        if (dk) atomicAdd(dk + ((size_t)c * T + b) * lddk + d, w * qe[d]);
+    }
+    if (ddiag && b == e && lane == 0) atomicAdd(ddiag + ((size_t)c * T + e) * lddd, g);
+}
+
+void launch_interval_score_path_bwd(const float* gout, const int* pairs, int K, const int* offsets, const float* q,
+                                    const float* k, int C, int T, int D, long long ldq, long long ldk, float qscale, int mode,
+                                    float* dq, float* dk, float* ddiag, long long lddq, long long lddk, long long lddd,
+                                    hipStream_t stream)
+{
+    if (K <= 0) return;
+    hipLaunchKernelGGL(interval_score_path_bwd_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, gout, pairs, K, offsets, q, k, C,
+                       T, D, ldq, ldk, qscale, mode, dq, dk, ddiag, lddq, lddk, lddd);
+}
+
 bool interval_score_bwd_supported(int C, int T, int D) { return D % 32 == 0 && D >= 32 && D <= 32 * BND_MAX && T >= 1 && C >= 1; }
 
 template <bool ROWS_E, bool FUSED>

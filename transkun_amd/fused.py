@@ -12,8 +12,8 @@ NeuralSemiCRFInterval.py:469-472: 1.48 GB at T=1024, NBatch=352), which the scor
 Here the backward runs the beta sweep only (`semicrf_beta`) and `interval_score_bwd_fused_ws` evaluates the marginals
 while it repacks the cotangent per chain for the two GEMMs that produce dq and dk -- the dense gradient in the CRF's
 layout never exists (without a workspace: rebuilt tile by tile inside the direct kernels).  The
-one-hot part of logProb's gradient (the path cells of evalPath, :540-548) is a few thousand rows and is added with
-index_put.
+one-hot part of logProb's gradient (the path cells of evalPath, :540-548) is a few thousand rows, added by
+`interval_score_path_bwd`.
 
 Opt-in: `scorer_crf_logprob(scorer, ctx, intervals)` replaces the three lines above; results and gradients are the
 same as the unfused route (tests/test_gpu_parity.py::test_fused_scorer_crf).
@@ -79,20 +79,10 @@ class _ScorerCRFLogProb(torch.autograd.Function):
         del ws
         if K > 0:
             # + g on the path cells: dq[c,e] += g qs len(e-b) k[c,b], dk[c,b] += g qs len(e-b) q[c,e], ddiag[c,t] += g (b == e)
-            pr = pairs[:K].long()
-            b, e = pr[:, 0], pr[:, 1]
-            counts = (offsets[1:] - offsets[:-1]).long()
-            cid = torch.repeat_interleave(torch.arange(C, device=S.device), counts)
-            ln = (e - b).to(torch.float32)
-            if mode == 1:
-                ln = ln.sqrt()
-            elif mode == 2:
-                ln = torch.ones_like(ln)
-            w = (g[cid] * qs * ln)[:, None]
-            dq.index_put_((cid, e), w * k[cid, b], accumulate=True)
-            dk.index_put_((cid, b), w * q[cid, e], accumulate=True)
-            single = b == e
-            dd.index_put_((cid[single], e[single]), g[cid[single]], accumulate=True)
+            rc = lib.interval_score_path_bwd(_lib.ptr(g), _lib.ptr(pairs), K, _lib.ptr(offsets), _lib.ptr(q), _lib.ptr(k), C, T, D,
+                                             q.stride(-2), k.stride(-2), qs, mode, _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dd), D, D, 1,
+                                             _lib.stream_of(S))
+            _lib.check(rc, "interval_score_path_bwd")
         return (dq.view(N, P, T, D), dk.view(N, P, T, D), dd.view(N, P, T), None, None, None, None, None, None, None)
 
 
