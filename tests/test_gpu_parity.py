@@ -320,12 +320,16 @@ def test_scorer_backward_kernel(gpu, N, P, T, D, ls):
     q = synth.hash_normal(C * T * D, 51, gpu).view(N, P, T, D).contiguous()
     k = synth.hash_normal(C * T * D, 52, gpu).view(N, P, T, D).contiguous()
     dg = synth.hash_normal(C * T, 53, gpu).view(N, P, T).contiguous()
-    qa, ka, da = (x.clone().requires_grad_() for x in (q, k, dg))
-    S, b = _IntervalScore.apply(qa, ka, da, N, P, T, D, _lib.LEN_MODES[ls], False)
+    from transkun_amd.scorer import QPAD
+    # the module hands [q | diag | zero pad] over as one tensor (one GEMM); its gradient comes back the same way
+    qda = torch.cat([q, dg[..., None], q.new_zeros(N, P, T, QPAD - 1)], dim=-1).requires_grad_()
+    ka = k.clone().requires_grad_()
+    S, b = _IntervalScore.apply(qda, ka, N, P, T, D, _lib.LEN_MODES[ls], False)
     cot = synth.hash_normal(T * T * C, 54, gpu).view(T, T, N, P)          # dense: e < b entries must not contribute
     S.backward(cot)
     ref = _IntervalScore._backward_torch(cot, q.view(C, T, D), k.view(C, T, D), N, P, T, D, _lib.LEN_MODES[ls], False)
-    for got, want, name in ((qa.grad, ref[0], "dq"), (ka.grad, ref[1], "dk"), (da.grad, ref[2], "ddiag")):
+    assert float(qda.grad[..., D + 1:].abs().max()) == 0.0
+    for got, want, name in ((qda.grad[..., :D], ref[0], "dq"), (ka.grad, ref[1], "dk"), (qda.grad[..., D], ref[2], "ddiag")):
         scale = float(want.abs().max()) + 1e-30
         err = float((got - want).abs().max()) / scale
         assert err < 2e-5, (name, err)

@@ -27,7 +27,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .scorer import ScaledInnerProductIntervalScorer, _interval_score_raw
+from .scorer import QPAD, ScaledInnerProductIntervalScorer, _interval_score_raw, qd_weights
 
 _nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
 
@@ -45,20 +45,21 @@ def _beta_raw(score, noise):
 
 class _ScorerCRFLogProb(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, diag, pairs, offsets, N, P, T, D, mode):
+    def forward(ctx, qd, k, pairs, offsets, N, P, T, D, mode):
+        # qd: [N,P,T,D+QPAD] = [q | diag | zeros] (one GEMM, see scorer.py); k: [N,P,T,D]
         C = N * P
-        q3, k3, d2 = q.reshape(C, T, D), k.reshape(C, T, D), diag.reshape(C, T)
+        qd3, k3 = qd.reshape(C, T, D + QPAD), k.reshape(C, T, D)
         qs = 1.0 / math.sqrt(D)
-        S, noise = _interval_score_raw(q3, k3, d2, T, C, D, qs, mode, False)
+        S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qs, mode, False)
         logz, v = _nsci._logz_fwd_raw(S, noise, True)
         path = _nsci._eval_path_raw(S, noise, pairs, offsets)
-        ctx.save_for_backward(q3, k3, S, noise, v, logz, pairs, offsets)
+        ctx.save_for_backward(qd3, k3, S, noise, v, logz, pairs, offsets)
         ctx.meta = (N, P, T, D, mode, getattr(pairs, "_semicrf_K", pairs.shape[0]))
         return path - logz
 
     @staticmethod
     def backward(ctx, g):
-        q, k, S, noise, v, logz, pairs, offsets = ctx.saved_tensors
+        qd3, k, S, noise, v, logz, pairs, offsets = ctx.saved_tensors
         N, P, T, D, mode, K = ctx.meta
         C = N * P
         qs = 1.0 / math.sqrt(D)
@@ -66,24 +67,27 @@ class _ScorerCRFLogProb(torch.autograd.Function):
         lib = _lib.load()
         beta = _beta_raw(S, noise)
         gneg = (-g).contiguous()                                   # d logProb / d logZ = -1
-        dq = torch.empty(C, T, D, dtype=torch.float32, device=S.device)
+        q = qd3[..., :D]
+        dqd = torch.empty(C, T, D + QPAD, dtype=torch.float32, device=S.device)       # gradient of [q | diag | pad]
+        dqd[..., D + 1:] = 0
+        dq, dd = dqd[..., :D], dqd[..., D]
         dk = torch.empty(C, T, D, dtype=torch.float32, device=S.device)
-        dd = torch.empty(C, T, dtype=torch.float32, device=S.device)
         # with a workspace: marginals evaluated by the repack kernel + two tiled GEMMs (scorer_bwd_gemm.hip)
         nws = int(lib.interval_score_bwd_workspace_bytes(C, T, D))
         ws = torch.empty(nws, dtype=torch.uint8, device=S.device) if nws > 0 else None
         rc = lib.interval_score_bwd_fused_ws(_lib.ptr(S), _lib.ptr(v), _lib.ptr(beta), _lib.ptr(logz), _lib.ptr(gneg), _lib.ptr(q),
                                              _lib.ptr(k), C, T, D, q.stride(-2), k.stride(-2), qs, mode, _lib.ptr(dq),
-                                             _lib.ptr(dk), _lib.ptr(dd), D, D, 1, _lib.ptr(ws), nws, _lib.stream_of(S))
+                                             _lib.ptr(dk), _lib.ptr(dd), dq.stride(-2), D, dd.stride(-1), _lib.ptr(ws), nws,
+                                             _lib.stream_of(S))
         _lib.check(rc, "interval_score_bwd_fused_ws")
         del ws
         if K > 0:
             # + g on the path cells: dq[c,e] += g qs len(e-b) k[c,b], dk[c,b] += g qs len(e-b) q[c,e], ddiag[c,t] += g (b == e)
             rc = lib.interval_score_path_bwd(_lib.ptr(g), _lib.ptr(pairs), K, _lib.ptr(offsets), _lib.ptr(q), _lib.ptr(k), C, T, D,
-                                             q.stride(-2), k.stride(-2), qs, mode, _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dd), D, D, 1,
-                                             _lib.stream_of(S))
+                                             q.stride(-2), k.stride(-2), qs, mode, _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dd),
+                                             dq.stride(-2), D, dd.stride(-1), _lib.stream_of(S))
             _lib.check(rc, "interval_score_path_bwd")
-        return (dq.view(N, P, T, D), dk.view(N, P, T, D), dd.view(N, P, T), None, None, None, None, None, None, None)
+        return (dqd.view(N, P, T, D + QPAD), dk.view(N, P, T, D), None, None, None, None, None, None, None)
 
 
 def scorer_crf_logprob(scorer: ScaledInnerProductIntervalScorer, ctx: torch.Tensor, intervals) -> torch.Tensor:
@@ -101,8 +105,8 @@ def scorer_crf_logprob(scorer: ScaledInnerProductIntervalScorer, ctx: torch.Tens
     lin = scorer.map[0]
     W, bias = lin.weight, lin.bias
     x = ctx.float()
-    q = F.linear(x, W[:D], bias[:D])
+    Wqd, bqd = qd_weights(W, bias, D)
+    qd = F.linear(x, Wqd, bqd)
     k = F.linear(x, W[D:2 * D], bias[D:2 * D])
-    diag = F.linear(x, W[2 * D:2 * D + 1], bias[2 * D:2 * D + 1]).squeeze(-1)
     pairs, offsets = _nsci.pack_intervals(intervals, T, N * P, ctx.device)
-    return _ScorerCRFLogProb.apply(q, k, diag, pairs, offsets, N, P, T, D, _lib.LEN_MODES[scorer.lengthScaling])
+    return _ScorerCRFLogProb.apply(qd, k, pairs, offsets, N, P, T, D, _lib.LEN_MODES[scorer.lengthScaling])

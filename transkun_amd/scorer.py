@@ -33,46 +33,62 @@ def _interval_score_raw(q, k, diag, T: int, C: int, D: int, qscale: float, mode:
     return S, noise
 
 
+QPAD = 4        # [q | diag | 3 zero columns]: one GEMM instead of a D-wide and a 1-wide one, rows stay 16-byte aligned
+
+
+def qd_weights(W, bias, D):
+    """Rows of the reference's Linear ([q (D) | k (D) | diag (1)], LayersTransformer.py:392-397) regrouped for the
+    [q | diag | pad] GEMM.  Differentiable views/cats of the same parameter (state_dict stays map.0.weight/bias)."""
+    Wqd = torch.cat([W[:D], W[2 * D:2 * D + 1], W.new_zeros(QPAD - 1, W.shape[1])])
+    bqd = torch.cat([bias[:D], bias[2 * D:2 * D + 1], bias.new_zeros(QPAD - 1)])
+    return Wqd, bqd
+
+
 class _IntervalScore(torch.autograd.Function):
     """S = lenscale * (q*qscale) k^T + diag, chain-minor layout; forward and backward are HIP kernels
-    (the backward falls back to torch for contraction sizes the kernel does not take)."""
+    (the backward falls back to torch for contraction sizes the kernel does not take).
+    qd: [N,P,T,D+QPAD] = [q | diag | zeros]; k: [N,P,T,D]."""
 
     @staticmethod
-    def forward(ctx, q, k, diag, N, P, T, D, mode, full_square):
-        # q, k: [N,P,T,D] contiguous (separate GEMM outputs: 16-byte aligned rows for the MFMA kernel), diag [N,P,T]
+    def forward(ctx, qd, k, N, P, T, D, mode, full_square):
         C = N * P
-        q3, k3, d2 = q.reshape(C, T, D), k.reshape(C, T, D), diag.reshape(C, T)
+        qd3, k3 = qd.reshape(C, T, D + QPAD), k.reshape(C, T, D)
         qscale = 1.0 / math.sqrt(D)
-        S, noise = _interval_score_raw(q3, k3, d2, T, C, D, qscale, mode, full_square)
-        ctx.save_for_backward(q3, k3)
+        S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qscale, mode, full_square)
+        ctx.save_for_backward(qd3, k3)
         ctx.meta = (N, P, T, D, mode, bool(full_square))
         return S.view(T, T, N, P), noise.view(max(T - 1, 0), N, P)
 
     @staticmethod
     def backward(ctx, dS, dnoise):
-        q, k = ctx.saved_tensors
+        qd3, k = ctx.saved_tensors
         N, P, T, D, mode, full = ctx.meta
         C = N * P
         qs = 1.0 / math.sqrt(D)
+        q = qd3[..., :D]
         if D % 32 == 0 and D <= 256 and dS.is_cuda and not full:
-            # HIP kernel: dq/dk from dS in its native [T,T,C] layout on the matrix cores (exact fp32)
+            # HIP kernels: dq/dk from dS in its native [T,T,C] layout on the matrix cores (exact fp32), written straight
+            # into the gradient of [q | diag | pad]
             lib = _lib.load()
             g = dS.reshape(T, T, C)
             if not g.is_contiguous():
                 g = g.contiguous()
-            dq = torch.empty(C, T, D, dtype=torch.float32, device=g.device)
+            dqd = torch.empty(C, T, D + QPAD, dtype=torch.float32, device=g.device)
+            dqd[..., D + 1:] = 0
+            dq, dd = dqd[..., :D], dqd[..., D]
             dk = torch.empty(C, T, D, dtype=torch.float32, device=g.device)
-            dd = torch.empty(C, T, dtype=torch.float32, device=g.device)
             # with a workspace the library repacks dS per chain and runs two LDS-tiled GEMMs (scorer_bwd_gemm.hip);
             # 0 bytes: shapes it does not take -- the direct kernels run
             nws = int(lib.interval_score_bwd_workspace_bytes(C, T, D))
             ws = torch.empty(nws, dtype=torch.uint8, device=g.device) if nws > 0 else None
             rc = lib.interval_score_bwd_ws(_lib.ptr(g), _lib.ptr(q), _lib.ptr(k), C, T, D, q.stride(-2), k.stride(-2), qs, mode,
-                                           _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dd), D, D, 1, _lib.ptr(ws), nws,
-                                           _lib.stream_of(g))
+                                           _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dd), dq.stride(-2), D, dd.stride(-1), _lib.ptr(ws),
+                                           nws, _lib.stream_of(g))
             _lib.check(rc, "interval_score_bwd_ws")
-            return (dq.view(N, P, T, D), dk.view(N, P, T, D), dd.view(N, P, T), None, None, None, None, None, None)
-        return _IntervalScore._backward_torch(dS, q, k, N, P, T, D, mode, full)
+            return (dqd.view(N, P, T, D + QPAD), dk.view(N, P, T, D), None, None, None, None, None, None)
+        dq, dk, dd = _IntervalScore._backward_torch(dS, q, k, N, P, T, D, mode, full)[:3]
+        dqd = torch.cat([dq.reshape(C, T, D), dd.reshape(C, T, 1), dq.new_zeros(C, T, QPAD - 1)], dim=-1)
+        return (dqd.view(N, P, T, D + QPAD), dk, None, None, None, None, None, None)
 
     @staticmethod
     def _backward_torch(dS, q, k, N, P, T, D, mode, full=False):
@@ -119,13 +135,14 @@ class ScaledInnerProductIntervalScorer(nn.Module):
         N, P, T, _ = ctx.shape
         D = self.size * self.expansionFactor
         _lib.require_gpu(ctx, "ctx")
-        # the Linear map as three GEMMs over slices of the same parameter (state_dict stays map.0.weight/bias):
-        # q and k come out contiguous with 16-byte aligned rows, no split copy of a packed [.., 2D+1] tensor
+        # the Linear map as two GEMMs over regrouped rows of the same parameter (state_dict stays map.0.weight/bias):
+        # [q | diag | pad] and k come out with 16-byte aligned rows, no split copy of a packed [.., 2D+1] tensor and no
+        # 1-wide GEMM for the diagonal term (0.9 ms fwd+bwd on its own at T=1024, NBatch=352)
         lin = self.map[0]
         W, bias = lin.weight, lin.bias
         x = ctx.float()
-        q = F.linear(x, W[:D], bias[:D])
+        Wqd, bqd = qd_weights(W, bias, D)
+        qd = F.linear(x, Wqd, bqd)
         k = F.linear(x, W[D:2 * D], bias[D:2 * D])
-        diag = F.linear(x, W[2 * D:2 * D + 1], bias[2 * D:2 * D + 1]).squeeze(-1)
-        S, b = _IntervalScore.apply(q, k, diag, N, P, T, D, _lib.LEN_MODES[self.lengthScaling], self.fullSquare)
+        S, b = _IntervalScore.apply(qd, k, N, P, T, D, _lib.LEN_MODES[self.lengthScaling], self.fullSquare)
         return S, b
