@@ -308,6 +308,25 @@ def test_scorer_forward_kernels(gpu, variant, C, T, D, mode, full, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("C,T,D", [(6, 70, 64), (9, 300, 128), (5, 130, 256)])
+def test_scorer_strided_operands(gpu, C, T, D):
+    """The C ABI takes q/k/diag by row stride: slices of the reference's packed Linear output [C,T,2D+1] (rows only 4-byte
+    aligned: the register-load kernel) and of the mirror's [q | diag | pad] tensor (16-byte aligned rows of D+4 floats: the
+    shared-operand kernels) must give the same scores as contiguous copies."""
+    from transkun_amd import synth
+    from transkun_amd.scorer import QPAD, _interval_score_raw
+    qs = 1.0 / D ** 0.5
+    y = synth.hash_normal(C * T * (2 * D + 1), 91, gpu).view(C, T, 2 * D + 1)
+    q, k, dg = y[..., :D], y[..., D:2 * D], y[..., 2 * D]
+    ref, _ = _interval_score_raw(q.contiguous(), k.contiguous(), dg.contiguous(), T, C, D, qs, 0, False)
+    got, _ = _interval_score_raw(q, k, dg, T, C, D, qs, 0, False)
+    assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    qd = torch.cat([q, dg[..., None], q.new_zeros(C, T, QPAD - 1)], dim=-1).contiguous()
+    got2, _ = _interval_score_raw(qd[..., :D], k.contiguous(), qd[..., D], T, C, D, qs, 0, False)
+    assert torch.equal(got2, ref)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,P,T,D,ls", [(1, 5, 70, 64, "linear"), (2, 9, 97, 256, "linear"), (1, 3, 33, 32, "sqrt"),
                                          (1, 8, 64, 128, "none"), (3, 11, 130, 96, "linear")])
 def test_scorer_backward_kernel(gpu, N, P, T, D, ls):
