@@ -115,3 +115,27 @@ def test_synth_numpy_torch_identical():
         for (b0, e0) in lst:
             assert 0 <= b0 <= e0 < 256 and b0 >= last
             last = e0
+
+
+def test_scorer_regrouped_linear_rows():
+    """The mirror runs the reference's Linear ([q | k | diag] rows, LayersTransformer.py:392-397) as [q | diag | pad] and k:
+    same numbers as slicing the packed output, gradients reach the original parameter rows, pad rows stay zero."""
+    import torch
+    import torch.nn.functional as F
+    from transkun_amd.scorer import QPAD, ScaledInnerProductIntervalScorer, qd_weights
+    D = 8
+    m = ScaledInnerProductIntervalScorer(D, 1)
+    assert list(m.state_dict().keys()) == ["map.0.weight", "map.0.bias"]          # checkpoints of the reference load
+    W, b = m.map[0].weight, m.map[0].bias
+    assert W.shape == (2 * D + 1, D)
+    x = torch.randn(3, 5, D)
+    packed = F.linear(x, W, b)
+    Wqd, bqd = qd_weights(W, b, D)
+    qd = F.linear(x, Wqd, bqd)
+    assert qd.shape[-1] == D + QPAD and (D + QPAD) % 4 == 0
+    assert torch.allclose(qd[..., :D], packed[..., :D], atol=1e-6)
+    assert torch.allclose(qd[..., D], packed[..., 2 * D], atol=1e-6)
+    assert float(qd[..., D + 1:].abs().max()) == 0.0
+    qd.sum().backward()
+    g = W.grad
+    assert float(g[D:2 * D].abs().max()) == 0.0 and float(g[:D].abs().max()) > 0 and float(g[2 * D].abs().max()) > 0
