@@ -187,6 +187,40 @@ def main():
         extra["decode_segments_per_s_device"] = round((Bd / 88) / dk, 1)
         extra["decode_chains_per_s_device"] = round(Bd / dk, 1)
         del sd, nd, crf_d
+        # the upstream T x T interval-score construction (SURVEY 8 "next" row), same NBatch and T, D = 256: kernels only
+        try:
+            from transkun_amd import _lib
+            from transkun_amd.scorer import _interval_score_raw
+            lib = _lib.load()
+            Cq, Dq = B, 256
+            qq = synth.hash_normal(Cq * T * Dq, 5, dev).view(Cq, T, Dq)
+            kk = synth.hash_normal(Cq * T * Dq, 6, dev).view(Cq, T, Dq)
+            dd = synth.hash_normal(Cq * T, 7, dev).view(Cq, T)
+            for _ in range(2):
+                Sq, _ = _interval_score_raw(qq, kk, dd, T, Cq, Dq, 1.0 / 16, 0, False)
+            e0.record()
+            for _ in range(5):
+                Sq, _ = _interval_score_raw(qq, kk, dd, T, Cq, Dq, 1.0 / 16, 0, False)
+            e1.record(); torch.cuda.synchronize(dev)
+            extra["interval_score_fwd_ms"] = round(e0.elapsed_time(e1) / 5, 3)
+            dq = torch.empty_like(qq); dk2 = torch.empty_like(kk); ddg = torch.empty_like(dd)
+            nws = int(lib.interval_score_bwd_workspace_bytes(Cq, T, Dq))
+            wsq = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)
+            def _bwd():
+                _lib.check(lib.interval_score_bwd_ws(_lib.ptr(Sq), _lib.ptr(qq), _lib.ptr(kk), Cq, T, Dq, Dq, Dq, 1.0 / 16, 0,
+                                                     _lib.ptr(dq), _lib.ptr(dk2), _lib.ptr(ddg), Dq, Dq, 1, _lib.ptr(wsq), nws,
+                                                     _lib.stream_of(Sq)), "interval_score_bwd_ws")
+            for _ in range(2):
+                _bwd()
+            e0.record()
+            for _ in range(5):
+                _bwd()
+            e1.record(); torch.cuda.synchronize(dev)
+            extra["interval_score_bwd_ms"] = round(e0.elapsed_time(e1) / 5, 3)
+            extra["interval_score_config"] = f"T={T}, chains={Cq}, D={Dq}, exact-fp32 MFMA, lower triangle"
+            del qq, kk, dd, Sq, dq, dk2, ddg, wsq
+        except Exception as ex:                       # the headline line must not depend on the extras
+            extra["interval_score_error"] = repr(ex)[:200]
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
