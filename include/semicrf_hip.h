@@ -207,6 +207,21 @@ int interval_score_bwd_fused_ws(const float* S, const float* alpha, const float*
                                 int64_t lddq, int64_t lddk, int64_t lddd, void* ws, size_t ws_bytes,
                                 semicrf_stream_t stream);
 
+/*
+ * Interval features for the attribute heads.  Replaces: TransKun.fetchIntervalFeaturesBatch
+ * (ModelTransformer.py:501-532) and the concatenation that feeds the velocity / onset-offset predictors (:578-582),
+ * consuming the packed decode output on the device (pairs [K][2], offsets [C+1] as written by semicrf_viterbi; chain
+ * c = segment * nSym + symbol) instead of Python lists:
+ *   out[i] = [ ctx[c,begin,:] | ctx[c,end,:] | ctx[c,begin,:] * ctx[c,end,:] ]   ([K][3D]; ctx is [C][T][D], row stride ldc)
+ *   symIdx[i] = c % nSym, scatterIdx[i] = c                                       (int64; either may be NULL)
+ * The backward ADDS into dctx ([C][T][D], row stride lddc; zero it first for a fresh gradient).
+ */
+int interval_features_gather(const float* ctx, int C, int T, int D, int64_t ldc, const int32_t* pairs, int64_t K,
+                             const int32_t* offsets, int nSym, float* out, int64_t* symIdx, int64_t* scatterIdx,
+                             semicrf_stream_t stream);
+int interval_features_gather_bwd(const float* gout, const float* ctx, int C, int T, int D, int64_t ldc, const int32_t* pairs,
+                                 int64_t K, const int32_t* offsets, float* dctx, int64_t lddc, semicrf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -242,3 +242,21 @@ def oploop_viterbi_backward(score, noise, forcedStartPos=None):
             cur.append((T - 1, T - 1))
         out.append(cur)
     return out
+
+
+def fetch_interval_features(ctx, intervals_batch):
+    """CPU restatement of TransKun.fetchIntervalFeaturesBatch (ModelTransformer.py:501-532) + listToIdx (Util.py:173-176).
+    ctx: numpy [N, SYM, T, D]; intervals_batch: per segment, per symbol, list of (begin, end).
+    Returns (ctx_a_all [K,D], ctx_b_all [K,D], symIdx_all [K] int64, scatterIdx_all [K] int64) in the reference's order
+    (segments in order, symbols in order, intervals in list order).  Test infrastructure only.  Pinned against the
+    reference's own method by tools/make_golden.py (tests/golden/attr_*.npz)."""
+    import numpy as np
+    N, SYM, T, D = ctx.shape
+    a, b, sym, sc = [], [], [], []
+    for idx, cur in enumerate(intervals_batch):                  # :509
+        for s_i, lst in enumerate(cur):                          # listToIdx: symbol index repeated per interval
+            for (bg, en) in lst:
+                a.append(ctx[idx, s_i, bg]); b.append(ctx[idx, s_i, en])      # :522-523: index begin/end + symIdx*T
+                sym.append(s_i); sc.append(idx * SYM + s_i)                   # :514, :516
+    return (np.stack(a).astype(np.float32), np.stack(b).astype(np.float32),
+            np.asarray(sym, np.int64), np.asarray(sc, np.int64))

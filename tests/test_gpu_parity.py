@@ -486,3 +486,56 @@ def test_persist_vs_oracle(gpu, oracle, T, B, kind):
     assert crf.decode(forward=True) == oracle.viterbi(sc, nc, forward=True)
     assert crf.decode(forcedStartPos=st, forward=True) == oracle.viterbi(sc, nc, st, forward=True)
     assert _lib.device_status() == 0
+
+
+# ---- attribute-head interval features --------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["small", "model"])
+def test_attribute_features(gpu, oracle, name):
+    """transkun_amd.attributes (HIP gather from packed intervals) against the reference's fetchIntervalFeaturesBatch outputs
+    (golden) and the oracle; decode -> features without leaving the device; gradient against torch's index_select."""
+    from test_oracle_golden import _attr_case, check_attr_outputs
+    from transkun_amd import attributes
+    g, ctx_h, flat, batch, (N, SYM, T, D) = _attr_case(name)
+    ctx = ctx_h.to(gpu)
+    a, b, sym, sc = attributes.fetchIntervalFeaturesBatch(ctx, batch)
+    check_attr_outputs(g, a.cpu().numpy(), b.cpu().numpy(), sym.cpu().numpy(), sc.cpu().numpy())
+    oa, ob, osym, osc = oracle.fetch_interval_features(ctx_h.numpy(), batch)
+    assert np.array_equal(a.cpu().numpy(), oa) and np.array_equal(b.cpu().numpy(), ob)          # a gather: bit-exact
+    # packed entry point (what decode leaves on the device) incl. the fused product
+    pairs = torch.from_numpy(g["pairs"].astype(np.int32)).to(gpu)
+    offsets = torch.from_numpy(g["offsets"].astype(np.int32)).to(gpu)
+    x = ctx.clone().requires_grad_()
+    out, sym2, sc2 = attributes.attribute_input_packed(x, pairs, offsets)
+    assert out.shape == (len(oa), 3 * D)
+    assert torch.equal(out[:, :D], a) and torch.equal(out[:, D:2 * D], b) and torch.equal(out[:, 2 * D:], a * b)
+    assert torch.equal(sym2, sym) and torch.equal(sc2, sc)
+    # gradient: the reference's formulation (index_select + cat), differentiated by torch
+    w = torch.sin(torch.arange(out.numel(), device=gpu, dtype=torch.float32)).view_as(out)
+    (out * w).sum().backward()
+    y = ctx.clone().requires_grad_()
+    flat_rows = y.view(N * SYM * T, D)
+    ia = sc * T + pairs[: len(oa), 0].long()
+    ib = sc * T + pairs[: len(oa), 1].long()
+    ra, rb = flat_rows.index_select(0, ia), flat_rows.index_select(0, ib)
+    (torch.cat([ra, rb, ra * rb], dim=-1) * w).sum().backward()
+    assert float((x.grad - y.grad).abs().max()) <= 1e-5 * float(y.grad.abs().max() + 1e-30)
+
+
+@pytest.mark.gpu
+def test_decode_to_attribute_features_on_device(gpu):
+    """NeuralSemiCRFInterval decode output (packed, in HBM) feeds the feature gather directly; same result as going through
+    the Python lists like the reference (ModelTransformer.py:549-582)."""
+    import importlib
+    from transkun_amd import CRF, attributes, synth
+    nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
+    N, SYM, T, D = 2, 8, 96, 64
+    score, noise = synth.crf_inputs(T, N * SYM, 77, gpu, "randn")
+    ctx = synth.hash_normal(N * SYM * T * D, 78, gpu).view(N, SYM, T, D)
+    pairs, offsets = nsci._viterbi_raw(score, noise, None, False)
+    out, sym, sc = attributes.attribute_input_packed(ctx, pairs, offsets)
+    lists = CRF.NeuralSemiCRFInterval(score, noise).decode()
+    batch = [lists[n * SYM:(n + 1) * SYM] for n in range(N)]
+    a, b, sym_l, sc_l = attributes.fetchIntervalFeaturesBatch(ctx, batch)
+    assert torch.equal(out[:, :D], a) and torch.equal(out[:, D:2 * D], b) and torch.equal(sym, sym_l) and torch.equal(sc, sc_l)

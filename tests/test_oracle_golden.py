@@ -138,3 +138,37 @@ def test_oploop_port_matches_oracle(oracle):
     st = [(c * 5) % 48 for c in range(5)]
     assert oracle.oploop_viterbi_backward(score, noise, st) == oracle.viterbi(score.numpy(), noise.numpy(), st)
     assert oracle.oploop_viterbi_backward(score, noise) == oracle.viterbi(score.numpy(), noise.numpy())
+
+
+def _attr_case(name):
+    """Inputs of an attr_* fixture (regenerated from the integer hash) + the reference's outputs."""
+    import torch
+    from transkun_amd import synth
+    g = load_golden("attr_" + name)
+    N, SYM, T, D, seed = (int(x) for x in g["meta"])
+    ctx = synth.hash_normal(N * SYM * T * D, 100 + seed, "cpu").view(N, SYM, T, D)
+    flat = unpack_lists(g["pairs"], g["offsets"])
+    batch = [flat[n * SYM:(n + 1) * SYM] for n in range(N)]
+    return g, ctx, flat, batch, (N, SYM, T, D)
+
+
+def check_attr_outputs(g, a, b, sym, sc):
+    """a, b: float64-able arrays [K, D] in the reference's order; compares with what the reference's own
+    fetchIntervalFeaturesBatch produced (full tensors for the small case, column sums / weighted sums for the large one)."""
+    assert np.array_equal(np.asarray(sym), g["symIdx"]) and np.array_equal(np.asarray(sc), g["scatterIdx"])
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    if "ctx_a" in g:
+        assert np.array_equal(a.astype(np.float32), g["ctx_a"]) and np.array_equal(b.astype(np.float32), g["ctx_b"])
+    else:
+        w = (np.arange(a.shape[0], dtype=np.float64) % 7 + 1)[:, None]
+        for got, key in ((a.sum(0), "ctx_a_sum"), (b.sum(0), "ctx_b_sum"), ((a * b).sum(0), "ab_sum"),
+                         ((a * w).sum(0), "ctx_a_wsum"), ((b * w).sum(0), "ctx_b_wsum")):
+            assert rel_err(got, g[key]) < 1e-6, key
+
+
+@pytest.mark.parametrize("name", ["small", "model"])
+def test_attribute_features_oracle(oracle, name):
+    """oracle.fetch_interval_features against the reference's TransKun.fetchIntervalFeaturesBatch."""
+    g, ctx, flat, batch, _ = _attr_case(name)
+    a, b, sym, sc = oracle.fetch_interval_features(ctx.numpy(), batch)
+    check_attr_outputs(g, a, b, sym, sc)

@@ -284,14 +284,65 @@ def case_large():
     save(f"large_T{T}_B{B}_decode", d)
 
 
+def reference_fetch_interval_features():
+    """The reference's TransKun.fetchIntervalFeaturesBatch itself (ModelTransformer.py:501-532).  The module cannot be
+    imported here (pretty_midi / torchaudio / moduleconf are absent), so the method is lifted out of the reference's
+    source file at run time (ast: the one FunctionDef) and executed with the reference's own Util.listToIdx -- nothing of
+    it is copied into this repository."""
+    import ast
+    import types
+    src_path = "/root/reference/transkun/ModelTransformer.py"
+    tree = ast.parse(open(src_path).read())
+    fn = None
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name == "fetchIntervalFeaturesBatch":
+            fn = node
+    assert fn is not None
+    mod = ast.Module(body=[fn], type_ignores=[])
+    util_src = open("/root/reference/transkun/Util.py").read()
+    util_tree = ast.parse(util_src)
+    lti = [n for n in util_tree.body if isinstance(n, ast.FunctionDef) and n.name == "listToIdx"]
+    assert len(lti) == 1
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=lti, type_ignores=[]), "/root/reference/transkun/Util.py", "exec"), ns)
+    exec(compile(mod, src_path, "exec"), ns)
+    return ns["fetchIntervalFeaturesBatch"]
+
+
+def case_attr():
+    """interval features for the attribute heads, from the reference's own method."""
+    import types
+    ref_fn = reference_fetch_interval_features()
+    for name, (N, SYM, T, D, seed) in {"small": (2, 5, 40, 8, 3), "model": (2, 90, 96, 256, 4)}.items():
+        ctx = synth.hash_normal(N * SYM * T * D, 100 + seed, "cpu").view(N, SYM, T, D)
+        flat = synth.synthetic_intervals(T, N * SYM, seed=seed)
+        if name == "small":
+            flat[1] = []                                   # an empty chain, singletons and touching intervals
+            flat[2] = [(3, 3), (4, 6), (6, 6), (7, 12)]
+        batch = [flat[n * SYM:(n + 1) * SYM] for n in range(N)]
+        self_like = types.SimpleNamespace(targetMIDIPitch=list(range(SYM)))      # the method only reads len(self.targetMIDIPitch)
+        a, b, sym, sc = ref_fn(self_like, ctx, batch)
+        pairs, off = pack(flat)
+        d = {"meta": np.asarray([N, SYM, T, D, seed]), "pairs": pairs, "offsets": off,
+             "symIdx": sym.numpy(), "scatterIdx": sc.numpy()}
+        if name == "small":
+            d["ctx_a"] = a.numpy(); d["ctx_b"] = b.numpy()
+        else:                                              # larger case: digests (inputs are regenerable from the hash)
+            d["ctx_a_sum"] = a.double().sum(0).numpy(); d["ctx_b_sum"] = b.double().sum(0).numpy()
+            d["ab_sum"] = (a.double() * b.double()).sum(0).numpy()
+            w = (torch.arange(a.shape[0], dtype=torch.float64) % 7 + 1)[:, None]
+            d["ctx_a_wsum"] = (a.double() * w).sum(0).numpy(); d["ctx_b_wsum"] = (b.double() * w).sum(0).numpy()
+        save(f"attr_{name}", d)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--large", action="store_true")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.manual_seed(0)
-    todo = a.only.split(",") if a.only else ["minimal", "edges", "medium", "scorer"] + (["large"] if a.large else [])
+    todo = a.only.split(",") if a.only else ["minimal", "edges", "medium", "scorer", "attr"] + (["large"] if a.large else [])
     for t in todo:
         print("case", t)
         {"minimal": case_minimal, "edges": case_edges, "medium": case_medium, "scorer": case_scorer,
-         "large": case_large}[t]()
+         "large": case_large, "attr": case_attr}[t]()

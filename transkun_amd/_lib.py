@@ -41,6 +41,8 @@ _SIGS = {
     "interval_score_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i64, ctypes.c_float, _i, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "interval_score_bwd_fused_ws": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, ctypes.c_float, _i, _vp, _vp, _vp, _i64, _i64, _i64, _vp, ctypes.c_size_t, _vp]),
     "interval_score_path_bwd": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, ctypes.c_float, _i, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "interval_features_gather": (_i, [_vp, _i, _i, _i, _i64, _vp, _i64, _vp, _i, _vp, _vp, _vp, _vp]),
+    "interval_features_gather_bwd": (_i, [_vp, _vp, _i, _i, _i, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
     "interval_score_bwd_ws": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i64, ctypes.c_float, _i, _vp, _vp, _vp, _i64, _i64, _i64, _vp, ctypes.c_size_t, _vp]),
     "interval_score_bwd_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i]),
 }

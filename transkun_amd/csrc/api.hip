@@ -44,6 +44,11 @@ void launch_interval_score_bwd(const float* dS, const float* q, const float* k, 
                                long long ldk, float qscale, int mode, float* dq, float* dk, float* ddiag,
                                long long lddq, long long lddk, long long lddd, hipStream_t stream);
 void launch_zero_upper(float* X, int T, int B, hipStream_t stream);
+void launch_interval_features(const float* ctx, int C, int T, int D, long long ldc, const int* pairs, int K,
+                              const int* offsets, int nSym, float* out, long long* symIdx, long long* scatterIdx,
+                              hipStream_t stream);
+void launch_interval_features_bwd(const float* gout, const float* ctx, int C, int T, int D, long long ldc, const int* pairs,
+                                  int K, const int* offsets, float* dctx, long long lddc, hipStream_t stream);
 void launch_interval_score_path_bwd(const float* gout, const int* pairs, int K, const int* offsets, const float* q,
                                     const float* k, int C, int T, int D, long long ldq, long long ldk, float qscale, int mode,
                                     float* dq, float* dk, float* ddiag, long long lddq, long long lddk, long long lddd,
@@ -368,6 +373,32 @@ int interval_score_path_bwd(const float* gout, const int32_t* pairs, int64_t K, 
     launch_interval_score_path_bwd(gout, pairs, (int)K, offsets, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, ddiag,
                                    lddq, lddk, lddd, (hipStream_t)stream);
     SEMICRF_CHECK_LAUNCH("interval_score_path_bwd");
+    return SEMICRF_OK;
+}
+
+int interval_features_gather(const float* ctx, int C, int T, int D, int64_t ldc, const int32_t* pairs, int64_t K,
+                             const int32_t* offsets, int nSym, float* out, int64_t* symIdx, int64_t* scatterIdx,
+                             semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(C >= 1 && T >= 1 && D >= 1 && nSym >= 1, "C=%d T=%d D=%d nSym=%d must be >= 1", C, T, D, nSym);
+    SEMICRF_CHECK_ARG(ctx && offsets, "ctx/offsets must be non-NULL");
+    SEMICRF_CHECK_ARG(ldc >= D, "bad row stride");
+    SEMICRF_CHECK_ARG(K >= 0 && K < (1ll << 31) && (K == 0 || (pairs && out)), "bad interval count / buffers");
+    launch_interval_features(ctx, C, T, D, ldc, pairs, (int)K, offsets, nSym, out, (long long*)symIdx, (long long*)scatterIdx,
+                             (hipStream_t)stream);
+    SEMICRF_CHECK_LAUNCH("interval_features_gather");
+    return SEMICRF_OK;
+}
+
+int interval_features_gather_bwd(const float* gout, const float* ctx, int C, int T, int D, int64_t ldc, const int32_t* pairs,
+                                 int64_t K, const int32_t* offsets, float* dctx, int64_t lddc, semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(C >= 1 && T >= 1 && D >= 1, "C=%d T=%d D=%d must be >= 1", C, T, D);
+    SEMICRF_CHECK_ARG(ctx && offsets && dctx, "ctx/offsets/dctx must be non-NULL");
+    SEMICRF_CHECK_ARG(ldc >= D && lddc >= D, "bad row stride");
+    SEMICRF_CHECK_ARG(K >= 0 && K < (1ll << 31) && (K == 0 || (pairs && gout)), "bad interval count / buffers");
+    launch_interval_features_bwd(gout, ctx, C, T, D, ldc, pairs, (int)K, offsets, dctx, lddc, (hipStream_t)stream);
+    SEMICRF_CHECK_LAUNCH("interval_features_gather_bwd");
     return SEMICRF_OK;
 }
 
