@@ -7,8 +7,8 @@
 // scorer_bwd.hip multiplies straight out of the CRF's chain-minor gradient layout: a 32-row tile of 8 chains per
 // workgroup, the k/q rows of every chain re-read by every row tile -- 16 B/clk/CU of operands at full matrix rate,
 // which is what a CU's L1 can deliver at best (see scorer_mfma.hip), and the kernel ends up at a quarter of the fp32
-// MFMA rate.  Here the cotangent is repacked ONCE into per-chain matrices Gt[c][e][b] (scaled, zero above the
-// diagonal; whole 128-byte lines in, 128-byte rows out), and both products become ordinary tiled GEMMs of one chain
+// MFMA rate.  Here the cotangent is repacked ONCE into per-chain block-triangular matrices Gt[c][e][b] (scaled, zero above
+// the diagonal inside the 128-aligned diagonal blocks; whole 128-byte lines in, 128-byte rows out), and both products become ordinary tiled GEMMs of one chain
 // at a time: a persistent workgroup of 8 waves owns a 128 x D output tile (wave = 32 rows x D/2 columns), the
 // operand chunks (32 contraction values: 16 KB of Gt + 32 rows of k or q) arrive by `buffer_load ... lds`, three
 // stages deep, one s_barrier per chunk: 6 B/clk/CU.  dq reads Gt rows along the contraction (ds_read_b128, swizzled as
@@ -52,7 +52,21 @@ __device__ __forceinline__ void static_for(F&& f)
 }
 
 // ---------------------------------------------------------------------------------------------
-// repack: dS [T][T][C] -> Gt [C][Tp][Tp] (Tp = T rounded up to 32), scaled; zero for b > e and for e >= T
+// Gt layout: per chain a block-triangular matrix.  Rows come in blocks of 128 (GM); the rows of block i hold columns
+// 0 .. RL(i)-1 with RL(i) = min(128 (i+1), Tp) -- everything an output tile ever reads (the diagonal block included,
+// zero above the diagonal) and nothing else: 56 % of the square at T=1024.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int gt_row_len(int blk, int Tp) { return (blk + 1) * GM < Tp ? (blk + 1) * GM : Tp; }
+// floats before block blk (blocks before it are full: 128 rows of 128 (i+1) columns)
+__host__ __device__ __forceinline__ size_t gt_block_off(int blk) { return (size_t)GM * GM * ((size_t)blk * (blk + 1) / 2); }
+__host__ __device__ __forceinline__ size_t gt_chain_floats(int Tp)
+{
+    const int nb = (Tp + GM - 1) / GM;
+    return gt_block_off(nb - 1) + (size_t)(Tp - (nb - 1) * GM) * Tp;
+}
+
+// ---------------------------------------------------------------------------------------------
+// repack: dS [T][T][C] -> Gt [C][block-triangular] (Tp = T rounded up to 32), scaled; zero for b > e and for e >= T
 // ---------------------------------------------------------------------------------------------
 // One block = 8 end frames x 32 begin frames x 32 chains (whole 128-byte lines in; 128-byte rows out).  Only the
 // b tiles up to the end of the row's 128-aligned diagonal block are written: the GEMMs read nothing beyond.
@@ -144,7 +158,9 @@ __global__ __launch_bounds__(256) void score_bwd_pack_kernel(const float* __rest
         const int c = cg + ch;
         if (c < C) {
             const float4 v = *(const float4*)(L + ch * PK_CHS + el * PK_ROW + 4 * j4);
-            *(float4*)(Gt + ((size_t)c * Tp + e0 + el) * Tp + b0 + 4 * j4) = v;
+            const int blk = e0 / GM;                          // the 8 rows of a block lie in one 128-row block
+            float* row = Gt + (size_t)c * gt_chain_floats(Tp) + gt_block_off(blk) + (size_t)(e0 + el - blk * GM) * gt_row_len(blk, Tp);
+            *(float4*)(row + b0 + 4 * j4) = v;
         }
     }
 }
@@ -214,10 +230,10 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __r
             if (!AT) {
                 const int row = 8 * p + (lane >> 3);   // m within the tile; 128 contiguous bytes along k
                 const int seg = (lane & 7) ^ ((row >> 1) & 7);
-                voA[j] = (unsigned)((((size_t)(nx_mi * GM + row)) * Tp + seg * 4) * 4);
+                voA[j] = (unsigned)((gt_block_off(nx_mi) + (size_t)row * gt_row_len(nx_mi, Tp) + seg * 4) * 4);
             } else {
                 const int row = 2 * p + (lane >> 5);   // k within the chunk; 512 contiguous bytes along m
-                voA[j] = (unsigned)(((size_t)row * Tp + nx_mi * GM + (lane & 31) * 4) * 4);
+                voA[j] = (unsigned)row;                  // the row length depends on the chunk: finished in issue_chunk
             }
         }
 #pragma unroll
@@ -231,17 +247,22 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __r
     auto issue_chunk = [&]() {
         const int k0 = (nx_kbeg + nx_j) * GK;
         // bounds-checked buffers over the chain's slab: rows past the end read as zero
-        const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)(Gt + (size_t)nx_c * Tp * Tp), 0, (int)((size_t)Tp * Tp * 4), 0x00020000);
+        const size_t slab = gt_chain_floats(Tp);
+        const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)(Gt + (size_t)nx_c * slab), 0, (int)(slab * 4), 0x00020000);
         const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)(other + (size_t)nx_c * T * ldo), 0, (int)((size_t)T * ldo * 4), 0x00020000);
         char* da = glds + nx_stage * GSTAGE + (2 * wave) * 1024;
         char* db = glds + nx_stage * GSTAGE + GA_BYTES + (NW * wave) * 1024;
-        const unsigned sa = AT ? (unsigned)((size_t)k0 * Tp * 4) : (unsigned)(k0 * 4);      // always inside the slab
+        // AT: the chunk's 32 rows (k = e) lie in one 128-row block kblk; its row length enters the per-lane offsets
+        const int kblk = k0 / GM, krl = gt_row_len(kblk, Tp);
+        const unsigned sa = AT ? (unsigned)((gt_block_off(kblk) + (size_t)(k0 - kblk * GM) * krl) * 4) : (unsigned)(k0 * 4);   // inside the slab
+        const unsigned va0 = AT ? (unsigned)((voA[0] * krl + nx_mi * GM + (lane & 31) * 4) * 4) : voA[0];
+        const unsigned va1 = AT ? (unsigned)((voA[1] * krl + nx_mi * GM + (lane & 31) * 4) * 4) : voA[1];
         // the k/q rows of the last chunk may lie past T: their offset goes into the per-lane part, which is what the
         // buffer's range check looks at (the scalar offset is not checked); such rows keep the stage's old contents
         // and meet Gt == 0 (the stages are cleared once at the start so that they never hold a NaN pattern)
         const unsigned kb = (unsigned)((size_t)k0 * ldo * 4);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)da, 16, voA[0], sa, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(da + 1024), 16, voA[1], sa, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)da, 16, va0, sa, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(da + 1024), 16, va1, sa, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)db, 16, voB[0] + kb, 0, 0, 0);
         if (NW >= 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(db + 1024), 16, voB[1] + kb, 0, 0, 0);
         if (NW >= 4) {
@@ -385,8 +406,9 @@ size_t interval_score_bwd_ws_bytes(int C, int T, int D)
 {
     if (!(D == 64 || D == 128 || D == 256) || T < 64 || C < 1) return 0;
     const size_t Tp = (size_t)round_up32(T);
-    if (Tp * Tp * 4 >= (1ull << 31)) return 0;                 // 32-bit buffer offsets inside a chain's slab
-    return (size_t)C * Tp * Tp * sizeof(float) + 4096;         // + slack for the transposed walk of the last tile
+    const size_t slab = gt_chain_floats((int)Tp);
+    if (slab * 4 >= (1ull << 31)) return 0;                    // 32-bit buffer offsets inside a chain's slab
+    return (size_t)C * slab * sizeof(float) + 4096;            // + slack for the transposed walk of the last tile
 }
 
 template <bool AT, int NW>
