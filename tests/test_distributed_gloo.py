@@ -67,3 +67,32 @@ def test_shard_chains_properties():
         assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= (4 if n % 4 == 0 else 1)
+
+
+def _grad_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from transkun_amd.dist import allreduce_gradients_flat
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+    m[0].bias.requires_grad_(False)                                   # frozen parameters are skipped
+    x = torch.full((4, 7), float(rank + 1))
+    m(x).sum().backward()
+    local = [p.grad.clone() for p in m.parameters() if p.requires_grad]
+    n = allreduce_gradients_flat(m.parameters(), bucket_bytes=64)     # tiny buckets: several collectives
+    torch.save({"local": local, "reduced": [p.grad.clone() for p in m.parameters() if p.requires_grad], "n": n},
+               os.path.join(out_dir, f"g{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce(tmp_path):
+    """SUM (no divide) of every trainable parameter's gradient across ranks, in flat buckets
+    (the semantics of TrainUtil.average_gradients, TrainUtil.py:36-48)."""
+    world = 2
+    mp.spawn(_grad_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), f"g{k}.pt")) for k in range(world)]
+    assert r[0]["n"] == r[1]["n"] and r[0]["n"] >= 2
+    for i in range(len(r[0]["local"])):
+        want = r[0]["local"][i] + r[1]["local"][i]
+        assert torch.allclose(r[0]["reduced"][i], want) and torch.allclose(r[1]["reduced"][i], want)
