@@ -433,7 +433,7 @@ def test_fused_scorer_crf(gpu, N, P, T, D, ls):
 @pytest.mark.parametrize("T,B,n", [(333, 46, 12), (1024, 352, 4)])
 def test_repeatable_bits(gpu, T, B, n):
     """Every reduction order is fixed by the task decomposition, not by timing: repeated launches give bit-identical
-    logZ, alpha, gradient and decoded intervals (a race in the hand-off protocol would show up here)."""
+    logZ, alpha, gradient, decoded intervals and path scores (a race in the hand-off protocol would show up here)."""
     import hashlib
     from transkun_amd import _lib, synth
     import importlib
@@ -442,12 +442,14 @@ def test_repeatable_bits(gpu, T, B, n):
     s, nz = synth.crf_inputs(T, B, 77, gpu)
     g = synth.hash_normal(B, 5, gpu)
     dig = lambda t: hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()
+    iv_pairs, iv_offs = nsci.pack_intervals(synth.synthetic_intervals(T, B, seed=3), T, B, gpu)
     ref = None
     for _ in range(n):
         lz, v = nsci._logz_fwd_raw(s, nz, True)
         ds, dn, q = nsci._logz_bwd_raw(s, nz, v, lz, g, True)
         pairs, offs = nsci._viterbi_raw(s, nz, None, False)
-        cur = (dig(lz), dig(v), dig(ds), dig(dn), dig(q), dig(offs), dig(pairs[:int(offs[-1])]))
+        path = nsci._eval_path_raw(s, nz, iv_pairs, iv_offs)             # fixed-order reduction: no atomics
+        cur = (dig(lz), dig(v), dig(ds), dig(dn), dig(q), dig(offs), dig(pairs[:int(offs[-1])]), dig(path))
         ref = ref or cur
         assert cur == ref
     assert _lib.device_status() == 0

@@ -5,43 +5,40 @@
 //   out[c] = sum_{(b,e) in path_c} ( s[e,b,c] - (cum[e]-cum[b]) ) + cum[T-1],  cum = prefix sums of noise
 //          = sum_path s[e,b,c]  -  sum_path sum_{t=b}^{e-1} noise[t,c]  +  sum_t noise[t,c]
 // The second form needs no prefix array: intervals are short and never overlap, so the inner sums touch
-// at most T-1 values per chain.  Sums are accumulated in double (torch's CPU cumsum does the same).
+// at most T-1 values per chain.  Sums are accumulated in double (torch's CPU cumsum does the same), in an order
+// that is fixed by the thread layout: evalPath is bit-reproducible run to run.
 #include "common.h"
 
 namespace semicrf {
 
-// blockIdx.y < NCHUNK: partial column sums of noise (chain = lane, a chunk of time steps per block row), folded
-// into out[c] with one float atomic per (chunk, chain); blockIdx.y == NCHUNK: one thread per interval adds
-// s[e,b,c] - sum_{t in [b,e)} noise[t,c].  out must be zeroed before the launch.
-constexpr int EP_NCHUNK = 64;
+// One 256-thread workgroup per chain: the threads stride over the chain's noise column and over its intervals (one
+// s[e,b,c] gather and the short covered-noise sum each), then a fixed-order tree reduction in double -- the result does
+// not depend on scheduling (no atomics), needs no zeroed output, and the whole call is one launch.
+constexpr int EP_THREADS = 256;
 
-__global__ __launch_bounds__(64) void eval_path_kernel(const float* __restrict__ score,
-                                                        const float* __restrict__ noise, int T, int B, int K,
-                                                        const int* __restrict__ pairs,
-                                                        const int* __restrict__ offsets, float* out)
+__global__ __launch_bounds__(EP_THREADS) void eval_path_kernel(const float* __restrict__ score,
+                                                               const float* __restrict__ noise, int T, int B, int K,
+                                                               const int* __restrict__ pairs,
+                                                               const int* __restrict__ offsets, float* __restrict__ out)
 {
-    if (blockIdx.y < EP_NCHUNK) {
-        const int c = blockIdx.x * 64 + threadIdx.x;
-        if (c >= B) return;
-        const int per = (T - 1 + EP_NCHUNK - 1) / EP_NCHUNK;
-        const int t0 = blockIdx.y * per, t1 = (t0 + per < T - 1) ? t0 + per : T - 1;
-        double acc = 0.0;
-        for (int t = t0; t < t1; ++t) acc += (double)noise[(size_t)t * B + c];
-        if (t1 > t0) atomicAdd(out + c, (float)acc);
-    } else {
-        const int k = blockIdx.x * 64 + threadIdx.x;
-        if (k >= K) return;
-        int lo = 0, hi = B;                       // chain of interval k: largest c with offsets[c] <= k
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (offsets[mid] <= k) lo = mid; else hi = mid;
-        }
-        const int c = lo;
+    __shared__ double red[EP_THREADS];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double acc = 0.0;
+    for (int t = tid; t < T - 1; t += EP_THREADS) acc += (double)noise[(size_t)t * B + c];          // cum[T-1]
+    const int k0 = offsets[c], k1 = offsets[c + 1];
+    for (int k = k0 + tid; k < k1 && k < K; k += EP_THREADS) {
         const int b = pairs[2 * k], e = pairs[2 * k + 1];
         double covered = 0.0;
         for (int t = b; t < e; ++t) covered += (double)noise[(size_t)t * B + c];
-        atomicAdd(out + c, (float)((double)score[((size_t)e * T + b) * B + c] - covered));
+        acc += (double)score[((size_t)e * T + b) * B + c] - covered;
     }
+    red[tid] = acc;
+    __syncthreads();
+    for (int d = EP_THREADS / 2; d > 0; d >>= 1) {
+        if (tid < d) red[tid] += red[tid + d];
+        __syncthreads();
+    }
+    if (tid == 0) out[c] = (float)red[0];
 }
 
 // dNoise[t][c] += gout[c]  (d cum[T-1] / d noise): fully parallel
@@ -79,10 +76,7 @@ __global__ __launch_bounds__(256) void eval_path_bwd_pairs_kernel(const float* _
 void launch_eval_path(const float* score, const float* noise, int T, int B, int K, const int* pairs,
                       const int* offsets, float* out, hipStream_t stream)
 {
-    (void)hipMemsetAsync(out, 0, (size_t)B * sizeof(float), stream);
-    const int gx = ((B > K ? B : K) + 63) / 64;
-    hipLaunchKernelGGL(eval_path_kernel, dim3(gx, EP_NCHUNK + 1), dim3(64), 0, stream, score, noise, T, B, K, pairs,
-                       offsets, out);
+    hipLaunchKernelGGL(eval_path_kernel, dim3(B), dim3(EP_THREADS), 0, stream, score, noise, T, B, K, pairs, offsets, out);
 }
 
 void launch_eval_path_bwd(const float* gout, int T, int B, int K, const int* pairs, const int* offsets,
