@@ -541,3 +541,128 @@ def test_decode_to_attribute_features_on_device(gpu):
     batch = [lists[n * SYM:(n + 1) * SYM] for n in range(N)]
     a, b, sym_l, sc_l = attributes.fetchIntervalFeaturesBatch(ctx, batch)
     assert torch.equal(out[:, :D], a) and torch.equal(out[:, D:2 * D], b) and torch.equal(sym, sym_l) and torch.equal(sc, sc_l)
+
+
+# ---- segment-shaped goldens: scorer -> CRF -> logProb -> backward, decode -> features (BASELINE configs[3]) ----
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("route", ["fused", "unfused", "two_nodes"])
+@pytest.mark.parametrize("name", ["small", "T691_P90", "T691_N4"])
+def test_segment_logprob_vs_reference(gpu, name, route):
+    """ctx -> ScaledInnerProductIntervalScorer -> NeuralSemiCRFInterval -> logProb -> backward at the model's real shape
+    (T=691, 90 symbols, 1 and 4 segments) against what the reference's own modules produced on the glue of
+    ModelTransformer.py:199-225, :256-266 (tests/golden/segment_*.npz): the fused route (transkun_amd.fused, the dense
+    gradient never written), the unfused one (logProb as one node) and the reference's unchanged call pattern
+    (evalPath + computeLogZ as two nodes, :263-265)."""
+    from segment_common import SEGMENT_CASES, check_segment_grads, segment_inputs
+    from transkun_amd import CRF, _lib
+    from transkun_amd.fused import scorer_crf_logprob
+    from transkun_amd.scorer import ScaledInnerProductIntervalScorer
+    _lib.set_impl(0)
+    g = load_golden("segment_" + name)
+    N, P, T, D = SEGMENT_CASES[name][:4]
+    ctx0, W, bias, iv, gout, starts = segment_inputs(name, gpu)
+    m = ScaledInnerProductIntervalScorer(D, 1).to(gpu)
+    with torch.no_grad():
+        m.map[0].weight.copy_(W); m.map[0].bias.copy_(bias)
+    ctx = ctx0.clone().requires_grad_()
+    if route == "fused":
+        lp = scorer_crf_logprob(m, ctx, iv)
+    else:
+        S, b = m(ctx)
+        crf = CRF.NeuralSemiCRFInterval(S.flatten(-2, -1), b.flatten(-2, -1))
+        if route == "unfused":
+            lp = crf.logProb(iv)
+        else:
+            lp = crf.evalPath(iv) - crf.computeLogZ()
+    assert rel_err(lp.detach().cpu().numpy(), g["logProb"]) < 2e-5
+    (lp * gout).sum().backward()
+    check_segment_grads(g, ctx.grad.cpu().numpy(), m.map[0].weight.grad.cpu().numpy(), m.map[0].bias.grad.cpu().numpy())
+    assert _lib.device_status() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["small", "T691_P90", "T691_N4"])
+def test_segment_decode_and_features_vs_reference(gpu, name):
+    """transcribeFrames' CRF part (ModelTransformer.py:537-582) at the model's real shape: scores from the HIP scorer,
+    decode(forcedStartPos) on the device, attribute-head inputs gathered from the packed result -- against the
+    reference's decode lists and its fetchIntervalFeaturesBatch outputs."""
+    import hashlib
+    import importlib
+    from segment_common import SEGMENT_CASES, check_segment_features, segment_inputs
+    from transkun_amd import CRF, _lib, attributes
+    from transkun_amd.scorer import ScaledInnerProductIntervalScorer
+    nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
+    _lib.set_impl(0)
+    g = load_golden("segment_" + name)
+    N, P, T, D = SEGMENT_CASES[name][:4]
+    ctx, W, bias, iv, gout, starts = segment_inputs(name, gpu)
+    m = ScaledInnerProductIntervalScorer(D, 1).to(gpu)
+    with torch.no_grad():
+        m.map[0].weight.copy_(W); m.map[0].bias.copy_(bias)
+        S, b = m(ctx)
+        score, noise = S.flatten(-2, -1), b.flatten(-2, -1)
+    Sh = S.cpu().numpy().reshape(T, T, N * P).astype(np.float64)
+    assert rel_err((Sh * np.tril(np.ones((T, T)))[:, :, None]).sum(axis=(0, 1)), g["S_tril_sum"]) < 1e-4
+    crf = CRF.NeuralSemiCRFInterval(score, noise)
+    dec = crf.decode(forcedStartPos=starts, forward=False)
+    assert dec == unpack_lists(g["decode_pairs"], g["decode_offsets"])
+    dec0 = crf.decode()
+    counts = [len(x) for x in dec0]
+    off = np.zeros(N * P + 1, np.int64); np.cumsum(counts, out=off[1:])
+    pairs = np.asarray([p for l in dec0 for p in l], dtype=np.int32).reshape(-1, 2)
+    h = hashlib.sha256(); h.update(off.astype("<i8").tobytes()); h.update(pairs.astype("<i4").tobytes())
+    assert h.hexdigest() == str(g["decode_nostart_sha256"])
+    # decode -> features on the device (packed pairs never leave HBM)
+    st = torch.tensor(starts, dtype=torch.int32, device=gpu)
+    pr, offs = nsci._viterbi_raw(score.contiguous(), noise.contiguous(), st, False)
+    out, sym, sc = attributes.attribute_input_packed(ctx, pr, offs)
+    K = int(offs[-1])
+    assert K == len(g["decode_pairs"])
+    check_segment_features(g, out[:K, :D].cpu().numpy(), out[:K, D:2 * D].cpu().numpy(), sym[:K].cpu().numpy(), sc[:K].cpu().numpy())
+    assert _lib.device_status() == 0
+
+
+MODEL_LARGE = [(1024, 88, "model"), (691, 90, "model"), (691, 90, "randn"), (691, 360, "model"), (691, 360, "randn")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,B,kind", MODEL_LARGE, ids=[f"T{t}_B{b}_{k}" for t, b, k in MODEL_LARGE])
+def test_model_shape_crf_vs_reference(gpu, T, B, kind):
+    """The CRF kernels on model-like scores (+-1e2..1e3 |e-b|, noise == 0) at T=1024 and at the model's real shape
+    T=691 x 90 / 360 chains (randn there too): logProb, gradients and two decodes against the reference's outputs."""
+    import hashlib
+    from transkun_amd import CRF, _lib, synth
+    _lib.set_impl(0)
+    g = load_golden(f"large_T{T}_B{B}_{kind}")
+    seed = int(g["meta"][2])
+    score, noise = synth.crf_inputs(T, B, seed, gpu, kind)
+    iv = synth.synthetic_intervals(T, B, seed=seed)
+    s = score.requires_grad_(); n = noise.requires_grad_()
+    crf = CRF.NeuralSemiCRFInterval(s, n)
+    lp = crf.logProb(iv)
+    assert rel_err(lp.detach().cpu().numpy(), g["logProb"]) < LOGZ_TOL
+    assert rel_err(crf.computeLogZ().detach().cpu().numpy(), g["logZ"]) < LOGZ_TOL
+    assert rel_err(crf.computeLogZ().detach().cpu().numpy(), g["truth_logZ"]) < LOGZ_TOL
+    assert rel_err(crf.evalPath(iv).detach().cpu().numpy(), g["evalPath"]) < LOGZ_TOL
+    (-lp.sum()).backward()
+    gt = grad_tol(g["logZ"])
+    dn = n.grad.cpu().numpy()
+    ref_err = max(float(np.abs(g["dNoise_logProb"] - g["truth_dNoise_logProb"]).max()), 1e-4)
+    assert float(np.abs(dn - g["truth_dNoise_logProb"]).max()) < 1.5 * ref_err
+    assert rel_err(dn, g["dNoise_logProb"]) < 2.5 * ref_err
+    rows = [int(x) for x in g["dScore_rows"]]
+    assert rel_err(s.grad[rows][:, :, :8].cpu().numpy(), g["dScore_logProb_rows"]) < 2.5 * ref_err
+    assert rel_err(s.grad.double().sum(dim=(0, 1)).cpu().numpy(), g["dScore_logProb_sum"]) < 4 * gt
+    iu = torch.triu_indices(T, T, 1, device=gpu)
+    assert float(s.grad[iu[0], iu[1]].abs().max()) == 0.0
+    for nm in ("none", "mixed"):
+        st = [int(x) for x in g[f"decode_{nm}_start"]] if f"decode_{nm}_start" in g else None
+        res = crf.decode(forcedStartPos=st)
+        counts = [len(x) for x in res]
+        off = np.zeros(B + 1, np.int64); np.cumsum(counts, out=off[1:])
+        assert np.array_equal(off, g[f"decode_{nm}_offsets"])
+        pairs = np.asarray([p for l in res for p in l], dtype=np.int32).reshape(-1, 2)
+        h = hashlib.sha256(); h.update(off.astype("<i8").tobytes()); h.update(pairs.astype("<i4").tobytes())
+        assert h.hexdigest() == str(g[f"decode_{nm}_sha256"])
+    assert _lib.device_status() == 0

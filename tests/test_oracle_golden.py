@@ -172,3 +172,51 @@ def test_attribute_features_oracle(oracle, name):
     g, ctx, flat, batch, _ = _attr_case(name)
     a, b, sym, sc = oracle.fetch_interval_features(ctx.numpy(), batch)
     check_attr_outputs(g, a, b, sym, sc)
+
+
+@pytest.mark.parametrize("name", ["small", "T691_P90"])
+def test_segment_oracle(oracle, name):
+    """The oracle's scorer + CRF composite (interval_score -> forward_backward / eval_path / viterbi -> the scorer's
+    gradient in f64 numpy -> fetch_interval_features) against the reference's own modules run on the model glue
+    (ModelTransformer.py:199-225, :256-266, :537-582): tests/golden/segment_*.npz."""
+    import torch
+    from segment_common import SEGMENT_CASES, check_segment_features, check_segment_grads, segment_inputs
+    g = load_golden("segment_" + name)
+    N, P, T, D = SEGMENT_CASES[name][:4]
+    C = N * P
+    ctx, W, bias, iv, gout, starts = segment_inputs(name)
+    y = torch.nn.functional.linear(ctx, W, bias)
+    q, k, diag = (t.reshape(C, T, -1).numpy() for t in y.split([D, D, 1], dim=-1))
+    S = oracle.interval_score(q, k, diag[..., 0], "linear")
+    Sd = S.astype(np.float64)
+    assert rel_err((Sd * np.tril(np.ones((T, T)))[:, :, None]).sum(axis=(0, 1)), g["S_tril_sum"]) < 1e-4
+    noise = np.zeros((T - 1, C), np.float32)
+    logz, marg, _, _, _ = oracle.forward_backward(S, noise)
+    path = oracle.eval_path(iv, S, noise)
+    assert rel_err(logz, g["logZ"]) < 2e-5
+    assert rel_err(path, g["evalPath"]) < 2e-5
+    assert rel_err(path - logz, g["logProb"]) < 2e-5
+    # decode on the oracle's scores == the reference's decode on the reference's scores
+    assert oracle.viterbi(S, noise, starts) == unpack_lists(g["decode_pairs"], g["decode_offsets"])
+    # gradient of sum(gout * logProb): dS = gout * (onehot(path) - marginals), pushed through the scorer in f64
+    go = gout.numpy().astype(np.float64)
+    dS = -marg.astype(np.float64) * go[None, None, :]
+    for c, lst in enumerate(iv):
+        for b0, e0 in lst:
+            dS[e0, b0, c] += go[c]
+    t = np.arange(T)
+    ln = np.abs(t[:, None] - t[None, :]).astype(np.float64)
+    G = np.tril(dS.transpose(2, 0, 1) * ln[None]) / np.sqrt(D)                # [C, e, b]
+    dq = np.matmul(G, k.astype(np.float64))
+    dk = np.matmul(G.transpose(0, 2, 1), q.astype(np.float64))
+    dd = np.diagonal(dS, axis1=0, axis2=1)                                   # [C, T]
+    dy = np.concatenate([dq, dk, dd[..., None]], axis=-1).reshape(C * T, 2 * D + 1)
+    x = ctx.numpy().astype(np.float64).reshape(C * T, D)
+    dctx = (dy @ W.numpy().astype(np.float64)).reshape(N, P, T, D)
+    dW = dy.T @ x
+    dbias = dy.sum(axis=0)
+    check_segment_grads(g, dctx, dW, dbias)
+    dec = unpack_lists(g["decode_pairs"], g["decode_offsets"])
+    batch = [dec[n * P:(n + 1) * P] for n in range(N)]
+    a, b, sym, sc = oracle.fetch_interval_features(ctx.numpy(), batch)
+    check_segment_features(g, a, b, sym, sc)

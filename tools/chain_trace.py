@@ -1,11 +1,15 @@
 """Hand-off chain probes (probe build, debug flag 16): publish u(k-4) -> panel sees it -> partial stored -> far wave -> owner."""
-import importlib, os, sys
+import argparse, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 os.environ["SEMICRF_DEBUG_FLAGS"] = "16"; os.environ["SEMICRF_DEBUG_KEEP_WS"] = "1"
 from transkun_amd import _lib, synth
 nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
-T, B = 1024, 352
+ap = argparse.ArgumentParser()
+ap.add_argument("--T", type=int, default=1024); ap.add_argument("--B", type=int, default=352)
+a = ap.parse_args()
+T, B = a.T, a.B
+K = (T + 15) // 16
 dev = torch.device("cuda:0")
 s, n = synth.crf_inputs(T, B, 1234, dev)
 for _ in range(3): nsci._logz_fwd_raw(s, n, True)
@@ -15,7 +19,15 @@ CT = 16 * 64 * 4
 ts = ws[CT:CT + T * 8].view(torch.int64).cpu().numpy().astype(np.float64) / 100.0     # s_memrealtime: 100 MHz -> us
 pub, got, far, seen, stored = ts[0:64], ts[64:128], ts[128:192], ts[192:256], ts[256:320]
 t0 = pub[0]
-print("k: publish(k-4)  seen(+)  stored(+)  far(+)  owner(+)   | block period")
+print(f"T={T} B={B}: k: publish(k-4)  seen(+)  stored(+)  far(+)  owner(+)   | block period")
 for k in list(range(4, 40, 3)) + [48, 56, 63]:
+    if k >= K: break
     p = pub[k - 4]
     print(f"{k:3d}: {p - t0:8.2f}  {seen[k] - p:6.2f}  {stored[k] - p:6.2f}  {far[k] - p:6.2f}  {got[k] - p:6.2f}   | {pub[k] - pub[k-1]:5.2f}")
+ks = np.arange(4, min(K, 64))
+p = pub[ks - 4]
+for name, arr in (("seen", seen), ("stored", stored), ("far", far), ("owner", got)):
+    d = arr[ks] - p
+    print(f"  {name:7s}: mean {d.mean():5.2f}  median {np.median(d):5.2f}  p90 {np.percentile(d, 90):5.2f}  max {d.max():5.2f}")
+per = np.diff(pub[:min(K, 64)])
+print(f"  block period: mean {per.mean():.2f} median {np.median(per):.2f} p90 {np.percentile(per, 90):.2f}; total {pub[min(K,64)-1]-t0:.1f} us")

@@ -335,14 +335,157 @@ def case_attr():
         save(f"attr_{name}", d)
 
 
+def ctx_weights(T, D):
+    t = np.arange(T)[:, None]
+    d = np.arange(D)[None, :]
+    return (((t * 31 + d * 17) % 64).astype(np.float64) / 64.0)
+
+
+SEGMENTS = {
+    # name: (N, P, T, D, ctx scale, weight scale, seed)      -- must match tests/conftest.py SEGMENT_CASES
+    "small": (2, 5, 48, 32, 0.5, 0.3, 3),
+    "T691_P90": (1, 90, 691, 256, 1.0, 1.0, 5),        # BASELINE.json configs[3]: one 16 s segment, model-scale scores
+    "T691_N4": (4, 90, 691, 256, 0.5, 0.3, 6),         # train.py's default batch of 4 segments (NBatch = 360), tame scores
+}
+
+
+def segment_inputs(N, P, T, D, cscale, wscale, seed, device="cpu"):
+    """ctx, Linear weight/bias, interval lists, upstream gradient and forced starts of a segment case -- all from the
+    integer hash (tests rebuild the same bits)."""
+    ctx = synth.hash_normal(N * P * T * D, 200 + seed, device).view(N, P, T, D) * cscale
+    W = synth.hash_normal((2 * D + 1) * D, 300 + seed, device).view(2 * D + 1, D) * (wscale / D ** 0.5)
+    bias = synth.hash_normal(2 * D + 1, 400 + seed, device) * 0.1
+    iv = synth.synthetic_intervals(T, N * P, seed=seed)
+    gout = synth.hash_normal(N * P, 500 + seed, device)
+    starts = [(c * 29 + 3) % (T // 2) for c in range(N * P)]
+    return ctx, W, bias, iv, gout, starts
+
+
+def case_segment(names=None):
+    """Scorer -> CRF -> logProb -> backward, decode(forcedStartPos) -> attribute features, all by the REFERENCE's modules
+    (LayersTransformer.ScaledInnerProductIntervalScorer, CRF.NeuralSemiCRFInterval, the lifted
+    fetchIntervalFeaturesBatch) on the glue of ModelTransformer.py:199-225, :256-266, :537-582.  Pins SURVEY 8f rank 1
+    (fused route) and BASELINE.json configs[3]'s scorer + CRF part at the model's real shape."""
+    import types
+    from transkun.LayersTransformer import ScaledInnerProductIntervalScorer
+    ref_fn = reference_fetch_interval_features()
+    torch.set_num_threads(8)
+    for name, (N, P, T, D, cscale, wscale, seed) in SEGMENTS.items():
+        if names and name not in names:
+            continue
+        t0 = time.time()
+        ctx, W, bias, iv, gout, starts = segment_inputs(N, P, T, D, cscale, wscale, seed)
+        m = ScaledInnerProductIntervalScorer(D, 1)
+        with torch.no_grad():
+            m.map[0].weight.copy_(W); m.map[0].bias.copy_(bias)
+        ctx = ctx.clone().requires_grad_()
+        S, b = m(ctx)                                                   # ModelTransformer.py:199-200
+        crf = REF.NeuralSemiCRFInterval(S.flatten(-2, -1), b.flatten(-2, -1))      # :215-222
+        path = crf.evalPath(iv)                                         # :263
+        logz = crf.computeLogZ()                                        # :264
+        lp = path - logz                                                # :265
+        (lp * gout).sum().backward()
+        C = N * P
+        g = ctx.grad.numpy().astype(np.float64)
+        w = ctx_weights(T, D)
+        psel = sorted(set([0, 1, P // 2, P - 1]))
+        tsel = sorted(set([0, 1, T // 3, T - 2, T - 1]))
+        d = {"meta": np.asarray([N, P, T, D, seed]), "scales": np.asarray([cscale, wscale]),
+             "logProb": lp.detach().numpy(), "logZ": logz.detach().numpy(), "evalPath": path.detach().numpy(),
+             "dctx_sum": g.sum(axis=(2, 3)), "dctx_wsum": (g * w[None, None]).sum(axis=(2, 3)),
+             "dctx_abs_sum": np.abs(g).sum(axis=(2, 3)),
+             "psel": np.asarray(psel), "tsel": np.asarray(tsel),
+             "dctx_rows": ctx.grad.numpy()[0][np.ix_(psel, tsel)].copy(),
+             "dW_rows": m.map[0].weight.grad.numpy()[[0, 1, D - 1, D, 2 * D - 1, 2 * D]].copy(),
+             "dW_rowsum": m.map[0].weight.grad.numpy().astype(np.float64).sum(axis=1),
+             "dbias": m.map[0].bias.grad.numpy().copy()}
+        Sd = S.detach()
+        d["S_tril_sum"] = torch.tril(Sd.permute(2, 3, 0, 1).double()).sum(dim=(2, 3)).reshape(-1).numpy()
+        print(f"  segment {name}: reference scorer + CRF logProb fwd+bwd {time.time() - t0:.1f}s; |logProb| max "
+              f"{np.abs(d['logProb']).max():.3g}")
+        # decode with forced starts (transcribeFrames :549) and the attribute-head inputs of the decoded path (:575-582)
+        t0 = time.time()
+        with torch.no_grad():
+            crf_d = REF.NeuralSemiCRFInterval(Sd.flatten(-2, -1), b.detach().flatten(-2, -1))
+            dec = crf_d.decode(forcedStartPos=starts, forward=False)
+            dec0 = crf_d.decode()
+        pr, off = pack(dec)
+        d["decode_start"] = np.asarray(starts, np.int32)
+        d["decode_pairs"] = pr; d["decode_offsets"] = off
+        d["decode_sha256"] = np.asarray(digest(dec))
+        d["decode_nostart_sha256"] = np.asarray(digest(dec0))
+        d["decode_nostart_offsets"] = pack(dec0)[1]
+        batch = [dec[n * P:(n + 1) * P] for n in range(N)]
+        if sum(len(x) for x in dec) > 0:
+            self_like = types.SimpleNamespace(targetMIDIPitch=list(range(P)))
+            a, bb, sym, sc = ref_fn(self_like, ctx.detach(), batch)
+            wv = (torch.arange(a.shape[0], dtype=torch.float64) % 7 + 1)[:, None]
+            d["attr_a_sum"] = a.double().sum(0).numpy(); d["attr_b_sum"] = bb.double().sum(0).numpy()
+            d["attr_ab_sum"] = (a.double() * bb.double()).sum(0).numpy()
+            d["attr_a_wsum"] = (a.double() * wv).sum(0).numpy(); d["attr_b_wsum"] = (bb.double() * wv).sum(0).numpy()
+            d["attr_symIdx"] = sym.numpy().astype(np.int32); d["attr_scatterIdx"] = sc.numpy().astype(np.int32)
+        print(f"  segment {name}: reference decode x2 + features {time.time() - t0:.1f}s; {len(pr)} intervals")
+        save(f"segment_{name}", d)
+        del S, crf, ctx, g
+
+
+MODEL_LARGE = [(1024, 88, 1234), (691, 90, 77), (691, 360, 78)]
+
+
+def case_model_large():
+    """CRF kernels on model-like scores (+-1e2..1e3 * |e-b|, noise == 0: SURVEY hard part 6) at the large sizes, and at the
+    model's real shape T=691 x 90/360 chains; randn at T=691 too.  Outputs only."""
+    torch.set_num_threads(8)
+    from oracle import oracle as cpu_oracle
+    for T, B, seed in MODEL_LARGE:
+        for kind in (("model",) if T == 1024 else ("model", "randn")):
+            t0 = time.time()
+            score, noise = synth.crf_inputs(T, B, seed, "cpu", kind)
+            intervals = synth.synthetic_intervals(T, B, seed=seed)
+            s = score.requires_grad_(); n = noise.requires_grad_()
+            crf = REF.NeuralSemiCRFInterval(s, n)
+            path = crf.evalPath(intervals); logz = crf.computeLogZ()
+            lp = path - logz
+            (-lp.sum()).backward()
+            g = s.grad.numpy(); w = grad_weights(T)
+            rows = [1, T // 2, T - 1]
+            d = {"meta": np.asarray([T, B, seed]), "evalPath": path.detach().numpy(), "logZ": logz.detach().numpy(),
+                 "logProb": lp.detach().numpy(), "dNoise_logProb": n.grad.numpy(),
+                 "dScore_logProb_sum": g.astype(np.float64).sum(axis=(0, 1)),
+                 "dScore_logProb_wsum": np.einsum("ebc,eb->c", g.astype(np.float64), w.astype(np.float64)),
+                 "dScore_rows": np.asarray(rows), "dScore_logProb_rows": g[rows][:, :, :8].copy()}
+            lz64, _, gn64, _, _ = cpu_oracle.forward_backward_f64(score.detach().numpy(), noise.detach().numpy())
+            unc = np.ones((T - 1, B))
+            for c, lst in enumerate(intervals):
+                for b0, e0 in lst:
+                    unc[b0:e0, c] -= 1.0
+            d["truth_logZ"] = lz64
+            d["truth_dNoise_logProb"] = (gn64 - unc).astype(np.float32)
+            with torch.no_grad():
+                sd, nd = score.detach(), noise.detach()
+                crf_d = REF.NeuralSemiCRFInterval(sd, nd)
+                for nm, st in (("none", None), ("mixed", [(c * 37) % T for c in range(B)])):
+                    res = crf_d.decode(forcedStartPos=st)
+                    p, o = pack(res)
+                    d[f"decode_{nm}_offsets"] = o
+                    d[f"decode_{nm}_sha256"] = np.asarray(digest(res))
+                    d[f"decode_{nm}_head"] = p[:64]
+                    if st is not None:
+                        d[f"decode_{nm}_start"] = np.asarray(st, np.int32)
+            print(f"  T={T} B={B} {kind}: reference logProb fwd+bwd + 2 decodes + f64 truth {time.time() - t0:.1f}s; "
+                  f"ref dNoise err vs truth {np.abs(d['dNoise_logProb'] - d['truth_dNoise_logProb']).max():.2e}")
+            save(f"large_T{T}_B{B}_{kind}", d)
+            del g, s, n, crf, score, noise
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--large", action="store_true")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.manual_seed(0)
-    todo = a.only.split(",") if a.only else ["minimal", "edges", "medium", "scorer", "attr"] + (["large"] if a.large else [])
+    todo = a.only.split(",") if a.only else ["minimal", "edges", "medium", "scorer", "attr", "segment"] + (["large", "model_large"] if a.large else [])
     for t in todo:
         print("case", t)
         {"minimal": case_minimal, "edges": case_edges, "medium": case_medium, "scorer": case_scorer,
-         "large": case_large, "attr": case_attr}[t]()
+         "large": case_large, "attr": case_attr, "segment": case_segment, "model_large": case_model_large}[t]()
