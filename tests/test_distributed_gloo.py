@@ -96,3 +96,68 @@ def test_flat_gradient_allreduce(tmp_path):
     for i in range(len(r[0]["local"])):
         want = r[0]["local"][i] + r[1]["local"][i]
         assert torch.allclose(r[0]["reduced"][i], want) and torch.allclose(r[1]["reduced"][i], want)
+
+
+def test_bench_launcher_creates_its_ranks():
+    """`python bench.py --gpus 2` without torchrun must create two ranks by itself and report the world size the
+    process group saw; a launcher/--gpus mismatch must refuse instead of printing a 1-rank line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-launch", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["allreduce_sum"] == 2.0
+    env2 = dict(env, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-launch"],
+                       capture_output=True, text=True, timeout=120, env=env2)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def _cpu_log_prob(scorer, ctx, intervals):
+    """CPU stand-in for scorer -> CRF -> logProb with the same signature and output shape ([N*P]); only the exchange
+    around it is under test here (the HIP path itself is covered by the -m gpu tests)."""
+    y = scorer.map[0](ctx)                                   # [N,P,T,2D+1]
+    return -(y ** 2).mean(dim=(-1, -2)).reshape(-1)
+
+
+def _train_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from transkun_amd import synth
+    from transkun_amd.trainstep import SegmentModel, train_step
+    torch.manual_seed(0)                                      # same replica on every rank (train.py:69-73 loads one checkpoint)
+    model = SegmentModel(size=8, total_params=5000)
+    N, P, T = 2, 3, 10
+    ctx = synth.hash_normal(N * P * T * 8, 50 + rank, "cpu").view(N, P, T, 8)
+    stats, ncoll = train_step(model, ctx, None, seconds_per_segment=16.0, log_prob=_cpu_log_prob, bucket_bytes=4096)
+    # the same step without any exchange, for the expected sums
+    local = SegmentModel(size=8, total_params=5000)
+    local.load_state_dict(model.state_dict())
+    logp = _cpu_log_prob(local.scorer, ctx, None).view(N, -1)
+    loss = -logp.sum(-1).mean()
+    (loss / 50).backward()
+    torch.save({"stats": stats, "ncoll": ncoll, "loss": float(loss),
+                "grads": [p.grad.clone() for p in model.parameters()],
+                "local": [(p.grad.clone() if p.grad is not None else torch.full_like(p, 1e-3)) for p in local.parameters()]},
+               os.path.join(out_dir, f"t{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_shaped_step_two_ranks(tmp_path):
+    """train.py:186-189 + :214-229 over two ranks: the [3] stats are summed, every parameter's gradient is the SUM of the
+    ranks' local gradients (no divide, TrainUtil.py:44-49), exchanged as a few flat buckets."""
+    world = 2
+    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(tmp_path, f"t{r}.pt"), weights_only=False) for r in range(world)]
+    for p in parts:
+        assert float(p["stats"][0]) == pytest.approx(sum(q["loss"] for q in parts), rel=1e-6)
+        assert float(p["stats"][1]) == 16.0 * 2 * world and float(p["stats"][2]) == world
+        assert 1 < p["ncoll"] < 10                                   # buckets, not one message per parameter
+        for i, g in enumerate(p["grads"]):
+            want = sum(q["local"][i] for q in parts)
+            assert torch.allclose(g, want, rtol=1e-6, atol=1e-9)

@@ -15,7 +15,7 @@ s, n = synth.crf_inputs(T, B, 1234, dev)
 for _ in range(3): nsci._logz_fwd_raw(s, n, True)
 torch.cuda.synchronize()
 ws = nsci._DEBUG_WS[0]
-CT = 16 * 64 * 4
+CT = 16 * 256 * 4
 ts = ws[CT:CT + T * 8].view(torch.int64).cpu().numpy().astype(np.float64) / 100.0     # s_memrealtime: 100 MHz -> us
 pub, got, far, seen, stored = ts[0:64], ts[64:128], ts[128:192], ts[192:256], ts[256:320]
 t0 = pub[0]
@@ -29,5 +29,10 @@ p = pub[ks - 4]
 for name, arr in (("seen", seen), ("stored", stored), ("far", far), ("owner", got)):
     d = arr[ks] - p
     print(f"  {name:7s}: mean {d.mean():5.2f}  median {np.median(d):5.2f}  p90 {np.percentile(d, 90):5.2f}  max {d.max():5.2f}")
+print("  publish time of block k (us):", [round(float(pub[k] - t0), 1) for k in range(0, min(K, 64), 4)])
 per = np.diff(pub[:min(K, 64)])
+ctl = ws[:1024].view(torch.int32).cpu().numpy().astype(np.int64)
+print("  probes: idle peeks %d, tasks last-part %d, full-part %d; prog %d; heads %s" % (
+    (ctl[80] + 1) % 2**32, (ctl[81] + 1) % 2**32, (ctl[82] + 1) % 2**32, ctl[128],
+    [int((x + 1) % 2**32) for x in ctl[32:37]]))
 print(f"  block period: mean {per.mean():.2f} median {np.median(per):.2f} p90 {np.percentile(per, 90):.2f}; total {pub[min(K,64)-1]-t0:.1f} us")

@@ -15,7 +15,7 @@ for _ in range(3):
     nsci._logz_fwd_raw(s, n, True)
 torch.cuda.synchronize()
 ws = nsci._DEBUG_WS[0]
-CT = 16 * 64 * 4
+CT = 16 * 256 * 4
 ts = ws[CT:CT + a.T * 8].view(torch.int64).cpu().numpy()
 d = np.diff(ts) if ts.any() else np.zeros(a.T - 1)
 print(f"T={a.T} B={a.B} flags={a.flags}: total {ts[-1]-ts[0]} ticks over {a.T-1} steps; mean {d.mean():.1f} median {np.median(d):.1f}")

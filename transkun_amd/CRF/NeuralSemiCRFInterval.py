@@ -16,7 +16,6 @@ What differs from the reference, invisibly at the API:
 from __future__ import annotations
 
 import os
-from itertools import chain
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -51,39 +50,40 @@ def _prep(t: torch.Tensor) -> torch.Tensor:
 
 
 def pack_intervals(intervals: Sequence[Sequence[Tuple[int, int]]], T: int, B: int, device):
-    """List[List[(begin,end)]] (len B) -> (pairs int32 [K,2], offsets int32 [B+1]) on `device`."""
+    """List[List[(begin,end)]] (len B) -> (pairs int32 [K,2], offsets int32 [B+1]) on `device`.
+    One pass in C (csrc/pymarshal.c) into pinned host buffers, then two asynchronous copies."""
     assert len(intervals) == B, f"expected {B} interval lists, got {len(intervals)}"
-    counts = np.fromiter((len(x) for x in intervals), dtype=np.int64, count=B)
-    offsets = np.zeros(B + 1, dtype=np.int32)
-    np.cumsum(counts, out=offsets[1:])
-    K = int(offsets[-1])
-    flat = np.fromiter(chain.from_iterable(chain.from_iterable(intervals)), dtype=np.int64, count=2 * K)
-    if K:
-        pr = flat.reshape(K, 2)
-        if (pr < 0).any() or (pr >= T).any():
-            raise IndexError(f"interval index out of range for T={T}")   # reference: gather index error
-    pairs_t = torch.from_numpy(flat.astype(np.int32).reshape(K, 2) if K else np.zeros((1, 2), np.int32))
-    offsets_t = torch.from_numpy(offsets)
-    pairs_d = pairs_t.to(device, non_blocking=True)
+    mm = _lib.marshal()
+    K = int(mm.count(intervals))
+    pin = torch.device(device).type == "cuda"
+    pairs_h = torch.empty(max(K, 1), 2, dtype=torch.int32, pin_memory=pin)
+    offsets_h = torch.empty(B + 1, dtype=torch.int32, pin_memory=pin)
+    if K == 0:
+        pairs_h.zero_()
+    k = mm.pack_into(intervals, pairs_h.data_ptr(), max(K, 1), offsets_h.data_ptr(), T)   # IndexError when out of range
+    assert k == K
+    pairs_d = pairs_h.to(device, non_blocking=True)
     pairs_d._semicrf_K = K          # number of real intervals (the tensor holds one dummy row when K == 0)
-    return pairs_d, offsets_t.to(device, non_blocking=True)
+    return pairs_d, offsets_h.to(device, non_blocking=True)
 
 
-_PAIR_DTYPE = np.dtype([("b", "<i4"), ("e", "<i4")])
-
-
-def unpack_intervals(pairs_host: torch.Tensor, offsets_host: torch.Tensor) -> Intervals:
-    """packed int32 [K,2] + offsets [B+1] -> List[List[Tuple[int,int]]] (the reference's result type).
-    A structured-dtype tolist() builds the (begin, end) tuples in C; the cyclic GC is paused meanwhile
-    (hundreds of thousands of fresh tuples would otherwise trigger several full collections)."""
+def unpack_intervals(pairs_host: torch.Tensor, offsets_host: torch.Tensor, T: int = 1 << 30) -> Intervals:
+    """packed int32 [K,2] + offsets [B+1] (host) -> List[List[Tuple[int,int]]] (the reference's result type), built in C
+    with one shared int object per frame index (csrc/pymarshal.c); the cyclic GC is paused meanwhile (hundreds of
+    thousands of fresh tuples would otherwise trigger several full collections)."""
     import gc
-    arr = np.ascontiguousarray(pairs_host.numpy().reshape(-1, 2).astype(np.int32, copy=False))
+    pairs_host = pairs_host.contiguous()
+    offsets_host = offsets_host.contiguous()
+    assert pairs_host.dtype == torch.int32 and offsets_host.dtype == torch.int32
+    B = offsets_host.numel() - 1
+    total = int(offsets_host[-1]) if B >= 0 else 0
+    assert pairs_host.numel() >= 2 * total
+    if T >= 1 << 30:
+        T = int(pairs_host[:total].max()) + 1 if total else 1
     was = gc.isenabled()
     gc.disable()
     try:
-        tuples = arr.view(_PAIR_DTYPE).reshape(-1).tolist()
-        off = offsets_host.tolist()
-        return [tuples[off[c]:off[c + 1]] for c in range(len(off) - 1)]
+        return _lib.marshal().unpack(pairs_host.data_ptr(), offsets_host.data_ptr(), B, T)
     finally:
         if was:
             gc.enable()
@@ -281,7 +281,7 @@ def _decode(score, noiseScore, forcedStartPos: Optional[Sequence[int]], forward:
         off_h = offsets.cpu()                      # the one host sync of decode
         total = int(off_h[-1])
         pairs_h = pairs[:total].cpu()
-    return unpack_intervals(pairs_h, off_h)
+    return unpack_intervals(pairs_h, off_h, T)
 
 
 def viterbiBackward(score, noiseScore, forcedStartPos: Optional[List[int]] = None) -> Intervals:

@@ -62,7 +62,24 @@ def build_variant(name: str, defines, verbose: bool = False) -> str:
     return out
 
 
+MARSHAL = os.path.join(HERE, "_semicrf_marshal.so")
+
+
+def build_marshal(force: bool = False) -> str:
+    """The CPython helper that packs / unpacks interval lists (host code, gcc)."""
+    import sysconfig
+    src = os.path.join(CSRC, "pymarshal.c")
+    if not force and os.path.exists(MARSHAL) and os.path.getmtime(MARSHAL) > os.path.getmtime(src):
+        return MARSHAL
+    cc = os.environ.get("CC") or shutil.which("gcc") or "cc"
+    tmp = MARSHAL + ".tmp"
+    subprocess.check_call([cc, "-O2", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"], src, "-o", tmp])
+    os.replace(tmp, MARSHAL)
+    return MARSHAL
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    build_marshal(force)
     if not force and not _stale():
         return LIB
     objdir = os.path.join(HERE, "csrc", "_obj")

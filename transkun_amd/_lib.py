@@ -72,6 +72,22 @@ def load():
     return _lib
 
 
+_marshal = None
+
+
+def marshal():
+    """The CPython helper module that packs / unpacks interval lists (csrc/pymarshal.c, built by _build.build())."""
+    global _marshal
+    if _marshal is None:
+        try:
+            from . import _semicrf_marshal as m
+        except ImportError as ex:
+            raise SemiCRFLibraryError("transkun_amd/_semicrf_marshal.so not found: build it with "
+                                      "`python -m transkun_amd._build`") from ex
+        _marshal = m
+    return _marshal
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().semicrf_last_error().decode(errors="replace")

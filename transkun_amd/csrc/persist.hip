@@ -51,7 +51,10 @@ constexpr int GP = 32;             // chains per panel task (4 per lane)
 #define SEMICRF_TPT 16
 #endif
 constexpr int TPT = SEMICRF_TPT;   // tiles (column blocks) per panel task
-constexpr int NT = 512;            // threads per workgroup (8 waves, 2 per SIMD)
+#ifndef SEMICRF_NT
+#define SEMICRF_NT 640
+#endif
+constexpr int NT = SEMICRF_NT;     // threads per workgroup (10 waves: a spine workgroup = 4 ring + loader + far + 2 recent + 2 streaming waves)
 constexpr int MAX_CHUNKS = 16;     // chain chunks (launches) per call
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
@@ -60,6 +63,25 @@ constexpr int SPIN_LIMIT_LDS = 1 << 24;   // LDS polls (s_sleep 1): ~0.5 s
 constexpr float RESCALE_THR = 64.0f;
 constexpr unsigned CTRL_INIT = 0xffffffffu;  // initial value of every workspace word (one 0xff fill per launch)
 constexpr unsigned U_EMPTY = 0xffffffffu;  // not-yet-published u (a NaN pattern the spine never stores): the value is its own flag
+
+#ifndef SEMICRF_LOADER_PACE
+#define SEMICRF_LOADER_PACE 0      // s_sleep argument after every second band load of the loader wave (0: back to back)
+#endif
+#ifndef SEMICRF_DIET
+#define SEMICRF_DIET 1             // 1: forward-sweep panel math on packed fp32 pairs, exponent argument formed by one fma
+#endif
+#ifndef SEMICRF_EARLY_REFILL
+#define SEMICRF_EARLY_REFILL 0     // 1: a stage is refilled as soon as its tile sits in registers (before the math), not after it
+#endif
+#ifndef SEMICRF_SCHED
+#define SEMICRF_SCHED 0            // 0: one task queue in (block, part) order; 1: per-part queues, earliest block first among the
+#endif                             //    parts whose columns the ring has already published (see panel_next_task)
+// control words of a launch (all start at 0xffffffff).  Three separate 128-byte lines: counters that take atomics must
+// not share a line with words that are polled (hundreds of idle waves reading a line that others update atomically
+// slow every dequeue down to tens of microseconds).
+constexpr int CTRL_QHEAD = 32;        // [32 + i]: next task of scheduler queue i (atomic counters only)
+constexpr int CTRL_PROG = 128;        // [128]: block the first spine has published; [129 + i]: block queue i hands out
+constexpr int MAX_QUEUES = 63;        // one lane per queue in the peek (T <= 16 * (RING + 63 * TPT))
 
 typedef unsigned long long u64;
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -77,6 +99,10 @@ struct SweepParams {
     int hybridPanelWaves;  // panel waves of a spine workgroup (0..2)
     int hybridStart;       // ... which start once the ring has reached this row block
     int zeroWaves;         // GRAD: waves per panel workgroup that write the zero upper triangle of dScore (0: separate kernel)
+    int xr;                // the newest xr far tiles of every block are left to the RECENT waves of the spine workgroups (0: none)
+    int recentWaves;       // recent waves per spine workgroup
+    int rpart;             // index of the recent waves' slab in farg
+    int runAhead;          // EDF scheduler: a last-part task of block k may be taken once the ring has published block k-4-runAhead
     unsigned tag;          // nonzero launch epoch
     unsigned dbg;          // SEMICRF_DEBUG_FLAGS (timing experiments only; results are wrong when set):
                            // 1 spine ignores far partials, 2 panels exit at once, 4 panels do not wait for u,
@@ -295,6 +321,7 @@ __device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* 
                 off = off < last4 ? off : last4;
                 __builtin_amdgcn_global_load_lds((gbl_void_t*)(score + off),
                                                  (lds_void_t*)(lds + LDS_TILES + (slot * RING + i) * TILE_BYTES + q * 1024), 16, 0, 0);
+                if (SEMICRF_LOADER_PACE > 0 && (q & 1)) __builtin_amdgcn_s_sleep(SEMICRF_LOADER_PACE);
             }
         }
         const int prow_c = kr * PB + cr < T ? kr * PB + cr : T - 1;
@@ -355,7 +382,9 @@ __device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds
     for (int k = RING; k < K; ++k) {
         const int prow = k * PB + r;
         const bool rvalid = cvalid && prow < T;
-        const int nparts = (k - RING) / TPT + 1;
+        // parts of block k: the panels' column parts of its far tiles 0 .. k-RING-xr, plus the recent waves' partial
+        const int npanel = k >= RING + P.xr ? (k - RING - P.xr) / TPT + 1 : 0;
+        const int nparts = npanel + (P.xr > 0 ? 1 : 0);
         float aM = SEMICRF_NEG_INF, aS = 0.f;
         int aK = 0x7fffffff;
         if (rvalid) {
@@ -368,7 +397,8 @@ __device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds
                 while (true) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        if (i < np && !have[i]) gq[i] = load_granule(farg + ((size_t)(p0 + i) * T + prow) * Bs + c);
+                        if (i < np && !have[i])
+                            gq[i] = load_granule(farg + ((size_t)(p0 + i < npanel ? p0 + i : P.rpart) * T + prow) * Bs + c);
                     bool all = true;
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
@@ -655,6 +685,8 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
                 dScore[((size_t)frow * T + frow) * Bs + c] = gz * fexp2(arow + mine + draw - 2.0f * sp);
             if (MODE == 1) code[(size_t)c * T + frow] = (mykey + 1) | (sp > 0.0f ? 0x40000000 : 0);
         }
+        if (SEMICRF_SCHED != 0 && sg == 0 && lane == 0)      // scheduling hint for the panels: block k is out
+            atomicMax((int*)(ctrl + CTRL_PROG), k);
         if (SEMICRF_PANEL_PROBES && trace) ts[k] = __builtin_amdgcn_s_memrealtime();                 // chain probe: u published
     }
 }
@@ -767,6 +799,93 @@ __device__ __forceinline__ void panel_wait_younger(int y)
     else wait_vmcnt<0>();
 }
 
+// ---- task selection -----------------------------------------------------------------------------------------------
+// Block k = RING + q has q + 1 far tiles, cut at fixed columns into parts of TPT tiles: the FULL parts p < q / TPT and
+// the LAST part q / TPT (1..TPT tiles, it ends with the newest tile, whose u the ring publishes four blocks before it
+// needs the result).  One queue in (block, part) order makes the waves run ahead of the ring by (#waves / tasks per
+// block) blocks and wait there, while most of the far field -- the full parts of all later blocks -- could already be
+// streamed: at T=1024, NBatch=352 the panels idle through the first 20 blocks and the sweep is bound by their
+// throughput afterwards.  Instead: queue 0 holds the last parts in block order, queue 1 + p the full parts p in block
+// order; a full part is AVAILABLE once the ring has published its last column block, a last part is ELIGIBLE
+// `runAhead` blocks before its newest tile (those waves wait at the frontier, as before).  A wave takes the eligible
+// head of the earliest block (earliest deadline first; the last part wins a tie).  `prog` (the block spine 0 has
+// published) is only a hint: every tile still checks its u values, so a stale or early hint costs time, not results.
+
+struct PanelTask { int k, part, g, q4; };
+
+__device__ __forceinline__ bool panel_next_task(const SweepParams& P, PanelTask& t)
+{
+    unsigned* const ctrl = P.ctrl;
+    const int lane = threadIdx.x & 63;
+    const int G4 = P.nPanelGroups * 4;
+    if (SEMICRF_SCHED == 0) {
+        int task = 0;
+        if (lane == 0) task = (int)(atomicAdd(ctrl + 2, 1u) + 1u);        // counters start at 0xffffffff (one 0xff fill)
+        task = __builtin_amdgcn_readfirstlane(task);
+        if (task >= P.nTasks) return false;
+        t.q4 = task & 3;
+        const int t2 = task >> 2;
+        t.g = t2 % P.nPanelGroups;
+        int tt = t2 / P.nPanelGroups;
+        int a = 0;
+        while (tt >= TPT * (a + 1) * (a + 2) / 2) ++a;          // group a: blocks with a+1 parts
+        tt -= TPT * a * (a + 1) / 2;
+        const int q = a * TPT + tt / (a + 1);
+        t.part = tt % (a + 1);
+        t.k = RING + P.xr + q;
+        return true;
+    }
+    const int FQ = RING + P.xr;                                 // first block with panel tiles
+    int nq = (P.K - 1 - FQ) / TPT + 1;                          // queue i >= 1 exists when some block has a full part i - 1
+    if (nq > MAX_QUEUES) nq = MAX_QUEUES;
+    int spins = 0;
+    u64 dead = 0;                                               // queues this wave has seen run out
+    while (true) {
+        // peek: the block every queue is handing out (raised once per block by the wave that opens it: a read-mostly line)
+        unsigned v = 0;
+        if (lane <= nq) v = __hip_atomic_load(ctrl + CTRL_PROG + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int prog = (int)__builtin_amdgcn_readlane(v, 0);              // -1: nothing published yet
+        int best = -1, bestk = 0x7fffffff;
+        bool left = false;
+        for (int i = 0; i < nq; ++i) {
+            const int k0 = FQ + i * TPT;                                    // first block of queue i
+            if (P.K <= k0) continue;
+            const unsigned hv = (unsigned)__builtin_amdgcn_readlane(v, 1 + i);
+            const int kq = hv == CTRL_INIT ? k0 : (int)hv;
+            if (kq >= P.K || ((dead >> i) & 1)) continue;                   // handed out completely
+            left = true;
+            const bool ok = i == 0 ? kq <= prog + FQ + P.runAhead : prog >= i * TPT - 1;
+            if (ok && kq < bestk) { bestk = kq; best = i; }
+        }
+        if (!left) return false;
+        if (best < 0) {
+            if (SEMICRF_PANEL_PROBES && lane == 0) atomicAdd(ctrl + 80, 1u);      // probe: idle peeks
+            __builtin_amdgcn_s_sleep(64);
+            if (spin_abort(ctrl, spins, SPIN_LIMIT, 11)) return false;
+            continue;
+        }
+        int idx = 0;
+        if (lane == 0) idx = (int)(atomicAdd(ctrl + CTRL_QHEAD + best, 1u) + 1u);
+        idx = __builtin_amdgcn_readfirstlane(idx);
+        const int k0 = FQ + best * TPT;
+        const int size = (P.K - k0) * G4;
+        if (idx >= size) {
+            // past the end: the queue is empty (the summary only ever grows: a late "opened block k" cannot undo this)
+            if (lane == 0) atomicMax((int*)(ctrl + CTRL_PROG + 1 + best), P.K);
+            dead |= (u64)1 << best;
+            continue;
+        }
+        t.k = k0 + idx / G4;
+        const int rem = idx % G4;
+        if (rem == 0 && lane == 0) atomicMax((int*)(ctrl + CTRL_PROG + 1 + best), t.k);      // this wave opens block t.k of the queue
+        t.q4 = rem & 3;
+        t.g = rem >> 2;
+        t.part = best == 0 ? (t.k - FQ) / TPT : best - 1;
+        if (SEMICRF_PANEL_PROBES && lane == 0) atomicAdd(ctrl + (best == 0 ? 81 : 82), 1u);   // probe: tasks by kind
+        return true;
+    }
+}
+
 template <int MODE, int DIR, bool GRAD>
 __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int wslot)
 {
@@ -775,7 +894,6 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
     const unsigned dbg = P.dbg;
     unsigned* const ctrl = P.ctrl;
     u64* const farg = P.farg;
-    const int nTasks = P.nTasks, nPanelGroups = P.nPanelGroups;
     const float* const vfwd = P.vfwd;
     const float* const logZp = P.logZ;
     const float* const goutp = P.gout;
@@ -788,23 +906,13 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
     const auto ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.ug, 0, (int)((size_t)T * Bs * 4), 0x00020000);
 
     while (true) {
-        // ---- next task: (k, part, g, q4), ordered so that a task only waits on spine progress below k-3 ----
-        int task = 0;
-        if (lane == 0) task = (int)(atomicAdd(ctrl + 2, 1u) + 1u);        // counters start at 0xffffffff (one 0xff fill)
-        task = __builtin_amdgcn_readfirstlane(task);
-        if (task >= nTasks) break;
-        const int q4 = task & 3;
-        const int t2 = task >> 2;
-        const int g = t2 % nPanelGroups;
-        int tt = t2 / nPanelGroups;
-        int a = 0;
-        while (tt >= TPT * (a + 1) * (a + 2) / 2) ++a;          // group a: blocks with a+1 parts
-        tt -= TPT * a * (a + 1) / 2;
-        const int q = a * TPT + tt / (a + 1);
-        const int part = tt % (a + 1);
-        const int k = RING + q;
-        const int m0 = part * TPT;
-        const int m1 = (m0 + TPT < q + 1) ? m0 + TPT : q + 1;   // tiles m0 .. m1-1 of the q+1 far tiles of block k
+        // ---- next task: (k, part, g, q4); a task only waits on spine progress below k-3 ----
+        PanelTask tk;
+        if (!panel_next_task(P, tk)) break;
+        const int q = tk.k - RING - P.xr;                           // the newest tile the panels have of this block
+        const int m0 = tk.part * TPT;
+        const int m1 = (m0 + TPT < q + 1) ? m0 + TPT : q + 1;       // tiles m0 .. m1-1 of the q+1 panel tiles of block k
+        const int k = tk.k, part = tk.part, g = tk.g, q4 = tk.q4;
         const int pbase = k * PB + q4 * 4;
         if (pbase >= T) continue;                               // rows past the end (last block)
         const int c = c0 + g * GP + q8 * 4;
@@ -860,6 +968,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
         const unsigned grbase = lds_addr(stage0) + 8192u + (unsigned)lane * 16u;
         const bool probe_stream = SEMICRF_PANEL_PROBES && (dbg & 32u);
         const bool probe_nowait = SEMICRF_PANEL_PROBES && (dbg & 4u);
+        const bool probe_nou = SEMICRF_PANEL_PROBES && (dbg & 64u);       // math on whatever the stage holds, no u traffic
         const int nst = GRAD ? 2 * (T - pbase < 4 ? T - pbase : 4) : 0;    // gradient stores per tile (a lower bound)
 
         // vector-memory operations issued so far in this task (a lower bound: the waits below may only under-count
@@ -873,7 +982,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
         for (int i = 0; i < PNS; ++i)
             if (m0 + i < m1) {
                 panel_fetch_cells<DIR>(score, G, stage0 + i * PSTAGE_BYTES, m0 + i, T, Bs);
-                if (!probe_stream) panel_fetch_gran<false>(ursrc, stage0 + i * PSTAGE_BYTES, G.gvoff, m0 + i, B);
+                if (!probe_stream && !probe_nou) panel_fetch_gran<false>(ursrc, stage0 + i * PSTAGE_BYTES, G.gvoff, m0 + i, B);
                 issued += 10;
                 if (i == 0) mark0 = issued; else if (i == 1) mark1 = issued; else mark2 = issued;
             }
@@ -884,6 +993,15 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
             panel_wait_younger(issued - (s == 0 ? mark0 : (s == 1 ? mark1 : mark2)));
             v4u xo[8];
             panel_read_cells<DIR>(rdbase + (unsigned)(s * PSTAGE_BYTES), xo);
+            const bool refill = m + PNS < m1;
+            if (SEMICRF_EARLY_REFILL && refill) {
+                // the tile is in registers: its stage can take the cells of tile m + PNS right away, so that PNS tiles
+                // stay in flight while this one is processed (the u part follows once this tile's u has been read)
+                asm volatile("" ::: "memory");          // the LDS reads above come first
+                panel_fetch_cells<DIR>(score, G, stage, m + PNS, T, Bs);
+                issued += 8;
+                if (probe_stream) { if (s == 0) mark0 = issued; else if (s == 1) mark1 = issued; else mark2 = issued; }
+            }
             if (probe_stream) {          // streaming probe: touch the data, nothing else
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
@@ -923,17 +1041,71 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                         panel_read_gran(grbase + (unsigned)(s * PSTAGE_BYTES), g0, g1);
                     }
                 }
+                if (SEMICRF_EARLY_REFILL && refill && !probe_nou) {
+                    panel_fetch_gran<false>(ursrc, stage, G.gvoff, m + PNS, B);
+                    issued += 2;
+                    if (s == 0) mark0 = issued; else if (s == 1) mark1 = issued; else mark2 = issued;
+                }
                 if (frontier && m + 1 < m1) {
                     const int sn = s + 1 == PNS ? 0 : s + 1;
                     panel_fetch_gran<true>(ursrc, stage0 + sn * PSTAGE_BYTES, G.gvoff, m + 1, B);
                     issued += 2;
                     if (sn == 0) mark0 = issued; else if (sn == 1) mark1 = issued; else mark2 = issued;
                 }
-                if (SEMICRF_PANEL_PROBES && (dbg & 16u) && g == 0 && q4 == 0 && m == q && lane == 0) P.ts[192 + k] = __builtin_amdgcn_s_memrealtime();   // chain probe: newest tile's u seen
+                if (SEMICRF_PANEL_PROBES && (dbg & 16u) && P.xr == 0 && g == 0 && q4 == 0 && m == q && lane == 0) P.ts[192 + k] = __builtin_amdgcn_s_memrealtime();   // chain probe: newest tile's u seen
                 const float uv[2][4] = {{__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z), __uint_as_float(g0.w)},
                                         {__uint_as_float(g1.x), __uint_as_float(g1.y), __uint_as_float(g1.z), __uint_as_float(g1.w)}};
 
-                if (MODE == 0) {
+                if (MODE == 0 && !GRAD && SEMICRF_DIET) {
+                    // The same accumulation with half the vector instructions (the panels are issue- and power-bound next
+                    // to their loads): the exponent argument t - M = cell*log2e + (u - M) is ONE packed fma per two chains
+                    // on top of one packed subtract, the overflow test is a max3 tree over those arguments, the sums are
+                    // packed adds: 17 plain instructions + 8 exps per row of 8 cells instead of 35 + 8.
+                    typedef float v2f __attribute__((ext_vector_type(2)));
+                    const v2f l2e = {LOG2E, LOG2E};
+                    const v2f u2[2][2] = {{{uv[0][0], uv[0][1]}, {uv[0][2], uv[0][3]}}, {{uv[1][0], uv[1][1]}, {uv[1][2], uv[1][3]}}};
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        v2f e[2][2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const v4u xv = xo[rr * 2 + h];
+                            const v2f x2[2] = {{__uint_as_float(xv.x), __uint_as_float(xv.y)}, {__uint_as_float(xv.z), __uint_as_float(xv.w)}};
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const v2f mj = {aM[rr][2 * j], aM[rr][2 * j + 1]};
+                                e[h][j] = __builtin_elementwise_fma(x2[j], l2e, u2[h][j] - mj);      // M = -inf (empty): +inf
+                            }
+                        }
+                        const float emax = fmaxf(fmaxf(fmaxf(e[0][0].x, e[0][0].y), fmaxf(e[0][1].x, e[0][1].y)),
+                                                 fmaxf(fmaxf(e[1][0].x, e[1][0].y), fmaxf(e[1][1].x, e[1][1].y)));
+                        if (__any(emax > RESCALE_THR)) {
+                            // some accumulator's reference point is too low (always on the first tile): move it up
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float x0 = __uint_as_float(i == 0 ? xo[rr * 2].x : (i == 1 ? xo[rr * 2].y : (i == 2 ? xo[rr * 2].z : xo[rr * 2].w)));
+                                const float x1 = __uint_as_float(i == 0 ? xo[rr * 2 + 1].x : (i == 1 ? xo[rr * 2 + 1].y : (i == 2 ? xo[rr * 2 + 1].z : xo[rr * 2 + 1].w)));
+                                const float t0 = fmaf(x0, LOG2E, uv[0][i]), t1 = fmaf(x1, LOG2E, uv[1][i]);
+                                const float mx = fmaxf(aM[rr][i], fmaxf(t0, t1));
+                                if (mx > aM[rr][i] + RESCALE_THR) {
+                                    aS[rr][i] = aS[rr][i] * fexp2(aM[rr][i] - mx);     // -inf - mx -> exp2 = 0, S = 0
+                                    aM[rr][i] = mx;
+                                }
+                                const float e0 = t0 - aM[rr][i], e1 = t1 - aM[rr][i];
+                                if (i & 1) { e[0][i >> 1].y = e0; e[1][i >> 1].y = e1; } else { e[0][i >> 1].x = e0; e[1][i >> 1].x = e1; }
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            v2f sj = {aS[rr][2 * j], aS[rr][2 * j + 1]};
+                            const v2f p0 = {fexp2(e[0][j].x), fexp2(e[0][j].y)};
+                            const v2f p1 = {fexp2(e[1][j].x), fexp2(e[1][j].y)};
+                            sj = (sj + p0) + p1;
+                            aS[rr][2 * j] = sj.x; aS[rr][2 * j + 1] = sj.y;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if (MODE == 0) {
                     // t = u + cell*log2e; lazily rescaled accumulators: one exp per cell, rare rescale branch.
                     // One row at a time (scheduling fences in between) to bound the live registers.
                     const auto gs = __builtin_amdgcn_make_buffer_rsrc((void*)(GRAD ? dScore + panel_tile_off<DIR>(G, m, T, Bs) : nullptr), 0,
@@ -1003,9 +1175,9 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                 }
             }
             // ---- refill the stage PNS tiles ahead ----------------------------------------------------------
-            if (m + PNS < m1) {
+            if (!SEMICRF_EARLY_REFILL && refill) {
                 panel_fetch_cells<DIR>(score, G, stage, m + PNS, T, Bs);
-                if (!probe_stream) panel_fetch_gran<false>(ursrc, stage, G.gvoff, m + PNS, B);
+                if (!probe_stream && !probe_nou) panel_fetch_gran<false>(ursrc, stage, G.gvoff, m + PNS, B);
                 issued += 10;
                 if (s == 0) mark0 = issued; else if (s == 1) mark1 = issued; else mark2 = issued;
             }
@@ -1059,8 +1231,264 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                 store_granule(fbase + (size_t)pi * Bs + cc, gr);
             }
         }
-        if (SEMICRF_PANEL_PROBES && (dbg & 16u) && g == 0 && q4 == 0 && m1 == q + 1 && lane == 0) P.ts[256 + k] = __builtin_amdgcn_s_memrealtime();     // chain probe: partial stored
+        if (SEMICRF_PANEL_PROBES && (dbg & 16u) && P.xr == 0 && g == 0 && q4 == 0 && m1 == q + 1 && lane == 0) P.ts[256 + k] = __builtin_amdgcn_s_memrealtime();     // chain probe: partial stored
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RECENT role (per wave, in the spine workgroups)
+// ---------------------------------------------------------------------------------------------
+// The ring needs the far-field result of block k four blocks after it published the u of that field's newest tile, and
+// every microsecond of that hand-off beyond the 3-block slack stalls all eight rings of a chain group.  In a panel task
+// the newest tile waits for a free wave behind the bulk of the far field, is polled from a compute unit with deep
+// memory queues, and ends in a 14-exchange reduction.  The recent waves take the newest xr tiles of every block out of
+// that path: two waves per spine workgroup (compute units that stream little), a FIXED share of the (block, chain group,
+// row quarter) triples each -- triple i belongs to recent wave i mod #waves, no queue -- and a lane mapping without any
+// cross-lane reduction: lane = (row of the quarter, PAIR of chains), the 16 columns of a tile are walked serially from
+// the LDS stage, so that a lane ends with the finished partial of its two (row, chain) cells and stores them itself.
+// The cells of the next tiles are prefetched (they do not depend on u); u is polled tile by tile.
+constexpr int RNS = 3;                        // LDS stages of a recent wave (PSTAGE_BYTES each, the panels' layout)
+
+template <int DIR>
+__device__ __forceinline__ unsigned recent_cell_off(int rr, int col, int cp)
+{
+    const int h = col >> 3, s8 = col & 7;
+    return DIR == 0 ? (unsigned)((rr * 2 + h) * 1024 + s8 * 128 + cp * 8)
+                    : (unsigned)(((s8 >> 1) + 4 * h) * 1024 + rr * 256 + (s8 & 1) * 128 + cp * 8);
+}
+
+// 16 ds_read_b64 in flight, one wait: value c comes from (c even ? base_even : base_odd) + off[c]
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+template <int O0, int O1, int O2, int O3, int O4, int O5, int O6, int O7, int O8, int O9, int O10, int O11, int O12, int O13, int O14, int O15>
+__device__ __forceinline__ void lds_read16_b64(unsigned be, unsigned bo, v2f_t (&o)[16])
+{
+    asm volatile("ds_read_b64 %0, %16 offset:%18\n\tds_read_b64 %1, %17 offset:%19\n\t"
+                 "ds_read_b64 %2, %16 offset:%20\n\tds_read_b64 %3, %17 offset:%21\n\t"
+                 "ds_read_b64 %4, %16 offset:%22\n\tds_read_b64 %5, %17 offset:%23\n\t"
+                 "ds_read_b64 %6, %16 offset:%24\n\tds_read_b64 %7, %17 offset:%25\n\t"
+                 "ds_read_b64 %8, %16 offset:%26\n\tds_read_b64 %9, %17 offset:%27\n\t"
+                 "ds_read_b64 %10, %16 offset:%28\n\tds_read_b64 %11, %17 offset:%29\n\t"
+                 "ds_read_b64 %12, %16 offset:%30\n\tds_read_b64 %13, %17 offset:%31\n\t"
+                 "ds_read_b64 %14, %16 offset:%32\n\tds_read_b64 %15, %17 offset:%33\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+                   "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15])
+                 : "v"(be), "v"(bo), "n"(O0), "n"(O1), "n"(O2), "n"(O3), "n"(O4), "n"(O5), "n"(O6), "n"(O7), "n"(O8), "n"(O9),
+                   "n"(O10), "n"(O11), "n"(O12), "n"(O13), "n"(O14), "n"(O15));
+}
+// byte offset of column c (before the per-lane swap of column pairs) in the u part / the cell part of a stage
+constexpr int r_uoff(int c) { return (c >> 3) * 1024 + (c & 7) * 128; }
+template <int DIR>
+constexpr int r_coff(int c) { return DIR == 0 ? (c >> 3) * 1024 + (c & 7) * 128 : (((c & 7) >> 1) + 4 * (c >> 3)) * 1024 + (c & 1) * 128; }
+
+template <int MODE, int DIR, bool GRAD>
+__device__ __forceinline__ void recent_role(const SweepParams& P, char* lds, int rid, int nrecent)
+{
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const int T = P.T, B = P.B, K = P.K;
+    const int c0 = P.c0, c1 = P.c1;
+    unsigned* const ctrl = P.ctrl;
+    const size_t Bs = (size_t)B;
+    const float* __restrict__ score = P.score;
+    float* const dScore = P.dScore;
+    const int lane = threadIdx.x & 63;
+    const int rr = lane >> 4, cp = lane & 15;              // processing mapping: (row of the quarter, chain pair)
+    const int fslot = lane >> 3, fq8 = lane & 7;           // fetch mapping of the panels' stage layout
+    const int G4 = P.nPanelGroups * 4;
+    const int ntask = (K - RING) * G4;
+    const auto ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.ug, 0, (int)((size_t)T * Bs * 4), 0x00020000);
+    const unsigned tag = P.tag;
+    u64* const fbase = P.farg + (size_t)P.rpart * T * Bs;
+    const v2f l2e = {LOG2E, LOG2E};
+
+    // the wave's tiles as one sequence: task i = rid + n * nrecent -> (k, g, q4), tiles mlo(k) .. k - RING
+    struct Cur { int task, k, m; };
+    auto task_k = [&](int task) { return RING + task / G4; };
+    auto mlo = [&](int k) { const int lo = k - RING + 1 - P.xr; return lo > 0 ? lo : 0; };
+    auto geom = [&](int task, PanelGeom& G, int& pbase, int& cl) {
+        const int k = task_k(task);
+        const int rem = task % G4;
+        const int q4 = rem & 3, g = rem >> 2;
+        pbase = k * PB + q4 * 4;
+        const int c = c0 + g * GP + fq8 * 4;
+        cl = c < c1 ? c : c0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) G.pirow[i] = pbase + i < T ? pbase + i : T - 1;
+        G.voff = DIR == 0 ? (unsigned)((fslot * B + cl) * 4) : (unsigned)(((size_t)(7 - fslot) * T * Bs + cl) * 4);
+        const int f_pisub = lane >> 4, f_pjsub = (lane >> 3) & 1;
+        const int f_pirow = pbase + f_pisub < T ? pbase + f_pisub : T - 1;
+        G.fvoff = DIR == 0 ? G.voff : (unsigned)((((size_t)(1 - f_pjsub) * T + (G.pirow[3] - f_pirow)) * Bs + cl) * 4);
+        G.gvoff = (unsigned)((fslot * B + cl) * 4);
+    };
+    auto advance = [&](Cur& c) {
+        if (c.m < c.k - RING) { ++c.m; return; }
+        c.task += nrecent;
+        c.k = c.task < ntask ? task_k(c.task) : K;
+        c.m = c.task < ntask ? mlo(c.k) : 0;
+    };
+    // cells AND u of a tile (10 loads): the u copy is checked when the tile's turn comes and fetched again while it is
+    // not complete (the newest tile of a triple is usually not published yet when it is prefetched)
+    auto fetch_cells = [&](const Cur& c, int stage) {
+        PanelGeom G; int pbase, cl;
+        geom(c.task, G, pbase, cl);
+        panel_fetch_cells<DIR>(score, G, lds + stage * PSTAGE_BYTES, c.m, T, Bs);
+        panel_fetch_gran<true>(ursrc, lds + stage * PSTAGE_BYTES, G.gvoff, c.m, B);
+    };
+
+    Cur cur{rid, 0, 0};
+    if (cur.task >= ntask) return;
+    cur.k = task_k(cur.task); cur.m = mlo(cur.k);
+    Cur pre = cur;                                          // prefetch cursor: RNS - 1 tiles ahead of `cur`
+    int pstage = 0;
+#pragma unroll
+    for (int i = 0; i < RNS - 1; ++i)
+        if (pre.task < ntask) { fetch_cells(pre, pstage); pstage = pstage + 1 == RNS ? 0 : pstage + 1; advance(pre); }
+
+    float aM[2] = {SEMICRF_NEG_INF, SEMICRF_NEG_INF}, aS[2] = {0.f, 0.f};
+    int aK[2] = {0x7fffffff, 0x7fffffff};
+    int stage = 0;
+    float gzA = 0.f, gzB = 0.f, garA = 0.f, garB = 0.f;
+    bool pre_inflight = false;          // the prefetch issued during the previous tile (the tile after this one)
+    {
+        // start-up: RNS - 1 tiles were requested together; the second of them is the one "in flight" behind the first
+        Cur t2 = cur; advance(t2);
+        pre_inflight = t2.task < ntask;
+    }
+    while (cur.task < ntask) {
+        PanelGeom G; int pbase, cl;
+        geom(cur.task, G, pbase, cl);
+        const int k = cur.k, m = cur.m;
+        const int rem = cur.task % G4;
+        const int g = rem >> 2;
+        const int cA = c0 + g * GP + cp * 2;                // this lane's two chains
+        const bool vA = cA < c1, vB = cA + 1 < c1;
+        const int pi = pbase + rr;
+        const bool rvalid = pi < T;
+        if (GRAD && m == mlo(k)) {      // first tile of the triple: its row constants (before anything of this tile is in flight)
+            const bool rv = rvalid;
+            const float lzA = vA ? P.logZ[cA] : 0.f, lzB = vB ? P.logZ[cA + 1] : 0.f;
+            gzA = vA ? P.gout[cA] : 0.f; gzB = vB ? P.gout[cA + 1] : 0.f;
+            const size_t fr = (size_t)frame_of<DIR>(rv ? pi : T - 1, T) * Bs;
+            garA = ((vA ? P.vfwd[fr + cA] : 0.f) - lzA) * LOG2E;
+            garB = ((vB ? P.vfwd[fr + cA + 1] : 0.f) - lzB) * LOG2E;
+        }
+        char* const st = lds + stage * PSTAGE_BYTES;
+        const unsigned ubase = lds_addr(st) + 8192u;
+        const unsigned cbase = lds_addr(st);
+        // ---- u of tile m: poll until the rings of this chain group have published block m ----------------------
+        // a lane with an odd row walks the columns in swapped pairs (c ^ 1): its 8-byte reads then fall into the other half of
+        // the banks than those of the even row that shares its half-wave.  The swap toggles address bit 7 of every read.
+        const int bsw = (rr & 1) * 128;
+        v2f uu[PB];
+        {
+            const unsigned ue = ubase + (unsigned)(cp * 8 + bsw), uo = ubase + (unsigned)(cp * 8 - bsw);
+            int spins = 0;
+            // this tile's loads are older than the (at most one) prefetch that is still in flight
+            if (pre_inflight) wait_vmcnt<10>(); else wait_vmcnt<0>();
+            while (true) {
+                lds_read16_b64<r_uoff(0), r_uoff(1), r_uoff(2), r_uoff(3), r_uoff(4), r_uoff(5), r_uoff(6), r_uoff(7), r_uoff(8), r_uoff(9),
+                               r_uoff(10), r_uoff(11), r_uoff(12), r_uoff(13), r_uoff(14), r_uoff(15)>(ue, uo, uu);
+                bool ok = true;
+#pragma unroll
+                for (int c = 0; c < PB; ++c)
+                    ok = ok && (__float_as_uint(uu[c].x) != U_EMPTY || !vA) && (__float_as_uint(uu[c].y) != U_EMPTY || !vB);
+                if (__all(ok)) break;
+                if (spins > 0) __builtin_amdgcn_s_sleep(2);
+                if (spin_abort(ctrl, spins, SPIN_LIMIT, 12)) break;
+                panel_fetch_gran<true>(ursrc, st, G.gvoff, m, B);
+                wait_vmcnt<0>();
+            }
+        }
+        if (SEMICRF_PANEL_PROBES && (P.dbg & 16u) && rem == 0 && m == k - RING && lane == 0) P.ts[192 + k] = __builtin_amdgcn_s_memrealtime();   // chain probe: newest tile's u seen
+        // ---- the stage that tile m - 1 left: cells of the tile RNS - 1 ahead ------------------------------------
+        pre_inflight = pre.task < ntask;
+        if (pre_inflight) { fetch_cells(pre, pstage); pstage = pstage + 1 == RNS ? 0 : pstage + 1; advance(pre); }
+        // cells of this tile: landed together with its u (loads return in order)
+        v2f xx[PB];
+        {
+            const unsigned rb = cbase + (unsigned)(cp * 8) + (DIR == 0 ? (unsigned)(rr * 2048) : (unsigned)(rr * 256));
+            lds_read16_b64<r_coff<DIR>(0), r_coff<DIR>(1), r_coff<DIR>(2), r_coff<DIR>(3), r_coff<DIR>(4), r_coff<DIR>(5), r_coff<DIR>(6),
+                           r_coff<DIR>(7), r_coff<DIR>(8), r_coff<DIR>(9), r_coff<DIR>(10), r_coff<DIR>(11), r_coff<DIR>(12), r_coff<DIR>(13),
+                           r_coff<DIR>(14), r_coff<DIR>(15)>(rb + (unsigned)bsw, rb - (unsigned)bsw, xx);
+        }
+        if (rvalid) {
+            if (MODE == 0) {
+                v2f mref = {aM[0], aM[1]};
+                v2f e[PB];
+                float emax = SEMICRF_NEG_INF;
+#pragma unroll
+                for (int c = 0; c < PB; ++c) {
+                    e[c] = __builtin_elementwise_fma(xx[c], l2e, uu[c] - mref);
+                    emax = fmaxf(emax, fmaxf(e[c].x, e[c].y));
+                }
+                if (emax > RESCALE_THR) {                    // per lane: no cross-lane dependence in this mapping
+                    float tx = SEMICRF_NEG_INF, ty = SEMICRF_NEG_INF;
+#pragma unroll
+                    for (int c = 0; c < PB; ++c) {
+                        tx = fmaxf(tx, fmaf(xx[c].x, LOG2E, uu[c].x));
+                        ty = fmaxf(ty, fmaf(xx[c].y, LOG2E, uu[c].y));
+                    }
+                    const float mx = fmaxf(aM[0], tx), my = fmaxf(aM[1], ty);
+                    aS[0] = aS[0] * fexp2(aM[0] - mx); aS[1] = aS[1] * fexp2(aM[1] - my);      // -inf - m -> 0
+                    aM[0] = mx; aM[1] = my;
+                    mref.x = mx; mref.y = my;
+#pragma unroll
+                    for (int c = 0; c < PB; ++c) {
+                        e[c].x = fmaf(xx[c].x, LOG2E, uu[c].x) - mx;
+                        e[c].y = fmaf(xx[c].y, LOG2E, uu[c].y) - my;
+                    }
+                }
+                if (GRAD) {
+                    // marginal(pi, pj) = gz * exp2(t + arow), t = e + M
+                    const float arA = garA + aM[0], arB = garB + aM[1];
+                    const auto gs = __builtin_amdgcn_make_buffer_rsrc((void*)(dScore + panel_tile_off<DIR>(G, m, T, Bs)), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+                    for (int c = 0; c < PB; ++c) {
+                        const int col = c ^ (rr & 1);
+                        const int h = col >> 3, s8 = col & 7;
+                        const unsigned so = panel_soff<DIR>(G, rr, h, T, Bs);
+                        const unsigned vo = (DIR == 0 ? (unsigned)(s8 * B * 4) : (unsigned)((size_t)(7 - s8) * T * Bs * 4)) + (unsigned)(cA * 4);
+                        const float ga = gzA * fexp2(e[c].x + arA), gb = gzB * fexp2(e[c].y + arB);
+                        if (vA) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ga), gs, vo, so, SEMICRF_GRAD_AUX);
+                        if (vB) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gb), gs, vo + 4, so, SEMICRF_GRAD_AUX);
+                    }
+                }
+                v2f sacc = {aS[0], aS[1]};
+#pragma unroll
+                for (int c = 0; c < PB; ++c) {
+                    const v2f pe = {fexp2(e[c].x), fexp2(e[c].y)};
+                    sacc += pe;
+                }
+                aS[0] = sacc.x; aS[1] = sacc.y;
+            } else {
+#pragma unroll
+                for (int c = 0; c < PB; ++c) {
+                    const int col = c ^ (rr & 1);
+                    const int key = frame_of<DIR>(m * PB + col, T);
+                    max_push(aM[0], aK[0], uu[c].x + xx[c].x, key);
+                    max_push(aM[1], aK[1], uu[c].y + xx[c].y, key);
+                }
+            }
+        }
+        // ---- last tile of the triple: the lane's two partials are complete ----------------------------------------
+        if (m == k - RING) {
+            if (rvalid) {
+                u64* fp = fbase + (size_t)pi * Bs + cA;
+                if (MODE == 0) {
+                    if (vA) store_granule(fp, make_granule(tag, aM[0] + flog2(aS[0])));
+                    if (vB) store_granule(fp + 1, make_granule(tag, aM[1] + flog2(aS[1])));
+                } else {
+                    if (vA) store_granule(fp, make_granule_key(tag, aM[0], aK[0]));
+                    if (vB) store_granule(fp + 1, make_granule_key(tag, aM[1], aK[1]));
+                }
+            }
+            if (SEMICRF_PANEL_PROBES && (P.dbg & 16u) && rem == 0 && lane == 0) P.ts[256 + k] = __builtin_amdgcn_s_memrealtime();     // chain probe: partial stored
+            aM[0] = aM[1] = SEMICRF_NEG_INF; aS[0] = aS[1] = 0.f; aK[0] = aK[1] = 0x7fffffff;
+        }
+        stage = stage + 1 == RNS ? 0 : stage + 1;
+        advance(cur);
+    }
+    wait_vmcnt<0>();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1129,7 +1557,11 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
             if (!(P.dbg & 8u)) loader_role<DIR, GRAD>(P, sg, s_dyn, wave - RING);
         } else if (wave == RING + NLOADER) {
             if (!(P.dbg & 9u)) far_role<MODE, DIR>(P, sg, s_dyn);
-        } else if (!(P.dbg & 2u) && wave - (RING + NLOADER + 1) >= 0 && wave - (RING + NLOADER + 1) < P.hybridPanelWaves) {
+        } else if (wave - (RING + NLOADER + 1) < P.recentWaves) {
+            const int wr = wave - (RING + NLOADER + 1);
+            if (!(P.dbg & 2u))
+                recent_role<MODE, DIR, GRAD>(P, s_dyn + LDS_HYBRID_PANEL + wr * (PNS * PSTAGE_BYTES), sg * P.recentWaves + wr, P.nSpine * P.recentWaves);
+        } else if (!(P.dbg & 2u) && wave - (RING + NLOADER + 1) < P.recentWaves + P.hybridPanelWaves) {
             // Spare waves stream tiles like the panel workgroups do (their stages lie behind the spine's LDS) -- but only
             // once the sweep is bound by the far field: during the first blocks the ring sets the pace and a streaming
             // wave on its CU only slows it down.  They wait until the ring has taken row block hybridStart.
@@ -1149,13 +1581,13 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
     }
 }
 
-constexpr size_t CTRL_WORDS = 64;
+constexpr size_t CTRL_WORDS = 256;
 constexpr size_t CTRL_BYTES = MAX_CHUNKS * CTRL_WORDS * sizeof(unsigned);
 
 static int max_parts(int T)
 {
     const int K = (T + PB - 1) / PB;
-    return K > RING ? (K - 1 - RING) / TPT + 1 : 1;
+    return (K > RING ? (K - 1 - RING) / TPT + 1 : 1) + 1;          // + the recent waves' slab
 }
 
 // writes the exact zeros of the upper triangle (begin > end) of the dense gradient: row e, columns e+1..T-1
@@ -1210,7 +1642,8 @@ size_t persist_workspace_bytes(int T, int B)
 bool persist_supported(int T, int B)
 {
     return B >= 2 && B % 2 == 0 && T >= 2 && T < 65535 && (long long)T * B * 64 < (1ll << 31) &&      // 32-bit buffer offsets
-           (B + GS - 1) / GS <= MAX_CHUNKS * 64;      // chain chunks of at most half the CUs' worth of rings
+           (B + GS - 1) / GS <= MAX_CHUNKS * 64 &&      // chain chunks of at most half the CUs' worth of rings
+           max_parts(T) <= MAX_QUEUES;                   // one scheduler queue per column part
 }
 
 static unsigned next_tag()
@@ -1219,6 +1652,9 @@ static unsigned next_tag()
     const unsigned lo = (counter.fetch_add(1) % 65534u) + 1u;   // 1..65534: never the workspace's fill pattern 0xffff
     return (lo << 16) | lo;                                      // both 16-bit halves nonzero
 }
+
+static int g_run_ahead_max = 6;
+static int g_recent_tiles = 0;      // recent waves off by default: measured slower, kept for the next attempt
 
 struct GradArgs {
     const float* vfwd; const float* logZ; const float* gout; float* dScore; float* dNoise;
@@ -1258,10 +1694,7 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
     // ONE fill: every word of the workspace starts as 0xffffffff -- u reads U_EMPTY, far-field granules carry a tag no
     // launch uses, the counters return 0 after their first increment, the error word reads CTRL_INIT
     if (hipMemsetAsync(ws, 0xff, persist_workspace_bytes(T, B), stream) != hipSuccess) return 1;
-    // panel tasks per chain group: block k = RING + q has q/TPT + 1 column parts, each split in 4 row quarters
-    long long ntask = 0;
-    for (int q = 0; q < P.K - RING; ++q) ntask += (q / TPT + 1);
-    ntask *= 4;
+    static const int xr_env = [] { const char* e = getenv("SEMICRF_XR"); return e ? atoi(e) : -1; }();      // tuning knob, read once
 
     // Chain chunks: at most a quarter of the CUs host spines in one launch (every workgroup must be resident
     // and the panels need the rest of the chip).
@@ -1278,6 +1711,17 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         const int nb = P.c1 - P.c0;
         P.nSpine = (nb + GS - 1) / GS;
         P.nPanelGroups = (nb + GP - 1) / GP;
+        // The newest xr far tiles of every block go to the recent waves (two per spine workgroup, static shares): only when
+        // there are enough of them to give every (block, chain group, row quarter) triple a wave for three block times.
+        int rw = HPW_MAX < 2 ? (HPW_MAX > 0 ? HPW_MAX : 0) : 2;
+        int xr = xr_env >= 0 ? xr_env : g_recent_tiles;
+        if (xr > P.K - RING) xr = P.K - RING > 0 ? P.K - RING : 0;
+        if (P.nSpine * rw < 3 * P.nPanelGroups * 4 || xr <= 0) { xr = 0; rw = 0; }
+        P.xr = xr; P.recentWaves = rw; P.rpart = max_parts(T) - 1;
+        // panel tasks per chain group: block k = RING + xr + q has q/TPT + 1 column parts, each split in 4 row quarters
+        long long ntask = 0;
+        for (int q = 0; q < P.K - RING - xr; ++q) ntask += (q / TPT + 1);
+        ntask *= 4;
         P.nTasks = (int)(ntask * P.nPanelGroups);
         P.ctrl = (unsigned*)w + (size_t)ci * CTRL_WORDS;
         // Panel waves.  Every CU streams (HBM bandwidth is limited per CU by the misses it can keep in flight):
@@ -1295,8 +1739,8 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         // bound by the far field and every CU helps.  Forward, T=1024: 205 us (start at 24-32) vs 214 (from the start)
         // vs 217 (never); T=691, NBatch=360: 158 vs 177 vs 173; T=2048: 651 vs 677 (from the start) vs 788 (never).
         // The gradient sweep is bandwidth-bound almost from the start.
-        int hpw = HPW_MAX > 0 ? HPW_MAX : 0;
-        if (const char* e = getenv("SEMICRF_HYBRID_PANEL_WAVES")) { const int v = atoi(e); if (v >= 0 && v <= HPW_MAX) hpw = v; }
+        int hpw = HPW_MAX - rw > 0 ? HPW_MAX - rw : 0;
+        if (const char* e = getenv("SEMICRF_HYBRID_PANEL_WAVES")) { const int v = atoi(e); if (v >= 0 && v <= HPW_MAX - rw) hpw = v; }
         int hstart = grad ? 12 : P.K * 3 / 8;
         hstart = hstart < 8 ? 8 : (hstart > 32 ? 32 : hstart);
         if (const char* e = getenv("SEMICRF_HYBRID_START")) { const int v = atoi(e); if (v >= 0) hstart = v; }
@@ -1308,6 +1752,16 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         if (pw > PW_MAX) pw = PW_MAX;
         (void)per_cu;
         P.panelWaves = pw;
+        {
+            // waves that may sit on last-part tasks whose newest u is not out yet: at most half of the panel waves, so
+            // that the full parts of earlier blocks always find a free wave (see panel_next_task)
+            const int g4 = P.nPanelGroups * 4;
+            int ra = g4 > 0 ? (nPanelWG * pw / 2) / g4 : 0;
+            static const int ra_env = [] { const char* e = getenv("SEMICRF_RUN_AHEAD"); return e ? atoi(e) : -1; }();   // tuning knob, read once
+            const int ra_max = ra_env >= 0 ? ra_env : g_run_ahead_max;
+            ra = ra < 0 ? 0 : (ra > ra_max ? ra_max : ra);
+            P.runAhead = ra;
+        }
         // the zero upper triangle of the gradient: by spare waves of the first chunk's panel workgroups, or (no
         // panel workgroups: short sequences) by its own kernel
         int zw = 0;
