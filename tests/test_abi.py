@@ -139,3 +139,18 @@ def test_scorer_regrouped_linear_rows():
     qd.sum().backward()
     g = W.grad
     assert float(g[D:2 * D].abs().max()) == 0.0 and float(g[:D].abs().max()) > 0 and float(g[2 * D].abs().max()) > 0
+
+
+def test_torch_ops_shim_registers_every_op():
+    """libsemicrf_torch.so (LibTorch stable ABI, csrc/torch_ops.cpp) registers the compute entry points of the C ABI as
+    torch.ops.semicrf.*; there is no CPU kernel behind them (a CPU tensor must fail in the dispatcher, not fall back)."""
+    import torch
+    from transkun_amd import _lib
+    ops = _lib.ops()
+    for name in ("logz_fwd", "logz_bwd", "beta", "viterbi", "eval_path", "eval_path_bwd", "interval_score_fwd",
+                 "interval_score_bwd_ws", "interval_score_bwd_fused_ws", "interval_score_path_bwd",
+                 "interval_features_gather", "interval_features_gather_bwd"):
+        assert hasattr(ops, name), name
+    s = torch.zeros(4, 4, 2); n = torch.zeros(3, 2)
+    with pytest.raises(NotImplementedError):
+        ops.logz_fwd(s, n, torch.zeros(2), torch.zeros(4, 2), True, torch.zeros(256, dtype=torch.uint8))

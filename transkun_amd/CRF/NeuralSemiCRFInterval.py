@@ -112,16 +112,13 @@ def _logz_fwd_raw(score, noise, want_v: bool):
         logz, v = _logz_fwd_raw(_pad1(score), _pad1(noise), want_v)
         return logz[:-1].contiguous(), (v[:, :-1].contiguous() if v is not None else None)
     T, B = score.shape[0], score.shape[2]
-    lib = _lib.load()
     logz = torch.empty(B, dtype=torch.float32, device=score.device)
-    v = torch.empty(T, B, dtype=torch.float32, device=score.device) if want_v else None
+    v = torch.empty((T, B) if want_v else (0,), dtype=torch.float32, device=score.device)
     ws = _lib.workspace(_lib.OP_LOGZ_FWD, T, B, score.device)
-    rc = lib.semicrf_logz_fwd(_lib.ptr(score), _lib.ptr(noise), T, B, _lib.ptr(logz), _lib.ptr(v),
-                              _lib.ptr(ws), ws.numel(), _lib.stream_of(score))
-    _lib.check(rc, "semicrf_logz_fwd")
+    _lib.ops().logz_fwd(score, noise, logz, v, want_v, ws)
     if os.environ.get("SEMICRF_DEBUG_KEEP_WS"):
         _DEBUG_WS[:] = [ws]
-    return logz, v
+    return logz, (v if want_v else None)
 
 
 def _logz_bwd_raw(score, noise, v, logz, gout, want_q: bool = False):
@@ -129,35 +126,37 @@ def _logz_bwd_raw(score, noise, v, logz, gout, want_q: bool = False):
         ds, dn, q = _logz_bwd_raw(_pad1(score), _pad1(noise), _pad1(v), _pad1(logz), _pad1(gout), want_q)
         return ds[:, :, :-1].contiguous(), dn[:, :-1].contiguous(), (q[:, :-1].contiguous() if q is not None else None)
     T, B = score.shape[0], score.shape[2]
-    lib = _lib.load()
     dscore = torch.empty_like(score)
     dnoise = torch.empty_like(noise)
-    q = torch.empty(T, B, dtype=torch.float32, device=score.device) if want_q else None
+    q = torch.empty((T, B) if want_q else (0,), dtype=torch.float32, device=score.device)
     ws = _lib.workspace(_lib.OP_LOGZ_BWD, T, B, score.device)
-    rc = lib.semicrf_logz_bwd(_lib.ptr(score), _lib.ptr(noise), _lib.ptr(v), _lib.ptr(logz), _lib.ptr(gout),
-                              T, B, _lib.ptr(dscore), _lib.ptr(dnoise), _lib.ptr(q), _lib.ptr(ws), ws.numel(),
-                              _lib.stream_of(score))
-    _lib.check(rc, "semicrf_logz_bwd")
-    return dscore, dnoise, q
+    _lib.ops().logz_bwd(score, noise, v, logz, gout, dscore, dnoise, q, want_q, ws)
+    return dscore, dnoise, (q if want_q else None)
 
 
 def _eval_path_raw(score, noise, pairs, offsets):
     T, B = score.shape[0], score.shape[2]
-    lib = _lib.load()
     out = torch.empty(B, dtype=torch.float32, device=score.device)
     ws = _lib.workspace(_lib.OP_EVAL_PATH, T, B, score.device)
     K = getattr(pairs, "_semicrf_K", pairs.shape[0])
-    rc = lib.semicrf_eval_path(_lib.ptr(score), _lib.ptr(noise), T, B, _lib.ptr(pairs), int(K), _lib.ptr(offsets),
-                               _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_of(score))
-    _lib.check(rc, "semicrf_eval_path")
+    _lib.ops().eval_path(score, noise, pairs, int(K), offsets, out, ws)
     return out
 
 
+_EMPTY = {}
+
+
+def _empty(device):
+    e = _EMPTY.get(device)
+    if e is None:
+        e = _EMPTY[device] = torch.empty(0, dtype=torch.float32, device=device)
+    return e
+
+
 def _eval_path_bwd_raw(gout, T, B, pairs, offsets, dscore, dnoise, K: int):
-    lib = _lib.load()
-    rc = lib.semicrf_eval_path_bwd(_lib.ptr(gout), T, B, _lib.ptr(pairs), int(K), _lib.ptr(offsets), _lib.ptr(dscore),
-                                   _lib.ptr(dnoise), _lib.stream_of(gout))
-    _lib.check(rc, "semicrf_eval_path_bwd")
+    e = _empty(gout.device)
+    _lib.ops().eval_path_bwd(gout, T, B, pairs, int(K), offsets, dscore if dscore is not None else e, dscore is not None,
+                             dnoise if dnoise is not None else e, dnoise is not None)
 
 
 def _gout(grad_output: torch.Tensor, B: int) -> torch.Tensor:
@@ -255,11 +254,8 @@ def _viterbi_raw(score_c, noise_c, start, forward: bool):
     pairs = torch.empty(cap, 2, dtype=torch.int32, device=dev)
     offsets = torch.empty(B + 1, dtype=torch.int32, device=dev)
     ws = _lib.workspace(_lib.OP_VITERBI, T, B, dev)
-    lib = _lib.load()
-    rc = lib.semicrf_viterbi(_lib.ptr(score_c), _lib.ptr(noise_c), T, B, _lib.ptr(start), 1 if forward else 0,
-                             _lib.ptr(pairs), cap, _lib.ptr(offsets), _lib.ptr(ws), ws.numel(),
-                             _lib.stream_of(score_c))
-    _lib.check(rc, "semicrf_viterbi")
+    has = start is not None
+    _lib.ops().viterbi(score_c, noise_c, start if has else offsets, has, bool(forward), pairs, offsets, ws)
     return pairs, offsets
 
 

@@ -57,8 +57,12 @@ def build_variant(name: str, defines, verbose: bool = False) -> str:
         if p.returncode != 0:
             sys.stderr.write(out.decode())
             raise RuntimeError("hipcc failed")
-    out = os.path.join(HERE, f"libsemicrf_{name}.so")
+    vdir = os.path.join(HERE, "_variants", name)
+    os.makedirs(vdir, exist_ok=True)
+    out = os.path.join(vdir, "libsemicrf_hip.so")
     subprocess.check_call([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs)
+    # the torch-ops shim next to it (it finds "libsemicrf_hip.so" by $ORIGIN): SEMICRF_LIB=<vdir>/libsemicrf_hip.so
+    shutil.copy(build_torch_shim(), os.path.join(vdir, "libsemicrf_torch.so"))
     return out
 
 
@@ -78,8 +82,40 @@ def build_marshal(force: bool = False) -> str:
     return MARSHAL
 
 
+TORCH_LIB = os.path.join(HERE, "libsemicrf_torch.so")
+
+
+def build_torch_shim(force: bool = False, verbose: bool = False) -> str:
+    """libsemicrf_torch.so: the LibTorch stable-ABI registration of the C ABI as torch.ops.semicrf.* (host C++ only:
+    torch/csrc/stable headers + the aoti C shim; links libsemicrf_hip.so by $ORIGIN and the torch libraries the process
+    has loaded anyway).  No hipify, no torch.utils.cpp_extension."""
+    import torch
+    src = os.path.join(CSRC, "torch_ops.cpp")
+    hdr = os.path.join(HERE, "..", "include", "semicrf_hip.h")
+    if (not force and os.path.exists(TORCH_LIB)
+            and os.path.getmtime(TORCH_LIB) > max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(LIB))):
+        return TORCH_LIB
+    troot = os.path.dirname(torch.__file__)
+    cxx = os.environ.get("CXX") or shutil.which("g++") or "c++"
+    tmp = TORCH_LIB + ".tmp"
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(troot, "include"), src, "-o", tmp,
+           "-L" + HERE, "-l:libsemicrf_hip.so", "-L" + os.path.join(troot, "lib"), "-ltorch_cpu", "-ltorch_hip", "-lc10",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(troot, "lib")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(tmp, TORCH_LIB)
+    return TORCH_LIB
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     build_marshal(force)
+    path = _build_hip(force, verbose)
+    build_torch_shim(force, verbose)
+    return path
+
+
+def _build_hip(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
     objdir = os.path.join(HERE, "csrc", "_obj")

@@ -1,4 +1,9 @@
-"""ctypes binding to libsemicrf_hip.so (the C ABI of include/semicrf_hip.h).
+"""Bindings to the HIP library.
+
+The compute calls of the Python mirror go through torch ops: `ops()` loads libsemicrf_torch.so, a LibTorch stable-ABI
+shim (csrc/torch_ops.cpp) that registers the C ABI of include/semicrf_hip.h as `torch.ops.semicrf.*` (dispatch key CUDA =
+HIP tensors): torch's dispatcher picks the tensors' device and current stream.  `load()` is the raw ctypes binding
+to libsemicrf_hip.so itself -- workspace sizes, the implementation switch, the debug status word, and the ABI tests.
 
 torch is imported first on purpose: the library needs libamdhip64.so.7 and must bind to the
 HIP runtime torch has already loaded (one runtime per process), not to a second copy.
@@ -72,6 +77,22 @@ def load():
     return _lib
 
 
+_ops = None
+TORCH_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libsemicrf_torch.so")     # next to the HIP library it links
+
+
+def ops():
+    """torch.ops.semicrf (the stable-ABI shim, loaded once).  Raises if it has not been built."""
+    global _ops
+    if _ops is None:
+        load()                                  # libsemicrf_hip.so first: the shim links against it
+        if not os.path.exists(TORCH_LIB_PATH):
+            raise SemiCRFLibraryError(f"{TORCH_LIB_PATH} not found: build it with `python -m transkun_amd._build`")
+        torch.ops.load_library(TORCH_LIB_PATH)
+        _ops = torch.ops.semicrf
+    return _ops
+
+
 _marshal = None
 
 
@@ -109,9 +130,15 @@ def require_gpu(t: torch.Tensor, name: str) -> None:
             "HIP kernels (there is deliberately no CPU fallback)")
 
 
+_WS_BYTES = {}
+
+
 def workspace(op: int, T: int, B: int, device) -> torch.Tensor:
-    n = load().semicrf_workspace_bytes(op, T, B)
-    return torch.empty(max(int(n), 256), dtype=torch.uint8, device=device)
+    key = (op, T, B)
+    n = _WS_BYTES.get(key)
+    if n is None:
+        n = _WS_BYTES[key] = max(int(load().semicrf_workspace_bytes(op, T, B)), 256)
+    return torch.empty(n, dtype=torch.uint8, device=device)
 
 
 def set_impl(impl: int) -> None:

@@ -26,13 +26,10 @@ class _IntervalFeatures(torch.autograd.Function):
     @staticmethod
     def forward(ctx_, ctx3, pairs, offsets, K, nSym):
         C, T, D = ctx3.shape
-        lib = _lib.load()
         out = torch.empty(K, 3 * D, dtype=torch.float32, device=ctx3.device)
         sym = torch.empty(K, dtype=torch.int64, device=ctx3.device)
         sc = torch.empty(K, dtype=torch.int64, device=ctx3.device)
-        rc = lib.interval_features_gather(_lib.ptr(ctx3), C, T, D, ctx3.stride(-2), _lib.ptr(pairs), K, _lib.ptr(offsets), nSym,
-                                          _lib.ptr(out), _lib.ptr(sym), _lib.ptr(sc), _lib.stream_of(ctx3))
-        _lib.check(rc, "interval_features_gather")
+        _lib.ops().interval_features_gather(ctx3, C, T, D, ctx3.stride(-2), pairs, int(K), offsets, int(nSym), out, sym, sc)
         ctx_.save_for_backward(ctx3, pairs, offsets)
         ctx_.K = K
         ctx_.mark_non_differentiable(sym, sc)
@@ -42,12 +39,9 @@ class _IntervalFeatures(torch.autograd.Function):
     def backward(ctx_, gout, gsym, gsc):
         ctx3, pairs, offsets = ctx_.saved_tensors
         C, T, D = ctx3.shape
-        lib = _lib.load()
         dctx = torch.zeros_like(ctx3)
         g = gout.contiguous()
-        rc = lib.interval_features_gather_bwd(_lib.ptr(g), _lib.ptr(ctx3), C, T, D, ctx3.stride(-2), _lib.ptr(pairs), ctx_.K,
-                                              _lib.ptr(offsets), _lib.ptr(dctx), dctx.stride(-2), _lib.stream_of(g))
-        _lib.check(rc, "interval_features_gather_bwd")
+        _lib.ops().interval_features_gather_bwd(g, ctx3, C, T, D, ctx3.stride(-2), pairs, int(ctx_.K), offsets, dctx, dctx.stride(-2))
         return dctx, None, None, None, None
 
 

@@ -27,19 +27,16 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .scorer import QPAD, ScaledInnerProductIntervalScorer, _interval_score_raw, qd_weights
+from .scorer import QPAD, ScaledInnerProductIntervalScorer, _interval_score_raw, bwd_workspace, qd_weights
 
 _nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
 
 
 def _beta_raw(score, noise):
     T, B = score.shape[0], score.shape[2]
-    lib = _lib.load()
     beta = torch.empty(T, B, dtype=torch.float32, device=score.device)
     ws = _lib.workspace(_lib.OP_LOGZ_FWD, T, B, score.device)
-    rc = lib.semicrf_beta(_lib.ptr(score), _lib.ptr(noise), T, B, _lib.ptr(beta), _lib.ptr(ws), ws.numel(),
-                          _lib.stream_of(score))
-    _lib.check(rc, "semicrf_beta")
+    _lib.ops().beta(score, noise, beta, ws)
     return beta
 
 
@@ -64,7 +61,7 @@ class _ScorerCRFLogProb(torch.autograd.Function):
         C = N * P
         qs = 1.0 / math.sqrt(D)
         g = g.reshape(C).to(torch.float32).contiguous()
-        lib = _lib.load()
+        ops = _lib.ops()
         beta = _beta_raw(S, noise)
         gneg = (-g).contiguous()                                   # d logProb / d logZ = -1
         q = qd3[..., :D]
@@ -73,20 +70,14 @@ class _ScorerCRFLogProb(torch.autograd.Function):
         dq, dd = dqd[..., :D], dqd[..., D]
         dk = torch.empty(C, T, D, dtype=torch.float32, device=S.device)
         # with a workspace: marginals evaluated by the repack kernel + two tiled GEMMs (scorer_bwd_gemm.hip)
-        nws = int(lib.interval_score_bwd_workspace_bytes(C, T, D))
-        ws = torch.empty(nws, dtype=torch.uint8, device=S.device) if nws > 0 else None
-        rc = lib.interval_score_bwd_fused_ws(_lib.ptr(S), _lib.ptr(v), _lib.ptr(beta), _lib.ptr(logz), _lib.ptr(gneg), _lib.ptr(q),
-                                             _lib.ptr(k), C, T, D, q.stride(-2), k.stride(-2), qs, mode, _lib.ptr(dq),
-                                             _lib.ptr(dk), _lib.ptr(dd), dq.stride(-2), D, dd.stride(-1), _lib.ptr(ws), nws,
-                                             _lib.stream_of(S))
-        _lib.check(rc, "interval_score_bwd_fused_ws")
+        ws = bwd_workspace(C, T, D, S.device)
+        ops.interval_score_bwd_fused_ws(S, v, beta, logz, gneg, q, k, C, T, D, q.stride(-2), k.stride(-2), qs, mode, dq, dk, dd,
+                                        dq.stride(-2), D, dd.stride(-1), ws)
         del ws
         if K > 0:
             # + g on the path cells: dq[c,e] += g qs len(e-b) k[c,b], dk[c,b] += g qs len(e-b) q[c,e], ddiag[c,t] += g (b == e)
-            rc = lib.interval_score_path_bwd(_lib.ptr(g), _lib.ptr(pairs), K, _lib.ptr(offsets), _lib.ptr(q), _lib.ptr(k), C, T, D,
-                                             q.stride(-2), k.stride(-2), qs, mode, _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dd),
-                                             dq.stride(-2), D, dd.stride(-1), _lib.stream_of(S))
-            _lib.check(rc, "interval_score_path_bwd")
+            ops.interval_score_path_bwd(g, pairs, int(K), offsets, q, k, C, T, D, q.stride(-2), k.stride(-2), qs, mode, dq, dk, dd,
+                                        dq.stride(-2), D, dd.stride(-1))
         return (dqd.view(N, P, T, D + QPAD), dk.view(N, P, T, D), None, None, None, None, None, None, None)
 
 

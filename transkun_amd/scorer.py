@@ -20,17 +20,26 @@ from . import _lib
 
 def _interval_score_raw(q, k, diag, T: int, C: int, D: int, qscale: float, mode: int, full_square: bool):
     """q,k: [C,T,D] views with unit stride in d; diag: [C,T] view.  Returns S [T,T,C], noise [T-1,C]."""
-    lib = _lib.load()
     dev = q.device
     assert q.stride(-1) == 1 and k.stride(-1) == 1
     # full_square=False: the library computes e >= b and zero-fills the rest itself (half the bytes of torch.zeros)
     S = torch.empty(T, T, C, dtype=torch.float32, device=dev)
     noise = torch.empty(max(T - 1, 0), C, dtype=torch.float32, device=dev)
-    rc = lib.interval_score_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(diag), C, T, D, q.stride(-2), k.stride(-2),
-                                diag.stride(-1), qscale, mode, 1 if full_square else 0, _lib.ptr(S),
-                                _lib.ptr(noise), _lib.stream_of(q))
-    _lib.check(rc, "interval_score_fwd")
+    _lib.ops().interval_score_fwd(q, k, diag, C, T, D, q.stride(-2), k.stride(-2), diag.stride(-1), float(qscale), int(mode),
+                                  bool(full_square), S, noise)
     return S, noise
+
+
+_BWD_WS = {}
+
+
+def bwd_workspace(C: int, T: int, D: int, device) -> torch.Tensor:
+    """Workspace of the packed scorer backward (0 bytes when that path does not apply)."""
+    key = (C, T, D)
+    n = _BWD_WS.get(key)
+    if n is None:
+        n = _BWD_WS[key] = int(_lib.load().interval_score_bwd_workspace_bytes(C, T, D))
+    return torch.empty(n, dtype=torch.uint8, device=device)
 
 
 QPAD = 4        # [q | diag | 3 zero columns]: one GEMM instead of a D-wide and a 1-wide one, rows stay 16-byte aligned
@@ -69,7 +78,6 @@ class _IntervalScore(torch.autograd.Function):
         if D % 32 == 0 and D <= 256 and dS.is_cuda and not full:
             # HIP kernels: dq/dk from dS in its native [T,T,C] layout on the matrix cores (exact fp32), written straight
             # into the gradient of [q | diag | pad]
-            lib = _lib.load()
             g = dS.reshape(T, T, C)
             if not g.is_contiguous():
                 g = g.contiguous()
@@ -79,12 +87,9 @@ class _IntervalScore(torch.autograd.Function):
             dk = torch.empty(C, T, D, dtype=torch.float32, device=g.device)
             # with a workspace the library repacks dS per chain and runs two LDS-tiled GEMMs (scorer_bwd_gemm.hip);
             # 0 bytes: shapes it does not take -- the direct kernels run
-            nws = int(lib.interval_score_bwd_workspace_bytes(C, T, D))
-            ws = torch.empty(nws, dtype=torch.uint8, device=g.device) if nws > 0 else None
-            rc = lib.interval_score_bwd_ws(_lib.ptr(g), _lib.ptr(q), _lib.ptr(k), C, T, D, q.stride(-2), k.stride(-2), qs, mode,
-                                           _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dd), dq.stride(-2), D, dd.stride(-1), _lib.ptr(ws),
-                                           nws, _lib.stream_of(g))
-            _lib.check(rc, "interval_score_bwd_ws")
+            ws = bwd_workspace(C, T, D, g.device)
+            _lib.ops().interval_score_bwd_ws(g, q, k, C, T, D, q.stride(-2), k.stride(-2), qs, mode, dq, dk, dd, dq.stride(-2), D,
+                                             dd.stride(-1), ws)
             return (dqd.view(N, P, T, D + QPAD), dk.view(N, P, T, D), None, None, None, None, None, None)
         dq, dk, dd = _IntervalScore._backward_torch(dS, q, k, N, P, T, D, mode, full)[:3]
         dqd = torch.cat([dq.reshape(C, T, D), dd.reshape(C, T, 1), dq.new_zeros(C, T, QPAD - 1)], dim=-1)
