@@ -60,8 +60,13 @@ void semicrf_set_impl(int impl);
 int semicrf_get_impl(void);
 
 /* Debug/test hook, SYNCHRONISES the device: returns and clears the sticky device-side status word.
- * 0 = no kernel ever gave up on a bounded spin; 2..5 = a hand-off wait timed out (results invalid);
- * -1 = HIP error.  The persistent kernels never hang: every wait is bounded. */
+ * 0 = no kernel ever gave up on a bounded spin; 2..12 = a hand-off wait timed out (results invalid);
+ * -1 = HIP error.  The persistent kernels never hang: every wait is bounded (0.3 - 2 s).
+ *
+ * What a caller sees WITHOUT this hook when a wait does time out (e.g. the GPU is shared and part of the persistent
+ * kernel was not resident in time): the calls still return SEMICRF_OK -- nothing synchronises the host -- but the results
+ * are poisoned, not silently wrong: logZ, the last row of v / q_out / beta and the gradient's last diagonal cells are NaN
+ * for the chains of every workgroup that saw a timeout, and semicrf_viterbi writes offsets[B] = -1. */
 int semicrf_debug_device_status(void);
 
 /*

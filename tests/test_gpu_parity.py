@@ -670,3 +670,43 @@ def test_model_shape_crf_vs_reference(gpu, T, B, kind):
         h = hashlib.sha256(); h.update(off.astype("<i8").tobytes()); h.update(pairs.astype("<i4").tobytes())
         assert h.hexdigest() == str(g[f"decode_{nm}_sha256"])
     assert _lib.device_status() == 0
+
+
+@pytest.mark.gpu
+def test_two_node_pattern_both_orders_and_dtype(gpu):
+    """evalPath + computeLogZ as two autograd nodes (ModelTransformer.py:263-265): whichever node autograd runs first, and
+    when only one of them is differentiated, the gradients equal those of the one-node logProb; a float64 score comes back
+    as float64 (values and gradients), like the reference preserves the input dtype."""
+    from transkun_amd import CRF, synth
+    T, B = 130, 12
+    score, noise = synth.crf_inputs(T, B, 9, gpu)
+    iv = synth.synthetic_intervals(T, B, seed=9)
+    w = synth.hash_normal(B, 10, gpu)
+
+    def grads(fn, dtype=torch.float32):
+        s = score.to(dtype).requires_grad_(); n = noise.to(dtype).requires_grad_()
+        out = fn(CRF.NeuralSemiCRFInterval(s, n))
+        (out * w.to(dtype)).sum().backward()
+        return out.detach(), s.grad, n.grad
+
+    ref = grads(lambda c: c.logProb(iv))
+    a = grads(lambda c: c.evalPath(iv) - c.computeLogZ())                    # logZ node created last: runs first, shares its buffer
+    def rev(c):
+        lz = c.computeLogZ()
+        return c.evalPath(iv) - lz                                           # evalPath node created last: dense fallback
+    b = grads(rev)
+    for got in (a, b):
+        for x, y in zip(got, ref):
+            assert float((x - y).abs().max()) <= 1e-5 * float(y.abs().max() + 1e-30)
+    # only one of the two nodes in the graph
+    p_only = grads(lambda c: c.evalPath(iv))
+    z_only = grads(lambda c: c.computeLogZ())
+    assert float((p_only[1] - z_only[1] - ref[1]).abs().max()) <= 1e-5 * float(ref[1].abs().max())
+    assert float((p_only[2] - z_only[2] - ref[2]).abs().max()) <= 1e-5 * float(ref[2].abs().max())
+    # a stale shared buffer must not be picked up by a later, unrelated backward pass
+    z2 = grads(lambda c: c.computeLogZ())
+    p2 = grads(lambda c: c.evalPath(iv))
+    assert torch.equal(p2[1], p_only[1]) and torch.equal(z2[1], z_only[1])
+    d = grads(lambda c: c.logProb(iv), torch.float64)
+    assert d[0].dtype == torch.float64 and d[1].dtype == torch.float64 and d[2].dtype == torch.float64
+    assert float((d[0].float() - ref[0]).abs().max()) <= 1e-5 * float(ref[0].abs().max())

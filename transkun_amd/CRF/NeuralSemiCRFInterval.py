@@ -6,6 +6,9 @@ in hand-written gfx950 HIP kernels behind the C ABI of include/semicrf_hip.h; th
 validates shapes, marshals the Python interval lists to/from packed int32 buffers and wires the
 kernels into autograd.  There is no CPU path: CPU tensors raise RuntimeError.
 
+Arithmetic is fp32 (the reference's callers are fp32 throughout); other floating dtypes are computed in fp32 and the
+results and gradients are cast back to the input dtype, as the reference preserves it.
+
 What differs from the reference, invisibly at the API:
   * computeLogZ saves alpha (v [T,B]) and logZ instead of the dense marginals [T,T,B]
     (reference :463-464) and recomputes them in backward, fused with the beta sweep.
@@ -171,6 +174,22 @@ def _gout(grad_output: torch.Tensor, B: int) -> torch.Tensor:
 # autograd nodes
 # --------------------------------------------------------------------------------------
 
+# The reference's own call pattern is evalPath(...) - computeLogZ() as TWO autograd nodes (ModelTransformer.py:263-265).
+# Differentiated naively, the evalPath node returns a dense zero [T,T,B] tensor with a few thousand cells set and autograd
+# adds it to the dense gradient of the logZ node: two more passes over 1.48 GB at T=1024, NBatch=352.  Both nodes belong
+# to the same backward pass and the logZ node (created later) runs first; it leaves the ADDRESS of its dense gradient here
+# (no reference: autograd must stay the only owner, or it would copy the buffer), keyed by the autograd graph-task id and
+# the identity of the score tensor object, and the evalPath node of the same pass and the same tensor scatters its cells
+# INTO that buffer (same stream; the engine holds the buffer until both nodes have run) and contributes no tensor of its
+# own.  Any other order or combination falls back to the dense gradient.
+_SHARED_GRAD = {"task": -1, "key": None, "dscore": 0, "dnoise": 0}
+
+
+def _graph_task_id() -> int:
+    fn = getattr(torch._C, "_current_graph_task_id", None)
+    return int(fn()) if fn is not None else -1
+
+
 class ComputeLogZFasterGrad(torch.autograd.Function):
     """logZ with a hand-written gradient (reference :459-475), recompute-in-backward flavour."""
 
@@ -181,14 +200,19 @@ class ComputeLogZFasterGrad(torch.autograd.Function):
         logz, v = _logz_fwd_raw(score_c, noise_c, want_v=need)
         if need:
             ctx.save_for_backward(score_c, noise_c, v, logz)
-        return logz
+        ctx.in_dtypes = (score.dtype, noiseScore.dtype)
+        ctx.key = (id(score), id(noiseScore), score_c.data_ptr(), tuple(score_c.shape))
+        return logz.to(score.dtype)
 
     @staticmethod
     def backward(ctx, grad_output):
         score, noise, v, logz = ctx.saved_tensors
         B = score.shape[2]
         dscore, dnoise, _ = _logz_bwd_raw(score, noise, v, logz, _gout(grad_output, B))
-        return dscore, dnoise
+        tid = _graph_task_id()
+        if tid >= 0 and ctx.in_dtypes == (torch.float32, torch.float32) and _odd_pad(score) is False:
+            _SHARED_GRAD.update(task=tid, key=ctx.key, dscore=dscore.data_ptr(), dnoise=dnoise.data_ptr())
+        return dscore.to(ctx.in_dtypes[0]), dnoise.to(ctx.in_dtypes[1])
 
 
 computeLogZFasterGrad = ComputeLogZFasterGrad.apply
@@ -200,18 +224,35 @@ class _EvalPath(torch.autograd.Function):
         score_c, noise_c = _prep(score), _prep(noiseScore)
         ctx.save_for_backward(pairs, offsets)
         ctx.shape = (score_c.shape[0], score_c.shape[2])
+        ctx.key = (id(score), id(noiseScore), score_c.data_ptr(), tuple(score_c.shape))
         ctx.K = getattr(pairs, "_semicrf_K", pairs.shape[0])
-        return _eval_path_raw(score_c, noise_c, pairs, offsets)
+        ctx.in_dtypes = (score.dtype, noiseScore.dtype)
+        return _eval_path_raw(score_c, noise_c, pairs, offsets).to(score.dtype)
 
     @staticmethod
     def backward(ctx, grad_output):
         pairs, offsets = ctx.saved_tensors
         T, B = ctx.shape
         g = _gout(grad_output, B)
+        sh = _SHARED_GRAD
+        if (sh["dscore"] and sh["task"] == _graph_task_id() and sh["key"] == ctx.key
+                and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]):
+            # the logZ node of this pass has already produced the dense gradient of the same score tensor: add the path
+            # cells to it in place (raw C ABI call on the buffer's address); this node contributes nothing of its own
+            ds_ptr, dn_ptr = sh["dscore"], sh["dnoise"]
+            sh.update(task=-1, key=None, dscore=0, dnoise=0)
+            lib = _lib.load()
+            with torch.cuda.device(g.device):
+                rc = lib.semicrf_eval_path_bwd(_lib.ptr(g), T, B, _lib.ptr(pairs), int(ctx.K), _lib.ptr(offsets),
+                                               _lib._vp(ds_ptr), _lib._vp(dn_ptr) if dn_ptr else None, _lib.stream_of(g))
+            _lib.check(rc, "semicrf_eval_path_bwd")
+            return None, None, None, None
+        sh.update(task=-1, key=None, dscore=0, dnoise=0)
         dscore = torch.zeros(T, T, B, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
         dnoise = torch.zeros(max(T - 1, 0), B, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1] else None
         _eval_path_bwd_raw(g, T, B, pairs, offsets, dscore, dnoise, ctx.K)
-        return dscore, dnoise, None, None
+        return (dscore.to(ctx.in_dtypes[0]) if dscore is not None else None,
+                dnoise.to(ctx.in_dtypes[1]) if dnoise is not None else None, None, None)
 
 
 class _LogProb(torch.autograd.Function):
@@ -226,7 +267,8 @@ class _LogProb(torch.autograd.Function):
         if need:
             ctx.save_for_backward(score_c, noise_c, v, logz, pairs, offsets)
             ctx.K = getattr(pairs, "_semicrf_K", pairs.shape[0])
-        return path - logz
+        ctx.in_dtypes = (score.dtype, noiseScore.dtype)
+        return (path - logz).to(score.dtype)
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -235,7 +277,7 @@ class _LogProb(torch.autograd.Function):
         g = _gout(grad_output, B)
         dscore, dnoise, _ = _logz_bwd_raw(score, noise, v, logz, -g)
         _eval_path_bwd_raw(g, T, B, pairs, offsets, dscore, dnoise, ctx.K)
-        return dscore, dnoise, None, None
+        return dscore.to(ctx.in_dtypes[0]), dnoise.to(ctx.in_dtypes[1]), None, None
 
 
 # --------------------------------------------------------------------------------------
@@ -276,6 +318,9 @@ def _decode(score, noiseScore, forcedStartPos: Optional[Sequence[int]], forward:
         pairs, offsets = _viterbi_raw(score_c, noise_c, start, forward)
         off_h = offsets.cpu()                      # the one host sync of decode
         total = int(off_h[-1])
+        if total < 0:
+            raise RuntimeError("semicrf_viterbi: a bounded hand-off wait timed out on the device (GPU shared with work that "
+                               "kept part of the persistent kernel from running?); the decode result is invalid")
         pairs_h = pairs[:total].cpu()
     return unpack_intervals(pairs_h, off_h, T)
 

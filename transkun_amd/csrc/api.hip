@@ -25,7 +25,8 @@ void launch_marginals(const float* score, const float* noise, const float* v, co
                       const float* logZ, const float* gout, int T, int B, float* dScore, float* dNoise,
                       hipStream_t stream);
 void launch_backtrack(const int* code, int T, int B, const int* start, int forward, int* region, int* counts,
-                      int* pairs, long long cap, int* offsets, hipStream_t stream);
+                      int* pairs, long long cap, int* offsets, hipStream_t stream, const unsigned* err, int nerr, int err_stride);
+const unsigned* persist_error_words(void* pws, int* n, int* stride);
 void launch_eval_path(const float* score, const float* noise, int T, int B, int K, const int* pairs,
                       const int* offsets, float* out, hipStream_t stream);
 void launch_eval_path_bwd(const float* gout, int T, int B, int K, const int* pairs, const int* offsets,
@@ -144,7 +145,7 @@ int semicrf_logz_fwd(const float* score, const float* noise, int T, int B, float
     hipStream_t st = (hipStream_t)stream;
     if (fast) {
         if (launch_persist_sweep(0, 0, score, noise, T, B, vv, logZ, nullptr, pws, st)) {
-            set_error("hipMemsetAsync failed"); return SEMICRF_ELAUNCH;
+            set_error("persistent sweep could not be enqueued (hipMemsetAsync failed or too many chain chunks)"); return SEMICRF_ELAUNCH;
         }
     } else {
         launch_rowseq_sweep(0, 0, score, noise, T, B, vv, nullptr, logZ, st);
@@ -169,7 +170,7 @@ int semicrf_logz_bwd(const float* score, const float* noise, const float* v, con
     if (fast) {
         // beta sweep fused with the marginals: score is read once, dScore written once
         if (launch_persist_logz_bwd(score, noise, v, logZ, gout, T, B, dScore, dNoise, q, pws, st)) {
-            set_error("hipMemsetAsync failed"); return SEMICRF_ELAUNCH;
+            set_error("persistent sweep could not be enqueued (hipMemsetAsync failed or too many chain chunks)"); return SEMICRF_ELAUNCH;
         }
     } else {
         launch_rowseq_sweep(0, 1, score, noise, T, B, q, nullptr, nullptr, st);
@@ -191,7 +192,7 @@ int semicrf_beta(const float* score, const float* noise, int T, int B, float* be
     hipStream_t st = (hipStream_t)stream;
     if (fast) {
         if (launch_persist_sweep(0, 1, score, noise, T, B, beta, nullptr, nullptr, pws, st)) {
-            set_error("hipMemsetAsync failed"); return SEMICRF_ELAUNCH;
+            set_error("persistent sweep could not be enqueued (hipMemsetAsync failed or too many chain chunks)"); return SEMICRF_ELAUNCH;
         }
     } else {
         launch_rowseq_sweep(0, 1, score, noise, T, B, beta, nullptr, nullptr, st);
@@ -218,12 +219,14 @@ int semicrf_viterbi(const float* score, const float* noise, int T, int B, const 
     hipStream_t st = (hipStream_t)stream;
     if (fast) {
         if (launch_persist_sweep(1, forward ? 0 : 1, score, noise, T, B, nullptr, nullptr, code, pws, st)) {
-            set_error("hipMemsetAsync failed"); return SEMICRF_ELAUNCH;
+            set_error("persistent sweep could not be enqueued (hipMemsetAsync failed or too many chain chunks)"); return SEMICRF_ELAUNCH;
         }
     } else {
         launch_rowseq_sweep(1, forward ? 0 : 1, score, noise, T, B, u, code, nullptr, st);
     }
-    launch_backtrack(code, T, B, start, forward ? 1 : 0, region, counts, pairs, (long long)cap, offsets, st);
+    int nerr = 0, estride = 0;
+    const unsigned* err = fast ? persist_error_words(pws, &nerr, &estride) : nullptr;
+    launch_backtrack(code, T, B, start, forward ? 1 : 0, region, counts, pairs, (long long)cap, offsets, st, err, nerr, estride);
     SEMICRF_CHECK_LAUNCH("semicrf_viterbi");
     return SEMICRF_OK;
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <stdio.h>
 #include <math.h>
 #include "../../include/semicrf_hip.h"
@@ -31,6 +32,19 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// "Once per DEVICE" latch for per-device settings such as hipFuncSetAttribute (a process may drive several GPUs).
+struct PerDeviceOnce {
+    std::atomic<bool> done[64];
+    bool first()
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (done[dev].load()) return false;
+        done[dev].store(true);
+        return true;
+    }
+};
 
 // ---- device math ---------------------------------------------------------------------------
 // F.softplus(beta=1, threshold=20): NeuralSemiCRFInterval.py:218,232,395,427

@@ -7,6 +7,7 @@
 //
 // code[c][t] = (key+1) | (s[t,t]>0 ? 1<<30 : 0), key = -1 (skip) or the absolute index of the
 // other endpoint chosen at t.
+#include <atomic>
 #include "common.h"
 
 namespace semicrf {
@@ -149,8 +150,11 @@ __global__ __launch_bounds__(BT_PAR_THREADS) void backtrack_par_kernel(const int
 }
 
 // exclusive prefix sum of counts[B] -> offsets[B+1]; single workgroup, any B
+// err: the sweep's error words (one per chain chunk, `nerr` of them `err_stride` words apart; 0xffffffff = fine) or
+// nullptr.  A sweep that gave up on a bounded wait leaves garbage codes: the total comes back as -1 instead.
 __global__ __launch_bounds__(256) void offsets_kernel(const int* __restrict__ counts, int B,
-                                                       int* __restrict__ offsets)
+                                                       int* __restrict__ offsets, const unsigned* __restrict__ err,
+                                                       int nerr, int err_stride)
 {
     __shared__ int part[256];
     __shared__ int carry;
@@ -172,7 +176,11 @@ __global__ __launch_bounds__(256) void offsets_kernel(const int* __restrict__ co
         if (threadIdx.x == 255) carry += part[255];
         __syncthreads();
     }
-    if (threadIdx.x == 0) offsets[B] = carry;
+    if (threadIdx.x == 0) {
+        bool bad = false;
+        for (int i = 0; err && i < nerr; ++i) bad = bad || err[(size_t)i * err_stride] != 0xffffffffu;
+        offsets[B] = bad ? -1 : carry;
+    }
 }
 
 __global__ __launch_bounds__(256) void pack_kernel(const int* __restrict__ region,
@@ -195,28 +203,31 @@ __global__ __launch_bounds__(256) void pack_kernel(const int* __restrict__ regio
 }
 
 void launch_backtrack(const int* code, int T, int B, const int* start, int forward, int* region,
-                      int* counts, int* pairs, long long cap, int* offsets, hipStream_t stream)
+                      int* counts, int* pairs, long long cap, int* offsets, hipStream_t stream,
+                      const unsigned* err, int nerr, int err_stride)
 {
     const size_t lds = T <= BT_LDS_MAX ? (size_t)T * sizeof(int) : 0;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // function attributes are per device (a process may drive several)
+    static std::atomic<bool> attr_set[64], par_attr_set[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev].load()) {
         (void)hipFuncSetAttribute((const void*)backtrack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   BT_LDS_MAX * (int)sizeof(int));
-        attr_set = true;
+        attr_set[dev].store(true);
     }
     if (T <= BT_PAR_MAX && T >= 2) {
-        static bool par_attr_set = false;
-        if (!par_attr_set) {
+        if (!par_attr_set[dev].load()) {
             (void)hipFuncSetAttribute((const void*)backtrack_par_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       4 * BT_PAR_MAX * (int)sizeof(int));
-            par_attr_set = true;
+            par_attr_set[dev].store(true);
         }
         hipLaunchKernelGGL(backtrack_par_kernel, dim3(B), dim3(BT_PAR_THREADS), (size_t)4 * T * sizeof(int), stream, code, T, B,
                            start, forward, region, counts);
     } else {
         hipLaunchKernelGGL(backtrack_kernel, dim3(B), dim3(64), lds, stream, code, T, B, start, forward, region, counts);
     }
-    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(256), 0, stream, counts, B, offsets);
+    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(256), 0, stream, counts, B, offsets, err, nerr, err_stride);
     hipLaunchKernelGGL(pack_kernel, dim3(B), dim3(256), 0, stream, region, counts, offsets, T, B, forward, pairs,
                        cap);
 }

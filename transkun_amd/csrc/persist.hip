@@ -196,6 +196,11 @@ __device__ __forceinline__ float softplus2(float x)
 
 // sticky device-side status word (0 = fine); read and cleared by semicrf_debug_device_status()
 __device__ unsigned g_dev_status = 0;
+// set (LDS) by any wave of this workgroup that gave up on a bounded wait or saw another one give up: a spine workgroup
+// whose flag is up poisons its final outputs with NaN (every wrong result is preceded by a timed-out wait in the
+// workgroup of the affected chains -- a missing far partial, band row or ring entry), so that a caller notices without
+// reading the status word: logZ / alpha / beta / the gradient come back NaN, decode returns a negative total.
+__shared__ int s_abort;
 
 __device__ __forceinline__ void set_error(unsigned* ctrl, unsigned code)
 {
@@ -209,9 +214,9 @@ __device__ __forceinline__ void set_error(unsigned* ctrl, unsigned code)
 __device__ __forceinline__ bool spin_abort(unsigned* ctrl, int& spins, int limit, unsigned code)
 {
     ++spins;
-    if (spins > limit) { set_error(ctrl, code); return true; }
+    if (spins > limit) { set_error(ctrl, code); s_abort = 1; return true; }
     if ((spins & 255) == 0 &&
-        __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != CTRL_INIT) return true;
+        __hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != CTRL_INIT) { s_abort = 1; return true; }
     return false;
 }
 
@@ -672,7 +677,8 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
 
         // ---- once per block: publish the 16 finished positions to HBM -----------------------------
         if (rvalid) {
-            const float mine = rd_base[(prow % NPOS) * 8];
+            float mine = rd_base[(prow % NPOS) * 8];
+            if (k == K - 1 && lds_flag_load(&s_abort) != 0) mine = __uint_as_float(0x7fc00000u);     // a wait timed out: poison the results
             {
                 unsigned ub = __float_as_uint(mine);
                 if (ub == U_EMPTY) ub = 0x7fc00000u;            // keep the one reserved pattern free (NaN input scores)
@@ -1540,7 +1546,7 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
 {
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];
     __shared__ int s_ticket;
-    if (threadIdx.x == 0) s_ticket = (int)(atomicAdd(P.ctrl, 1u) + 1u);
+    if (threadIdx.x == 0) { s_ticket = (int)(atomicAdd(P.ctrl, 1u) + 1u); s_abort = 0; }
     // flags and sequence numbers start at 0
     for (int i = threadIdx.x; i < (LDS_DUMMY - LDS_FAR) / 4; i += NT) ((int*)(s_dyn + LDS_FAR))[i] = 0;
     __syncthreads();
@@ -1619,16 +1625,25 @@ void launch_zero_upper(float* X, int T, int B, hipStream_t stream)
     hipLaunchKernelGGL(zero_upper_kernel, dim3(gx, T - 1), dim3(256), 0, stream, X, T, B);
 }
 
+constexpr int MAX_DEVICES = 64;
+static int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+    return dev;
+}
 static int device_cus()
 {
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0, v = 0;
-        ncu = 256;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+    static std::atomic<int> ncu[MAX_DEVICES];                    // 0: not asked yet (per device: a process may drive several)
+    const int dev = current_device();
+    int n = ncu[dev].load();
+    if (n == 0) {
+        int v = 0;
+        n = 256;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        ncu[dev].store(n);
     }
-    return ncu;
+    return n;
 }
 
 size_t persist_workspace_bytes(int T, int B)
@@ -1642,7 +1657,7 @@ size_t persist_workspace_bytes(int T, int B)
 bool persist_supported(int T, int B)
 {
     return B >= 2 && B % 2 == 0 && T >= 2 && T < 65535 && (long long)T * B * 64 < (1ll << 31) &&      // 32-bit buffer offsets
-           (B + GS - 1) / GS <= MAX_CHUNKS * 64 &&      // chain chunks of at most half the CUs' worth of rings
+           (B + GS - 1) / GS <= MAX_CHUNKS * (device_cus() / 2 > 0 ? device_cus() / 2 : 1) &&      // chain chunks of at most half the CUs' worth of rings
            max_parts(T) <= MAX_QUEUES;                   // one scheduler queue per column part
 }
 
@@ -1656,6 +1671,14 @@ static unsigned next_tag()
 static int g_run_ahead_max = 6;
 static int g_recent_tiles = 0;      // recent waves off by default: measured slower, kept for the next attempt
 
+struct Knobs { int xr, run_ahead, hybrid_waves, hybrid_start, panel_waves, zero_waves; };
+static Knobs read_knobs()
+{
+    auto get = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : -1; };
+    return Knobs{get("SEMICRF_XR"), get("SEMICRF_RUN_AHEAD"), get("SEMICRF_HYBRID_PANEL_WAVES"), get("SEMICRF_HYBRID_START"),
+                 get("SEMICRF_PANEL_WAVES"), get("SEMICRF_ZERO_WAVES")};
+}
+
 struct GradArgs {
     const float* vfwd; const float* logZ; const float* gout; float* dScore; float* dNoise;
 };
@@ -1663,11 +1686,12 @@ struct GradArgs {
 template <int MODE, int DIR, bool GRAD>
 static void launch_one(const SweepParams& P, int grid, hipStream_t stream)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<bool> attr_set[MAX_DEVICES];              // the attribute is per device
+    const int dev = current_device();
+    if (!attr_set[dev].load()) {
         (void)hipFuncSetAttribute((const void*)persist_sweep_kernel<MODE, DIR, GRAD>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN_BYTES);
-        attr_set = true;
+        attr_set[dev].store(true);
     }
     hipLaunchKernelGGL((persist_sweep_kernel<MODE, DIR, GRAD>), dim3(grid), dim3(NT), LDS_DYN_BYTES, stream, P);
 }
@@ -1682,8 +1706,11 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
     if (grad) { P.vfwd = grad->vfwd; P.logZ = grad->logZ; P.gout = grad->gout; P.dScore = grad->dScore; P.dNoise = grad->dNoise; }
     P.score = score; P.noise = noise; P.T = T; P.B = B; P.K = (T + PB - 1) / PB;
     P.tag = next_tag();
-    const char* dbg = getenv("SEMICRF_DEBUG_FLAGS");
-    P.dbg = dbg ? (unsigned)atoi(dbg) : 0u;
+    P.dbg = 0u;
+#if SEMICRF_PANEL_PROBES
+    // timing ablations (results are wrong when set): only the probe build reads them
+    if (const char* dbg = getenv("SEMICRF_DEBUG_FLAGS")) P.dbg = (unsigned)atoi(dbg);
+#endif
     char* w = (char*)ws;
     P.ts = (u64*)(w + CTRL_BYTES);
     const size_t ts_bytes = align_up((size_t)2 * T * sizeof(u64));
@@ -1694,7 +1721,8 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
     // ONE fill: every word of the workspace starts as 0xffffffff -- u reads U_EMPTY, far-field granules carry a tag no
     // launch uses, the counters return 0 after their first increment, the error word reads CTRL_INIT
     if (hipMemsetAsync(ws, 0xff, persist_workspace_bytes(T, B), stream) != hipSuccess) return 1;
-    static const int xr_env = [] { const char* e = getenv("SEMICRF_XR"); return e ? atoi(e) : -1; }();      // tuning knob, read once
+    static const Knobs knobs = read_knobs();                    // tuning knobs of the development tools: the environment is read ONCE
+    const int xr_env = knobs.xr;
 
     // Chain chunks: at most a quarter of the CUs host spines in one launch (every workgroup must be resident
     // and the panels need the rest of the chip).
@@ -1740,14 +1768,14 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         // vs 217 (never); T=691, NBatch=360: 158 vs 177 vs 173; T=2048: 651 vs 677 (from the start) vs 788 (never).
         // The gradient sweep is bandwidth-bound almost from the start.
         int hpw = HPW_MAX - rw > 0 ? HPW_MAX - rw : 0;
-        if (const char* e = getenv("SEMICRF_HYBRID_PANEL_WAVES")) { const int v = atoi(e); if (v >= 0 && v <= HPW_MAX - rw) hpw = v; }
+        if (knobs.hybrid_waves >= 0 && knobs.hybrid_waves <= HPW_MAX - rw) hpw = knobs.hybrid_waves;
         int hstart = grad ? 12 : P.K * 3 / 8;
         hstart = hstart < 8 ? 8 : (hstart > 32 ? 32 : hstart);
-        if (const char* e = getenv("SEMICRF_HYBRID_START")) { const int v = atoi(e); if (v >= 0) hstart = v; }
+        if (knobs.hybrid_start >= 0) hstart = knobs.hybrid_start;
         P.hybridStart = hstart;
         P.hybridPanelWaves = hpw;
         int pw = PW_MAX;
-        if (const char* e = getenv("SEMICRF_PANEL_WAVES")) { const int v = atoi(e); if (v > 0) pw = v; }   // tuning knob
+        if (knobs.panel_waves > 0) pw = knobs.panel_waves;
         if (pw < 1) pw = 1;
         if (pw > PW_MAX) pw = PW_MAX;
         (void)per_cu;
@@ -1757,8 +1785,7 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
             // that the full parts of earlier blocks always find a free wave (see panel_next_task)
             const int g4 = P.nPanelGroups * 4;
             int ra = g4 > 0 ? (nPanelWG * pw / 2) / g4 : 0;
-            static const int ra_env = [] { const char* e = getenv("SEMICRF_RUN_AHEAD"); return e ? atoi(e) : -1; }();   // tuning knob, read once
-            const int ra_max = ra_env >= 0 ? ra_env : g_run_ahead_max;
+            const int ra_max = knobs.run_ahead >= 0 ? knobs.run_ahead : g_run_ahead_max;
             ra = ra < 0 ? 0 : (ra > ra_max ? ra_max : ra);
             P.runAhead = ra;
         }
@@ -1767,7 +1794,7 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         int zw = 0;
         if (grad && ci == 0) {
             zw = 2;
-            if (const char* e = getenv("SEMICRF_ZERO_WAVES")) { const int v = atoi(e); if (v >= 0) zw = v; }
+            if (knobs.zero_waves >= 0) zw = knobs.zero_waves;
             if (zw > NT / 64 - pw) zw = NT / 64 - pw;
             if (nPanelWG <= 0 || P.nTasks == 0) zw = 0;
             if (zw == 0 && T > 1) {
@@ -1799,6 +1826,13 @@ int launch_persist_logz_bwd(const float* score, const float* noise, const float*
 {
     GradArgs ga{v, logZ, gout, dScore, dNoise};
     return launch_persist_sweep_impl(0, 1, score, noise, T, B, q_out, nullptr, nullptr, ws, stream, &ga);
+}
+
+// the error word of every chain chunk of a sweep launched into `pws` (0xffffffff = no wait timed out)
+const unsigned* persist_error_words(void* pws, int* n, int* stride)
+{
+    *n = MAX_CHUNKS; *stride = (int)CTRL_WORDS;
+    return (const unsigned*)pws + 1;
 }
 
 int read_and_clear_device_status()

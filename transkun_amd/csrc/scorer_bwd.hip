@@ -275,11 +275,10 @@ static void launch_bwd_pass(const float* dS, const float* other, float* out, int
     switch (D / 32) {
 #define SEMICRF_BWD_CASE(N)                                                                                             \
     case N: {                                                                                                           \
-        static bool attr_set = false;                                                                                   \
-        if (!attr_set) {                                                                                                \
+        static PerDeviceOnce attr_once;                                                                                   \
+        if (attr_once.first()) {                                                                                                \
             (void)hipFuncSetAttribute((const void*)interval_score_bwd_kernel<ROWS_E, N, FUSED>,                                \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
-            attr_set = true;                                                                                            \
         }                                                                                                               \
         hipLaunchKernelGGL((interval_score_bwd_kernel<ROWS_E, N, FUSED>), grid, block, lds, stream, dS, other, out, C, T,  \
                            ldo, ldout, qscale, mode, F);                                                                        \

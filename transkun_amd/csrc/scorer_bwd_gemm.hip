@@ -416,10 +416,9 @@ static void launch_gemm(const float* Gt, int Tp, const float* other, long long l
                         int T, hipStream_t stream)
 {
     const size_t lds = (size_t)GNS * (GA_BYTES + GK * 64 * NW * 4);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)score_bwd_gemm_kernel<AT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     int ncu = 256, dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)

@@ -150,17 +150,24 @@ bool interval_score_mfma_supported(int C, int T, int D) { return D % 64 == 0 && 
 
 constexpr int NXCD = 8;
 
-// builds (once per shape) the device-resident work list described above
-static const int2* score_work_list(int nt, int ngroups, int full, int band, int* grid_out)
+// builds (once per device and shape) the device-resident work list described above.  The cache holds the SCORE_WL_MAX most
+// recently used lists (least recently used one freed first), the upload is enqueued on the caller's stream (from a pageable
+// staging vector kept alive in the cache entry), and a failed upload frees the allocation.  The first call for a shape
+// allocates (hipMalloc: not stream-capturable); later calls only look the list up.
+constexpr size_t SCORE_WL_MAX = 16;
+struct ScoreWorkList { int2* dev = nullptr; int n = 0; unsigned long long stamp = 0; std::vector<int2> host; };
+
+static const int2* score_work_list(int nt, int ngroups, int full, int band, int* grid_out, hipStream_t stream)
 {
     static std::mutex mu;
-    static std::map<std::tuple<int, int, int, int, int>, std::pair<int2*, int>> cache;
+    static std::map<std::tuple<int, int, int, int, int>, ScoreWorkList> cache;
+    static unsigned long long clock = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mu);
     const auto key = std::make_tuple(dev, nt, ngroups, full, band);
     auto it = cache.find(key);
-    if (it != cache.end()) { *grid_out = it->second.second; return it->second.first; }
+    if (it != cache.end()) { it->second.stamp = ++clock; *grid_out = it->second.n; return it->second.dev; }
     // units: (chain group, pair of bands p and nb-1-p) -- equal work per unit in the triangle
     const int nb = (nt + band - 1) / band;
     std::vector<std::vector<int2>> per(NXCD);
@@ -180,15 +187,31 @@ static const int2* score_work_list(int nt, int ngroups, int full, int band, int*
         }
     size_t longest = 0;
     for (auto& v : per) longest = v.size() > longest ? v.size() : longest;
-    std::vector<int2> flat(longest * NXCD, make_int2(-1, 0));
+    ScoreWorkList e;
+    e.host.assign(longest * NXCD, make_int2(-1, 0));
     for (int x = 0; x < NXCD; ++x)
-        for (size_t i = 0; i < per[x].size(); ++i) flat[i * NXCD + x] = per[x][i];
-    int2* d = nullptr;
-    if (hipMalloc((void**)&d, flat.size() * sizeof(int2)) != hipSuccess) return nullptr;
-    if (hipMemcpy(d, flat.data(), flat.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-    cache[key] = std::make_pair(d, (int)flat.size());
-    *grid_out = (int)flat.size();
-    return d;
+        for (size_t i = 0; i < per[x].size(); ++i) e.host[i * NXCD + x] = per[x][i];
+    if (cache.size() >= SCORE_WL_MAX) {                  // evict the least recently used list of this process
+        auto lru = cache.begin();
+        for (auto c = cache.begin(); c != cache.end(); ++c)
+            if (c->second.stamp < lru->second.stamp) lru = c;
+        // kernels that still read the list were enqueued before this call: free after they have drained
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(lru->second.dev);
+        cache.erase(lru);
+    }
+    if (hipMalloc((void**)&e.dev, e.host.size() * sizeof(int2)) != hipSuccess) return nullptr;
+    e.n = (int)e.host.size();
+    e.stamp = ++clock;
+    auto ins = cache.emplace(key, std::move(e)).first;          // the staging vector lives on in the cache entry
+    if (hipMemcpyAsync(ins->second.dev, ins->second.host.data(), ins->second.host.size() * sizeof(int2), hipMemcpyHostToDevice,
+                       stream) != hipSuccess) {
+        (void)hipFree(ins->second.dev);
+        cache.erase(ins);
+        return nullptr;
+    }
+    *grid_out = ins->second.n;
+    return ins->second.dev;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -441,12 +464,11 @@ static int launch_score_stream(const float* q, const float* k, const float* diag
     const int nt = (T + ST - 1) / ST;
     const size_t lds = (size_t)YW * YNS * ZSTAGE;
     int nlist = 0;
-    const int2* work = score_work_list(nt, (C + YG - 1) / YG, full ? 1 : 0, band, &nlist);
+    const int2* work = score_work_list(nt, (C + YG - 1) / YG, full ? 1 : 0, band, &nlist, stream);
     if (!work) return 1;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)interval_score_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     int ncu = 256, dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
@@ -736,10 +758,9 @@ static int launch_score_tile(const float* q, const float* k, const float* diag, 
         for (int et = 0; et < net; ++et) ntiles += (et * XTE + XTE - 1) / XTB + 1 < nbt ? (et * XTE + XTE - 1) / XTB + 1 : nbt;
     const int nquadp = ((C + 3) / 4 + 7) / 8 * 8;
     const size_t lds = (size_t)XNS * (XTE + XTB) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)interval_score_tile_kernel<XTE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     int ncu = 256, dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
@@ -751,7 +772,9 @@ static int launch_score_tile(const float* q, const float* k, const float* diag, 
     const long long need = (nitems + 8 * NXCD - 1) / (8 * NXCD) * (8 * NXCD);
     if (grid > need) grid = (int)need;
     int dbg = 0;
-    if (const char* e = getenv("SEMICRF_SCORE_DEBUG")) dbg = atoi(e) & 0xff;
+#ifdef SEMICRF_DEBUG_BUILD
+    if (const char* e = getenv("SEMICRF_SCORE_DEBUG")) dbg = atoi(e) & 0xff;      // timing ablations (wrong results): debug builds only
+#endif
     hipLaunchKernelGGL(interval_score_tile_kernel<XTE>, dim3(grid), dim3(XTE * 4), lds, stream, q, k, diag, C, T, D, ldq, ldk, ldd,
                        qscale, mode | (dbg << 8), full, S, ntiles, nquadp);
     return 0;
@@ -766,7 +789,8 @@ int launch_interval_score_mfma(const float* q, const float* k, const float* diag
     const bool aligned = ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ldq % 4 == 0 && ldk % 4 == 0;
     const int nch = (D / 64 <= 4) ? D / 64 : 0;
     int band = 4;
-    if (const char* e = getenv("SEMICRF_SCORE_BAND")) { const int v = atoi(e); if (v >= 1 && v <= 64) band = v; }   // tuning knob
+    static const int band_env = [] { const char* e = getenv("SEMICRF_SCORE_BAND"); return e ? atoi(e) : 0; }();     // tuning knob, read once
+    if (band_env >= 1 && band_env <= 64) band = band_env;
     // 16-byte aligned rows: the LDS-staged kernel (T*ld*4 < 2^31: 32-bit buffer offsets)
     if (aligned && D % 64 == 0 && (long long)T * ldq * 4 < (1ll << 31) && (long long)T * ldk * 4 < (1ll << 31)) {
         // 64-row tiles when they waste less of the last tile row (e.g. T=691: 704 vs 768 rows) -- measured 779 vs 814 us
@@ -780,16 +804,15 @@ int launch_interval_score_mfma(const float* q, const float* k, const float* diag
             return launch_score_stream(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, band, stream);
     }
     int ngrid = 0;
-    const int2* work = score_work_list(nt, (C + SC - 1) / SC, full ? 1 : 0, band, &ngrid);
+    const int2* work = score_work_list(nt, (C + SC - 1) / SC, full ? 1 : 0, band, &ngrid, stream);
     if (!work) return 1;
     const dim3 grid(ngrid), block(256);
 #define SEMICRF_FWD_LAUNCH(A, N)                                                                                        \
     do {                                                                                                                \
-        static bool attr_set = false;                                                                                   \
-        if (!attr_set) {                                                                                                \
+        static PerDeviceOnce attr_once;                                                                                   \
+        if (attr_once.first()) {                                                                                                \
             (void)hipFuncSetAttribute((const void*)interval_score_mfma_kernel<A, N>,                                    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
-            attr_set = true;                                                                                            \
         }                                                                                                               \
         hipLaunchKernelGGL((interval_score_mfma_kernel<A, N>), grid, block, lds, stream, q, k, diag, C, T, D, ldq, ldk, \
                            ldd, qscale, mode, full, S, work);                                                           \
