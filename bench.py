@@ -423,6 +423,27 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
             extra[tag + "_scorer_crf_logprob_fwd_bwd_ms_unfused"] = round(ev_time(lambda: seg_step(False), 5), 3)
             extra[tag + "_scorer_decode_features_ms_device"] = round(ev_time(seg_decode, 5), 3)
             del ctx
+        # ---- the transcription segment loop: decode -> heads -> events -> next forced start, F recordings in
+        # lock step, incomplete-event merge on the host; the shipped geometry (16 s segments, 8 s hop: T = 691, 90 symbols) ----
+        from transkun_amd.transcribe import SegmentTranscriber
+        tr = SegmentTranscriber(D).to(dev).eval()
+        n_audio = int(56.0 * tr.fs)                                   # 56 s of audio: 9 segments per recording
+        for Fn in (1, 4):
+            plan = tr.segment_plan(n_audio)
+            nseg_f = len(plan["begins"])
+            ctxs = [(synth.hash_normal(P * plan["nFrame"] * D, 31 + i, dev).view(1, P, plan["nFrame"], D) * 0.5) for i in range(3)]
+            fns = [(lambda i, T, f=f: ctxs[(i + f) % 3]) for f in range(Fn)]
+            tr.transcribe_many(fns, [n_audio] * Fn)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            ev = tr.transcribe_many(fns, [n_audio] * Fn)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t1
+            tag = f"transcribe_loop_T691_P90_F{Fn}"
+            extra[tag + "_segments_per_s_end_to_end"] = round(Fn * nseg_f / dt, 1)
+            extra[tag + "_ms_per_step"] = round(dt / nseg_f * 1e3, 3)
+            extra[tag + "_events"] = sum(len(x) for x in ev)
+        del tr, ctxs
         log("segment-shaped path done; train-shaped step next")
 
     # ---- train.py-shaped step (BASELINE configs[4]): every rank, its own 4 segments ---------------------------------

@@ -227,6 +227,29 @@ int interval_features_gather(const float* ctx, int C, int T, int D, int64_t ldc,
 int interval_features_gather_bwd(const float* gout, const float* ctx, int C, int T, int D, int64_t ldc, const int32_t* pairs,
                                  int64_t K, const int32_t* offsets, float* dctx, int64_t lddc, semicrf_stream_t stream);
 
+/*
+ * Transcription segment loop, on the packed decode output in HBM.
+ *
+ * segment_onset_filter.  Replaces: the onsetBound filter of TransKun.transcribeFrames (ModelTransformer.py:554-555),
+ *   `path = [[e for e in _ if e[0] < onsetBound] for _ in path]`: pairs/offsets (as written by semicrf_viterbi) ->
+ *   pairs_out [cap][2] / offsets_out [B+1]; counts_ws: B ints of scratch.  offsets_out[B] is exact even if it exceeds cap.
+ *
+ * segment_events.  Replaces: the per-interval event assembly of transcribeFrames (:672-718) and the hand-off of
+ *   TransKun.transcribe (:789-800), for chains c = segment * nSym + symbol in list order:
+ *     start = (begin + ofValue[i][0]) * frameDur, end = (end + ofValue[i][1]) * frameDur   (double, the reference's order)
+ *     hasOnset = begin > 0 || ofPresence[i][0];  hasOffset = end < lastFrameIdx || ofPresence[i][1]
+ *     start = max(start, lastEnd); end = max(end, start + 1e-8); lastEnd = end            (per chain)
+ *     times[i] = the two shifted by beginTime[segment], clamped (start >= 0, end >= start);  flags[i] = {hasOnset, hasOffset}
+ *     lastP[c] = end frame of the chain's last interval with hasOffset (0 if none);  nextStart[c] = max(lastP[c] - stepFrames, 0)
+ *   ofValue: float [K][2] (already (mean - 0.5) / 0.99 clamped, :650-653), ofPresence: bytes [K][2] (logit > 0, :655),
+ *   beginTime: double [B / nSym].  nextStart is what the next semicrf_viterbi takes as `start`.
+ */
+int segment_onset_filter(const int32_t* pairs, const int32_t* offsets, int B, int bound, int32_t* pairs_out, int64_t cap,
+                         int32_t* offsets_out, int32_t* counts_ws, semicrf_stream_t stream);
+int segment_events(const int32_t* pairs, int64_t K, const int32_t* offsets, int B, int nSym, const float* ofValue,
+                   const unsigned char* ofPresence, int lastFrameIdx, double frameDur, const double* beginTime, int stepFrames,
+                   double* times, unsigned char* flags, int32_t* lastP, int32_t* nextStart, semicrf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

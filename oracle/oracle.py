@@ -260,3 +260,67 @@ def fetch_interval_features(ctx, intervals_batch):
                 sym.append(s_i); sc.append(idx * SYM + s_i)                   # :514, :516
     return (np.stack(a).astype(np.float32), np.stack(b).astype(np.float32),
             np.asarray(sym, np.int64), np.asarray(sc, np.int64))
+
+
+# --------------------------------------------------------------------------------------
+# transcription segment loop -- test infrastructure only
+# --------------------------------------------------------------------------------------
+
+def segment_events(lists, nSym, ofValue, ofPresence, lastFrameIdx, frameDur, beginTime, stepFrames):
+    """CPU restatement of the per-interval event assembly of TransKun.transcribeFrames (ModelTransformer.py:672-718) and of
+    the hand-off of TransKun.transcribe (:789-800), in Python floats like the reference.
+    lists: decoded intervals per chain (chain = segment * nSym + symbol); ofValue [K][2] floats and ofPresence [K][2] bools
+    in list order; beginTime: one float per segment.  Returns (events, lastP, nextStart): events = per chain a list of
+    (start, end, hasOnset, hasOffset) already shifted by the segment's begin time and clamped (:794-800).
+    Pinned against the reference's own loop by tools/make_golden.py (tests/golden/transcribe_*.npz)."""
+    events, lastP, nextStart = [], [], []
+    n = 0
+    for c, cur in enumerate(lists):
+        bt = beginTime[c // nSym]
+        lastEnd = 0                                            # :678
+        curLastP = 0                                           # :679
+        out = []
+        for (b, e) in cur:
+            start = (b + float(ofValue[n][0])) * frameDur      # :684
+            end = (e + float(ofValue[n][1])) * frameDur        # :685
+            hasOnset = (b > 0) or bool(ofPresence[n][0])       # :689
+            hasOffset = (e < lastFrameIdx) or bool(ofPresence[n][1])   # :690
+            start = max(start, lastEnd)                        # :694
+            end = max(end, start + 1e-8)                       # :695
+            lastEnd = end                                      # :696
+            if hasOffset:                                      # :708-709
+                curLastP = e
+            s2 = start + bt; e2 = end + bt                     # transcribe :795-796
+            s2 = max(s2, 0); e2 = max(e2, s2)                  # :798-799
+            out.append((s2, e2, hasOnset, hasOffset))
+            n += 1
+        events.append(out)
+        lastP.append(curLastP)                                 # :718
+        nextStart.append(max(curLastP - stepFrames, 0))        # transcribe :789-791
+    return events, lastP, nextStart
+
+
+def merge_segments(per_segment_events, mergeIncompleteEvent=True):
+    """CPU restatement of the cross-segment merge of TransKun.transcribe (:803-843, without resolveOverlapping).
+    per_segment_events: for every segment a list of (start, end, pitch, velocity, hasOnset, hasOffset) in the reference's
+    order (sorted by (start, end, pitch) within the segment).  Returns the surviving events as tuples."""
+    by_type = {}
+    for seg in per_segment_events:
+        for e in seg:
+            e = list(e)
+            lst = by_type.setdefault(e[2], [])
+            if mergeIncompleteEvent and lst:
+                last = lst[-1]
+                if e[0] < last[1]:
+                    if e[4]:
+                        lst[-1] = e
+                    else:
+                        last[5] = e[5]
+                        last[1] = max(e[1], last[1])
+                    continue
+            if e[4]:
+                lst.append(e)
+    for lst in by_type.values():
+        if lst:
+            lst[-1][5] = True
+    return [tuple(e) for lst in by_type.values() for e in lst if e[5]]

@@ -684,7 +684,7 @@ def test_two_node_pattern_both_orders_and_dtype(gpu):
     w = synth.hash_normal(B, 10, gpu)
 
     def grads(fn, dtype=torch.float32):
-        s = score.to(dtype).requires_grad_(); n = noise.to(dtype).requires_grad_()
+        s = score.to(dtype).clone().requires_grad_(); n = noise.to(dtype).clone().requires_grad_()
         out = fn(CRF.NeuralSemiCRFInterval(s, n))
         (out * w.to(dtype)).sum().backward()
         return out.detach(), s.grad, n.grad
@@ -710,3 +710,128 @@ def test_two_node_pattern_both_orders_and_dtype(gpu):
     d = grads(lambda c: c.logProb(iv), torch.float64)
     assert d[0].dtype == torch.float64 and d[1].dtype == torch.float64 and d[2].dtype == torch.float64
     assert float((d[0].float() - ref[0]).abs().max()) <= 1e-5 * float(ref[0].abs().max())
+
+
+# ---- transcription segment loop -----------------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["small", "real"])
+def test_segment_events_kernel_bit_exact(gpu, oracle, name):
+    """segment_events on the reference's own decoded paths and head outputs: event times (float64, the reference's operation
+    order), flags, lastP and the next forced start are bit-identical to the oracle, which reproduces TransKun.transcribe
+    (tests/test_oracle_golden.py::test_transcribe_loop_oracle)."""
+    from segment_common import golden_of_heads, transcribe_inputs
+    from transkun_amd import _lib
+    g = load_golden("transcribe_" + name)
+    I = transcribe_inputs(name)
+    P = I["P"]
+    frameDur = I["hop"] / I["fs"]
+    stepFrames = int(I["step"] / I["hop"])
+    lastFrameIdx = round(I["seg"] / I["hop"])
+    ops = _lib.ops()
+    hi = 0
+    for i in range(I["n_seg"]):
+        pairs_h, off_h = g[f"seg{i}_pairs"].astype(np.int32), g[f"seg{i}_offsets"].astype(np.int32)
+        K = len(pairs_h)
+        if K == 0:
+            continue
+        lists = unpack_lists(pairs_h, off_h)
+        ofValue, ofPresence, _ = golden_of_heads(g, hi); hi += 1
+        beginTime = (i * I["step"]) / I["fs"] - I["pad_t"]
+        ev, lastP, nextStart = oracle.segment_events(lists, P, ofValue.tolist(), ofPresence.tolist(), lastFrameIdx, frameDur, [beginTime],
+                                                     stepFrames)
+        pairs = torch.from_numpy(pairs_h).to(gpu); offsets = torch.from_numpy(off_h).to(gpu)
+        times = torch.empty(K, 2, dtype=torch.float64, device=gpu); flags = torch.empty(K, 2, dtype=torch.uint8, device=gpu)
+        lp = torch.empty(P, dtype=torch.int32, device=gpu); ns = torch.empty(P, dtype=torch.int32, device=gpu)
+        ops.segment_events(pairs, K, offsets, P, P, ofValue.to(gpu), ofPresence.to(gpu).view(torch.uint8), lastFrameIdx, frameDur,
+                           torch.tensor([beginTime], dtype=torch.float64, device=gpu), stepFrames, times, flags, lp, ns)
+        want_t = np.asarray([[e[0], e[1]] for c in ev for e in c], np.float64)
+        want_f = np.asarray([[e[2], e[3]] for c in ev for e in c], np.uint8)
+        assert np.array_equal(times.cpu().numpy(), want_t)                     # bit-exact doubles
+        assert np.array_equal(flags.cpu().numpy(), want_f)
+        assert lp.cpu().tolist() == lastP == [int(x) for x in g[f"seg{i}_lastP"]]
+        assert ns.cpu().tolist() == nextStart
+
+
+@pytest.mark.gpu
+def test_onset_filter(gpu):
+    """segment_onset_filter against the reference's list comprehension (ModelTransformer.py:554-555) on decoded paths."""
+    from transkun_amd import CRF, _lib, synth
+    import importlib
+    nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
+    T, B = 97, 46
+    score, noise = synth.crf_inputs(T, B, 31, gpu)
+    pairs, offsets = nsci._viterbi_raw(score, noise, None, False)
+    lists = CRF.NeuralSemiCRFInterval(score, noise).decode()
+    for bound in (0, 1, 40, 96, 200):
+        want = [[e for e in l if e[0] < bound] for l in lists]
+        p2 = torch.empty_like(pairs); o2 = torch.empty_like(offsets); cnt = torch.empty(B, dtype=torch.int32, device=gpu)
+        _lib.ops().segment_onset_filter(pairs, offsets, B, bound, p2, o2, cnt)
+        got = nsci.unpack_intervals(p2[:int(o2[-1])].cpu(), o2.cpu(), T)
+        assert got == want, bound
+
+
+def _transcriber(name, gpu):
+    from segment_common import transcribe_inputs
+    from transkun_amd.transcribe import SegmentTranscriber
+    I = transcribe_inputs(name, gpu)
+    m = SegmentTranscriber(I["D"], I["H"], I["H"], I["hop"], I["win"], I["fs"], I["step_s"], I["seg_s"]).to(gpu).eval()
+    with torch.no_grad():
+        m.scorer.map[0].weight.copy_(I["W"]); m.scorer.map[0].bias.copy_(I["bias"])
+        for mod, w in ((m.velocityPredictor, I["heads"]["velocity"]), (m.refinedOFPredictor, I["heads"]["of"])):
+            mod[0].weight.copy_(w[0]); mod[0].bias.copy_(w[1]); mod[3].weight.copy_(w[2]); mod[3].bias.copy_(w[3])
+    return m, I
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["small", "real"])
+def test_transcribe_end_to_end_vs_reference(gpu, name):
+    """SegmentTranscriber.transcribe (scorer, decode, heads and the segment loop all on the GPU) against the events the
+    reference's TransKun.transcribe produced from the same per-segment ctx and weights.  The attribute heads are stock fp32
+    GEMMs on both sides: everything discrete is compared exactly, refined times to 2e-4 s (see below)."""
+    from segment_common import golden_events
+    g = load_golden("transcribe_" + name)
+    m, I = _transcriber(name, gpu)
+    events = m.transcribe(lambda i, T: I["ctxs"][i], I["n_sample_unpadded"])
+    want = golden_events(g, "final")
+    assert len(events) == len(want)
+    # compare pitch by pitch (the global order by start time may swap neighbours whose refined times differ in the last bits)
+    by_pitch_got, by_pitch_want = {}, {}
+    for e in events:
+        by_pitch_got.setdefault(e.pitch, []).append((e.start, e.end, e.velocity, e.hasOnset, e.hasOffset))
+    for e in want:
+        by_pitch_want.setdefault(e[2], []).append((e[0], e[1], e[3], e[4], e[5]))
+    assert sorted(by_pitch_got) == sorted(by_pitch_want)
+    n_time, n_vel, n_flag, worst = 0, 0, 0, 0.0
+    for pitch, wl in by_pitch_want.items():
+        gl = sorted(by_pitch_got[pitch]); wl = sorted(wl)
+        assert len(gl) == len(wl), pitch
+        for a, b in zip(gl, wl):
+            dt = max(abs(a[0] - b[0]), abs(a[1] - b[1]))
+            worst = max(worst, dt)
+            n_time += dt > 2e-4
+            n_vel += a[2] != b[2]
+            n_flag += a[3:] != b[3:]
+    print(name, "events", len(want), "time mismatches", n_time, "velocity mismatches", n_vel, "flag mismatches", n_flag, "worst dt", worst)
+    # Decoded intervals, velocities and flags must match exactly (observed: all of them).  The refined times come from
+    # ContinuousBernoulli(logits).mean (ModelTransformer.py:648-651), whose closed form cancels catastrophically for logits
+    # near 0 (two terms of size 1/(1-2p)): fp32 round-off of the head GEMMs on different hardware moves it by up to 4e-3 of a
+    # frame there = 9e-5 s (observed worst case), against a frame of 23 ms.  Tolerance 2e-4 s.  The heads are fp32 GEMMs + GELU
+    # on different hardware: an argmax over 128 velocity logits or the sign of a presence logit could flip when two values
+    # agree to ~1e-6 -- allowed for at most 0.5 % / 0.05 % of the events.
+    assert n_time == 0 and n_flag <= len(want) // 2000 and n_vel <= len(want) // 200, (n_time, n_vel, n_flag)
+
+
+@pytest.mark.gpu
+def test_transcribe_many_equals_one_by_one(gpu):
+    """Recordings of different lengths decoded in lock step (one batch of 90 x #files chains per step, forced starts handed over
+    on the device) give exactly the events of transcribing each recording alone."""
+    m, I = _transcriber("small", gpu)
+    n_full = I["n_sample_unpadded"]
+    n_short = int(n_full * 0.55)
+    fn_a = lambda i, T: I["ctxs"][i]
+    fn_b = lambda i, T: I["ctxs"][(i + 2) % len(I["ctxs"])]
+    alone = [m.transcribe(fn_a, n_full), m.transcribe(fn_b, n_short), m.transcribe(fn_b, n_full)]
+    together = m.transcribe_many([fn_a, fn_b, fn_b], [n_full, n_short, n_full])
+    for x, y in zip(alone, together):
+        assert [e.astuple() for e in x] == [e.astuple() for e in y]

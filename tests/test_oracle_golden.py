@@ -220,3 +220,47 @@ def test_segment_oracle(oracle, name):
     batch = [dec[n * P:(n + 1) * P] for n in range(N)]
     a, b, sym, sc = oracle.fetch_interval_features(ctx.numpy(), batch)
     check_segment_features(g, a, b, sym, sc)
+
+
+@pytest.mark.parametrize("name", ["small", "real"])
+def test_transcribe_loop_oracle(oracle, name):
+    """The oracle's restatement of the segment loop (event assembly, lastP, next forced start, incomplete-event merge) and the
+    product's host-side merge + resolveOverlapping against the reference's own TransKun.transcribe run on the same decoded
+    paths and head outputs (tests/golden/transcribe_*.npz)."""
+    import math
+    from segment_common import TARGET_PITCH, event_table, golden_events, golden_of_heads, transcribe_inputs
+    from transkun_amd.transcribe import EventMerger, Note
+    g = load_golden("transcribe_" + name)
+    I = transcribe_inputs(name)
+    n_seg, P = I["n_seg"], I["P"]
+    frameDur = I["hop"] / I["fs"]
+    stepFrames = int(I["step"] / I["hop"])
+    lastFrameIdx = round(I["seg"] / I["hop"])
+    per_segment, merger = [], EventMerger()
+    hi = 0                                                   # head outputs exist only for segments with intervals
+    for i in range(n_seg):
+        lists = unpack_lists(g[f"seg{i}_pairs"], g[f"seg{i}_offsets"])
+        beginTime = (i * I["step"]) / I["fs"] - I["pad_t"]
+        K = sum(len(x) for x in lists)
+        if K == 0:
+            per_segment.append([])
+            continue
+        ofValue, ofPresence, vel = golden_of_heads(g, hi); hi += 1
+        ev, lastP, nextStart = oracle.segment_events(lists, P, ofValue.tolist(), ofPresence.tolist(), lastFrameIdx, frameDur, [beginTime],
+                                                     stepFrames)
+        assert lastP == [int(x) for x in g[f"seg{i}_lastP"]]
+        if i + 1 < n_seg:
+            assert nextStart == [int(x) for x in g[f"seg{i + 1}_start"]]        # the next segment's forcedStartPos (:789-791)
+        seg, n = [], 0
+        for c, cur in enumerate(ev):
+            for (s, e, on, off) in cur:
+                seg.append((s, e, TARGET_PITCH[c % P], int(vel[n]), on, off)); n += 1
+        seg.sort(key=lambda x: (x[0], x[1], x[2]))
+        per_segment.append(seg)
+        merger.add_segment([Note(*x) for x in seg])
+    assert event_table(oracle.merge_segments(per_segment)) == golden_events(g, "merged")
+    assert event_table(n.astuple() for n in merger.finish(resolve=False)) == golden_events(g, "merged")
+    merger2 = EventMerger()
+    for seg in per_segment:
+        merger2.add_segment([Note(*x) for x in seg])
+    assert event_table(n.astuple() for n in merger2.finish(resolve=True)) == golden_events(g, "final")

@@ -478,14 +478,159 @@ def case_model_large():
             del g, s, n, crf, score, noise
 
 
+TRANSCRIBE = {
+    # name: (D, hidden, fs, hop, window, segment s, step s, audio s, ctx scale, weight scale, seed)   -- tests/segment_common.py mirrors this
+    "small": (32, 48, 44100, 1024, 4096, 1.2, 0.6, 1.9, 0.5, 0.3, 11),
+    "real": (256, 512, 44100, 1024, 4096, 16.0, 8.0, 37.0, 0.5, 0.3, 12),        # the shipped 2.0.conf geometry: T = 691 frames per segment
+}
+
+
+def transcribe_inputs(name, device="cpu"):
+    """Everything the segment loop consumes besides the (out of scope) backbone: one ctx tensor per segment, the scorer's and
+    the two attribute heads' weights -- all from the integer hash."""
+    import math
+    D, H, fs, hop, win, seg_s, step_s, audio_s, cscale, wscale, seed = TRANSCRIBE[name]
+    P = 90
+    pad_t = seg_s - step_s
+    n_sample = int(audio_s * fs) + 2 * math.ceil(pad_t * fs)
+    step = math.ceil(step_s * fs / hop) * hop
+    seg = math.ceil(seg_s * fs)
+    n_seg = len(range(0, n_sample, step))
+    T = math.ceil(seg / hop) + 1
+    ctxs = [synth.hash_normal(P * T * D, 700 + 10 * seed + i, device).view(1, P, T, D) * cscale for i in range(n_seg)]
+    W = synth.hash_normal((2 * D + 1) * D, 800 + seed, device).view(2 * D + 1, D) * (wscale / D ** 0.5)
+    bias = synth.hash_normal(2 * D + 1, 810 + seed, device) * 0.1
+    heads = {}
+    for nm, nout, sd in (("velocity", 128, 820), ("of", 4, 830)):
+        heads[nm] = (synth.hash_normal(H * 3 * D, sd + seed, device).view(H, 3 * D) * (1.0 / (3 * D) ** 0.5),
+                     synth.hash_normal(H, sd + 1 + seed, device) * 0.1,
+                     synth.hash_normal(nout * H, sd + 2 + seed, device).view(nout, H) * (1.0 / H ** 0.5),
+                     synth.hash_normal(nout, sd + 3 + seed, device) * 0.1)
+    return dict(D=D, H=H, fs=fs, hop=hop, win=win, seg_s=seg_s, step_s=step_s, audio_s=audio_s, P=P, T=T, n_seg=n_seg,
+                ctxs=ctxs, W=W, bias=bias, heads=heads, n_sample_unpadded=int(audio_s * fs))
+
+
+def lift_reference_transcribe():
+    """The reference's segment loop itself: TransKun.transcribe (ModelTransformer.py:726-848), .transcribeFrames (:537-725)
+    and .fetchIntervalFeaturesBatch (:501-532) lifted out of the source file with ast at run time, together with Note and
+    resolveOverlapping (Data.py:20-30, :170-201), makeFrame and listToIdx (Util.py:21-43, :173-176).  The module itself
+    cannot be imported here (pretty_midi / torchaudio / moduleconf are absent); nothing of it is copied into this
+    repository."""
+    import ast
+    import math
+    from collections import defaultdict
+    ns = {"torch": torch, "F": torch.nn.functional, "nn": torch.nn, "math": math, "defaultdict": defaultdict}
+
+    def lift(path, names, kinds=(ast.FunctionDef, ast.ClassDef)):
+        tree = ast.parse(open(path).read())
+        found = {}
+        for node in ast.walk(tree):
+            if isinstance(node, kinds) and node.name in names and node.name not in found:
+                found[node.name] = node
+        assert set(found) == set(names), (names, list(found))
+        exec(compile(ast.Module(body=[found[n] for n in names], type_ignores=[]), path, "exec"), ns)
+
+    lift("/root/reference/transkun/Data.py", ["Note", "resolveOverlapping", "validateNotes"])
+    lift("/root/reference/transkun/Util.py", ["makeFrame", "listToIdx"])
+    lift("/root/reference/transkun/ModelTransformer.py", ["fetchIntervalFeaturesBatch", "transcribeFrames", "transcribe"])
+    return ns
+
+
+def case_transcribe(names=None):
+    """the transcription segment loop (forcedStartPos hand-off, lastP, event assembly, incomplete-event
+    merge) run by the reference's own code on synthetic per-segment ctx (the backbone is replaced by a stub that hands the
+    reference scorer + CRF the prepared ctx of the segment)."""
+    import types
+    from transkun.LayersTransformer import ScaledInnerProductIntervalScorer
+    ns = lift_reference_transcribe()
+    torch.set_num_threads(8)
+    for name in TRANSCRIBE:
+        if names and name not in names:
+            continue
+        t0 = time.time()
+        I = transcribe_inputs(name)
+        D, H, P, T = I["D"], I["H"], I["P"], I["T"]
+        scorer = ScaledInnerProductIntervalScorer(D, 1)
+        with torch.no_grad():
+            scorer.map[0].weight.copy_(I["W"]); scorer.map[0].bias.copy_(I["bias"])
+
+        def head(nout, w):
+            m = torch.nn.Sequential(torch.nn.Linear(3 * D, H), torch.nn.GELU(), torch.nn.Dropout(0.1), torch.nn.Linear(H, nout))
+            with torch.no_grad():
+                m[0].weight.copy_(w[0]); m[0].bias.copy_(w[1]); m[3].weight.copy_(w[2]); m[3].bias.copy_(w[3])
+            return m.eval()
+
+        vel, of = head(128, I["heads"]["velocity"]), head(4, I["heads"]["of"])
+        rec = {"start": [], "lastP": [], "pairs": [], "offsets": [], "velocity": [], "of": []}
+        state = {"i": 0}
+
+        class CrfRec:
+            def __init__(self, crf): self.crf = crf
+            def decode(self, forcedStartPos=None, forward=False):
+                out = self.crf.decode(forcedStartPos=forcedStartPos, forward=forward)
+                rec["start"].append(np.asarray(forcedStartPos, np.int32))
+                p, o = pack(out)
+                rec["pairs"].append(p); rec["offsets"].append(o)
+                return out
+
+        def processFramesBatch(framesBatch):
+            ctx = I["ctxs"][state["i"]]
+            state["i"] += 1
+            with torch.no_grad():
+                S, b = scorer(ctx)
+                return CrfRec(REF.NeuralSemiCRFInterval(S.flatten(-2, -1), b.flatten(-2, -1))), ctx
+
+        vel.register_forward_hook(lambda m, i, o: rec["velocity"].append(o.detach().numpy().copy()))
+        of.register_forward_hook(lambda m, i, o: rec["of"].append(o.detach().numpy().copy()))
+        me = types.SimpleNamespace(hopSize=I["hop"], windowSize=I["win"], fs=I["fs"], segmentHopSizeInSecond=I["step_s"],
+                                   segmentSizeInSecond=I["seg_s"], targetMIDIPitch=[-64, -67] + list(range(21, 108 + 1)),
+                                   velocityPredictor=vel, refinedOFPredictor=of, processFramesBatch=processFramesBatch)
+        me.fetchIntervalFeaturesBatch = types.MethodType(ns["fetchIntervalFeaturesBatch"], me)
+        tf = ns["transcribeFrames"]
+
+        def transcribeFrames(framesBatch, **kw):
+            notes, lastP = tf(me, framesBatch, **kw)
+            rec["lastP"].append(np.asarray(lastP, np.int32))
+            return notes, lastP
+
+        me.transcribeFrames = transcribeFrames
+        x = synth.hash_normal(I["n_sample_unpadded"], 900, "cpu").view(-1, 1)           # [nSample, nChannel]; only its length matters
+        ns_resolve = ns["resolveOverlapping"]
+        kept = {}
+        ns["resolveOverlapping"] = lambda ev: kept.setdefault("before", [(e.start, e.end, e.pitch, e.velocity, e.hasOnset, e.hasOffset) for e in ev]) and ns_resolve(ev) or ns_resolve(ev)
+        with torch.no_grad():
+            events = ns["transcribe"](me, x)
+        ns["resolveOverlapping"] = ns_resolve
+
+        def table(evs):
+            return (np.asarray([[e[0], e[1]] for e in evs], np.float64).reshape(-1, 2), np.asarray([[e[2], e[3]] for e in evs], np.int32).reshape(-1, 2),
+                    np.asarray([[e[4], e[5]] for e in evs], np.uint8).reshape(-1, 2))
+
+        final = [(e.start, e.end, e.pitch, e.velocity, e.hasOnset, e.hasOffset) for e in events]
+        d = {"meta": np.asarray([I["n_seg"], P, T, D, H]), "n_lastP": np.asarray([len(x) for x in rec["lastP"]])}
+        for k, evs in (("final", final), ("merged", kept["before"])):
+            t, pv, fl = table(evs)
+            d[k + "_times"] = t; d[k + "_pitch_velocity"] = pv; d[k + "_flags"] = fl
+        for i in range(len(rec["start"])):
+            d[f"seg{i}_start"] = rec["start"][i]; d[f"seg{i}_pairs"] = rec["pairs"][i]; d[f"seg{i}_offsets"] = rec["offsets"][i]
+        for i in range(len(rec["lastP"])):
+            d[f"seg{i}_lastP"] = rec["lastP"][i]
+        for i in range(len(rec["velocity"])):
+            d[f"head{i}_velocity_argmax"] = rec["velocity"][i].argmax(-1).astype(np.int32)
+            d[f"head{i}_of"] = rec["of"][i].astype(np.float32)
+        print(f"  transcribe {name}: {I['n_seg']} segments of T={T}, {len(final)} events after the merge ({len(kept['before'])} before "
+              f"resolveOverlapping), {sum(len(p) for p in rec['pairs'])} decoded intervals, {time.time() - t0:.1f}s")
+        save(f"transcribe_{name}", d)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--large", action="store_true")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.manual_seed(0)
-    todo = a.only.split(",") if a.only else ["minimal", "edges", "medium", "scorer", "attr", "segment"] + (["large", "model_large"] if a.large else [])
+    todo = a.only.split(",") if a.only else ["minimal", "edges", "medium", "scorer", "attr", "segment", "transcribe"] + (["large", "model_large"] if a.large else [])
     for t in todo:
         print("case", t)
         {"minimal": case_minimal, "edges": case_edges, "medium": case_medium, "scorer": case_scorer,
-         "large": case_large, "attr": case_attr, "segment": case_segment, "model_large": case_model_large}[t]()
+         "large": case_large, "attr": case_attr, "segment": case_segment, "model_large": case_model_large, "transcribe": case_transcribe}[t]()

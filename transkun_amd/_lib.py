@@ -50,6 +50,8 @@ _SIGS = {
     "interval_features_gather_bwd": (_i, [_vp, _vp, _i, _i, _i, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
     "interval_score_bwd_ws": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i64, ctypes.c_float, _i, _vp, _vp, _vp, _i64, _i64, _i64, _vp, ctypes.c_size_t, _vp]),
     "interval_score_bwd_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i]),
+    "segment_onset_filter": (_i, [_vp, _vp, _i, _i, _vp, _i64, _vp, _vp, _vp]),
+    "segment_events": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp, _i, ctypes.c_double, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
 }
 
 EXPORTED = tuple(_SIGS)

@@ -27,6 +27,11 @@ void launch_marginals(const float* score, const float* noise, const float* v, co
 void launch_backtrack(const int* code, int T, int B, const int* start, int forward, int* region, int* counts,
                       int* pairs, long long cap, int* offsets, hipStream_t stream, const unsigned* err, int nerr, int err_stride);
 const unsigned* persist_error_words(void* pws, int* n, int* stride);
+void launch_onset_filter(const int* pairs, const int* offsets, int B, int bound, int* pairs_out, long long cap, int* offsets_out,
+                         int* counts, hipStream_t stream);
+void launch_segment_events(const int* pairs, const int* offsets, int B, int nSym, const float* ofValue, const unsigned char* ofPresence,
+                           int lastFrameIdx, double frameDur, const double* beginTime, int stepFrames, double* times, unsigned char* flags,
+                           int* lastP, int* nextStart, hipStream_t stream);
 void launch_eval_path(const float* score, const float* noise, int T, int B, int K, const int* pairs,
                       const int* offsets, float* out, hipStream_t stream);
 void launch_eval_path_bwd(const float* gout, int T, int B, int K, const int* pairs, const int* offsets,
@@ -402,6 +407,29 @@ int interval_features_gather_bwd(const float* gout, const float* ctx, int C, int
     SEMICRF_CHECK_ARG(K >= 0 && K < (1ll << 31) && (K == 0 || (pairs && gout)), "bad interval count / buffers");
     launch_interval_features_bwd(gout, ctx, C, T, D, ldc, pairs, (int)K, offsets, dctx, lddc, (hipStream_t)stream);
     SEMICRF_CHECK_LAUNCH("interval_features_gather_bwd");
+    return SEMICRF_OK;
+}
+
+int segment_onset_filter(const int32_t* pairs, const int32_t* offsets, int B, int bound, int32_t* pairs_out, int64_t cap,
+                         int32_t* offsets_out, int32_t* counts_ws, semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(B >= 1, "B=%d must be >= 1", B);
+    SEMICRF_CHECK_ARG(offsets && offsets_out && counts_ws && cap >= 0 && (cap == 0 || (pairs && pairs_out)), "NULL buffer");
+    launch_onset_filter(pairs, offsets, B, bound, pairs_out, (long long)cap, offsets_out, counts_ws, (hipStream_t)stream);
+    SEMICRF_CHECK_LAUNCH("segment_onset_filter");
+    return SEMICRF_OK;
+}
+
+int segment_events(const int32_t* pairs, int64_t K, const int32_t* offsets, int B, int nSym, const float* ofValue,
+                   const unsigned char* ofPresence, int lastFrameIdx, double frameDur, const double* beginTime, int stepFrames,
+                   double* times, unsigned char* flags, int32_t* lastP, int32_t* nextStart, semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(B >= 1 && nSym >= 1 && B % nSym == 0, "B=%d must be a positive multiple of nSym=%d", B, nSym);
+    SEMICRF_CHECK_ARG(offsets && beginTime && lastP && nextStart, "offsets/beginTime/lastP/nextStart must be non-NULL");
+    SEMICRF_CHECK_ARG(K >= 0 && (K == 0 || (pairs && ofValue && ofPresence && times && flags)), "bad interval count / buffers");
+    launch_segment_events(pairs, offsets, B, nSym, ofValue, ofPresence, lastFrameIdx, frameDur, beginTime, stepFrames, times, flags,
+                          lastP, nextStart, (hipStream_t)stream);
+    SEMICRF_CHECK_LAUNCH("segment_events");
     return SEMICRF_OK;
 }
 

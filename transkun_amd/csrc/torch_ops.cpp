@@ -140,6 +140,26 @@ void interval_features_gather_bwd_op(Tensor gout, Tensor ctx, int64_t C, int64_t
           "interval_features_gather_bwd");
 }
 
+// ---- transcription segment loop ----------------------------------------------------------------------------------------
+void segment_onset_filter_op(Tensor pairs, Tensor offsets, int64_t B, int64_t bound, Tensor pairs_out, Tensor offsets_out, Tensor counts_ws)
+{
+    Ctx c(offsets); same_device(offsets, pairs_out); same_device(offsets, offsets_out);
+    check(segment_onset_filter(ip(pairs), ip(offsets), (int)B, (int)bound, ip(pairs_out), pairs_out.numel() / 2, ip(offsets_out),
+                               ip(counts_ws), c.stream),
+          "segment_onset_filter");
+}
+void segment_events_op(Tensor pairs, int64_t K, Tensor offsets, int64_t B, int64_t nSym, Tensor ofValue, Tensor ofPresence,
+                       int64_t lastFrameIdx, double frameDur, Tensor beginTime, int64_t stepFrames, Tensor times, Tensor flags, Tensor lastP,
+                       Tensor nextStart)
+{
+    Ctx c(offsets); same_device(offsets, beginTime); same_device(offsets, lastP); same_device(offsets, nextStart);
+    check(segment_events(ip(pairs), K, ip(offsets), (int)B, (int)nSym, cfp(ofValue),
+                         K > 0 ? (const unsigned char*)ofPresence.data_ptr() : nullptr, (int)lastFrameIdx, frameDur,
+                         (const double*)beginTime.data_ptr(), (int)stepFrames, K > 0 ? (double*)times.data_ptr() : nullptr,
+                         K > 0 ? (unsigned char*)flags.data_ptr() : nullptr, ip(lastP), ip(nextStart), c.stream),
+          "segment_events");
+}
+
 }  // namespace
 
 STABLE_TORCH_LIBRARY(semicrf, m)
@@ -166,6 +186,10 @@ STABLE_TORCH_LIBRARY(semicrf, m)
           "Tensor(b!) symIdx, Tensor(c!) scatterIdx) -> ()");
     m.def("interval_features_gather_bwd(Tensor gout, Tensor ctx, int C, int T, int D, int ldc, Tensor pairs, int K, Tensor offsets, "
           "Tensor(a!) dctx, int lddc) -> ()");
+    m.def("segment_onset_filter(Tensor pairs, Tensor offsets, int B, int bound, Tensor(a!) pairs_out, Tensor(b!) offsets_out, "
+          "Tensor(c!) counts_ws) -> ()");
+    m.def("segment_events(Tensor pairs, int K, Tensor offsets, int B, int nSym, Tensor ofValue, Tensor ofPresence, int lastFrameIdx, "
+          "float frameDur, Tensor beginTime, int stepFrames, Tensor(a!) times, Tensor(b!) flags, Tensor(c!) lastP, Tensor(d!) nextStart) -> ()");
 }
 
 STABLE_TORCH_LIBRARY_IMPL(semicrf, CUDA, m)
@@ -182,4 +206,6 @@ STABLE_TORCH_LIBRARY_IMPL(semicrf, CUDA, m)
     m.impl("interval_score_path_bwd", TORCH_BOX(&interval_score_path_bwd_op));
     m.impl("interval_features_gather", TORCH_BOX(&interval_features_gather_op));
     m.impl("interval_features_gather_bwd", TORCH_BOX(&interval_features_gather_bwd_op));
+    m.impl("segment_onset_filter", TORCH_BOX(&segment_onset_filter_op));
+    m.impl("segment_events", TORCH_BOX(&segment_events_op));
 }

@@ -1,0 +1,289 @@
+"""The transcription segment loop on top of the HIP path -- host-side mirror of
+TransKun.transcribeFrames (/root/reference/transkun/ModelTransformer.py:537-725) and TransKun.transcribe (:729-848).
+
+The reference transcribes a recording segment by segment (16 s windows, 8 s hop).  Per segment it decodes the semi-CRF
+with a forced start position per symbol, walks the decoded Python lists on the host to build one Note per interval
+(onset/offset refined by a small head), remembers per symbol the last confirmed offset (`lastP`), derives the next
+segment's forced start from it (:789-791) and merges events that were cut by the segment boundary (:803-825).  One file
+gives NBatch = 90 chains per decode and a host round trip per segment.
+
+Here the per-segment work stays on the device: scorer -> Viterbi (packed intervals in HBM) -> optional onset-bound filter
+-> attribute-head inputs gathered from the packed intervals -> the two heads (stock torch MLPs, as in the reference) ->
+`segment_events` (event times in double with the reference's operation order, hasOnset/hasOffset, lastP and the NEXT forced
+start as an int32 vector the next decode consumes directly).  Segments of DIFFERENT recordings run in lock step as one batch
+(`transcribe_many`: F files -> NBatch = 90 F chains per launch), which is what keeps the decode kernels busy -- consecutive
+segments of one file depend on each other.  Only the finished events of a step cross PCIe (asynchronously); the
+incomplete-event merge is a short per-pitch walk on the host.
+
+Out of scope: the audio front-end and the backbone.  What they produce -- `ctx` [segments, 90, T, D] --
+is the input, through a callable that plays the role of makeFrame + processFramesBatch's backbone part.
+"""
+from __future__ import annotations
+
+import importlib
+import math
+from collections import defaultdict
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib, attributes
+from .scorer import ScaledInnerProductIntervalScorer
+
+_nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
+
+
+class Note:
+    """Same fields as the reference's event object (Data.py:20-30)."""
+    __slots__ = ("start", "end", "pitch", "velocity", "hasOnset", "hasOffset")
+
+    def __init__(self, start, end, pitch, velocity, hasOnset=True, hasOffset=True):
+        self.start = start
+        self.end = end
+        self.pitch = pitch
+        self.velocity = velocity
+        self.hasOnset = hasOnset
+        self.hasOffset = hasOffset
+
+    def __repr__(self):
+        return str({k: getattr(self, k) for k in self.__slots__})
+
+    def astuple(self):
+        return (self.start, self.end, self.pitch, self.velocity, bool(self.hasOnset), bool(self.hasOffset))
+
+
+def resolveOverlapping(note_events: List[Note]) -> List[Note]:
+    """Data.py:170-214: in (start, end, pitch) order, an event that starts before the previous event of its pitch has ended
+    cuts that event short; events left without duration are dropped."""
+    note_events.sort(key=lambda x: (x.start, x.end, x.pitch))
+    last_of_pitch = {}
+    for i, ev in enumerate(note_events):
+        j = last_of_pitch.get(ev.pitch)
+        if j is not None and note_events[j].end > ev.start:
+            note_events[j].end = ev.start
+        last_of_pitch[ev.pitch] = i
+    out = [n for n in note_events if n.start < n.end]
+    out.sort(key=lambda x: (x.start, x.end, x.pitch))
+    return out
+
+
+class EventMerger:
+    """The cross-segment bookkeeping of TransKun.transcribe for ONE recording (:745-746, :803-843): per pitch the list of
+    events so far; a new event that starts before the last one of its pitch ended either replaces it (it has its own
+    onset) or extends it (it is the continuation of an event cut by the previous segment's end)."""
+
+    def __init__(self, mergeIncompleteEvent: bool = True):
+        self.byType = defaultdict(list)
+        self.merge = mergeIncompleteEvent
+
+    def add_segment(self, events: Sequence[Note]) -> None:
+        for e in events:                                             # :803-825
+            lst = self.byType[e.pitch]
+            if self.merge and lst:
+                last_e = lst[-1]
+                if e.start < last_e.end:
+                    if e.hasOnset:
+                        lst[-1] = e
+                    else:
+                        last_e.hasOffset = e.hasOffset
+                        last_e.end = max(e.end, last_e.end)
+                    continue
+            if e.hasOnset:
+                lst.append(e)
+
+    def finish(self, resolve: bool = True) -> List[Note]:
+        for lst in self.byType.values():                             # :831-834
+            if lst:
+                lst[-1].hasOffset = True
+        events = [n for lst in self.byType.values() for n in lst if n.hasOffset]      # :837-841
+        return resolveOverlapping(events) if resolve else events
+
+
+def _head(n_in: int, hidden: int, n_out: int, dropout: float) -> nn.Sequential:
+    return nn.Sequential(nn.Linear(n_in, hidden), nn.GELU(), nn.Dropout(dropout), nn.Linear(hidden, n_out))
+
+
+class SegmentTranscriber(nn.Module):
+    """The modules of TransKun that sit behind the backbone (ModelTransformer.py:97-124) with the reference's parameter
+    names -- `scorer.map.0.*`, `velocityPredictor.{0,3}.*`, `refinedOFPredictor.{0,3}.*` load from its checkpoints -- and
+    its segment loop."""
+
+    def __init__(self, size: int = 256, velocityPredictorHiddenSize: int = 512, refinedOFPredictorHiddenSize: int = 512,
+                 hopSize: int = 1024, windowSize: int = 4096, fs: int = 44100, segmentHopSizeInSecond: float = 8,
+                 segmentSizeInSecond: float = 16, velocityDropoutProb: float = 0.1, refinedOFDropoutProb: float = 0.1,
+                 targetMIDIPitch: Optional[Sequence[int]] = None):
+        super().__init__()
+        self.hopSize, self.windowSize, self.fs = hopSize, windowSize, fs
+        self.segmentHopSizeInSecond, self.segmentSizeInSecond = segmentHopSizeInSecond, segmentSizeInSecond
+        self.targetMIDIPitch = list(targetMIDIPitch) if targetMIDIPitch is not None else [-64, -67] + list(range(21, 108 + 1))   # :97
+        self.scorer = ScaledInnerProductIntervalScorer(size, 1)
+        self.velocityPredictor = _head(size * 3, velocityPredictorHiddenSize, 128, velocityDropoutProb)           # :109-115
+        self.refinedOFPredictor = _head(size * 3, refinedOFPredictorHiddenSize, 4, refinedOFDropoutProb)          # :119-125
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # one step on the device
+    # ------------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def decode_step(self, ctxBatch: torch.Tensor, start: Optional[torch.Tensor], beginTime: torch.Tensor, lastFrameIdx: int,
+                    stepFrames: int, onsetBound: Optional[int] = None, velocityCriteron: str = "hamming"):
+        """ctxBatch [F, P, T, D] (one segment of each of F recordings); start: int32 [F*P] forced start positions on the device
+        or None; beginTime: float64 [F] on the device.  Returns a dict of DEVICE tensors: pairs [K,2], offsets [F*P+1],
+        symIdx [K], scatterIdx [K], velocity [K], times [K,2] f64, flags [K,2] u8, lastP [F*P], nextStart [F*P], and K."""
+        assert ctxBatch.dim() == 4
+        Fn, P, T, D = ctxBatch.shape
+        assert P == len(self.targetMIDIPitch)
+        B = Fn * P
+        dev = ctxBatch.device
+        ops = _lib.ops()
+        S, b = self.scorer(ctxBatch)                                                     # processFramesBatch :199-222
+        score, noise = S.flatten(-2, -1), b.flatten(-2, -1)
+        pairs, offsets = _nsci._viterbi_raw(score, noise, start, False)                  # transcribeFrames :549
+        if onsetBound is not None:                                                       # :554-555
+            pairs2 = torch.empty_like(pairs)
+            offsets2 = torch.empty_like(offsets)
+            counts = torch.empty(B, dtype=torch.int32, device=dev)
+            ops.segment_onset_filter(pairs, offsets, B, int(onsetBound), pairs2, offsets2, counts)
+            pairs, offsets = pairs2, offsets2
+        K = int(offsets[-1])                                                             # the step's one host sync
+        if K < 0:
+            raise RuntimeError("semicrf_viterbi: a bounded hand-off wait timed out on the device; the decode result is invalid")
+        lastP = torch.empty(B, dtype=torch.int32, device=dev)
+        nextStart = torch.empty(B, dtype=torch.int32, device=dev)
+        if K == 0:                                                                       # :570-572: nothing detected
+            lastP.zero_(); nextStart.zero_()
+            e = torch.empty(0, device=dev)
+            return dict(K=0, pairs=pairs[:0], offsets=offsets, symIdx=e.long(), scatterIdx=e.long(), velocity=e.long(),
+                        times=torch.empty(0, 2, dtype=torch.float64, device=dev), flags=torch.empty(0, 2, dtype=torch.uint8, device=dev),
+                        lastP=lastP, nextStart=nextStart)
+        attributeInput, sym, sc = attributes.attribute_input_packed(ctxBatch, pairs, offsets, K)       # :578-586
+        logitsVelocity = self.velocityPredictor(attributeInput)
+        velocity = self._velocity(logitsVelocity, velocityCriteron)
+        ofValue, ofPresence = self.refinedOFPredictor(attributeInput).chunk(2, dim=-1)               # :646-655
+        ofDist = torch.distributions.ContinuousBernoulli(logits=ofValue)
+        ofValue = torch.clamp((ofDist.mean - 0.5) / 0.99, -0.5, 0.5).float().contiguous()
+        ofPresence = (ofPresence > 0).contiguous()
+        times = torch.empty(K, 2, dtype=torch.float64, device=dev)
+        flags = torch.empty(K, 2, dtype=torch.uint8, device=dev)
+        ops.segment_events(pairs, K, offsets, B, P, ofValue, ofPresence.view(torch.uint8), int(lastFrameIdx), self.hopSize / self.fs,
+                           beginTime, int(stepFrames), times, flags, lastP, nextStart)
+        return dict(K=K, pairs=pairs[:K], offsets=offsets, symIdx=sym, scatterIdx=sc, velocity=velocity, times=times, flags=flags,
+                    lastP=lastP, nextStart=nextStart, ofValue=ofValue, ofPresence=ofPresence)
+
+    @staticmethod
+    def _velocity(logitsVelocity: torch.Tensor, criterion: str) -> torch.Tensor:
+        pVelocity = F.softmax(logitsVelocity, dim=-1)                                    # :590-637
+        dev = pVelocity.device
+        if criterion == "hamming":
+            return torch.argmax(pVelocity, dim=-1)
+        if criterion == "mse":
+            return (pVelocity * torch.arange(128, device=dev)).sum(-1)
+        if criterion == "match":
+            w = torch.arange(128, device=dev)
+            utility = ((w.unsqueeze(1) - w.unsqueeze(0)).abs() < 0.1 * 128).float()
+            return torch.argmax(pVelocity @ utility, dim=-1)
+        if criterion == "mae":
+            tmp = (pVelocity.cumsum(-1) - 0.5) > 0
+            return torch.argmax(tmp * torch.arange(128, 0., -1, device=dev), dim=-1)
+        raise Exception("Unrecognized criterion: {}".format(criterion))
+
+    def _notes_of_step(self, step: dict, n_files: int) -> List[List[Note]]:
+        """Host objects of a step: per recording the Notes in the reference's order (sorted by (start, end, pitch), :722)."""
+        K = step["K"]
+        out: List[List[Note]] = [[] for _ in range(n_files)]
+        if K == 0:
+            return out
+        P = len(self.targetMIDIPitch)
+        times = step["times"].cpu().numpy()
+        flags = step["flags"].cpu().numpy()
+        vel = step["velocity"].cpu().tolist()
+        sym = step["symIdx"].cpu().numpy()
+        seg = (step["scatterIdx"].cpu().numpy() // P)
+        for i in range(K):
+            out[int(seg[i])].append(Note(float(times[i, 0]), float(times[i, 1]), self.targetMIDIPitch[int(sym[i])], vel[i],
+                                         bool(flags[i, 0]), bool(flags[i, 1])))
+        for lst in out:
+            lst.sort(key=lambda x: (x.start, x.end, x.pitch))
+        return out
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # the reference's two entry points
+    # ------------------------------------------------------------------------------------------------------------------
+    def transcribeFrames(self, ctxBatch, forcedStartPos=None, velocityCriteron="hamming", onsetBound=None, lastFrameIdx=None):
+        """ModelTransformer.py:537-725 with the backbone's output in the place of the frames: returns (notes per segment of
+        the batch, lastP per chain) as host objects.  Times are relative to the segment, as in the reference."""
+        Fn, P, T, D = ctxBatch.shape
+        dev = ctxBatch.device
+        if lastFrameIdx is None:
+            lastFrameIdx = T - 1
+        start = None
+        if forcedStartPos is not None:
+            assert len(forcedStartPos) == Fn * P
+            start = torch.tensor(list(forcedStartPos), dtype=torch.int32, device=dev)
+        step = self.decode_step(ctxBatch, start, torch.zeros(Fn, dtype=torch.float64, device=dev), lastFrameIdx, 0, onsetBound,
+                                velocityCriteron)
+        if step["K"] == 0:
+            return [[] for _ in range(Fn)], [0 for _ in range(Fn * P)]                  # :570-572
+        return self._notes_of_step(step, Fn), step["lastP"].cpu().tolist()
+
+    def transcribe(self, ctx_of_segment: Callable[[int, int], torch.Tensor], nSample: int, stepInSecond=None, segmentSizeInSecond=None,
+                   discardSecondHalf=False, mergeIncompleteEvent=True, resolve=True) -> List[Note]:
+        """ModelTransformer.py:729-848 for one recording of nSample samples (before padding); ctx_of_segment(i, T) returns the
+        backbone output [1, 90, T, D] of segment i.  See transcribe_many for the batched form."""
+        return self.transcribe_many([ctx_of_segment], [nSample], stepInSecond, segmentSizeInSecond, discardSecondHalf,
+                                    mergeIncompleteEvent, resolve)[0]
+
+    def segment_plan(self, nSample: int, stepInSecond=None, segmentSizeInSecond=None):
+        """The segment geometry of TransKun.transcribe (:731-757, :778): padding, step and segment sizes, frames per segment."""
+        if stepInSecond is None and segmentSizeInSecond is None:
+            stepInSecond = self.segmentHopSizeInSecond
+            segmentSizeInSecond = self.segmentSizeInSecond
+        padTimeBegin = segmentSizeInSecond - stepInSecond
+        pad = math.ceil(padTimeBegin * self.fs)
+        total = nSample + 2 * pad
+        startFrameIdx = math.floor(padTimeBegin * self.fs / self.hopSize)
+        stepSize = math.ceil(stepInSecond * self.fs / self.hopSize) * self.hopSize
+        segmentSize = math.ceil(segmentSizeInSecond * self.fs)
+        nFrame = math.ceil(segmentSize / self.hopSize) + 1                              # makeFrame, Util.py:24
+        return dict(padTimeBegin=padTimeBegin, nTotal=total, startFrameIdx=startFrameIdx, stepSize=stepSize, segmentSize=segmentSize,
+                    nFrame=nFrame, lastFrameIdx=round(segmentSize / self.hopSize), begins=list(range(0, total, stepSize)))
+
+    @torch.no_grad()
+    def transcribe_many(self, ctx_fns: Sequence[Callable[[int, int], torch.Tensor]], nSamples: Sequence[int], stepInSecond=None,
+                        segmentSizeInSecond=None, discardSecondHalf=False, mergeIncompleteEvent=True, resolve=True) -> List[List[Note]]:
+        """Several recordings in lock step: step s decodes segment s of every recording that still has one as ONE batch
+        (NBatch = 90 x #recordings).  The forced start positions of step s+1 never leave the device."""
+        plans = [self.segment_plan(n, stepInSecond, segmentSizeInSecond) for n in nSamples]
+        P = len(self.targetMIDIPitch)
+        dev = next(self.parameters()).device
+        mergers = [EventMerger(mergeIncompleteEvent) for _ in plans]
+        nsteps = max(len(p["begins"]) for p in plans)
+        T = plans[0]["nFrame"]
+        stepFrames = int(plans[0]["stepSize"] / self.hopSize)                           # :791
+        onsetBound = plans[0]["stepSize"] if discardSecondHalf else None                # :779-782 (the reference passes samples)
+        start = torch.full((len(plans) * P,), plans[0]["startFrameIdx"], dtype=torch.int32, device=dev)      # :751-752
+        active_prev = list(range(len(plans)))
+        pending = None                                                                  # (step dict, active files): host part runs one step late
+        for s in range(nsteps):
+            active = [f for f, p in enumerate(plans) if s < len(p["begins"])]
+            if active != active_prev:                                                   # recordings that ended drop out of the batch
+                keep = torch.tensor([active_prev.index(f) for f in active], device=dev)
+                start = start.view(len(active_prev), P)[keep].reshape(-1).contiguous()
+                active_prev = active
+            ctxBatch = torch.cat([ctx_fns[f](s, T) for f in active], dim=0)
+            beginTime = torch.tensor([plans[f]["begins"][s] / self.fs - plans[f]["padTimeBegin"] for f in active], dtype=torch.float64,
+                                     device=dev)                                         # :766
+            step = self.decode_step(ctxBatch, start, beginTime, plans[0]["lastFrameIdx"], stepFrames, onsetBound)
+            start = step["nextStart"]                                                   # :789-791, stays on the device
+            if pending is not None:
+                self._merge_step(*pending, mergers)
+            pending = (step, active)
+        if pending is not None:
+            self._merge_step(*pending, mergers)
+        return [m.finish(resolve) for m in mergers]
+
+    def _merge_step(self, step, active, mergers):
+        for f, notes in zip(active, self._notes_of_step(step, len(active))):
+            mergers[f].add_segment(notes)
