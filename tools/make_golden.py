@@ -623,14 +623,45 @@ def case_transcribe(names=None):
         save(f"transcribe_{name}", d)
 
 
+def case_frontend():
+    """framing + six-window spectrum by the reference's own classes (Util.py:21-124; MelSpectrum itself needs
+    torchaudio, absent here: the mel filterbank stays parity-unpinned)."""
+    from transkun.Util import GaussianWindows, Spectrum, makeFrame
+    x = synth.hash_normal(2 * 20000, 950, "cpu").view(2, 20000)
+    d = {}
+    for hop, win in ((1024, 4096), (160, 400)):
+        fr = makeFrame(x, hop, win)
+        d[f"frames_{hop}_shape"] = np.asarray(fr.shape)
+        d[f"frames_{hop}_rowsum"] = fr.double().sum(-1).numpy()
+        d[f"frames_{hop}_first"] = fr[0, :2, :8].numpy().copy(); d[f"frames_{hop}_last"] = fr[1, -2:, -8:].numpy().copy()
+    torch.manual_seed(3)
+    gw = GaussianWindows(5, 4096)
+    with torch.no_grad():
+        gw.sigma.add_(synth.hash_normal(5, 951, "cpu") * 0.3); gw.center.add_(synth.hash_normal(5, 952, "cpu") * 0.3)
+    d["gw_sigma"] = gw.sigma.detach().numpy().copy(); d["gw_center"] = gw.center.detach().numpy().copy()
+    Y = gw.get().detach()
+    d["gw_colsum"] = Y.double().sum(0).numpy(); d["gw_rows"] = Y[[0, 1000, 2048, 4095]].numpy().copy()
+    sp = Spectrum(4096, nExtraWins=5)
+    with torch.no_grad():
+        sp.winGen.sigma.copy_(gw.sigma); sp.winGen.center.copy_(gw.center)
+        frames = makeFrame(x, 1024, 4096)
+        S = sp(frames)                                        # [2, nFrame, 2049, 6] complex
+    P = S.abs().pow(2)
+    d["spec_shape"] = np.asarray(S.shape)
+    d["spec_power_sum"] = P.double().sum(dim=(0, 1, 2)).numpy()
+    d["spec_power_bins"] = P[0, 3, [0, 1, 17, 500, 2048], :].numpy().copy()
+    d["spec_re_im"] = torch.view_as_real(S[1, 5, [2, 300], :]).numpy().copy()
+    save("frontend", d)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--large", action="store_true")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.manual_seed(0)
-    todo = a.only.split(",") if a.only else ["minimal", "edges", "medium", "scorer", "attr", "segment", "transcribe"] + (["large", "model_large"] if a.large else [])
+    todo = a.only.split(",") if a.only else ["minimal", "edges", "medium", "scorer", "attr", "segment", "transcribe", "frontend"] + (["large", "model_large"] if a.large else [])
     for t in todo:
         print("case", t)
         {"minimal": case_minimal, "edges": case_edges, "medium": case_medium, "scorer": case_scorer,
-         "large": case_large, "attr": case_attr, "segment": case_segment, "model_large": case_model_large, "transcribe": case_transcribe}[t]()
+         "large": case_large, "attr": case_attr, "segment": case_segment, "model_large": case_model_large, "transcribe": case_transcribe, "frontend": case_frontend}[t]()
