@@ -32,6 +32,9 @@ for fl in a.flags.split(","):
         elif op == "bwd":
             lz, v = nsci._logz_fwd_raw(s, n, True); g = torch.ones(a.B, device=dev)
             us = timeit(lambda: nsci._logz_bwd_raw(s, n, v, lz, g), a.n)
+        elif op == "beta":
+            from transkun_amd.fused import _beta_raw
+            us = timeit(lambda: _beta_raw(s, n), a.n)
         elif op == "vit":
             crf = nsci.NeuralSemiCRFInterval(s, n)
             torch.cuda.synchronize(); t = time.perf_counter()

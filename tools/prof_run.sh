@@ -1,13 +1,19 @@
+# The exact sequence behind profiles/r02_*: bench.py under rocprofv3 --kernel-trace --stats, then separate --pmc passes
+# (FETCH_SIZE and WRITE_SIZE cannot share a pass) for the forward sweep, and cache / stall counters of the gradient sweep.
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -3
-timeout 600 python bench.py 2>&1 | tail -3
-mkdir -p gpurun_out/prof
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r02
+mkdir -p $OUT
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof/kt -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof/kt.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof/pmc_fetch -- python $GRAFT_REPO_ROOT/tools/bench_sweep.py --ops fwd --n 5 > $GRAFT_REPO_ROOT/gpurun_out/prof/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof/pmc_write -- python $GRAFT_REPO_ROOT/tools/bench_sweep.py --ops fwd --n 5 > $GRAFT_REPO_ROOT/gpurun_out/prof/pmc_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/kt.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_fwd_$c -- python $GRAFT_REPO_ROOT/tools/bench_sweep.py --ops fwd --n 5 > $OUT/pmc_fwd_$c.log 2>&1
+done
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+  n=$(echo $c | tr ' ' '_')
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_bwd_$n -- python $GRAFT_REPO_ROOT/tools/bench_sweep.py --ops bwd --n 5 > $OUT/pmc_bwd_$n.log 2>&1
+done
 cd $GRAFT_REPO_ROOT
-find gpurun_out/prof -name "*.csv" | head -30
-tail -2 gpurun_out/prof/kt.log
+find gpurun_out/prof_r02 -name "*.csv" | head -40
+tail -2 $OUT/kt.log | cut -c1-600

@@ -73,6 +73,9 @@ constexpr unsigned U_EMPTY = 0xffffffffu;  // not-yet-published u (a NaN pattern
 #ifndef SEMICRF_EARLY_REFILL
 #define SEMICRF_EARLY_REFILL 0     // 1: a stage is refilled as soon as its tile sits in registers (before the math), not after it
 #endif
+#ifndef SEMICRF_TASK_PREFETCH
+#define SEMICRF_TASK_PREFETCH 0     // (measured slower: 220 vs 206 us at T=1024, 720 vs 633 at T=2048) 1: a panel wave that is behind the ring takes its next task while the last tiles of the current one are in flight
+#endif
 #ifndef SEMICRF_SCHED
 #define SEMICRF_SCHED 0            // 0: one task queue in (block, part) order; 1: per-part queues, earliest block first among the
 #endif                             //    parts whose columns the ring has already published (see panel_next_task)
@@ -706,7 +709,10 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
 #ifndef SEMICRF_CELL_AUX
 #define SEMICRF_CELL_AUX 2      // nt: every cell is read once -- keep the stream from evicting the (re-read) u granules from L2
 #endif
-constexpr int PNS = 3;                       // LDS stages per panel wave (tiles fetched ahead)
+#ifndef SEMICRF_PNS
+#define SEMICRF_PNS 3
+#endif
+constexpr int PNS = SEMICRF_PNS;             // LDS stages per panel wave (tiles fetched ahead)
 constexpr int PSTAGE_BYTES = 10240;          // 8 KB of cells + 2 KB of u values
 #ifndef SEMICRF_PW_MAX
 #define SEMICRF_PW_MAX 4
@@ -911,10 +917,37 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
     const unsigned tag = P.tag;
     const auto ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.ug, 0, (int)((size_t)T * Bs * 4), 0x00020000);
 
+    // geometry of a task's tiles (see "addressing" below)
+    auto geom_of = [&](const PanelTask& t, PanelGeom& G) {
+        const int pb = t.k * PB + t.q4 * 4;
+        const int cc = c0 + t.g * GP + q8 * 4;
+        const int ccl = cc < c1 ? cc : c0;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) G.pirow[rr] = pb + rr < T ? pb + rr : T - 1;
+        G.voff = DIR == 0 ? (unsigned)((slot * B + ccl) * 4) : (unsigned)(((size_t)(7 - slot) * T * Bs + ccl) * 4);
+        const int f_pisub = lane >> 4, f_pjsub = (lane >> 3) & 1;
+        const int f_pirow = pb + f_pisub < T ? pb + f_pisub : T - 1;
+        G.fvoff = DIR == 0 ? G.voff : (unsigned)((((size_t)(1 - f_pjsub) * T + (G.pirow[3] - f_pirow)) * Bs + ccl) * 4);
+        G.gvoff = (unsigned)((slot * B + ccl) * 4);
+    };
+    // vector-memory operations issued so far by this wave (a lower bound: the waits below may only under-count the operations
+    // younger than the fetch they wait for), and its value right after each stage's fetch.  They run on across tasks.
+    int issued = 0, mark0 = 0, mark1 = 0, mark2 = 0;
+    // Task prefetch: a wave whose previous task never had to wait for the ring is BEHIND it (the sweep is bound by the far
+    // field, every task is late): it takes its next task while the last tiles of the current one are still in flight and
+    // fills the stages they leave with the first tiles of the next one, so that dequeue and pipeline fill (3-4 us of a
+    // ~20 us task) overlap with streaming.  A wave that does wait for the ring must not hold a second task: the task would
+    // start late, and at that point of the sweep it is on the critical path.
+    bool late_mode = false, have_next = false;
+    PanelTask nxt;
+    int nxt_fetched = 0, s_first = 0;
+
     while (true) {
         // ---- next task: (k, part, g, q4); a task only waits on spine progress below k-3 ----
         PanelTask tk;
-        if (!panel_next_task(P, tk)) break;
+        int pre = 0;                                                // tiles of this task that are already in flight
+        if (have_next) { tk = nxt; pre = nxt_fetched; have_next = false; nxt_fetched = 0; }
+        else { if (!panel_next_task(P, tk)) break; s_first = 0; }
         const int q = tk.k - RING - P.xr;                           // the newest tile the panels have of this block
         const int m0 = tk.part * TPT;
         const int m1 = (m0 + TPT < q + 1) ? m0 + TPT : q + 1;       // tiles m0 .. m1-1 of the q+1 panel tiles of block k
@@ -959,15 +992,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
         //   DIR 1: cell(pi, pj) = ((T-1-pj)*T + (T-1-pi))*B: tile base at (pi_3, 16m+15), lane part (7-slot)*T*B,
         //          soffset ((1-h)*8*T + (pi_3-pi_rr))*B            (pi_rr = min(pbase+rr, T-1))
         PanelGeom G;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) G.pirow[rr] = pbase + rr < T ? pbase + rr : T - 1;
-        G.voff = DIR == 0 ? (unsigned)((slot * B + cl) * 4) : (unsigned)(((size_t)(7 - slot) * T * Bs + cl) * 4);
-        {
-            const int f_pisub = lane >> 4, f_pjsub = (lane >> 3) & 1;
-            const int f_pirow = pbase + f_pisub < T ? pbase + f_pisub : T - 1;
-            G.fvoff = DIR == 0 ? G.voff : (unsigned)((((size_t)(1 - f_pjsub) * T + (G.pirow[3] - f_pirow)) * Bs + cl) * 4);
-        }
-        G.gvoff = (unsigned)((slot * B + cl) * 4);
+        geom_of(tk, G);
         char* const stage0 = lds + wslot * (PNS * PSTAGE_BYTES);
         const unsigned rdbase = lds_addr(stage0) + (DIR == 0 ? (unsigned)lane * 16u
                                                              : (unsigned)((slot >> 1) * 1024 + (slot & 1) * 128 + q8 * 16));
@@ -977,23 +1002,28 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
         const bool probe_nou = SEMICRF_PANEL_PROBES && (dbg & 64u);       // math on whatever the stage holds, no u traffic
         const int nst = GRAD ? 2 * (T - pbase < 4 ? T - pbase : 4) : 0;    // gradient stores per tile (a lower bound)
 
-        // vector-memory operations issued so far in this task (a lower bound: the waits below may only under-count
-        // the operations younger than the fetch they wait for), and its value right after each stage's fetch
-        int issued = 0, mark0 = 0, mark1 = 0, mark2 = 0;
         // A task that has met an unpublished u runs at the spine's frontier: the u copies it prefetched three tiles ahead
         // are stale by construction.  From then on it fetches the NEXT tile's u again (device scope) while it works on
         // the current tile, so that a published value is found on the first look instead of two round trips later.
         bool frontier = false;
+        bool tried_next = false;
+        PanelGeom Gn;
+        int nm0 = 0, nm1 = 0;
+        {
+            int si = s_first;
+            for (int i = 0; i < pre; ++i) si = si + 1 == PNS ? 0 : si + 1;
 #pragma unroll
-        for (int i = 0; i < PNS; ++i)
-            if (m0 + i < m1) {
-                panel_fetch_cells<DIR>(score, G, stage0 + i * PSTAGE_BYTES, m0 + i, T, Bs);
-                if (!probe_stream && !probe_nou) panel_fetch_gran<false>(ursrc, stage0 + i * PSTAGE_BYTES, G.gvoff, m0 + i, B);
-                issued += 10;
-                if (i == 0) mark0 = issued; else if (i == 1) mark1 = issued; else mark2 = issued;
-            }
+            for (int i = 0; i < PNS; ++i)
+                if (i >= pre && m0 + i < m1) {
+                    panel_fetch_cells<DIR>(score, G, stage0 + si * PSTAGE_BYTES, m0 + i, T, Bs);
+                    if (!probe_stream && !probe_nou) panel_fetch_gran<false>(ursrc, stage0 + si * PSTAGE_BYTES, G.gvoff, m0 + i, B);
+                    issued += 10;
+                    if (si == 0) mark0 = issued; else if (si == 1) mark1 = issued; else mark2 = issued;
+                    si = si + 1 == PNS ? 0 : si + 1;
+                }
+        }
 
-        for (int m = m0, s = 0; m < m1; ++m, s = (s + 1 == PNS ? 0 : s + 1)) {
+        for (int m = m0, s = s_first; m < m1; ++m, s = (s + 1 == PNS ? 0 : s + 1)) {
             char* const stage = stage0 + s * PSTAGE_BYTES;
             // ---- wait for the stage, move it to registers ------------------------------------------------
             panel_wait_younger(issued - (s == 0 ? mark0 : (s == 1 ? mark1 : mark2)));
@@ -1186,9 +1216,33 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                 if (!probe_stream && !probe_nou) panel_fetch_gran<false>(ursrc, stage, G.gvoff, m + PNS, B);
                 issued += 10;
                 if (s == 0) mark0 = issued; else if (s == 1) mark1 = issued; else mark2 = issued;
+            } else if (SEMICRF_TASK_PREFETCH && !refill && late_mode && !frontier && !probe_stream && !probe_nou) {
+                // nothing of this task is left to request: this stage takes a tile of the wave's NEXT task
+                if (!tried_next) {
+                    tried_next = true;
+                    have_next = panel_next_task(P, nxt);
+                    if (have_next) {
+                        const int nq = nxt.k - RING - P.xr;
+                        nm0 = nxt.part * TPT;
+                        nm1 = (nm0 + TPT < nq + 1) ? nm0 + TPT : nq + 1;
+                        if (nxt.k * PB + nxt.q4 * 4 >= T) nm1 = nm0;          // rows past the end: nothing to fetch
+                        geom_of(nxt, Gn);
+                        nxt_fetched = 0;
+                        // its first tile goes into THIS stage: the stage cursor of the next task starts here
+                        s_first = s;
+                    }
+                }
+                if (have_next && nm0 + nxt_fetched < nm1) {
+                    panel_fetch_cells<DIR>(score, Gn, stage, nm0 + nxt_fetched, T, Bs);
+                    panel_fetch_gran<false>(ursrc, stage, Gn.gvoff, nm0 + nxt_fetched, B);
+                    issued += 10;
+                    if (s == 0) mark0 = issued; else if (s == 1) mark1 = issued; else mark2 = issued;
+                    ++nxt_fetched;
+                }
             }
         }
-        wait_vmcnt<0>();      // nothing of this task is in flight when its stages are reused
+        if (!have_next) wait_vmcnt<0>();      // nothing of this task is in flight when its stages are reused
+        late_mode = !frontier;
 
         // ---- reduce over the 8 column slots (lane bits 3..5) as a reduce-scatter: each stage halves the
         // accumulators a lane keeps, so 14 exchanges instead of 48; every lane ends with 2 of the 16 results
