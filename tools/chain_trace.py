@@ -18,6 +18,7 @@ ws = nsci._DEBUG_WS[0]
 CT = 16 * 256 * 4
 ts = ws[CT:CT + T * 8].view(torch.int64).cpu().numpy().astype(np.float64) / 100.0     # s_memrealtime: 100 MHz -> us
 pub, got, far, seen, stored = ts[0:64], ts[64:128], ts[128:192], ts[192:256], ts[256:320]
+stored_q = np.stack([ts[256 + 64 * i:320 + 64 * i] for i in range(4)])          # per row quarter
 t0 = pub[0]
 print(f"T={T} B={B}: k: publish(k-4)  seen(+)  stored(+)  far(+)  owner(+)   | block period")
 for k in list(range(4, 40, 3)) + [48, 56, 63]:
@@ -29,6 +30,11 @@ p = pub[ks - 4]
 for name, arr in (("seen", seen), ("stored", stored), ("far", far), ("owner", got)):
     d = arr[ks] - p
     print(f"  {name:7s}: mean {d.mean():5.2f}  median {np.median(d):5.2f}  p90 {np.percentile(d, 90):5.2f}  max {d.max():5.2f}")
+if stored_q[1:].any():
+    d = stored_q[:, ks] - p[None, :]
+    print("  stored per quarter: mean %s; slowest quarter mean %.2f p90 %.2f; far - slowest: mean %.2f p90 %.2f" % (
+        np.round(d.mean(1), 2).tolist(), d.max(0).mean(), np.percentile(d.max(0), 90), (far[ks] - p - d.max(0)).mean(),
+        np.percentile(far[ks] - p - d.max(0), 90)))
 print("  publish time of block k (us):", [round(float(pub[k] - t0), 1) for k in range(0, min(K, 64), 4)])
 per = np.diff(pub[:min(K, 64)])
 ctl = ws[:1024].view(torch.int32).cpu().numpy().astype(np.int64)

@@ -73,6 +73,9 @@ constexpr unsigned U_EMPTY = 0xffffffffu;  // not-yet-published u (a NaN pattern
 #ifndef SEMICRF_EARLY_REFILL
 #define SEMICRF_EARLY_REFILL 0     // 1: a stage is refilled as soon as its tile sits in registers (before the math), not after it
 #endif
+#ifndef SEMICRF_LDS_REDUCE
+#define SEMICRF_LDS_REDUCE 1      // 1: the panels' final reduction over the column slots goes through LDS (see panel_role)
+#endif
 #ifndef SEMICRF_TASK_PREFETCH
 #define SEMICRF_TASK_PREFETCH 0     // (measured slower: 220 vs 206 us at T=1024, 720 vs 633 at T=2048) 1: a panel wave that is behind the ring takes its next task while the last tiles of the current one are in flight
 #endif
@@ -105,6 +108,7 @@ struct SweepParams {
     int xr;                // the newest xr far tiles of every block are left to the RECENT waves of the spine workgroups (0: none)
     int recentWaves;       // recent waves per spine workgroup
     int rpart;             // index of the recent waves' slab in farg
+    int fullLead;          // full column parts enter the task queue this many blocks before the last part of their block
     int runAhead;          // EDF scheduler: a last-part task of block k may be taken once the ring has published block k-4-runAhead
     unsigned tag;          // nonzero launch epoch
     unsigned dbg;          // SEMICRF_DEBUG_FLAGS (timing experiments only; results are wrong when set):
@@ -835,6 +839,30 @@ __device__ __forceinline__ bool panel_next_task(const SweepParams& P, PanelTask&
         if (lane == 0) task = (int)(atomicAdd(ctrl + 2, 1u) + 1u);        // counters start at 0xffffffff (one 0xff fill)
         task = __builtin_amdgcn_readfirstlane(task);
         if (task >= P.nTasks) return false;
+        if (P.fullLead > 0) {
+            // One queue, but the FULL parts of block k (16 tiles: ~20 us of streaming, all of their columns published long
+            // before) are handed out fullLead blocks earlier than the block's last part (a few tiles that end with the newest
+            // one).  In plain (block, part) order the waves reach block k only 4-8 blocks ahead of the ring once a block has
+            // several parts, the full parts finish after the last part, and the ring waits for them (chain trace: the far
+            // wave has everything 6 us after the slowest last-part task stored).  Key kappa holds: the full parts of block
+            // kappa + fullLead, then the last part of block kappa.
+            const int FQ = RING + P.xr;
+            const int rem = task % G4;
+            int tt = task / G4;
+            t.q4 = rem & 3;
+            t.g = rem >> 2;
+            for (int kappa = FQ - P.fullLead; kappa < P.K; ++kappa) {
+                const int kf = kappa + P.fullLead;
+                const int nfull = kf < P.K ? (kf - FQ) / TPT : 0;             // kf >= FQ always
+                if (tt < nfull) { t.k = kf; t.part = tt; return true; }
+                tt -= nfull;
+                if (kappa >= FQ) {
+                    if (tt == 0) { t.k = kappa; t.part = (kappa - FQ) / TPT; return true; }
+                    --tt;
+                }
+            }
+            return false;
+        }
         t.q4 = task & 3;
         const int t2 = task >> 2;
         t.g = t2 % P.nPanelGroups;
@@ -1244,9 +1272,56 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
         if (!have_next) wait_vmcnt<0>();      // nothing of this task is in flight when its stages are reused
         late_mode = !frontier;
 
-        // ---- reduce over the 8 column slots (lane bits 3..5) as a reduce-scatter: each stage halves the
-        // accumulators a lane keeps, so 14 exchanges instead of 48; every lane ends with 2 of the 16 results
+        // ---- reduce over the 8 column slots (lane bits 3..5) --------------------------------------------------------------
+        // The task's last tile is the newest one: what follows sits on the ring's critical path (16 hand-off rounds per
+        // sweep at T=1024: a microsecond here is 16 in the total).  SEMICRF_LDS_REDUCE: the 16 accumulators of every lane go
+        // through LDS once (the wave's stages are idle now) and each lane merges the 8 slot values of its two results with
+        // ONE exact maximum and 8 independent exps, instead of a 3-stage shuffle tree with two dependent exps per stage.
         const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
+        u64* fbase = farg + (size_t)part * T * Bs;
+        const int pi = pbase + (b5 ? 2 : 0) + (b4 ? 1 : 0);
+#if SEMICRF_LDS_REDUCE
+        if (!SEMICRF_TASK_PREFETCH) {
+            constexpr int RSTR = 65 * 8;                                  // bytes between accumulators (65 lanes: spreads the banks)
+            float2* const red = (float2*)stage0;
+            (void)red;
+            char* const rb = stage0;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *(float2*)(rb + (rr * 4 + i) * RSTR + lane * 8) =
+                        make_float2(aM[rr][i], MODE == 0 ? aS[rr][i] : __int_as_float(aK[rr][i]));
+            const int orow = (b5 ? 2 : 0) + (b4 ? 1 : 0);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int oi = (b3 ? 2 : 0) + e;
+                const char* src = rb + (orow * 4 + oi) * RSTR + q8 * 8;
+                float2 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = *(const float2*)(src + j * 64);            // slot j, same chain quad
+                const int cc = c + oi;
+                u64 gr;
+                if (MODE == 0) {
+                    float mx = v[0].x;
+#pragma unroll
+                    for (int j = 1; j < 8; ++j) mx = fmaxf(mx, v[j].x);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sum += v[j].y == 0.0f ? 0.0f : v[j].y * fexp2(v[j].x - mx);   // empty: (-inf, 0)
+                    gr = make_granule(tag, mx + flog2(sum));
+                } else {
+                    float bm = v[0].x;
+                    int bk = __float_as_int(v[0].y);
+#pragma unroll
+                    for (int j = 1; j < 8; ++j) max_push(bm, bk, v[j].x, __float_as_int(v[j].y));
+                    gr = make_granule_key(tag, bm, bk);
+                }
+                if (pi < T && cc < c1 && !(SEMICRF_PANEL_PROBES && (dbg & 32u))) store_granule(fbase + (size_t)pi * Bs + cc, gr);
+            }
+        } else
+#endif
+        {
         auto xmerge = [&](float& kM, float& kS, int& kK, float sM, float sS, int sK, int off) {
             const float oM = __shfl_xor(sM, off);
             if (MODE == 0) {
@@ -1278,8 +1353,6 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
             xmerge(kM, kS, kK, b4 ? M1[0][i] : M1[1][i], b4 ? S1[0][i] : S1[1][i], b4 ? K1[0][i] : K1[1][i], 16);
             M2[i] = kM; S2[i] = kS; K2[i] = kK;
         }
-        u64* fbase = farg + (size_t)part * T * Bs;
-        const int pi = pbase + (b5 ? 2 : 0) + (b4 ? 1 : 0);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             float kM = b3 ? M2[2 + e] : M2[e], kS = b3 ? S2[2 + e] : S2[e];
@@ -1291,7 +1364,9 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                 store_granule(fbase + (size_t)pi * Bs + cc, gr);
             }
         }
-        if (SEMICRF_PANEL_PROBES && (dbg & 16u) && P.xr == 0 && g == 0 && q4 == 0 && m1 == q + 1 && lane == 0) P.ts[256 + k] = __builtin_amdgcn_s_memrealtime();     // chain probe: partial stored
+        }
+        if (SEMICRF_PANEL_PROBES && (dbg & 16u) && P.xr == 0 && g == 0 && m1 == q + 1 && lane == 0 && k < 64)
+            P.ts[256 + 64 * q4 + k] = __builtin_amdgcn_s_memrealtime();     // chain probe: partial stored (per row quarter)
     }
 }
 
@@ -1723,14 +1798,15 @@ static unsigned next_tag()
 }
 
 static int g_run_ahead_max = 6;
+static int g_full_lead = 0;          // off: measured slower at T=1024/2048 (the waves are the bottleneck: a lead only moves the wait), -5 % at T=691
 static int g_recent_tiles = 0;      // recent waves off by default: measured slower, kept for the next attempt
 
-struct Knobs { int xr, run_ahead, hybrid_waves, hybrid_start, panel_waves, zero_waves; };
+struct Knobs { int xr, run_ahead, hybrid_waves, hybrid_start, panel_waves, zero_waves, full_lead; };
 static Knobs read_knobs()
 {
     auto get = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : -1; };
     return Knobs{get("SEMICRF_XR"), get("SEMICRF_RUN_AHEAD"), get("SEMICRF_HYBRID_PANEL_WAVES"), get("SEMICRF_HYBRID_START"),
-                 get("SEMICRF_PANEL_WAVES"), get("SEMICRF_ZERO_WAVES")};
+                 get("SEMICRF_PANEL_WAVES"), get("SEMICRF_ZERO_WAVES"), get("SEMICRF_FULL_LEAD")};
 }
 
 struct GradArgs {
@@ -1834,6 +1910,15 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         if (pw > PW_MAX) pw = PW_MAX;
         (void)per_cu;
         P.panelWaves = pw;
+        {
+            // full parts may wait for columns whose blocks need tasks that come later in the queue: at most (lead - 5) blocks'
+            // worth of them can be blocked at a time, which must stay well below the number of panel waves
+            int lead = knobs.full_lead >= 0 ? knobs.full_lead : g_full_lead;
+            const int g4 = P.nPanelGroups * 4;
+            while (lead > 5 && (lead - 5) * g4 > nPanelWG * pw / 2) --lead;
+            if (nPanelWG * pw < 2 * g4) lead = 0;
+            P.fullLead = lead;
+        }
         {
             // waves that may sit on last-part tasks whose newest u is not out yet: at most half of the panel waves, so
             // that the full parts of earlier blocks always find a free wave (see panel_next_task)
