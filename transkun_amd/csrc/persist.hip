@@ -1681,6 +1681,9 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
     __syncthreads();
     const int ticket = s_ticket;
     const int wave = (int)(threadIdx.x >> 6);
+    // clock probe (probe build, debug flag 128): shader cycles and 100 MHz ticks of one panel workgroup over the launch
+    const bool clk = SEMICRF_PANEL_PROBES && (P.dbg & 128u) && ticket == P.nSpine + 3 && threadIdx.x == 0;
+    if (clk) { P.ts[600] = __builtin_readcyclecounter(); P.ts[601] = __builtin_amdgcn_s_memrealtime(); }
     if (ticket < P.nSpine) {
         // chain group = ticket: neighbouring groups read neighbouring 16-byte pieces of the same sectors, and
         // measured fetch traffic is 3x lower this way than with groups spread 8 tickets apart (0.13 vs 0.36 GB for
@@ -1714,6 +1717,7 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
         if (!(P.dbg & 2u) && wave < P.panelWaves) panel_role<MODE, DIR, GRAD>(P, s_dyn, wave);
         else if (GRAD && wave - P.panelWaves >= 0 && wave - P.panelWaves < P.zeroWaves) zero_role(P);
     }
+    if (clk) { P.ts[602] = __builtin_readcyclecounter(); P.ts[603] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 constexpr size_t CTRL_WORDS = 256;
