@@ -2,7 +2,7 @@
 import argparse, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-os.environ["SEMICRF_DEBUG_FLAGS"] = "16"; os.environ["SEMICRF_DEBUG_KEEP_WS"] = "1"
+os.environ["SEMICRF_DEBUG_FLAGS"] = str(16 | int(os.environ.get("CHAIN_TRACE_FLAGS", "0"))); os.environ["SEMICRF_DEBUG_KEEP_WS"] = "1"
 from transkun_amd import _lib, synth
 nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
 ap = argparse.ArgumentParser()

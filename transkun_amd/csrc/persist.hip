@@ -61,6 +61,15 @@ constexpr float LN2 = 0.6931471805599453f;
 constexpr int SPIN_LIMIT = 1 << 20;       // global-memory polls (with s_sleep): ~0.3 s
 constexpr int SPIN_LIMIT_LDS = 1 << 24;   // LDS polls (s_sleep 1): ~0.5 s
 constexpr float RESCALE_THR = 64.0f;
+// Panel accumulators (reference M, sum S of exp2(t - M)).  u grows by ~45 log2 units per tile of 16 positions on N(0,1)
+// scores, so the old rule -- "move M when a term exceeds M + 64, to exactly that term" -- moved every accumulator every
+// 1.4 tiles, each at its own time; the test is a wave-wide __any over 32 chains x 8 columns, so the slow path ran on EVERY
+// tile and cost as much as the accumulation itself (a tile of real values took 1.5 us, one of NaNs 0.9).  Now: M is an
+// integer placed RESC_LIFT ABOVE the largest term seen when it is (re)set -- fp32 still holds every term within 2^-24 of
+// that one -- the slow path is entered when a term exceeds M + RESC_HI, and it then moves every accumulator of the wave
+// that is within RESC_EARLY of that limit, so that the chains stay in step: one visit every ~4 tiles.  A move is exact: S
+// is scaled by a power of two (ldexp), no exponential.  Bounds: S <= 32 terms x 2^RESC_HI, 8 such in the final reduction.
+constexpr float RESC_LIFT = 96.0f, RESC_HI = 108.0f, RESC_EARLY = 56.0f;
 constexpr unsigned CTRL_INIT = 0xffffffffu;  // initial value of every workspace word (one 0xff fill per launch)
 constexpr unsigned U_EMPTY = 0xffffffffu;  // not-yet-published u (a NaN pattern the spine never stores): the value is its own flag
 
@@ -733,6 +742,16 @@ constexpr int LDS_DYN_BYTES = LDS_HYBRID_BYTES > LDS_DYN_MAX2 ? LDS_HYBRID_BYTES
 // q8 selects 4 of the 32 chains (8 consecutive lanes read one 128-byte line), slot selects the columns
 // pj = 16m + slot + 8h (h < 2) of tile m.  Cells and u values of the next tiles are requested before tile m is
 // processed.  The same mapping serves both directions (only cell_index differs).
+// slow path of the panel accumulation: move the reference above tm when tm is within RESC_EARLY of the limit (see RESC_LIFT)
+__device__ __forceinline__ void acc_lift(float& M, float& S, float tm)
+{
+    const bool need = tm > M + (RESC_HI - RESC_EARLY);                       // true for the empty accumulator (M = -inf)
+    const float newM = need ? floorf(tm) + RESC_LIFT : M;
+    const int sh = (int)fmaxf(M - newM, -4096.0f);                            // an integer; 0 when nothing moves
+    S = __builtin_ldexpf(S, sh);                                              // exact; empty: S = 0 stays 0
+    M = newM;
+}
+
 // ---- panel helpers (free functions: a lambda that calls another lambda keeps its closure in scratch once
 // the body contains operations the optimiser treats as memory writes -- the global->LDS loads) ----------------
 struct PanelGeom {
@@ -766,7 +785,7 @@ __device__ __forceinline__ void panel_fetch_gran(__amdgpu_buffer_rsrc_t ursrc, c
 {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {       // positions 16m + 8h + slot, 4 chains (16 bytes) per lane
-        const unsigned so = (unsigned)((m * PB + 8 * h) * B * 4);
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((m * PB + 8 * h) * B * 4);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void_t*)(stage + 8192 + h * 1024), 16, gvoff, so, 0, COHERENT ? 16 : 0);   // 16 = sc1
     }
 }
@@ -778,10 +797,17 @@ __device__ __forceinline__ void panel_fetch_gran(__amdgpu_buffer_rsrc_t ursrc, c
 template <int DIR>
 __device__ __forceinline__ void panel_fetch_cells(const float* score, const PanelGeom& G, char* stage, int m, int T, size_t Bs)
 {
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(score + panel_tile_off<DIR>(G, m, T, Bs)), 0, 0x7fffffff, 0x00020000);
+    // The tile base and the piece offsets are wave-uniform by construction; said explicitly, because a load whose descriptor
+    // or offset the compiler takes for divergent (task state that passed a lane-dependent loop exit) is wrapped in a
+    // waterfall loop -- ten of them per tile.
+    const size_t toff = panel_tile_off<DIR>(G, m, T, Bs);
+    const size_t toff_u = (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)toff) |
+                          ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(toff >> 32)) << 32);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(score + toff_u), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const unsigned so = DIR == 0 ? panel_soff<DIR>(G, e >> 1, e & 1, T, Bs) : (unsigned)(((size_t)(14 - 2 * e) * T * Bs) * 4);
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(
+            (int)(DIR == 0 ? panel_soff<DIR>(G, e >> 1, e & 1, T, Bs) : (unsigned)(((size_t)(14 - 2 * e) * T * Bs) * 4)));
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(stage + e * 1024), 16, G.fvoff, so, 0, SEMICRF_CELL_AUX);
     }
 }
@@ -829,6 +855,21 @@ __device__ __forceinline__ void panel_wait_younger(int y)
 
 struct PanelTask { int k, part, g, q4; };
 
+// queue position -> task (single queue in (block, part, chain group, row quarter) order)
+__device__ __forceinline__ void panel_task_decode(const SweepParams& P, int task, PanelTask& t)
+{
+    t.q4 = task & 3;
+    const int t2 = task >> 2;
+    t.g = t2 % P.nPanelGroups;
+    int tt = t2 / P.nPanelGroups;
+    int a = 0;
+    while (tt >= TPT * (a + 1) * (a + 2) / 2) ++a;          // group a: blocks with a+1 parts
+    tt -= TPT * a * (a + 1) / 2;
+    const int q = a * TPT + tt / (a + 1);
+    t.part = tt % (a + 1);
+    t.k = RING + P.xr + q;
+}
+
 __device__ __forceinline__ bool panel_next_task(const SweepParams& P, PanelTask& t)
 {
     unsigned* const ctrl = P.ctrl;
@@ -863,16 +904,7 @@ __device__ __forceinline__ bool panel_next_task(const SweepParams& P, PanelTask&
             }
             return false;
         }
-        t.q4 = task & 3;
-        const int t2 = task >> 2;
-        t.g = t2 % P.nPanelGroups;
-        int tt = t2 / P.nPanelGroups;
-        int a = 0;
-        while (tt >= TPT * (a + 1) * (a + 2) / 2) ++a;          // group a: blocks with a+1 parts
-        tt -= TPT * a * (a + 1) / 2;
-        const int q = a * TPT + tt / (a + 1);
-        t.part = tt % (a + 1);
-        t.k = RING + P.xr + q;
+        panel_task_decode(P, task, t);
         return true;
     }
     const int FQ = RING + P.xr;                                 // first block with panel tiles
@@ -969,13 +1001,23 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
     bool late_mode = false, have_next = false;
     PanelTask nxt;
     int nxt_fetched = 0, s_first = 0;
+    // task timeline probe (probe build, dbg & 256; tools/task_trace.py): the wave that drew task 0 stamps 5 words per task at ts[3T/2 + 5n]
+    bool tracer = false;
+    int tn = 0;
 
     while (true) {
         // ---- next task: (k, part, g, q4); a task only waits on spine progress below k-3 ----
         PanelTask tk;
         int pre = 0;                                                // tiles of this task that are already in flight
         if (have_next) { tk = nxt; pre = nxt_fetched; have_next = false; nxt_fetched = 0; }
-        else { if (!panel_next_task(P, tk)) break; s_first = 0; }
+        else {
+            if (!panel_next_task(P, tk)) break;
+            s_first = 0;
+            if (SEMICRF_PANEL_PROBES && (dbg & 256u) && tk.k == RING + P.xr && tk.part == 0 && tk.g == 0 && tk.q4 == 0) tracer = true;
+        }
+        u64* const tsp = P.ts + (3 * T) / 2 + 5 * tn;
+        const bool tr = SEMICRF_PANEL_PROBES && tracer && lane == 0 && 5 * tn + 5 <= T / 2;
+        if (tr) tsp[0] = __builtin_amdgcn_s_memrealtime();
         const int q = tk.k - RING - P.xr;                           // the newest tile the panels have of this block
         const int m0 = tk.part * TPT;
         const int m1 = (m0 + TPT < q + 1) ? m0 + TPT : q + 1;       // tiles m0 .. m1-1 of the q+1 panel tiles of block k
@@ -1055,6 +1097,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
             char* const stage = stage0 + s * PSTAGE_BYTES;
             // ---- wait for the stage, move it to registers ------------------------------------------------
             panel_wait_younger(issued - (s == 0 ? mark0 : (s == 1 ? mark1 : mark2)));
+            if (tr && m == m0) tsp[1] = __builtin_amdgcn_s_memrealtime();
             v4u xo[8];
             panel_read_cells<DIR>(rdbase + (unsigned)(s * PSTAGE_BYTES), xo);
             const bool refill = m + PNS < m1;
@@ -1143,18 +1186,14 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                         }
                         const float emax = fmaxf(fmaxf(fmaxf(e[0][0].x, e[0][0].y), fmaxf(e[0][1].x, e[0][1].y)),
                                                  fmaxf(fmaxf(e[1][0].x, e[1][0].y), fmaxf(e[1][1].x, e[1][1].y)));
-                        if (__any(emax > RESCALE_THR)) {
+                        if (__any(emax > RESC_HI)) {
                             // some accumulator's reference point is too low (always on the first tile): move it up
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 const float x0 = __uint_as_float(i == 0 ? xo[rr * 2].x : (i == 1 ? xo[rr * 2].y : (i == 2 ? xo[rr * 2].z : xo[rr * 2].w)));
                                 const float x1 = __uint_as_float(i == 0 ? xo[rr * 2 + 1].x : (i == 1 ? xo[rr * 2 + 1].y : (i == 2 ? xo[rr * 2 + 1].z : xo[rr * 2 + 1].w)));
                                 const float t0 = fmaf(x0, LOG2E, uv[0][i]), t1 = fmaf(x1, LOG2E, uv[1][i]);
-                                const float mx = fmaxf(aM[rr][i], fmaxf(t0, t1));
-                                if (mx > aM[rr][i] + RESCALE_THR) {
-                                    aS[rr][i] = aS[rr][i] * fexp2(aM[rr][i] - mx);     // -inf - mx -> exp2 = 0, S = 0
-                                    aM[rr][i] = mx;
-                                }
+                                acc_lift(aM[rr][i], aS[rr][i], fmaxf(t0, t1));
                                 const float e0 = t0 - aM[rr][i], e1 = t1 - aM[rr][i];
                                 if (i & 1) { e[0][i >> 1].y = e0; e[1][i >> 1].y = e1; } else { e[0][i >> 1].x = e0; e[1][i >> 1].x = e1; }
                             }
@@ -1185,7 +1224,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 t[h][i] = fmaf(xe[i], LOG2E, uv[h][i]);
-                                exc = fmaxf(exc, t[h][i] - (aM[rr][i] + RESCALE_THR));
+                                exc = fmaxf(exc, t[h][i] - (aM[rr][i] + RESC_HI));
                             }
                         }
                         if (GRAD) {
@@ -1210,13 +1249,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                         if (__any(exc > 0.0f)) {
                             // some accumulator's reference point is too low (always on the first tile): move it up
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const float mx = fmaxf(aM[rr][i], fmaxf(t[0][i], t[1][i]));
-                                if (mx > aM[rr][i] + RESCALE_THR) {
-                                    aS[rr][i] = aS[rr][i] * fexp2(aM[rr][i] - mx);     // -inf - mx -> exp2 = 0, S = 0
-                                    aM[rr][i] = mx;
-                                }
-                            }
+                            for (int i = 0; i < 4; ++i) acc_lift(aM[rr][i], aS[rr][i], fmaxf(t[0][i], t[1][i]));
                         }
 #pragma unroll
                         for (int h = 0; h < 2; ++h)
@@ -1269,6 +1302,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                 }
             }
         }
+        if (tr) { tsp[2] = __builtin_amdgcn_s_memrealtime(); tsp[4] = (u64)(m1 - m0) | ((u64)k << 8) | ((u64)(frontier ? 1 : 0) << 16) | ((u64)part << 20); }
         if (!have_next) wait_vmcnt<0>();      // nothing of this task is in flight when its stages are reused
         late_mode = !frontier;
 
@@ -1367,6 +1401,8 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
         }
         if (SEMICRF_PANEL_PROBES && (dbg & 16u) && P.xr == 0 && g == 0 && m1 == q + 1 && lane == 0 && k < 64)
             P.ts[256 + 64 * q4 + k] = __builtin_amdgcn_s_memrealtime();     // chain probe: partial stored (per row quarter)
+        if (tr) tsp[3] = __builtin_amdgcn_s_memrealtime();
+        ++tn;
     }
 }
 
