@@ -48,9 +48,23 @@ constexpr int RS = 4;              // chains per ring (one per lane)
 constexpr int GS = RS;              // chains per spine workgroup
 constexpr int GP = 32;             // chains per panel task (4 per lane)
 #ifndef SEMICRF_TPT
-#define SEMICRF_TPT 16
+#define SEMICRF_TPT 12            // 12 tiles per task and a last part of at least 4: 184-186 us vs 188-190 with 16 / 1 (T=1024, NBatch=352)
 #endif
 constexpr int TPT = SEMICRF_TPT;   // tiles (column blocks) per panel task
+#ifndef SEMICRF_LEADT
+#define SEMICRF_LEADT 4
+#endif
+// Parts of a block with far tiles 0..q: FULL parts of TPT tiles at fixed columns, then the LAST part, which ends with the
+// newest tile and is at least LEADT tiles long (when the block has that many): every full part lies LEADT tiles or more
+// behind the newest one, i.e. all of its columns are published LEADT + RING blocks before its result is needed.
+constexpr int LEADT = SEMICRF_LEADT;
+__host__ __device__ inline int nfull_of(int q) { return q + 1 - LEADT >= 0 ? (q + 1 - LEADT) / TPT : 0; }
+__host__ __device__ inline int nparts_of(int q) { return nfull_of(q) + 1; }
+__host__ __device__ inline void part_tiles(int q, int part, int& m0, int& m1)
+{
+    m0 = part * TPT;
+    m1 = part < nfull_of(q) ? m0 + TPT : q + 1;
+}
 #ifndef SEMICRF_NT
 #define SEMICRF_NT 640
 #endif
@@ -404,7 +418,7 @@ __device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds
         const int prow = k * PB + r;
         const bool rvalid = cvalid && prow < T;
         // parts of block k: the panels' column parts of its far tiles 0 .. k-RING-xr, plus the recent waves' partial
-        const int npanel = k >= RING + P.xr ? (k - RING - P.xr) / TPT + 1 : 0;
+        const int npanel = k >= RING + P.xr ? nparts_of(k - RING - P.xr) : 0;
         const int nparts = npanel + (P.xr > 0 ? 1 : 0);
         float aM = SEMICRF_NEG_INF, aS = 0.f;
         int aK = 0x7fffffff;
@@ -862,10 +876,12 @@ __device__ __forceinline__ void panel_task_decode(const SweepParams& P, int task
     const int t2 = task >> 2;
     t.g = t2 % P.nPanelGroups;
     int tt = t2 / P.nPanelGroups;
+    if (tt < LEADT - 1) { t.part = 0; t.k = RING + P.xr + tt; return; }      // the first LEADT - 1 blocks: one part
+    tt -= LEADT - 1;
     int a = 0;
     while (tt >= TPT * (a + 1) * (a + 2) / 2) ++a;          // group a: blocks with a+1 parts
     tt -= TPT * a * (a + 1) / 2;
-    const int q = a * TPT + tt / (a + 1);
+    const int q = a * TPT + tt / (a + 1) + LEADT - 1;
     t.part = tt % (a + 1);
     t.k = RING + P.xr + q;
 }
@@ -894,11 +910,11 @@ __device__ __forceinline__ bool panel_next_task(const SweepParams& P, PanelTask&
             t.g = rem >> 2;
             for (int kappa = FQ - P.fullLead; kappa < P.K; ++kappa) {
                 const int kf = kappa + P.fullLead;
-                const int nfull = kf < P.K ? (kf - FQ) / TPT : 0;             // kf >= FQ always
+                const int nfull = kf < P.K ? nfull_of(kf - FQ) : 0;             // kf >= FQ always
                 if (tt < nfull) { t.k = kf; t.part = tt; return true; }
                 tt -= nfull;
                 if (kappa >= FQ) {
-                    if (tt == 0) { t.k = kappa; t.part = (kappa - FQ) / TPT; return true; }
+                    if (tt == 0) { t.k = kappa; t.part = nfull_of(kappa - FQ); return true; }
                     --tt;
                 }
             }
@@ -908,7 +924,7 @@ __device__ __forceinline__ bool panel_next_task(const SweepParams& P, PanelTask&
         return true;
     }
     const int FQ = RING + P.xr;                                 // first block with panel tiles
-    int nq = (P.K - 1 - FQ) / TPT + 1;                          // queue i >= 1 exists when some block has a full part i - 1
+    int nq = nparts_of(P.K - 1 - FQ);                           // queue i >= 1 exists when some block has a full part i - 1
     if (nq > MAX_QUEUES) nq = MAX_QUEUES;
     int spins = 0;
     u64 dead = 0;                                               // queues this wave has seen run out
@@ -920,7 +936,7 @@ __device__ __forceinline__ bool panel_next_task(const SweepParams& P, PanelTask&
         int best = -1, bestk = 0x7fffffff;
         bool left = false;
         for (int i = 0; i < nq; ++i) {
-            const int k0 = FQ + i * TPT;                                    // first block of queue i
+            const int k0 = i == 0 ? FQ : FQ + i * TPT + LEADT - 1;          // first block of queue i
             if (P.K <= k0) continue;
             const unsigned hv = (unsigned)__builtin_amdgcn_readlane(v, 1 + i);
             const int kq = hv == CTRL_INIT ? k0 : (int)hv;
@@ -939,7 +955,7 @@ __device__ __forceinline__ bool panel_next_task(const SweepParams& P, PanelTask&
         int idx = 0;
         if (lane == 0) idx = (int)(atomicAdd(ctrl + CTRL_QHEAD + best, 1u) + 1u);
         idx = __builtin_amdgcn_readfirstlane(idx);
-        const int k0 = FQ + best * TPT;
+        const int k0 = best == 0 ? FQ : FQ + best * TPT + LEADT - 1;
         const int size = (P.K - k0) * G4;
         if (idx >= size) {
             // past the end: the queue is empty (the summary only ever grows: a late "opened block k" cannot undo this)
@@ -952,14 +968,14 @@ __device__ __forceinline__ bool panel_next_task(const SweepParams& P, PanelTask&
         if (rem == 0 && lane == 0) atomicMax((int*)(ctrl + CTRL_PROG + 1 + best), t.k);      // this wave opens block t.k of the queue
         t.q4 = rem & 3;
         t.g = rem >> 2;
-        t.part = best == 0 ? (t.k - FQ) / TPT : best - 1;
+        t.part = best == 0 ? nfull_of(t.k - FQ) : best - 1;
         if (SEMICRF_PANEL_PROBES && lane == 0) atomicAdd(ctrl + (best == 0 ? 81 : 82), 1u);   // probe: tasks by kind
         return true;
     }
 }
 
 template <int MODE, int DIR, bool GRAD>
-__device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int wslot)
+__device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int wslot, int hist_role = 0)
 {
     const int T = P.T, B = P.B;
     const int c0 = P.c0, c1 = P.c1;
@@ -1019,8 +1035,8 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
         const bool tr = SEMICRF_PANEL_PROBES && tracer && lane == 0 && 5 * tn + 5 <= T / 2;
         if (tr) tsp[0] = __builtin_amdgcn_s_memrealtime();
         const int q = tk.k - RING - P.xr;                           // the newest tile the panels have of this block
-        const int m0 = tk.part * TPT;
-        const int m1 = (m0 + TPT < q + 1) ? m0 + TPT : q + 1;       // tiles m0 .. m1-1 of the q+1 panel tiles of block k
+        int m0, m1;
+        part_tiles(q, tk.part, m0, m1);                             // tiles m0 .. m1-1 of the q+1 panel tiles of block k
         const int k = tk.k, part = tk.part, g = tk.g, q4 = tk.q4;
         const int pbase = k * PB + q4 * 4;
         if (pbase >= T) continue;                               // rows past the end (last block)
@@ -1098,6 +1114,15 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
             // ---- wait for the stage, move it to registers ------------------------------------------------
             panel_wait_younger(issued - (s == 0 ? mark0 : (s == 1 ? mark1 : mark2)));
             if (tr && m == m0) tsp[1] = __builtin_amdgcn_s_memrealtime();
+            if (SEMICRF_PANEL_PROBES && (dbg & 1024u) && lane == 0) {
+                // activity histogram (tools/activity_hist.py): tiles taken per 4 us bucket, panel and spare waves apart
+                u64* const hb = P.ts + (3 * T) / 2;
+                const u64 now = __builtin_amdgcn_s_memrealtime();
+                const u64 t0 = __hip_atomic_load(hb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u64 b = now > t0 ? (now - t0) / 400 : 0;
+                if (b > 63) b = 63;
+                atomicAdd((unsigned long long*)(hb + 1 + 64 * hist_role + b), 1ull);
+            }
             v4u xo[8];
             panel_read_cells<DIR>(rdbase + (unsigned)(s * PSTAGE_BYTES), xo);
             const bool refill = m + PNS < m1;
@@ -1284,8 +1309,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                     have_next = panel_next_task(P, nxt);
                     if (have_next) {
                         const int nq = nxt.k - RING - P.xr;
-                        nm0 = nxt.part * TPT;
-                        nm1 = (nm0 + TPT < nq + 1) ? nm0 + TPT : nq + 1;
+                        part_tiles(nq, nxt.part, nm0, nm1);
                         if (nxt.k * PB + nxt.q4 * 4 >= T) nm1 = nm0;          // rows past the end: nothing to fetch
                         geom_of(nxt, Gn);
                         nxt_fetched = 0;
@@ -1720,6 +1744,8 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
     // clock probe (probe build, debug flag 128): shader cycles and 100 MHz ticks of one panel workgroup over the launch
     const bool clk = SEMICRF_PANEL_PROBES && (P.dbg & 128u) && ticket == P.nSpine + 3 && threadIdx.x == 0;
     if (clk) { P.ts[600] = __builtin_readcyclecounter(); P.ts[601] = __builtin_amdgcn_s_memrealtime(); }
+    if (SEMICRF_PANEL_PROBES && (P.dbg & 1024u) && threadIdx.x == 0)          // activity histogram: t0 = the first workgroup's start
+        atomicMin((unsigned long long*)(P.ts + (3 * P.T) / 2), (unsigned long long)__builtin_amdgcn_s_memrealtime());
     if (ticket < P.nSpine) {
         // chain group = ticket: neighbouring groups read neighbouring 16-byte pieces of the same sectors, and
         // measured fetch traffic is 3x lower this way than with groups spread 8 tickets apart (0.13 vs 0.36 GB for
@@ -1747,7 +1773,7 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
                     if (spin_abort(P.ctrl, spins, SPIN_LIMIT_LDS, 10)) break;
                 }
             }
-            panel_role<MODE, DIR, GRAD>(P, s_dyn + LDS_HYBRID_PANEL, wave - (RING + NLOADER + 1));
+            panel_role<MODE, DIR, GRAD>(P, s_dyn + LDS_HYBRID_PANEL, wave - (RING + NLOADER + 1), 1);
         }
     } else {
         if (!(P.dbg & 2u) && wave < P.panelWaves) panel_role<MODE, DIR, GRAD>(P, s_dyn, wave);
@@ -1890,7 +1916,9 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
     P.u_out = u_out; P.last_out = last_out; P.code = code;
     // ONE fill: every word of the workspace starts as 0xffffffff -- u reads U_EMPTY, far-field granules carry a tag no
     // launch uses, the counters return 0 after their first increment, the error word reads CTRL_INIT
-    if (hipMemsetAsync(ws, 0xff, persist_workspace_bytes(T, B), stream) != hipSuccess) return 1;
+    // (probe build, flag 512: the u values of the previous launch in the same workspace stay -- panels alone on real values)
+    const size_t fill_bytes = (SEMICRF_PANEL_PROBES && (P.dbg & 512u)) ? ug_off : persist_workspace_bytes(T, B);
+    if (hipMemsetAsync(ws, 0xff, fill_bytes, stream) != hipSuccess) return 1;
     static const Knobs knobs = read_knobs();                    // tuning knobs of the development tools: the environment is read ONCE
     const int xr_env = knobs.xr;
 
@@ -1918,7 +1946,7 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         P.xr = xr; P.recentWaves = rw; P.rpart = max_parts(T) - 1;
         // panel tasks per chain group: block k = RING + xr + q has q/TPT + 1 column parts, each split in 4 row quarters
         long long ntask = 0;
-        for (int q = 0; q < P.K - RING - xr; ++q) ntask += (q / TPT + 1);
+        for (int q = 0; q < P.K - RING - xr; ++q) ntask += nparts_of(q);
         ntask *= 4;
         P.nTasks = (int)(ntask * P.nPanelGroups);
         P.ctrl = (unsigned*)w + (size_t)ci * CTRL_WORDS;
@@ -1939,8 +1967,10 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         // The gradient sweep is bandwidth-bound almost from the start.
         int hpw = HPW_MAX - rw > 0 ? HPW_MAX - rw : 0;
         if (knobs.hybrid_waves >= 0 && knobs.hybrid_waves <= HPW_MAX - rw) hpw = knobs.hybrid_waves;
-        int hstart = grad ? 12 : P.K * 3 / 8;
-        hstart = hstart < 8 ? 8 : (hstart > 32 ? 32 : hstart);
+        // (round 2, after the panel math got cheaper: later is better -- T=691: 143-150 us from block 28 vs 160 from 16;
+        // T=512: 89 from 20 vs 92 from 12; T=1024: 185 from 40 vs 188 from 32; T=2048: 583-598 from 32-48 vs 602-617 from 64-80)
+        int hstart = grad ? 12 : P.K * 5 / 8;
+        hstart = hstart < 8 ? 8 : (hstart > 40 ? 40 : hstart);
         if (knobs.hybrid_start >= 0) hstart = knobs.hybrid_start;
         P.hybridStart = hstart;
         P.hybridPanelWaves = hpw;
@@ -1966,6 +1996,7 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
             int ra = g4 > 0 ? (nPanelWG * pw / 2) / g4 : 0;
             const int ra_max = knobs.run_ahead >= 0 ? knobs.run_ahead : g_run_ahead_max;
             ra = ra < 0 ? 0 : (ra > ra_max ? ra_max : ra);
+            if (knobs.run_ahead >= 0) ra = knobs.run_ahead;          // development knob: taken as given
             P.runAhead = ra;
         }
         // the zero upper triangle of the gradient: by spare waves of the first chunk's panel workgroups, or (no
