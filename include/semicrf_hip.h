@@ -54,6 +54,20 @@ int semicrf_abi_version(void);
 const char* semicrf_last_error(void);
 size_t semicrf_workspace_bytes(int op, int T, int B);
 
+/* Optional: LEASED workspaces.  The sweeps (semicrf_logz_fwd / _logz_bwd / _beta / _viterbi) need their scratch to read
+ * 0xff when they start and therefore fill a caller-owned buffer in front of every launch (17 MB, 6.8 us at T=1024,
+ * NBatch=352).  A buffer the caller registers is filled once; every launch leaves it the way the fill would.  The caller
+ * promises, until semicrf_workspace_unregister:
+ *   - nothing but this library's sweeps writes to the buffer (pass the registered base pointer as `ws`, unchanged);
+ *   - at most one stream uses it at a time (launches into one workspace are ordered by the stream they are enqueued on);
+ *   - the calling thread's current device is the buffer's device when it registers.
+ * A change of (operation, T, B) costs one fill.  A launch that aborted (see below: NaN outputs / negative decode total)
+ * raises a pinned host word; the next launch of ANY lease is preceded by a fill again.  semicrf_workspace_register may
+ * synchronise the device (once per device); call it at set-up time.  (No counterpart in the reference: its
+ * NeuralSemiCRFInterval.py:207-246, :386-414 allocate their temporaries per call.) */
+int semicrf_workspace_register(void* ws, size_t ws_bytes);
+int semicrf_workspace_unregister(void* ws);
+
 /* Select kernel implementation: 0 = auto (fastest valid), 1 = row-sequential reference kernels.
  * Process-wide; meant for tests and A/B benchmarking. */
 void semicrf_set_impl(int impl);

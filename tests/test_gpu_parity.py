@@ -455,6 +455,62 @@ def test_repeatable_bits(gpu, T, B, n):
     assert _lib.device_status() == 0
 
 
+@pytest.mark.gpu
+def test_leased_workspace_bitwise(gpu):
+    """A registered (leased) workspace is filled once and left clean by every launch: results must equal, bit for bit,
+    those of a freshly filled buffer -- for repeated launches, for a change of shape or of operation in the SAME buffer
+    (costs one fill), for many chains (several chain chunks share the buffer) and after unregistering."""
+    import ctypes
+    from transkun_amd import _lib, synth
+    _lib.set_impl(0)
+    lib = _lib.load()
+    shapes = [(333, 46), (130, 600), (1024, 352), (64, 12)]
+    # two data sets per shape: consecutive launches in one leased buffer must not see each other's u values
+    data = {(sh, var): synth.crf_inputs(sh[0], sh[1], 91 + sh[0] + 1000 * var, gpu) for sh in shapes for var in (0, 1)}
+    nbytes = max(max(int(lib.semicrf_workspace_bytes(op, T, B)) for op in (_lib.OP_LOGZ_FWD, _lib.OP_LOGZ_BWD, _lib.OP_VITERBI))
+                 for T, B in shapes)
+
+    def run(ws, sh, op, var):
+        T, B = sh
+        s, nz = data[(sh, var)]
+        lz = torch.empty(B, device=gpu); v = torch.empty(T, B, device=gpu)
+        if op == "fwd":
+            _lib.ops().logz_fwd(s, nz, lz, v, True, ws)
+            return (lz, v)
+        if op == "bwd":
+            _lib.ops().logz_fwd(s, nz, lz, v, True, ws)
+            g = synth.hash_normal(B, 5, gpu)
+            ds = torch.empty(T, T, B, device=gpu); dn = torch.empty(max(T - 1, 0), B, device=gpu); q = torch.empty(T, B, device=gpu)
+            _lib.ops().logz_bwd(s, nz, v, lz, g, ds, dn, q, True, ws)
+            return (ds, dn, q)
+        pairs = torch.empty(B * 2 * T, 2, dtype=torch.int32, device=gpu); offs = torch.empty(B + 1, dtype=torch.int32, device=gpu)
+        _lib.ops().viterbi(s, nz, offs, False, False, pairs, offs, ws)
+        n = int(offs[-1]); assert n >= 0
+        return (offs, pairs[:n])
+
+    plain = torch.empty(nbytes, dtype=torch.uint8, device=gpu)
+    want = {(sh, op, var): [t.clone() for t in run(plain, sh, op, var)] for sh in shapes for op in ("fwd", "bwd", "vit") for var in (0, 1)}
+    assert not torch.equal(want[((333, 46), "fwd", 0)][0], want[((333, 46), "fwd", 1)][0])
+    leased = torch.empty(nbytes, dtype=torch.uint8, device=gpu)
+    leased.random_(0, 256)                                  # arbitrary contents: the first launch fills
+    with torch.cuda.device(gpu):
+        assert lib.semicrf_workspace_register(ctypes.c_void_p(leased.data_ptr()), ctypes.c_size_t(nbytes)) == 0
+    try:
+        seq = [((333, 46), "fwd")] * 4 + [((333, 46), "vit")] * 3 + [((333, 46), "bwd")] * 3 + \
+              [((130, 600), "fwd")] * 3 + [((1024, 352), "fwd")] * 4 + [((1024, 352), "bwd")] * 3 + [((64, 12), "vit")] * 2 + \
+              [((1024, 352), "vit")] * 3 + [((333, 46), "fwd"), ((130, 600), "bwd"), ((333, 46), "fwd"), ((333, 46), "fwd")]
+        for i, (sh, op) in enumerate(seq):
+            var = (i * 7 // 3) & 1                          # 0 0 0 1 1 0 0 1 1 1 ...: same and different data back to back
+            got = run(leased, sh, op, var)
+            for a, b in zip(got, want[(sh, op, var)]):
+                assert torch.equal(a, b), (i, sh, op, var)
+    finally:
+        lib.semicrf_workspace_unregister(ctypes.c_void_p(leased.data_ptr()))
+    got = run(leased, (333, 46), "fwd", 1)                  # an ordinary buffer again: filled by the launch
+    assert all(torch.equal(a, b) for a, b in zip(got, want[((333, 46), "fwd", 1)]))
+    assert _lib.device_status() == 0
+
+
 # ---- the persistent blocked kernels against the oracle over a grid of shapes -------------------
 
 PERSIST_SHAPES = [(1, 4), (2, 4), (15, 8), (16, 4), (17, 12), (33, 16), (48, 20), (63, 36), (64, 32), (65, 4),

@@ -117,7 +117,7 @@ def _logz_fwd_raw(score, noise, want_v: bool):
     T, B = score.shape[0], score.shape[2]
     logz = torch.empty(B, dtype=torch.float32, device=score.device)
     v = torch.empty((T, B) if want_v else (0,), dtype=torch.float32, device=score.device)
-    ws = _lib.workspace(_lib.OP_LOGZ_FWD, T, B, score.device)
+    ws = _lib.leased_workspace(_lib.OP_LOGZ_FWD, T, B, score.device)
     _lib.ops().logz_fwd(score, noise, logz, v, want_v, ws)
     if os.environ.get("SEMICRF_DEBUG_KEEP_WS"):
         _DEBUG_WS[:] = [ws]
@@ -132,7 +132,7 @@ def _logz_bwd_raw(score, noise, v, logz, gout, want_q: bool = False):
     dscore = torch.empty_like(score)
     dnoise = torch.empty_like(noise)
     q = torch.empty((T, B) if want_q else (0,), dtype=torch.float32, device=score.device)
-    ws = _lib.workspace(_lib.OP_LOGZ_BWD, T, B, score.device)
+    ws = _lib.leased_workspace(_lib.OP_LOGZ_BWD, T, B, score.device)
     _lib.ops().logz_bwd(score, noise, v, logz, gout, dscore, dnoise, q, want_q, ws)
     return dscore, dnoise, (q if want_q else None)
 
@@ -295,7 +295,7 @@ def _viterbi_raw(score_c, noise_c, start, forward: bool):
     cap = B * 2 * T
     pairs = torch.empty(cap, 2, dtype=torch.int32, device=dev)
     offsets = torch.empty(B + 1, dtype=torch.int32, device=dev)
-    ws = _lib.workspace(_lib.OP_VITERBI, T, B, dev)
+    ws = _lib.leased_workspace(_lib.OP_VITERBI, T, B, dev)
     has = start is not None
     _lib.ops().viterbi(score_c, noise_c, start if has else offsets, has, bool(forward), pairs, offsets, ws)
     return pairs, offsets

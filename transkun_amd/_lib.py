@@ -11,6 +11,7 @@ There is NO fallback: a missing library or a non-GPU tensor raises.
 """
 from __future__ import annotations
 
+import collections
 import ctypes
 import os
 from typing import Optional
@@ -32,6 +33,8 @@ _SIGS = {
     "semicrf_abi_version": (ctypes.c_int, []),
     "semicrf_last_error": (ctypes.c_char_p, []),
     "semicrf_workspace_bytes": (_sz, [_i, _i, _i]),
+    "semicrf_workspace_register": (_i, [_vp, _sz]),
+    "semicrf_workspace_unregister": (_i, [_vp]),
     "semicrf_set_impl": (None, [_i]),
     "semicrf_get_impl": (ctypes.c_int, []),
     "semicrf_debug_device_status": (ctypes.c_int, []),
@@ -141,6 +144,37 @@ def workspace(op: int, T: int, B: int, device) -> torch.Tensor:
     if n is None:
         n = _WS_BYTES[key] = max(int(load().semicrf_workspace_bytes(op, T, B)), 256)
     return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+_LEASES: Optional[collections.OrderedDict] = None
+_LEASE_MAX = 16
+
+
+def leased_workspace(op: int, T: int, B: int, device, kind: str = "") -> torch.Tensor:
+    """A sweep workspace that is registered with the library (semicrf_workspace_register): one per (device, stream, op,
+    T, B), kept alive here, filled once -- every launch leaves it clean for the next one on the same stream.
+    SEMICRF_NO_LEASE=1 falls back to a fresh buffer per call (filled by every launch)."""
+    global _LEASES
+    if os.environ.get("SEMICRF_NO_LEASE") or os.environ.get("SEMICRF_DEBUG_KEEP_WS"):
+        return workspace(op, T, B, device)
+    if _LEASES is None:
+        _LEASES = collections.OrderedDict()
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev, torch.cuda.current_stream(device).cuda_stream, op, T, B, kind)
+    ws = _LEASES.get(key)
+    if ws is not None:
+        _LEASES.move_to_end(key)
+        return ws
+    ws = workspace(op, T, B, device)
+    with torch.cuda.device(device):
+        rc = load().semicrf_workspace_register(ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()))
+    if rc != 0:
+        check(rc, "semicrf_workspace_register")
+    _LEASES[key] = ws
+    while len(_LEASES) > _LEASE_MAX:
+        _, old = _LEASES.popitem(last=False)
+        load().semicrf_workspace_unregister(ctypes.c_void_p(old.data_ptr()))
+    return ws
 
 
 def set_impl(impl: int) -> None:

@@ -3,6 +3,8 @@
 #include <stdarg.h>
 #include <string.h>
 #include <atomic>
+#include <mutex>
+#include <unordered_map>
 #include "common.h"
 
 namespace semicrf {
@@ -70,13 +72,14 @@ int launch_interval_score_mfma(const float* q, const float* k, const float* diag
 size_t persist_workspace_bytes(int T, int B);
 bool persist_supported(int T, int B);
 int launch_persist_sweep(int mode, int dir, const float* score, const float* noise, int T, int B, float* u_out,
-                         float* last_out, int* code, void* ws, hipStream_t stream);
+                         float* last_out, int* code, void* ws, hipStream_t stream, int lease, unsigned lease_tag);
+int persist_set_host_abort_word(unsigned* devptr);
 
 int read_and_clear_device_status();
 
 int launch_persist_logz_bwd(const float* score, const float* noise, const float* v, const float* logZ,
                             const float* gout, int T, int B, float* dScore, float* dNoise, float* q_out, void* ws,
-                            hipStream_t stream);
+                            hipStream_t stream, int lease, unsigned lease_tag);
 
 static bool use_persist(int T, int B) { return g_impl.load() == 0 && persist_supported(T, B); }
 
@@ -99,6 +102,38 @@ struct Carver {
 
 static size_t tb(int T, int B) { return align_up((size_t)T * (size_t)B * 4); }
 
+// ---- leased workspaces (semicrf_workspace_register) ------------------------------------------------------------------
+// A sweep needs its scratch to read 0xff everywhere when it starts: u values are their own "not published yet" flag.  For a
+// caller-owned buffer that means one fill (17 MB at T=1024, NBatch=352: 6.8 us) in front of every launch.  A workspace
+// that the caller REGISTERS -- promising that nothing but sweeps of this library writes to it, that at most one stream
+// uses it at a time -- is filled once; every launch then leaves it the way the fill would (persist.hip: the rings put
+// their u values back, the last wave resets the control words, far partials carry the workspace's own launch count).
+// A launch that timed out raises a pinned host word; the host then distrusts every lease and fills again.
+struct Lease { size_t bytes; int op, T, B; bool clean; unsigned count; };
+static std::mutex g_lease_mu;
+static std::unordered_map<void*, Lease> g_leases;
+static unsigned* g_abort_word = nullptr;                 // pinned + mapped: the device address equals the host address
+
+// what the next sweep into `ws` has to do: 0 ordinary, 1 fill + self-clean, 2 clean already; tag = the lease's launch count
+static int lease_acquire(void* ws, int op, int T, int B, unsigned* tag)
+{
+    *tag = 0;
+    std::lock_guard<std::mutex> lk(g_lease_mu);
+    if (g_leases.empty()) return 0;
+    auto it = g_leases.find(ws);
+    if (it == g_leases.end()) return 0;
+    if (g_abort_word && __atomic_load_n(g_abort_word, __ATOMIC_RELAXED) != 0u) {
+        __atomic_store_n(g_abort_word, 0u, __ATOMIC_RELAXED);
+        for (auto& kv : g_leases) kv.second.clean = false;          // some launch gave up: its workspace is in an unknown state
+    }
+    Lease& L = it->second;
+    const bool clean = L.clean && L.op == op && L.T == T && L.B == B;
+    L.op = op; L.T = T; L.B = B; L.clean = true;                    // the launch enqueued next leaves it clean
+    *tag = ++L.count;
+    if (L.count == 0u) *tag = ++L.count;
+    return clean ? 2 : 1;
+}
+
 }  // namespace semicrf
 
 using namespace semicrf;
@@ -110,6 +145,36 @@ const char* semicrf_last_error(void) { return g_err; }
 void semicrf_set_impl(int impl) { g_impl.store(impl); }
 int semicrf_get_impl(void) { return g_impl.load(); }
 int semicrf_debug_device_status(void) { return read_and_clear_device_status(); }
+
+int semicrf_workspace_register(void* ws, size_t ws_bytes)
+{
+    SEMICRF_CHECK_ARG(ws != nullptr && ws_bytes > 0, "workspace is NULL or empty");
+    {
+        std::lock_guard<std::mutex> lk(g_lease_mu);
+        if (!g_abort_word) {
+            void* p = nullptr;
+            if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+                set_error("hipHostMalloc of the abort word failed"); return SEMICRF_ELAUNCH;
+            }
+            memset(p, 0, 64);
+            g_abort_word = (unsigned*)p;
+        }
+    }
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, g_abort_word, 0) != hipSuccess || persist_set_host_abort_word((unsigned*)dp)) {
+        set_error("could not hand the abort word to the device"); return SEMICRF_ELAUNCH;
+    }
+    std::lock_guard<std::mutex> lk(g_lease_mu);
+    g_leases[ws] = Lease{ws_bytes, -1, 0, 0, false, 0u};
+    return SEMICRF_OK;
+}
+
+int semicrf_workspace_unregister(void* ws)
+{
+    std::lock_guard<std::mutex> lk(g_lease_mu);
+    g_leases.erase(ws);
+    return SEMICRF_OK;
+}
 
 size_t semicrf_workspace_bytes(int op, int T, int B)
 {
@@ -149,7 +214,9 @@ int semicrf_logz_fwd(const float* score, const float* noise, int T, int B, float
     if (!cv.ok || !ws) { set_error("workspace too small for logz_fwd"); return SEMICRF_EWORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     if (fast) {
-        if (launch_persist_sweep(0, 0, score, noise, T, B, vv, logZ, nullptr, pws, st)) {
+        unsigned ltag = 0;
+        const int lease = lease_acquire(ws, SEMICRF_OP_LOGZ_FWD, T, B, &ltag);
+        if (launch_persist_sweep(0, 0, score, noise, T, B, vv, logZ, nullptr, pws, st, lease, ltag)) {
             set_error("persistent sweep could not be enqueued (hipMemsetAsync failed or too many chain chunks)"); return SEMICRF_ELAUNCH;
         }
     } else {
@@ -174,7 +241,9 @@ int semicrf_logz_bwd(const float* score, const float* noise, const float* v, con
     hipStream_t st = (hipStream_t)stream;
     if (fast) {
         // beta sweep fused with the marginals: score is read once, dScore written once
-        if (launch_persist_logz_bwd(score, noise, v, logZ, gout, T, B, dScore, dNoise, q, pws, st)) {
+        unsigned ltag = 0;
+        const int lease = lease_acquire(ws, SEMICRF_OP_LOGZ_BWD, T, B, &ltag);
+        if (launch_persist_logz_bwd(score, noise, v, logZ, gout, T, B, dScore, dNoise, q, pws, st, lease, ltag)) {
             set_error("persistent sweep could not be enqueued (hipMemsetAsync failed or too many chain chunks)"); return SEMICRF_ELAUNCH;
         }
     } else {
@@ -196,7 +265,9 @@ int semicrf_beta(const float* score, const float* noise, int T, int B, float* be
     if (!cv.ok || (fast && !ws)) { set_error("workspace too small for beta"); return SEMICRF_EWORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     if (fast) {
-        if (launch_persist_sweep(0, 1, score, noise, T, B, beta, nullptr, nullptr, pws, st)) {
+        unsigned ltag = 0;
+        const int lease = lease_acquire(ws, SEMICRF_OP_LOGZ_FWD + 100, T, B, &ltag);
+        if (launch_persist_sweep(0, 1, score, noise, T, B, beta, nullptr, nullptr, pws, st, lease, ltag)) {
             set_error("persistent sweep could not be enqueued (hipMemsetAsync failed or too many chain chunks)"); return SEMICRF_ELAUNCH;
         }
     } else {
@@ -223,7 +294,9 @@ int semicrf_viterbi(const float* score, const float* noise, int T, int B, const 
     if (!cv.ok || !ws) { set_error("workspace too small for viterbi"); return SEMICRF_EWORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     if (fast) {
-        if (launch_persist_sweep(1, forward ? 0 : 1, score, noise, T, B, nullptr, nullptr, code, pws, st)) {
+        unsigned ltag = 0;
+        const int lease = lease_acquire(ws, SEMICRF_OP_VITERBI, T, B, &ltag);
+        if (launch_persist_sweep(1, forward ? 0 : 1, score, noise, T, B, nullptr, nullptr, code, pws, st, lease, ltag)) {
             set_error("persistent sweep could not be enqueued (hipMemsetAsync failed or too many chain chunks)"); return SEMICRF_ELAUNCH;
         }
     } else {

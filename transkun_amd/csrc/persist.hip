@@ -108,12 +108,15 @@ constexpr unsigned U_EMPTY = 0xffffffffu;  // not-yet-published u (a NaN pattern
 // control words of a launch (all start at 0xffffffff).  Three separate 128-byte lines: counters that take atomics must
 // not share a line with words that are polled (hundreds of idle waves reading a line that others update atomically
 // slow every dequeue down to tens of microseconds).
+constexpr size_t CTRL_WORDS = 256;   // control words per chain chunk
+constexpr int CTRL_EXIT = 64;         // [64]: workgroups that have left (leased workspaces: the last one resets the control words)
 constexpr int CTRL_QHEAD = 32;        // [32 + i]: next task of scheduler queue i (atomic counters only)
 constexpr int CTRL_PROG = 128;        // [128]: block the first spine has published; [129 + i]: block queue i hands out
 constexpr int MAX_QUEUES = 63;        // one lane per queue in the peek (T <= 16 * (RING + 63 * TPT))
 
 typedef unsigned long long u64;
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v4u_a4 __attribute__((ext_vector_type(4), aligned(4)));      // rows of odd multiples of 8 bytes
 template <int V>
 struct IC { static constexpr int value = V; };
 
@@ -134,6 +137,7 @@ struct SweepParams {
     int fullLead;          // full column parts enter the task queue this many blocks before the last part of their block
     int runAhead;          // EDF scheduler: a last-part task of block k may be taken once the ring has published block k-4-runAhead
     unsigned tag;          // nonzero launch epoch
+    int selfclean;         // leased workspace (semicrf_workspace_register): the launch leaves u and its control words as the fill would
     unsigned dbg;          // SEMICRF_DEBUG_FLAGS (timing experiments only; results are wrong when set):
                            // 1 spine ignores far partials, 2 panels exit at once, 4 panels do not wait for u,
                            // 8 spine exits at once, 16 spine 0 records per-block timestamps,
@@ -232,10 +236,15 @@ __device__ unsigned g_dev_status = 0;
 // reading the status word: logZ / alpha / beta / the gradient come back NaN, decode returns a negative total.
 __shared__ int s_abort;
 
+// pinned host word (or null) that an aborting launch raises: the host looks at it before it trusts a leased workspace again
+__device__ unsigned* g_host_abort = nullptr;
+
 __device__ __forceinline__ void set_error(unsigned* ctrl, unsigned code)
 {
     __hip_atomic_store(ctrl + 1, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&g_dev_status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned* const h = g_host_abort;
+    if (h) __hip_atomic_store(h, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Bounded waiting: returns true when the caller must give up.  The first waiter to exceed its limit
@@ -709,7 +718,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
         if (rvalid) {
             float mine = rd_base[(prow % NPOS) * 8];
             if (k == K - 1 && lds_flag_load(&s_abort) != 0) mine = __uint_as_float(0x7fc00000u);     // a wait timed out: poison the results
-            {
+            if (k < K - RING) {                                 // the far field of block k' ends at block k' - RING: nobody reads the last RING blocks' u
                 unsigned ub = __float_as_uint(mine);
                 if (ub == U_EMPTY) ub = 0x7fc00000u;            // keep the one reserved pattern free (NaN input scores)
                 __hip_atomic_store(ug + (size_t)prow * Bs + c, ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1735,7 +1744,8 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
 {
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];
     __shared__ int s_ticket;
-    if (threadIdx.x == 0) { s_ticket = (int)(atomicAdd(P.ctrl, 1u) + 1u); s_abort = 0; }
+    __shared__ int s_exit;
+    if (threadIdx.x == 0) { s_ticket = (int)(atomicAdd(P.ctrl, 1u) + 1u); s_abort = 0; s_exit = 0; }
     // flags and sequence numbers start at 0
     for (int i = threadIdx.x; i < (LDS_DUMMY - LDS_FAR) / 4; i += NT) ((int*)(s_dyn + LDS_FAR))[i] = 0;
     __syncthreads();
@@ -1753,6 +1763,30 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
         const int sg = ticket;
         if (wave < RING) {
             if (!(P.dbg & 8u)) spine_role<MODE, DIR, GRAD>(P, sg, wave, s_dyn);
+            if (P.selfclean && wave == (P.K - 1) % RING) {
+                // Leased workspace: u goes back to U_EMPTY.  When ANY ring of a 32-chain group is through, so is every panel
+                // task of the group (a task stores its partials for all of the group's chains at once, after its last look
+                // at u, and this ring took its last partials before its last block), and every u a task reads has been
+                // published (the last RING blocks' u is never stored).  So the group's u is dead, and each of its rings --
+                // through its last block's owner, the ring mates return earlier -- clears one share of the rows in whole
+                // 128-byte pieces (its own 16 bytes of every row would be 8x the line writes: measured +25 us).
+                const int lane = threadIdx.x & 63;
+                const int g = sg / (GP / GS), j = sg % (GP / GS);
+                const int spines_in_group = P.nSpine - g * (GP / GS) < GP / GS ? P.nSpine - g * (GP / GS) : GP / GS;
+                const int p0 = (int)((long long)P.T * j / spines_in_group), p1 = (int)((long long)P.T * (j + 1) / spines_in_group);
+                const int cq = P.c0 + g * GP + (lane & 7) * 4;                  // this lane's four chains
+                for (int p = p0 + (lane >> 3); p < p1; p += 8) {
+                    unsigned* const dst = P.ug + (size_t)p * P.B + cq;
+                    if (cq + 3 < P.c1) {
+                        const v4u_a4 e = {U_EMPTY, U_EMPTY, U_EMPTY, U_EMPTY};
+                        *(v4u_a4*)dst = e;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (cq + i < P.c1) dst[i] = U_EMPTY;
+                    }
+                }
+            }
         } else if (wave < RING + NLOADER) {
             if (!(P.dbg & 8u)) loader_role<DIR, GRAD>(P, sg, s_dyn, wave - RING);
         } else if (wave == RING + NLOADER) {
@@ -1780,9 +1814,27 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
         else if (GRAD && wave - P.panelWaves >= 0 && wave - P.panelWaves < P.zeroWaves) zero_role(P);
     }
     if (clk) { P.ts[602] = __builtin_readcyclecounter(); P.ts[603] = __builtin_amdgcn_s_memrealtime(); }
+    if (P.selfclean) {
+        // The last wave out puts the control words back (unless a wait timed out: the error word stays for the backtrack
+        // kernel, the host has been told through g_host_abort and fills the workspace before its next use).  Counted per
+        // workgroup (LDS first) and in a line of its own: one device-scope atomic per WAVE on the line of the ticket
+        // counter -- 1500 idle waves leave at the very start -- delayed every workgroup's ticket: +21 us.
+        int left = 0;
+        if ((threadIdx.x & 63) == 0) left = atomicAdd(&s_exit, 1) + 1;
+        left = __builtin_amdgcn_readfirstlane(left);
+        if (left == NT / 64) {
+            unsigned before = 0;
+            if ((threadIdx.x & 63) == 0) before = atomicAdd(P.ctrl + CTRL_EXIT, 1u) + 1u;      // workgroups that left before this one
+            before = (unsigned)__builtin_amdgcn_readfirstlane((int)before);
+            if (before + 1u == gridDim.x &&
+                __hip_atomic_load(P.ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == CTRL_INIT) {
+                for (int i = threadIdx.x & 63; i < (int)CTRL_WORDS; i += 64)
+                    __hip_atomic_store(P.ctrl + i, CTRL_INIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
-constexpr size_t CTRL_WORDS = 256;
 constexpr size_t CTRL_BYTES = MAX_CHUNKS * CTRL_WORDS * sizeof(unsigned);
 
 static int max_parts(int T)
@@ -1893,16 +1945,20 @@ static void launch_one(const SweepParams& P, int grid, hipStream_t stream)
 }
 
 // mode 0 = LSE, 1 = MAX.  ws must hold persist_workspace_bytes().  Enqueues a memset + one kernel per chain chunk.
+// lease: 0 = ordinary workspace (filled here, every launch); 1 = leased, not known to be clean (filled here, the launch
+// cleans up after itself); 2 = leased and left clean by the previous launch (no fill).  lease_tag: the workspace's own
+// launch count (consecutive launches in one workspace must not share a granule tag), 0 = the process-wide counter.
 static int launch_persist_sweep_impl(int mode, int dir, const float* score, const float* noise, int T, int B,
                                      float* u_out, float* last_out, int* code, void* ws, hipStream_t stream,
-                                     const GradArgs* grad)
+                                     const GradArgs* grad, int lease, unsigned lease_tag)
 {
     SweepParams P;
     P.vfwd = nullptr; P.logZ = nullptr; P.gout = nullptr; P.dScore = nullptr; P.dNoise = nullptr;
     if (grad) { P.vfwd = grad->vfwd; P.logZ = grad->logZ; P.gout = grad->gout; P.dScore = grad->dScore; P.dNoise = grad->dNoise; }
     P.score = score; P.noise = noise; P.T = T; P.B = B; P.K = (T + PB - 1) / PB;
-    P.tag = next_tag();
+    P.tag = lease_tag ? (lease_tag % 65534u) + 1u : next_tag();
     P.dbg = 0u;
+    P.selfclean = 0;
 #if SEMICRF_PANEL_PROBES
     // timing ablations (results are wrong when set): only the probe build reads them
     if (const char* dbg = getenv("SEMICRF_DEBUG_FLAGS")) P.dbg = (unsigned)atoi(dbg);
@@ -1918,7 +1974,9 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
     // launch uses, the counters return 0 after their first increment, the error word reads CTRL_INIT
     // (probe build, flag 512: the u values of the previous launch in the same workspace stay -- panels alone on real values)
     const size_t fill_bytes = (SEMICRF_PANEL_PROBES && (P.dbg & 512u)) ? ug_off : persist_workspace_bytes(T, B);
-    if (hipMemsetAsync(ws, 0xff, fill_bytes, stream) != hipSuccess) return 1;
+    if (P.dbg != 0u) lease = lease ? 1 : 0;                       // timing ablations leave anything behind
+    if (lease != 2 && hipMemsetAsync(ws, 0xff, fill_bytes, stream) != hipSuccess) return 1;
+    P.selfclean = lease != 0 && P.dbg == 0u;
     static const Knobs knobs = read_knobs();                    // tuning knobs of the development tools: the environment is read ONCE
     const int xr_env = knobs.xr;
 
@@ -2024,18 +2082,18 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
 }
 
 int launch_persist_sweep(int mode, int dir, const float* score, const float* noise, int T, int B, float* u_out,
-                         float* last_out, int* code, void* ws, hipStream_t stream)
+                         float* last_out, int* code, void* ws, hipStream_t stream, int lease, unsigned lease_tag)
 {
-    return launch_persist_sweep_impl(mode, dir, score, noise, T, B, u_out, last_out, code, ws, stream, nullptr);
+    return launch_persist_sweep_impl(mode, dir, score, noise, T, B, u_out, last_out, code, ws, stream, nullptr, lease, lease_tag);
 }
 
 // Fused backward: beta sweep + marginals (dScore fully written incl. the zero upper triangle, dNoise).
 int launch_persist_logz_bwd(const float* score, const float* noise, const float* v, const float* logZ,
                             const float* gout, int T, int B, float* dScore, float* dNoise, float* q_out, void* ws,
-                            hipStream_t stream)
+                            hipStream_t stream, int lease, unsigned lease_tag)
 {
     GradArgs ga{v, logZ, gout, dScore, dNoise};
-    return launch_persist_sweep_impl(0, 1, score, noise, T, B, q_out, nullptr, nullptr, ws, stream, &ga);
+    return launch_persist_sweep_impl(0, 1, score, noise, T, B, q_out, nullptr, nullptr, ws, stream, &ga, lease, lease_tag);
 }
 
 // the error word of every chain chunk of a sweep launched into `pws` (0xffffffff = no wait timed out)
@@ -2043,6 +2101,17 @@ const unsigned* persist_error_words(void* pws, int* n, int* stride)
 {
     *n = MAX_CHUNKS; *stride = (int)CTRL_WORDS;
     return (const unsigned*)pws + 1;
+}
+
+// Tell the sweep kernels of the current device where the host's abort word lives (pinned, mapped memory).  Synchronises.
+int persist_set_host_abort_word(unsigned* devptr)
+{
+    static std::atomic<bool> done[MAX_DEVICES];
+    const int dev = current_device();
+    if (done[dev].load()) return 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_host_abort), &devptr, sizeof(devptr)) != hipSuccess) return 1;
+    done[dev].store(true);
+    return 0;
 }
 
 int read_and_clear_device_status()

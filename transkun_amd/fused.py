@@ -35,7 +35,7 @@ _nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
 def _beta_raw(score, noise):
     T, B = score.shape[0], score.shape[2]
     beta = torch.empty(T, B, dtype=torch.float32, device=score.device)
-    ws = _lib.workspace(_lib.OP_LOGZ_FWD, T, B, score.device)
+    ws = _lib.leased_workspace(_lib.OP_LOGZ_FWD, T, B, score.device, "beta")
     _lib.ops().beta(score, noise, beta, ws)
     return beta
 
