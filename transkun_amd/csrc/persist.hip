@@ -51,6 +51,12 @@ constexpr int GP = 32;             // chains per panel task (4 per lane)
 #define SEMICRF_TPT 12            // 12 tiles per task and a last part of at least 4: 184-186 us vs 188-190 with 16 / 1 (T=1024, NBatch=352)
 #endif
 constexpr int TPT = SEMICRF_TPT;   // tiles (column blocks) per panel task
+#ifndef SEMICRF_TICKET_ATOMIC
+#define SEMICRF_TICKET_ATOMIC 0
+#endif
+#ifndef SEMICRF_STATIC_FIRST
+#define SEMICRF_STATIC_FIRST 1
+#endif
 #ifndef SEMICRF_LEADT
 #define SEMICRF_LEADT 4
 #endif
@@ -127,6 +133,7 @@ struct SweepParams {
     int c0, c1;            // chains [c0, c1) of the batch are handled by this launch
     int nSpine, nPanelGroups;
     int nTasks;            // panel tasks (k ascending, then column part, then chain group, then row quarter)
+    int taskBase;          // tasks [0, taskBase) are the first tasks of the panel workgroups' waves (no draw); the queue hands out the rest
     int panelWaves;        // waves per non-spine workgroup that work as panels (the rest exit at once)
     int hybridPanelWaves;  // panel waves of a spine workgroup (0..2)
     int hybridStart;       // ... which start once the ring has reached this row block
@@ -903,7 +910,7 @@ __device__ __forceinline__ bool panel_next_task(const SweepParams& P, PanelTask&
     if (SEMICRF_SCHED == 0) {
         int task = 0;
         if (lane == 0) task = (int)(atomicAdd(ctrl + 2, 1u) + 1u);        // counters start at 0xffffffff (one 0xff fill)
-        task = __builtin_amdgcn_readfirstlane(task);
+        task = __builtin_amdgcn_readfirstlane(task) + P.taskBase;
         if (task >= P.nTasks) return false;
         if (P.fullLead > 0) {
             // One queue, but the FULL parts of block k (16 tiles: ~20 us of streaming, all of their columns published long
@@ -984,7 +991,7 @@ __device__ __forceinline__ bool panel_next_task(const SweepParams& P, PanelTask&
 }
 
 template <int MODE, int DIR, bool GRAD>
-__device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int wslot, int hist_role = 0)
+__device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int wslot, int hist_role = 0, int first_task = -1)
 {
     const int T = P.T, B = P.B;
     const int c0 = P.c0, c1 = P.c1;
@@ -1036,7 +1043,9 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
         int pre = 0;                                                // tiles of this task that are already in flight
         if (have_next) { tk = nxt; pre = nxt_fetched; have_next = false; nxt_fetched = 0; }
         else {
-            if (!panel_next_task(P, tk)) break;
+            if (first_task >= 0 && first_task < P.nTasks) { panel_task_decode(P, first_task, tk); first_task = -1; }
+            else if (!panel_next_task(P, tk)) break;
+            first_task = -1;
             s_first = 0;
             if (SEMICRF_PANEL_PROBES && (dbg & 256u) && tk.k == RING + P.xr && tk.part == 0 && tk.g == 0 && tk.q4 == 0) tracer = true;
         }
@@ -1733,6 +1742,44 @@ __device__ __forceinline__ void zero_role(const SweepParams& P)
     }
 }
 
+// Workgroup index -> role ticket (spines: tickets < nSpine = the chain group; panel workgroups: nSpine + a dense rank).
+// The eight rings of a 32-chain panel group read the 16-byte pieces of the SAME 128-byte lines of the band, and their far
+// waves take partials from the same tasks: they belong on ONE XCD (one L2).  Block b is observed to run on XCD b % 8 (a
+// placement HIP does not promise: only speed depends on it), so panel group g gets the first blocks of XCD g % 8.  Groups
+// dealt to the XCDs by block index alone -- every ring of a group on a different XCD -- cost 216-228 us instead of 185; the
+// earlier first-come ticket (an atomic per workgroup) clustered them by luck of arrival.
+__device__ __forceinline__ int wg_ticket(int nSpine, int grid, int b)
+{
+    constexpr int X = 8, SPG = GP / GS;                      // XCDs, spines per panel group
+    const int ngroups = (nSpine + SPG - 1) / SPG;
+    int S[X], W[X];
+    bool fits = true;
+#pragma unroll
+    for (int x = 0; x < X; ++x) {
+        W[x] = x < grid ? (grid - x + X - 1) / X : 0;        // workgroups of the launch on XCD x
+        int sx = 0;
+        for (int g = x; g < ngroups; g += X) sx += nSpine - g * SPG < SPG ? nSpine - g * SPG : SPG;
+        S[x] = sx;
+        fits = fits && sx <= W[x];
+    }
+    if (!fits) return b;                                     // too few workgroups per XCD: plain order
+    const int x = b % X, slot = b / X;
+    int Sx = 0, Px = 0;
+#pragma unroll
+    for (int i = 0; i < X; ++i) if (i == x) { Sx = S[i]; Px = W[i] - S[i]; }
+    (void)Px;
+    if (slot < Sx) return (x + X * (slot / SPG)) * SPG + slot % SPG;       // ring slot % SPG of panel group x + 8 (slot / SPG)
+    const int ps = slot - Sx;                                // panel workgroups: dense rank, level by level across the XCDs
+    int rank = 0;
+#pragma unroll
+    for (int i = 0; i < X; ++i) {
+        const int pn = W[i] - S[i];
+        rank += ps < pn ? ps : pn;
+        if (i < x && pn > ps) ++rank;
+    }
+    return nSpine + rank;
+}
+
 // ---------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------
@@ -1743,13 +1790,24 @@ template <int MODE, int DIR, bool GRAD>
 __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
 {
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];
-    __shared__ int s_ticket;
     __shared__ int s_exit;
-    if (threadIdx.x == 0) { s_ticket = (int)(atomicAdd(P.ctrl, 1u) + 1u); s_abort = 0; s_exit = 0; }
+#if SEMICRF_TICKET_ATOMIC
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = (int)(atomicAdd(P.ctrl, 1u) + 1u);
+#endif
+    if (threadIdx.x == 0) { s_abort = 0; s_exit = 0; }
     // flags and sequence numbers start at 0
     for (int i = threadIdx.x; i < (LDS_DUMMY - LDS_FAR) / 4; i += NT) ((int*)(s_dyn + LDS_FAR))[i] = 0;
     __syncthreads();
+    // Roles by workgroup index: every workgroup of the launch is resident (one per CU, the grid never exceeds the CUs) and
+    // the dispatcher starts them in index order, so a workgroup still only waits on earlier ones.  (An atomic ticket cost
+    // every workgroup a device-scope round trip before it could do anything, on a line that hundreds of waves hit with
+    // their first task draws at the same moment.)
+#if SEMICRF_TICKET_ATOMIC
     const int ticket = s_ticket;
+#else
+    const int ticket = wg_ticket(P.nSpine, (int)gridDim.x, (int)blockIdx.x);
+#endif
     const int wave = (int)(threadIdx.x >> 6);
     // clock probe (probe build, debug flag 128): shader cycles and 100 MHz ticks of one panel workgroup over the launch
     const bool clk = SEMICRF_PANEL_PROBES && (P.dbg & 128u) && ticket == P.nSpine + 3 && threadIdx.x == 0;
@@ -1810,7 +1868,8 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
             panel_role<MODE, DIR, GRAD>(P, s_dyn + LDS_HYBRID_PANEL, wave - (RING + NLOADER + 1), 1);
         }
     } else {
-        if (!(P.dbg & 2u) && wave < P.panelWaves) panel_role<MODE, DIR, GRAD>(P, s_dyn, wave);
+        if (!(P.dbg & 2u) && wave < P.panelWaves)
+            panel_role<MODE, DIR, GRAD>(P, s_dyn, wave, 0, P.taskBase > 0 ? (ticket - P.nSpine) * P.panelWaves + wave : -1);
         else if (GRAD && wave - P.panelWaves >= 0 && wave - P.panelWaves < P.zeroWaves) zero_role(P);
     }
     if (clk) { P.ts[602] = __builtin_readcyclecounter(); P.ts[603] = __builtin_amdgcn_s_memrealtime(); }
@@ -2072,6 +2131,9 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         P.zeroWaves = zw;
         if (P.nTasks == 0) nPanelWG = 0;
         const int grid = P.nSpine + nPanelWG;
+        // the panel workgroups' waves know their first task (the first draws of ~700 waves all hit one counter at the start)
+        P.taskBase = (SEMICRF_STATIC_FIRST && SEMICRF_SCHED == 0 && P.fullLead == 0 && !SEMICRF_TASK_PREFETCH) ? nPanelWG * P.panelWaves : 0;
+        if (P.taskBase > P.nTasks) P.taskBase = P.nTasks;
         if (grad) launch_one<0, 1, true>(P, grid, stream);
         else if (mode == 0 && dir == 0) launch_one<0, 0, false>(P, grid, stream);
         else if (mode == 0 && dir == 1) launch_one<0, 1, false>(P, grid, stream);
