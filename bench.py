@@ -426,6 +426,7 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
         # ---- the transcription segment loop: decode -> heads -> events -> next forced start, F recordings in
         # lock step, incomplete-event merge on the host; the shipped geometry (16 s segments, 8 s hop: T = 691, 90 symbols) ----
         from transkun_amd.transcribe import SegmentTranscriber
+        torch.manual_seed(0)                                          # the heads are random-init: the event count depends on them
         tr = SegmentTranscriber(D).to(dev).eval()
         n_audio = int(56.0 * tr.fs)                                   # 56 s of audio: 9 segments per recording
         for Fn in (1, 4):

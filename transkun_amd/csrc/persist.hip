@@ -37,6 +37,10 @@
 #define SEMICRF_PANEL_PROBES 0      // 1: keep the panel timing probes (debug flags 4 and 32) in the hot loop
 #endif
 
+#ifndef SEMICRF_PROBE_HIST
+#define SEMICRF_PROBE_HIST 0       // 1 (with SEMICRF_PANEL_PROBES): the per-tile activity histogram of tools/activity_hist.py (spills: its own build)
+#endif
+
 namespace semicrf {
 
 constexpr int PB = 16;             // positions per block
@@ -1132,7 +1136,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
             // ---- wait for the stage, move it to registers ------------------------------------------------
             panel_wait_younger(issued - (s == 0 ? mark0 : (s == 1 ? mark1 : mark2)));
             if (tr && m == m0) tsp[1] = __builtin_amdgcn_s_memrealtime();
-            if (SEMICRF_PANEL_PROBES && (dbg & 1024u) && lane == 0) {
+            if (SEMICRF_PROBE_HIST && (dbg & 1024u) && lane == 0) {
                 // activity histogram (tools/activity_hist.py): tiles taken per 4 us bucket, panel and spare waves apart
                 u64* const hb = P.ts + (3 * T) / 2;
                 const u64 now = __builtin_amdgcn_s_memrealtime();
@@ -1812,7 +1816,7 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
     // clock probe (probe build, debug flag 128): shader cycles and 100 MHz ticks of one panel workgroup over the launch
     const bool clk = SEMICRF_PANEL_PROBES && (P.dbg & 128u) && ticket == P.nSpine + 3 && threadIdx.x == 0;
     if (clk) { P.ts[600] = __builtin_readcyclecounter(); P.ts[601] = __builtin_amdgcn_s_memrealtime(); }
-    if (SEMICRF_PANEL_PROBES && (P.dbg & 1024u) && threadIdx.x == 0)          // activity histogram: t0 = the first workgroup's start
+    if (SEMICRF_PROBE_HIST && (P.dbg & 1024u) && threadIdx.x == 0)          // activity histogram: t0 = the first workgroup's start
         atomicMin((unsigned long long*)(P.ts + (3 * P.T) / 2), (unsigned long long)__builtin_amdgcn_s_memrealtime());
     if (ticket < P.nSpine) {
         // chain group = ticket: neighbouring groups read neighbouring 16-byte pieces of the same sectors, and
@@ -1960,9 +1964,12 @@ size_t persist_workspace_bytes(int T, int B)
 
 // Even NBatch: the loader's 16-byte global->LDS loads and the panels' 16-byte loads need 8-byte aligned
 // addresses (4-byte aligned ones, i.e. odd NBatch, return wrong data); chains past the end of the range are masked.
+// (An odd NBatch runs too: the 16-byte accesses to four neighbouring chains are then only 4-byte aligned, which the
+// global->LDS loads and the 16-byte stores take -- bit-identical results, 271 vs 184 us at T=1024, NBatch=351 / 352: every
+// 128-byte piece straddles two lines -- where a padded copy of the tensor cost 1.0 ms.)
 bool persist_supported(int T, int B)
 {
-    return B >= 2 && B % 2 == 0 && T >= 2 && T < 65535 && (long long)T * B * 64 < (1ll << 31) &&      // 32-bit buffer offsets
+    return B >= 2 && T >= 2 && T < 65535 && (long long)T * B * 64 < (1ll << 31) &&      // 32-bit buffer offsets
            (B + GS - 1) / GS <= MAX_CHUNKS * (device_cus() / 2 > 0 ? device_cus() / 2 : 1) &&      // chain chunks of at most half the CUs' worth of rings
            max_parts(T) <= MAX_QUEUES;                   // one scheduler queue per column part
 }
