@@ -196,16 +196,17 @@ class SegmentTranscriber(nn.Module):
         if K == 0:
             return out
         P = len(self.targetMIDIPitch)
-        times = step["times"].cpu().numpy()
-        flags = step["flags"].cpu().numpy()
-        vel = step["velocity"].cpu().tolist()
-        sym = step["symIdx"].cpu().numpy()
-        seg = (step["scatterIdx"].cpu().numpy() // P)
-        for i in range(K):
-            out[int(seg[i])].append(Note(float(times[i, 0]), float(times[i, 1]), self.targetMIDIPitch[int(sym[i])], vel[i],
-                                         bool(flags[i, 0]), bool(flags[i, 1])))
-        for lst in out:
-            lst.sort(key=lambda x: (x.start, x.end, x.pitch))
+        # ONE copy to the host: every field is exactly representable in float64
+        packed = torch.stack([step["times"][:, 0], step["times"][:, 1], step["flags"][:, 0].to(torch.float64),
+                              step["flags"][:, 1].to(torch.float64), step["velocity"].to(torch.float64),
+                              step["symIdx"].to(torch.float64), step["scatterIdx"].to(torch.float64)], dim=1).cpu().numpy()
+        seg = packed[:, 6].astype(np.int64) // P
+        pitch = np.asarray(self.targetMIDIPitch, dtype=np.int64)[packed[:, 5].astype(np.int64)]
+        order = np.lexsort((pitch, packed[:, 1], packed[:, 0], seg))             # by recording, then (start, end, pitch)
+        cols = (seg[order].tolist(), packed[order, 0].tolist(), packed[order, 1].tolist(), pitch[order].tolist(),
+                packed[order, 4].astype(np.int64).tolist(), (packed[order, 2] != 0).tolist(), (packed[order, 3] != 0).tolist())
+        for sg, a, b, p, v, f0, f1 in zip(*cols):
+            out[sg].append(Note(a, b, p, v, f0, f1))
         return out
 
     # ------------------------------------------------------------------------------------------------------------------
