@@ -1207,6 +1207,14 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                     if (sn == 0) mark0 = issued; else if (sn == 1) mark1 = issued; else mark2 = issued;
                 }
                 if (SEMICRF_PANEL_PROBES && (dbg & 16u) && P.xr == 0 && g == 0 && q4 == 0 && m == q && lane == 0) P.ts[192 + k] = __builtin_amdgcn_s_memrealtime();   // chain probe: newest tile's u seen
+                // chains past the end of the batch (a ragged last quad reads the NEXT position's first chains there, published or
+                // not; a quad that lies past the end altogether reads the first chains, waited for or not): their u is set to 0,
+                // so that what they contribute to the wave-wide rescale test -- and with it the other chains' reference points
+                // and the last bits of their sums -- does not depend on timing
+                if (c >= c1) { g0.x = 0u; g1.x = 0u; }
+                if (c + 1 >= c1) { g0.y = 0u; g1.y = 0u; }
+                if (c + 2 >= c1) { g0.z = 0u; g1.z = 0u; }
+                if (c + 3 >= c1) { g0.w = 0u; g1.w = 0u; }
                 const float uv[2][4] = {{__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z), __uint_as_float(g0.w)},
                                         {__uint_as_float(g1.x), __uint_as_float(g1.y), __uint_as_float(g1.z), __uint_as_float(g1.w)}};
 
