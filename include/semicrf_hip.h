@@ -83,6 +83,11 @@ int semicrf_get_impl(void);
  * for the chains of every workgroup that saw a timeout, and semicrf_viterbi writes offsets[B] = -1. */
 int semicrf_debug_device_status(void);
 
+/* Host-side view of the sweeps' workgroup -> role map (test hook, no device work): the role ticket of workgroup `block`
+ * in a launch of `grid` workgroups of which `n_spine` are ring workgroups.  Tickets < n_spine are rings (ticket = the
+ * 4-chain group); the eight rings of a 32-chain panel group get workgroup indices that are equal modulo 8 (one XCD). */
+int semicrf_debug_wg_ticket(int n_spine, int grid, int block);
+
 /*
  * Log-partition, forward (alpha) sweep.
  * Replaces: computeLogZ (NeuralSemiCRFInterval.py:207-246) and the un-flipped half of

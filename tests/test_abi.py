@@ -154,3 +154,19 @@ def test_torch_ops_shim_registers_every_op():
     s = torch.zeros(4, 4, 2); n = torch.zeros(3, 2)
     with pytest.raises(NotImplementedError):
         ops.logz_fwd(s, n, torch.zeros(2), torch.zeros(4, 2), True, torch.zeros(256, dtype=torch.uint8))
+
+
+def test_workgroup_role_map_is_a_permutation():
+    """The sweeps deal roles by workgroup index (rings of one 32-chain panel group on one XCD): for every launch shape the map
+    must hit every ticket exactly once, and the rings of a panel group must share their index modulo 8 when they fit."""
+    from transkun_amd import _lib
+    lib = _lib.load()
+    for n_spine, grid in [(88, 256), (90, 256), (22, 256), (12, 40), (5, 256), (128, 256), (1, 9), (3, 7), (64, 100), (88, 88), (2, 2),
+                          (23, 256), (75, 256), (128, 304)]:
+        t = [lib.semicrf_debug_wg_ticket(n_spine, grid, b) for b in range(grid)]
+        assert sorted(t) == list(range(grid)), (n_spine, grid)
+        where = {tk: b for b, tk in enumerate(t)}
+        if t != list(range(grid)):                           # the XCD-aware map is in force
+            for g in range((n_spine + 7) // 8):
+                xs = {where[sg] % 8 for sg in range(8 * g, min(8 * g + 8, n_spine))}
+                assert len(xs) == 1, (n_spine, grid, g, xs)

@@ -38,6 +38,7 @@ _SIGS = {
     "semicrf_set_impl": (None, [_i]),
     "semicrf_get_impl": (ctypes.c_int, []),
     "semicrf_debug_device_status": (ctypes.c_int, []),
+    "semicrf_debug_wg_ticket": (_i, [_i, _i, _i]),
     "semicrf_logz_fwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "semicrf_logz_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "semicrf_viterbi": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i64, _vp, _vp, _sz, _vp]),

@@ -74,6 +74,7 @@ bool persist_supported(int T, int B);
 int launch_persist_sweep(int mode, int dir, const float* score, const float* noise, int T, int B, float* u_out,
                          float* last_out, int* code, void* ws, hipStream_t stream, int lease, unsigned lease_tag);
 int persist_set_host_abort_word(unsigned* devptr);
+int persist_wg_ticket(int nSpine, int grid, int b);
 
 int read_and_clear_device_status();
 
@@ -145,6 +146,7 @@ const char* semicrf_last_error(void) { return g_err; }
 void semicrf_set_impl(int impl) { g_impl.store(impl); }
 int semicrf_get_impl(void) { return g_impl.load(); }
 int semicrf_debug_device_status(void) { return read_and_clear_device_status(); }
+int semicrf_debug_wg_ticket(int n_spine, int grid, int block) { return persist_wg_ticket(n_spine, grid, block); }
 
 int semicrf_workspace_register(void* ws, size_t ws_bytes)
 {

@@ -1760,7 +1760,7 @@ __device__ __forceinline__ void zero_role(const SweepParams& P)
 // placement HIP does not promise: only speed depends on it), so panel group g gets the first blocks of XCD g % 8.  Groups
 // dealt to the XCDs by block index alone -- every ring of a group on a different XCD -- cost 216-228 us instead of 185; the
 // earlier first-come ticket (an atomic per workgroup) clustered them by luck of arrival.
-__device__ __forceinline__ int wg_ticket(int nSpine, int grid, int b)
+__host__ __device__ __forceinline__ int wg_ticket(int nSpine, int grid, int b)
 {
     constexpr int X = 8, SPG = GP / GS;                      // XCDs, spines per panel group
     const int ngroups = (nSpine + SPG - 1) / SPG;
@@ -2172,6 +2172,9 @@ int launch_persist_logz_bwd(const float* score, const float* noise, const float*
     GradArgs ga{v, logZ, gout, dScore, dNoise};
     return launch_persist_sweep_impl(0, 1, score, noise, T, B, q_out, nullptr, nullptr, ws, stream, &ga, lease, lease_tag);
 }
+
+// host-side view of the workgroup -> role map (tests/test_abi.py checks that it is a permutation for every launch shape)
+int persist_wg_ticket(int nSpine, int grid, int b) { return wg_ticket(nSpine, grid, b); }
 
 // the error word of every chain chunk of a sweep launched into `pws` (0xffffffff = no wait timed out)
 const unsigned* persist_error_words(void* pws, int* n, int* stride)
