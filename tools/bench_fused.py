@@ -5,7 +5,7 @@ from transkun_amd import CRF, synth
 from transkun_amd.fused import scorer_crf_logprob
 from transkun_amd.scorer import ScaledInnerProductIntervalScorer
 dev = torch.device("cuda:0")
-for (N, P, T) in ((4, 88, 1024), (4, 90, 691), (1, 90, 691)):
+for (N, P, T) in ((4, 88, 1024), (4, 90, 691), (4, 96, 691), (1, 90, 691), (1, 96, 691)):
     m = ScaledInnerProductIntervalScorer(256).to(dev)
     with torch.no_grad(): m.map[0].weight.mul_(0.3)
     ctx0 = torch.randn(N, P, T, 256, device=dev) * 0.5
