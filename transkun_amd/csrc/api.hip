@@ -134,6 +134,13 @@ static int lease_acquire(void* ws, int op, int T, int B, unsigned* tag)
     if (L.count == 0u) *tag = ++L.count;
     return clean ? 2 : 1;
 }
+// a sweep that could not be enqueued leaves nothing behind: the lease does not count as clean
+static void lease_failed(void* ws)
+{
+    std::lock_guard<std::mutex> lk(g_lease_mu);
+    auto it = g_leases.find(ws);
+    if (it != g_leases.end()) it->second.clean = false;
+}
 
 }  // namespace semicrf
 
@@ -219,6 +226,7 @@ int semicrf_logz_fwd(const float* score, const float* noise, int T, int B, float
         unsigned ltag = 0;
         const int lease = lease_acquire(ws, SEMICRF_OP_LOGZ_FWD, T, B, &ltag);
         if (launch_persist_sweep(0, 0, score, noise, T, B, vv, logZ, nullptr, pws, st, lease, ltag)) {
+            lease_failed(ws);
             set_error("persistent sweep could not be enqueued (hipMemsetAsync failed or too many chain chunks)"); return SEMICRF_ELAUNCH;
         }
     } else {
@@ -246,6 +254,7 @@ int semicrf_logz_bwd(const float* score, const float* noise, const float* v, con
         unsigned ltag = 0;
         const int lease = lease_acquire(ws, SEMICRF_OP_LOGZ_BWD, T, B, &ltag);
         if (launch_persist_logz_bwd(score, noise, v, logZ, gout, T, B, dScore, dNoise, q, pws, st, lease, ltag)) {
+            lease_failed(ws);
             set_error("persistent sweep could not be enqueued (hipMemsetAsync failed or too many chain chunks)"); return SEMICRF_ELAUNCH;
         }
     } else {
@@ -270,6 +279,7 @@ int semicrf_beta(const float* score, const float* noise, int T, int B, float* be
         unsigned ltag = 0;
         const int lease = lease_acquire(ws, SEMICRF_OP_LOGZ_FWD + 100, T, B, &ltag);
         if (launch_persist_sweep(0, 1, score, noise, T, B, beta, nullptr, nullptr, pws, st, lease, ltag)) {
+            lease_failed(ws);
             set_error("persistent sweep could not be enqueued (hipMemsetAsync failed or too many chain chunks)"); return SEMICRF_ELAUNCH;
         }
     } else {
@@ -299,6 +309,7 @@ int semicrf_viterbi(const float* score, const float* noise, int T, int B, const 
         unsigned ltag = 0;
         const int lease = lease_acquire(ws, SEMICRF_OP_VITERBI, T, B, &ltag);
         if (launch_persist_sweep(1, forward ? 0 : 1, score, noise, T, B, nullptr, nullptr, code, pws, st, lease, ltag)) {
+            lease_failed(ws);
             set_error("persistent sweep could not be enqueued (hipMemsetAsync failed or too many chain chunks)"); return SEMICRF_ELAUNCH;
         }
     } else {
