@@ -464,7 +464,7 @@ def test_leased_workspace_bitwise(gpu):
     from transkun_amd import _lib, synth
     _lib.set_impl(0)
     lib = _lib.load()
-    shapes = [(333, 46), (130, 600), (1024, 352), (64, 12)]
+    shapes = [(333, 46), (130, 600), (1024, 352), (64, 12), (200, 33)]
     # two data sets per shape: consecutive launches in one leased buffer must not see each other's u values
     data = {(sh, var): synth.crf_inputs(sh[0], sh[1], 91 + sh[0] + 1000 * var, gpu) for sh in shapes for var in (0, 1)}
     nbytes = max(max(int(lib.semicrf_workspace_bytes(op, T, B)) for op in (_lib.OP_LOGZ_FWD, _lib.OP_LOGZ_BWD, _lib.OP_VITERBI))
@@ -498,7 +498,8 @@ def test_leased_workspace_bitwise(gpu):
     try:
         seq = [((333, 46), "fwd")] * 4 + [((333, 46), "vit")] * 3 + [((333, 46), "bwd")] * 3 + \
               [((130, 600), "fwd")] * 3 + [((1024, 352), "fwd")] * 4 + [((1024, 352), "bwd")] * 3 + [((64, 12), "vit")] * 2 + \
-              [((1024, 352), "vit")] * 3 + [((333, 46), "fwd"), ((130, 600), "bwd"), ((333, 46), "fwd"), ((333, 46), "fwd")]
+              [((1024, 352), "vit")] * 3 + [((333, 46), "fwd"), ((130, 600), "bwd"), ((333, 46), "fwd"), ((333, 46), "fwd")] + \
+              [((200, 33), "fwd")] * 3 + [((200, 33), "bwd")] * 2 + [((200, 33), "vit")] * 2      # odd NBatch: 4-byte aligned clears
         for i, (sh, op) in enumerate(seq):
             var = (i * 7 // 3) & 1                          # 0 0 0 1 1 0 0 1 1 1 ...: same and different data back to back
             got = run(leased, sh, op, var)
