@@ -1,4 +1,4 @@
-"""Task timeline of ONE panel wave (probe build, debug flag 256): per task, when it was drawn, when its first tile had landed,
+"""Task timeline of ONE panel wave (build with SEMICRF_PANEL_PROBES=1 SEMICRF_PROBE_TASKS=1, debug flag 256): per task, when it was drawn, when its first tile had landed,
 when its last tile was done and when its partial was stored.  --flags adds other debug flags (12 = panels alone, 44 = stream only)."""
 import argparse, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -37,6 +37,9 @@
 #define SEMICRF_PANEL_PROBES 0      // 1: keep the panel timing probes (debug flags 4 and 32) in the hot loop
 #endif
 
+#ifndef SEMICRF_PROBE_TASKS
+#define SEMICRF_PROBE_TASKS 0      // 1 (with SEMICRF_PANEL_PROBES): the task timeline of tools/task_trace.py (its own build: registers)
+#endif
 #ifndef SEMICRF_PROBE_HIST
 #define SEMICRF_PROBE_HIST 0       // 1 (with SEMICRF_PANEL_PROBES): the per-tile activity histogram of tools/activity_hist.py (spills: its own build)
 #endif
@@ -1051,10 +1054,10 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
             else if (!panel_next_task(P, tk)) break;
             first_task = -1;
             s_first = 0;
-            if (SEMICRF_PANEL_PROBES && (dbg & 256u) && tk.k == RING + P.xr && tk.part == 0 && tk.g == 0 && tk.q4 == 0) tracer = true;
+            if (SEMICRF_PROBE_TASKS && (dbg & 256u) && tk.k == RING + P.xr && tk.part == 0 && tk.g == 0 && tk.q4 == 0) tracer = true;
         }
         u64* const tsp = P.ts + (3 * T) / 2 + 5 * tn;
-        const bool tr = SEMICRF_PANEL_PROBES && tracer && lane == 0 && 5 * tn + 5 <= T / 2;
+        const bool tr = SEMICRF_PROBE_TASKS && tracer && lane == 0 && 5 * tn + 5 <= T / 2;
         if (tr) tsp[0] = __builtin_amdgcn_s_memrealtime();
         const int q = tk.k - RING - P.xr;                           // the newest tile the panels have of this block
         int m0, m1;
