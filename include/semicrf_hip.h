@@ -153,9 +153,10 @@ int semicrf_eval_path_bwd(const float* gout, int T, int B, const int32_t* pairs,
  *   q,k: [C][T][D] with row strides ldq/ldk (in floats; >= D); diag: [C][T] with stride ldd between
  *   consecutive t (so the packed Linear output [C][T][2D+1] can be passed without a split copy).
  *   S[e,b,c] = (sum_d (q[c,e,d]*qscale) * k[c,b,d]) * len(|e-b|)  (+ diag[c,t] on e==b)
- *   S is [T][T][C] (chain axis contiguous, the CRF's layout).  Only e >= b is computed unless
- *   full_square != 0 (the reference materialises the full square; the CRF never reads e < b); with
- *   full_square == 0 the cells e < b are set to zero, so S needs no initialisation by the caller.
+ *   S is [T][T][C] (chain axis contiguous, the CRF's layout).  full_square: 0 = e >= b is computed and the cells e < b
+ *   are set to zero (S needs no initialisation by the caller); 1 = the full square, as the reference materialises it;
+ *   2 = e >= b only, the rest of S is left untouched -- for callers that hand S to the sweeps of this library only, which
+ *   never read e < b (tests/test_gpu_parity.py::test_upper_triangle_is_never_read): saves the 2 T^2 C bytes of zeros.
  *   noise_out [T-1][C] is zero-filled when non-NULL (:436-437).
  */
 int interval_score_fwd(const float* q, const float* k, const float* diag, int C, int T, int D,

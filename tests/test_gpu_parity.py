@@ -512,6 +512,54 @@ def test_leased_workspace_bitwise(gpu):
     assert _lib.device_status() == 0
 
 
+@pytest.mark.gpu
+def test_upper_triangle_is_never_read(gpu):
+    """No kernel of the layer reads score[end, begin] with begin > end: NaN / +-inf / huge values there change no output bit
+    (log-partition, alpha, the gradient, both decodes).  This is what lets the scorer skip the zero fill (full_square = 2)
+    for a score tensor that goes straight into the CRF."""
+    import importlib
+    from transkun_amd import _lib, synth
+    nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
+    _lib.set_impl(0)
+    for T, B in [(333, 46), (200, 33), (691, 90), (64, 12)]:
+        s, n = synth.crf_inputs(T, B, 5 + T, gpu)
+        g = synth.hash_normal(B, 3, gpu)
+        iv_pairs, iv_offs = nsci.pack_intervals(synth.synthetic_intervals(T, B, seed=3), T, B, gpu)
+
+        def run(sc):
+            lz, v = nsci._logz_fwd_raw(sc, n, True)
+            ds, dn, q = nsci._logz_bwd_raw(sc, n, v, lz, g, True)
+            pairs, offs = nsci._viterbi_raw(sc, n, None, False)
+            pf, of = nsci._viterbi_raw(sc, n, None, True)
+            path = nsci._eval_path_raw(sc, n, iv_pairs, iv_offs)
+            return lz, v, ds, dn, q, offs, pairs[:int(offs[-1])], of, pf[:int(of[-1])], path
+        ref = run(s)
+        iu = torch.triu_indices(T, T, offset=1, device=gpu)              # [end, begin] with begin > end
+        for val in (float("nan"), float("inf"), float("-inf"), 1e30):
+            s2 = s.clone()
+            s2[iu[0], iu[1], :] = val
+            for a, b in zip(ref, run(s2)):
+                assert torch.equal(a, b), (T, B, val)
+    assert _lib.device_status() == 0
+
+
+@pytest.mark.gpu
+def test_scorer_lower_triangle_only(gpu):
+    """interval_score_fwd with full_square = 2 writes exactly the cells of full_square = 0's lower triangle and leaves the
+    rest of S alone."""
+    from transkun_amd import _lib, synth
+    for T, C, D in [(200, 20, 64), (333, 12, 256), (130, 36, 128)]:
+        y = synth.hash_normal(C * T * (2 * D + 1), 5, gpu).view(C, T, 2 * D + 1)
+        q, k, dg = y[..., :D].contiguous(), y[..., D:2 * D].contiguous(), y[..., 2 * D].contiguous()
+        S0 = torch.empty(T, T, C, device=gpu); S2 = torch.full((T, T, C), 7.5, device=gpu)
+        nz = torch.empty(T - 1, C, device=gpu)
+        for full, S in ((0, S0), (2, S2)):
+            _lib.ops().interval_score_fwd(q, k, dg, C, T, D, q.stride(-2), k.stride(-2), dg.stride(-1), 1.0 / 8, 0, full, S, nz)
+        lower = torch.tril(torch.ones(T, T, dtype=torch.bool, device=gpu))
+        assert torch.equal(S0[lower], S2[lower])
+        assert bool((S2[~lower] == 7.5).all()) and bool((S0[~lower] == 0).all())
+
+
 # ---- the persistent blocked kernels against the oracle over a grid of shapes -------------------
 
 PERSIST_SHAPES = [(1, 4), (2, 4), (15, 8), (16, 4), (17, 12), (33, 16), (48, 20), (63, 36), (64, 32), (65, 4),

@@ -354,14 +354,15 @@ int interval_score_fwd(const float* q, const float* k, const float* diag, int C,
     SEMICRF_CHECK_ARG(ldq >= D && ldk >= D && ldd >= 1, "bad leading dimensions");
     SEMICRF_CHECK_ARG(length_scaling >= 0 && length_scaling <= 2, "bad length_scaling %d", length_scaling);
     hipStream_t st = (hipStream_t)stream;
-    if (!full_square) launch_zero_upper(S, T, C, st);          // begin > end: defined (zero), half the bytes of a full fill
+    if (full_square == 0) launch_zero_upper(S, T, C, st);      // begin > end: defined (zero), half the bytes of a full fill
+    const int full_kernel = full_square == 1 ? 1 : 0;           // 2: lower triangle only, the rest of S is left as it is
     if (g_impl.load() == 0 && interval_score_mfma_supported(C, T, D)) {
-        if (launch_interval_score_mfma(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, length_scaling, full_square, S, st) != 0) {
+        if (launch_interval_score_mfma(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, length_scaling, full_kernel, S, st) != 0) {
             set_error("interval_score_fwd: work list allocation failed");
             return SEMICRF_ELAUNCH;
         }
     } else
-        launch_interval_score_naive(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, length_scaling, full_square, S, st);
+        launch_interval_score_naive(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, length_scaling, full_kernel, S, st);
     if (noise_out && T > 1) {
         if (hipMemsetAsync(noise_out, 0, (size_t)(T - 1) * C * sizeof(float), st) != hipSuccess) {
             set_error("hipMemsetAsync failed");

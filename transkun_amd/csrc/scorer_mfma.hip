@@ -495,7 +495,13 @@ static int launch_score_stream(const float* q, const float* k, const float* diag
 // workgroups, static schedule: slot % 8 = chain quad), so its L2 assembles whole lines.  One s_barrier per chunk (no
 // fence: the prefetch stays in flight); the matrix instructions of a wave alternate between its two accumulators.
 constexpr int XTB = 128;                   // tile columns (begin positions)
-constexpr int XNS = 3;                     // LDS stages
+#ifndef SEMICRF_SCORE_PRIO
+#define SEMICRF_SCORE_PRIO 0      // 1: raised priority during a chunk's matrix instructions (measured: profiles/r02_scorer.md)
+#endif
+#ifndef SEMICRF_SCORE_XNS
+#define SEMICRF_SCORE_XNS 3
+#endif
+constexpr int XNS = SEMICRF_SCORE_XNS;     // LDS stages (4: measured no faster, profiles/r02_scorer.md)
 
 // XTE = tile rows (end positions): 128 -> 8 waves, one workgroup per CU; 64 -> 4 waves, two (independent) workgroups
 // per CU whose barriers and operand reads fall into each other's matrix phases (24 instead of 32 flop per byte).
@@ -644,7 +650,10 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
         for (int j = 0; j < 4; ++j) {
             for (int ch = 0; ch < nchunk; ++ch) {
                 // this wave's pieces of the current chunk have landed (a younger request may stay in flight) ...
-                if (inflight >= 2) {
+                if (XNS >= 4 && inflight >= 3) {
+                    if (KP == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                } else if (inflight >= 2) {
                     if (KP == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 } else {
@@ -672,6 +681,9 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
                              : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]), "+v"(ka0[0]), "+v"(ka0[1]), "+v"(ka0[2]),
                                "+v"(ka0[3]), "+v"(ka1[0]), "+v"(ka1[1]), "+v"(ka1[2]), "+v"(ka1[3]));
                 __builtin_amdgcn_sched_barrier(0);
+#if SEMICRF_SCORE_PRIO
+                __builtin_amdgcn_s_setprio(2);
+#endif
                 if (dbg & 1) {
                     acc0[0] += qa[0].x + qa[1].y + qa[2].z + qa[3].w + ka0[0].x + ka0[3].w;
                     acc1[0] += ka1[0].x + ka1[3].w;
@@ -696,6 +708,9 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
                         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[m].w, ka0[m].w, acc0, 0, 0, 0);
                     }
                 }
+#if SEMICRF_SCORE_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (j < 3) {

@@ -88,10 +88,10 @@ void eval_path_bwd(Tensor gout, int64_t T, int64_t B, Tensor pairs, int64_t K, T
 
 // ---- interval scorer ---------------------------------------------------------------------------------------------------
 void interval_score_fwd_op(Tensor q, Tensor k, Tensor diag, int64_t C, int64_t T, int64_t D, int64_t ldq, int64_t ldk, int64_t ldd,
-                           double qscale, int64_t mode, bool full, Tensor S, Tensor noise)
+                           double qscale, int64_t mode, int64_t full, Tensor S, Tensor noise)
 {
     Ctx c(q); same_device(q, k); same_device(q, diag); same_device(q, S);
-    check(interval_score_fwd(cfp(q), cfp(k), cfp(diag), (int)C, (int)T, (int)D, ldq, ldk, ldd, (float)qscale, (int)mode, full ? 1 : 0, fp(S),
+    check(interval_score_fwd(cfp(q), cfp(k), cfp(diag), (int)C, (int)T, (int)D, ldq, ldk, ldd, (float)qscale, (int)mode, (int)full, fp(S),
                              fp(noise), c.stream),
           "interval_score_fwd");
 }
@@ -174,7 +174,7 @@ STABLE_TORCH_LIBRARY(semicrf, m)
     m.def("eval_path_bwd(Tensor gout, int T, int B, Tensor pairs, int K, Tensor offsets, Tensor(a!) dScore, bool has_ds, Tensor(b!) dNoise, "
           "bool has_dn) -> ()");
     m.def("interval_score_fwd(Tensor q, Tensor k, Tensor diag, int C, int T, int D, int ldq, int ldk, int ldd, float qscale, int mode, "
-          "bool full, Tensor(a!) S, Tensor(b!) noise) -> ()");
+          "int full, Tensor(a!) S, Tensor(b!) noise) -> ()");
     m.def("interval_score_bwd_ws(Tensor dS, Tensor q, Tensor k, int C, int T, int D, int ldq, int ldk, float qscale, int mode, Tensor(a!) dq, "
           "Tensor(b!) dk, Tensor(c!) ddiag, int lddq, int lddk, int lddd, Tensor(d!) ws) -> ()");
     m.def("interval_score_bwd_fused_ws(Tensor S, Tensor alpha, Tensor beta, Tensor logZ, Tensor gout, Tensor q, Tensor k, int C, int T, int D, "

@@ -47,7 +47,7 @@ class _ScorerCRFLogProb(torch.autograd.Function):
         C = N * P
         qd3, k3 = qd.reshape(C, T, D + QPAD), k.reshape(C, T, D)
         qs = 1.0 / math.sqrt(D)
-        S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qs, mode, False)
+        S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qs, mode, 2)      # S never leaves this node
         logz, v = _nsci._logz_fwd_raw(S, noise, True)
         path = _nsci._eval_path_raw(S, noise, pairs, offsets)
         ctx.save_for_backward(qd3, k3, S, noise, v, logz, pairs, offsets)

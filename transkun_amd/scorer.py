@@ -18,15 +18,17 @@ import torch.nn.functional as F
 from . import _lib
 
 
-def _interval_score_raw(q, k, diag, T: int, C: int, D: int, qscale: float, mode: int, full_square: bool):
-    """q,k: [C,T,D] views with unit stride in d; diag: [C,T] view.  Returns S [T,T,C], noise [T-1,C]."""
+def _interval_score_raw(q, k, diag, T: int, C: int, D: int, qscale: float, mode: int, full_square):
+    """q,k: [C,T,D] views with unit stride in d; diag: [C,T] view.  Returns S [T,T,C], noise [T-1,C].
+    full_square: False/0 lower triangle + zeros above, True/1 the full square, 2 lower triangle only (the cells with
+    begin > end stay uninitialised: for S that only this library's CRF kernels read)."""
     dev = q.device
     assert q.stride(-1) == 1 and k.stride(-1) == 1
     # full_square=False: the library computes e >= b and zero-fills the rest itself (half the bytes of torch.zeros)
     S = torch.empty(T, T, C, dtype=torch.float32, device=dev)
     noise = torch.empty(max(T - 1, 0), C, dtype=torch.float32, device=dev)
     _lib.ops().interval_score_fwd(q, k, diag, C, T, D, q.stride(-2), k.stride(-2), diag.stride(-1), float(qscale), int(mode),
-                                  bool(full_square), S, noise)
+                                  int(full_square), S, noise)
     return S, noise
 
 
@@ -65,7 +67,7 @@ class _IntervalScore(torch.autograd.Function):
         qscale = 1.0 / math.sqrt(D)
         S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qscale, mode, full_square)
         ctx.save_for_backward(qd3, k3)
-        ctx.meta = (N, P, T, D, mode, bool(full_square))
+        ctx.meta = (N, P, T, D, mode, int(full_square) == 1)
         return S.view(T, T, N, P), noise.view(max(T - 1, 0), N, P)
 
     @staticmethod
@@ -132,7 +134,8 @@ class ScaledInnerProductIntervalScorer(nn.Module):
             raise Exception("Unrecognized lengthScaling")
         self.lengthScaling = lengthScaling
         self.withScoreEps = withScoreEps
-        self.fullSquare = False   # True: also materialise e<b like the reference (the CRF never reads it)
+        self.fullSquare = False   # True: also materialise e<b like the reference (the CRF never reads it); 2: leave e<b
+                                  # uninitialised (only for S that goes straight into this package's CRF)
 
     def forward(self, ctx):
         # ctx: [N, P, T, size]

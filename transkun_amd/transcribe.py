@@ -120,6 +120,7 @@ class SegmentTranscriber(nn.Module):
         self.segmentHopSizeInSecond, self.segmentSizeInSecond = segmentHopSizeInSecond, segmentSizeInSecond
         self.targetMIDIPitch = list(targetMIDIPitch) if targetMIDIPitch is not None else [-64, -67] + list(range(21, 108 + 1))   # :97
         self.scorer = ScaledInnerProductIntervalScorer(size, 1)
+        self.scorer.fullSquare = 2      # S goes straight into this package's decode, which never reads begin > end: no zero fill
         self.velocityPredictor = _head(size * 3, velocityPredictorHiddenSize, 128, velocityDropoutProb)           # :109-115
         self.refinedOFPredictor = _head(size * 3, refinedOFPredictorHiddenSize, 4, refinedOFDropoutProb)          # :119-125
 
