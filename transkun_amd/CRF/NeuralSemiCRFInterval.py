@@ -52,9 +52,30 @@ def _prep(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
-def pack_intervals(intervals: Sequence[Sequence[Tuple[int, int]]], T: int, B: int, device):
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    st = _SIDE.get(key)
+    if st is None:
+        st = _SIDE[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _ready(pairs) -> None:
+    """Intervals packed with overlap=True travel on a side stream: make the current stream wait for them (once)."""
+    ev = getattr(pairs, "_semicrf_ready", None)
+    if ev is not None:
+        torch.cuda.current_stream(pairs.device).wait_event(ev)
+        pairs._semicrf_ready = None
+
+
+def pack_intervals(intervals: Sequence[Sequence[Tuple[int, int]]], T: int, B: int, device, overlap: bool = False):
     """List[List[(begin,end)]] (len B) -> (pairs int32 [K,2], offsets int32 [B+1]) on `device`.
-    One pass in C (csrc/pymarshal.c) into pinned host buffers, then two asynchronous copies."""
+    One pass in C (csrc/pymarshal.c) into pinned host buffers, then two asynchronous copies.
+    overlap=True: the copies go to a side stream (they need nothing from the GPU and would otherwise sit in front of the
+    sweep that the caller enqueues next: 20-100 us per call); the caller must pass `pairs` to _ready() before its first use."""
     assert len(intervals) == B, f"expected {B} interval lists, got {len(intervals)}"
     mm = _lib.marshal()
     K = int(mm.count(intervals))
@@ -65,9 +86,20 @@ def pack_intervals(intervals: Sequence[Sequence[Tuple[int, int]]], T: int, B: in
         pairs_h.zero_()
     k = mm.pack_into(intervals, pairs_h.data_ptr(), max(K, 1), offsets_h.data_ptr(), T)   # IndexError when out of range
     assert k == K
-    pairs_d = pairs_h.to(device, non_blocking=True)
+    if overlap and pin:
+        main = torch.cuda.current_stream(device)
+        side = _side_stream(device)
+        with torch.cuda.stream(side):
+            pairs_d = pairs_h.to(device, non_blocking=True)
+            offsets_d = offsets_h.to(device, non_blocking=True)
+            ev = side.record_event()
+        pairs_d.record_stream(main); offsets_d.record_stream(main)      # allocated in the side stream's pool, used on `main`
+        pairs_d._semicrf_ready = ev
+    else:
+        pairs_d = pairs_h.to(device, non_blocking=True)
+        offsets_d = offsets_h.to(device, non_blocking=True)
     pairs_d._semicrf_K = K          # number of real intervals (the tensor holds one dummy row when K == 0)
-    return pairs_d, offsets_h.to(device, non_blocking=True)
+    return pairs_d, offsets_d
 
 
 def unpack_intervals(pairs_host: torch.Tensor, offsets_host: torch.Tensor, T: int = 1 << 30) -> Intervals:
@@ -263,6 +295,7 @@ class _LogProb(torch.autograd.Function):
         score_c, noise_c = _prep(score), _prep(noiseScore)
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         logz, v = _logz_fwd_raw(score_c, noise_c, want_v=need)
+        _ready(pairs)                                   # the intervals' copy ran beside the sweep
         path = _eval_path_raw(score_c, noise_c, pairs, offsets)
         if need:
             ctx.save_for_backward(score_c, noise_c, v, logz, pairs, offsets)
@@ -390,5 +423,5 @@ class NeuralSemiCRFInterval:
 
     def logProb(self, intervals, noBackward=False):
         T, B = _check_inputs(self.score, self.noiseScore)
-        pairs, offsets = pack_intervals(intervals, T, B, self.score.device)
+        pairs, offsets = pack_intervals(intervals, T, B, self.score.device, overlap=not os.environ.get("SEMICRF_NO_COPY_OVERLAP"))
         return _LogProb.apply(self.score, self.noiseScore, pairs, offsets)
