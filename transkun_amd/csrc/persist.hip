@@ -24,8 +24,8 @@
 //   * Hand-offs carry their own flag -- u: a float that reads U_EMPTY until published; far-field partials: 8-byte
 //     {tag, value} granules -- written with relaxed agent-scope atomic stores and polled with tagged loads
 //     (no fences, placement independent).
-//     Roles are drawn from an atomic ticket so that a workgroup only ever waits on lower tickets; every
-//     spin is bounded and raises the error word instead of hanging.
+//     Roles go by workgroup index (wg_ticket: the eight rings of a 32-chain panel group share one XCD); every workgroup of
+//     a launch is resident (one per CU), every spin is bounded and raises the error word instead of hanging.
 //
 // HBM traffic: every lower-triangle cell is read exactly once (128-byte lines, non-temporal, in the panels;
 // 16-byte segments in the band).  Algorithmic bytes per sweep: 4*B*(T(T+1)/2 + T-1).
@@ -156,7 +156,8 @@ struct SweepParams {
                            // 1 spine ignores far partials, 2 panels exit at once, 4 panels do not wait for u,
                            // 8 spine exits at once, 16 spine 0 records per-block timestamps,
                            // 32 panels only stream their cells (no granules, no math)
-    unsigned* ctrl;        // [0] ticket, [1] error, [2] panel task queue head, [3] zero-fill row queue head
+    unsigned* ctrl;        // [0] (ticket: unused unless SEMICRF_TICKET_ATOMIC), [1] error, [2] panel task queue head, [3] zero-fill row queue head,
+                           // [32..] scheduler queues (SEMICRF_SCHED=1), [64] workgroups that have left (leases), [128..] scheduling hints
     u64* ts;               // [2T] debug timestamps of spine 0, ring 0 (dbg & 16)
     unsigned* ug;          // [T][B] u as float bits (position-major: index p*B + c); U_EMPTY until the spine publishes it
     u64* farg;             // [parts][T][B] granules of far-field partials (part = column range of TPT tiles)
