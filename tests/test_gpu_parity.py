@@ -3,6 +3,8 @@ hence through the C ABI, against (a) golden vectors produced by the reference it
 (b) the C oracle on the same seeded inputs.  Decoded intervals: bit-exact.  logZ/logProb:
 1e-4 relative (BASELINE.json); we hold 1e-5.  Marginals: fp32 noise floor of the reference
 (2e-6 * |logZ|, see tests/test_oracle_golden.py)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -421,8 +423,18 @@ def test_fused_scorer_crf(gpu, N, P, T, D, ls):
         (lp * gout).sum().backward()
         return lp.detach(), ctx.grad.clone(), m.map[0].weight.grad.clone(), m.map[0].bias.grad.clone()
 
-    a, b = run(True), run(False)
+    # the fused node keeps S to itself and lets the scorer write end >= begin only: with the unwritten cells poisoned (NaN) every
+    # read of them would show up in the results
+    monkey = os.environ.get("SEMICRF_POISON_UNWRITTEN")
+    os.environ["SEMICRF_POISON_UNWRITTEN"] = "1"
+    try:
+        a = run(True)
+    finally:
+        if monkey is None:
+            os.environ.pop("SEMICRF_POISON_UNWRITTEN", None)
+    b = run(False)
     for x, y, name in zip(a, b, ("logp", "dctx", "dW", "dbias")):
+        assert bool(torch.isfinite(x).all()), name
         scale = float(y.abs().max()) + 1e-30
         err = float((x - y).abs().max()) / scale
         assert err < 2e-4, (name, err)

@@ -463,16 +463,21 @@ __device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds
                     for (int i = 0; i < 4; ++i)
                         if (i < np && !have[i]) {
                             const bool ok = MODE == 0 ? (unsigned)(gq[i] >> 32) == tag : (unsigned)(gq[i] >> 48) == (tag & 0xffffu);
-                            if (ok) {
-                                have[i] = true;
-                                if (MODE == 0) acc_push1(aM, aS, __uint_as_float((unsigned)gq[i]));
-                                else max_push(aM, aK, __uint_as_float((unsigned)gq[i]), (int)((gq[i] >> 32) & 0xffffu));
-                            } else all = false;
+                            if (ok) have[i] = true;          // gq[i] keeps the granule: it is not requested again
+                            else all = false;
                         }
                     if (all) break;
                     __builtin_amdgcn_s_sleep(1);
                     if (spin_abort(ctrl, spins, SPIN_LIMIT, 3)) break;
                 }
+                // the parts are merged in index order, not in the order they arrived in: the sum's last bit (and a tie
+                // between two maxima) must not depend on timing
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < np && have[i]) {
+                        if (MODE == 0) acc_push1(aM, aS, __uint_as_float((unsigned)gq[i]));
+                        else max_push(aM, aK, __uint_as_float((unsigned)gq[i]), (int)((gq[i] >> 32) & 0xffffu));
+                    }
             }
         }
         const float val = MODE == 0 ? aM + flog2(aS) : aM;

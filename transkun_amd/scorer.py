@@ -10,6 +10,7 @@ CRF layout -- is one kernel that writes the chain-contiguous layout directly.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -26,6 +27,8 @@ def _interval_score_raw(q, k, diag, T: int, C: int, D: int, qscale: float, mode:
     assert q.stride(-1) == 1 and k.stride(-1) == 1
     # full_square=False: the library computes e >= b and zero-fills the rest itself (half the bytes of torch.zeros)
     S = torch.empty(T, T, C, dtype=torch.float32, device=dev)
+    if int(full_square) == 2 and os.environ.get("SEMICRF_POISON_UNWRITTEN"):
+        S.fill_(float("nan"))           # test hook: whatever reads begin > end of a lower-triangle-only S shows up as NaN
     noise = torch.empty(max(T - 1, 0), C, dtype=torch.float32, device=dev)
     _lib.ops().interval_score_fwd(q, k, diag, C, T, D, q.stride(-2), k.stride(-2), diag.stride(-1), float(qscale), int(mode),
                                   int(full_square), S, noise)
