@@ -101,6 +101,8 @@ def main(argv=None):
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # not under torchrun: create the N ranks here (one process per GPU)
         import torch.multiprocessing as mp
+        if not args.selftest_launch and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but this node has {torch.cuda.device_count()} GPU(s)")
         port = _free_port()
         log(f"spawning {args.gpus} ranks (MASTER_ADDR=127.0.0.1 port {port})")
         mp.spawn(_spawn_entry, args=(args.gpus, port, argv), nprocs=args.gpus, join=True)
