@@ -572,6 +572,42 @@ def test_scorer_lower_triangle_only(gpu):
         assert bool((S2[~lower] == 7.5).all()) and bool((S0[~lower] == 0).all())
 
 
+@pytest.mark.gpu
+def test_graph_capture_is_refused_or_works(gpu):
+    """The persistent sweeps do not replay from a HIP graph yet (second replay: hand-off timeouts): a capturing stream must be
+    refused loudly, not produce a graph that breaks; the row-sequential kernels (impl 1) and evalPath capture and replay."""
+    import importlib
+    from transkun_amd import _lib, synth
+    nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
+    T, B = 130, 12
+    data = [synth.crf_inputs(T, B, 500 + i, gpu) for i in range(3)]
+    _lib.set_impl(1)
+    want = [nsci._logz_fwd_raw(s, n, True)[0].clone() for s, n in data]
+    s_in, n_in = data[0][0].clone(), data[0][1].clone()
+    side = torch.cuda.Stream(device=gpu)
+    side.wait_stream(torch.cuda.current_stream(gpu))
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            nsci._logz_fwd_raw(s_in, n_in, True)
+    torch.cuda.current_stream(gpu).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        lz, _ = nsci._logz_fwd_raw(s_in, n_in, True)
+    for i in (1, 2, 1, 0):
+        s_in.copy_(data[i][0]); n_in.copy_(data[i][1])
+        graph.replay()
+        torch.cuda.synchronize(gpu)
+        assert torch.equal(lz, want[i]), i
+    _lib.set_impl(0)
+    graph2 = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="HIP graph"):
+        with torch.cuda.graph(graph2):
+            nsci._logz_fwd_raw(s_in, n_in, True)
+    torch.cuda.synchronize(gpu)
+    lz0, _ = nsci._logz_fwd_raw(data[1][0], data[1][1], True)          # eager launches are unaffected
+    assert float((lz0 - want[1]).abs().max()) < 1e-3 * float(want[1].abs().max())
+
+
 # ---- the persistent blocked kernels against the oracle over a grid of shapes -------------------
 
 PERSIST_SHAPES = [(1, 4), (2, 4), (15, 8), (16, 4), (17, 12), (33, 16), (48, 20), (63, 36), (64, 32), (65, 4),

@@ -2,6 +2,7 @@
 // workspace carving and dispatch to the kernels.  Nothing here synchronises the host.
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 #include <atomic>
 #include <mutex>
 #include <unordered_map>
@@ -201,6 +202,19 @@ size_t semicrf_workspace_bytes(int op, int T, int B)
     }
 }
 
+// The persistent sweeps do not survive being replayed from a HIP graph (measured: the second launch of an instantiated graph
+// times out in its hand-off waits or faults; plain kernels of this library -- evalPath, the row-sequential sweeps -- replay fine).
+// Until that is understood a capturing stream is refused instead of producing a graph that breaks on replay.
+static int refuse_capture(hipStream_t st, const char* what)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        set_error("%s: the persistent sweep kernels cannot be captured into a HIP graph (semicrf_set_impl(1) selects kernels that can)", what);
+        return SEMICRF_EINVAL;
+    }
+    return SEMICRF_OK;
+}
+
 static int check_common(const float* score, const float* noise, int T, int B)
 {
     SEMICRF_CHECK_ARG(T >= 1 && B >= 1, "T=%d, B=%d must be >= 1", T, B);
@@ -223,6 +237,7 @@ int semicrf_logz_fwd(const float* score, const float* noise, int T, int B, float
     if (!cv.ok || !ws) { set_error("workspace too small for logz_fwd"); return SEMICRF_EWORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     if (fast) {
+        if (int rc = refuse_capture(st, "semicrf_logz_fwd")) return rc;
         unsigned ltag = 0;
         const int lease = lease_acquire(ws, SEMICRF_OP_LOGZ_FWD, T, B, &ltag);
         if (launch_persist_sweep(0, 0, score, noise, T, B, vv, logZ, nullptr, pws, st, lease, ltag)) {
@@ -251,6 +266,7 @@ int semicrf_logz_bwd(const float* score, const float* noise, const float* v, con
     hipStream_t st = (hipStream_t)stream;
     if (fast) {
         // beta sweep fused with the marginals: score is read once, dScore written once
+        if (int rc = refuse_capture(st, "semicrf_logz_bwd")) return rc;
         unsigned ltag = 0;
         const int lease = lease_acquire(ws, SEMICRF_OP_LOGZ_BWD, T, B, &ltag);
         if (launch_persist_logz_bwd(score, noise, v, logZ, gout, T, B, dScore, dNoise, q, pws, st, lease, ltag)) {
@@ -276,6 +292,7 @@ int semicrf_beta(const float* score, const float* noise, int T, int B, float* be
     if (!cv.ok || (fast && !ws)) { set_error("workspace too small for beta"); return SEMICRF_EWORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     if (fast) {
+        if (int rc = refuse_capture(st, "semicrf_beta")) return rc;
         unsigned ltag = 0;
         const int lease = lease_acquire(ws, SEMICRF_OP_LOGZ_FWD + 100, T, B, &ltag);
         if (launch_persist_sweep(0, 1, score, noise, T, B, beta, nullptr, nullptr, pws, st, lease, ltag)) {
@@ -306,6 +323,7 @@ int semicrf_viterbi(const float* score, const float* noise, int T, int B, const 
     if (!cv.ok || !ws) { set_error("workspace too small for viterbi"); return SEMICRF_EWORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     if (fast) {
+        if (int rc = refuse_capture(st, "semicrf_viterbi")) return rc;
         unsigned ltag = 0;
         const int lease = lease_acquire(ws, SEMICRF_OP_VITERBI, T, B, &ltag);
         if (launch_persist_sweep(1, forward ? 0 : 1, score, noise, T, B, nullptr, nullptr, code, pws, st, lease, ltag)) {
