@@ -61,8 +61,8 @@ size_t semicrf_workspace_bytes(int op, int T, int B);
  *   - nothing but this library's sweeps writes to the buffer (pass the registered base pointer as `ws`, unchanged);
  *   - at most one stream uses it at a time (launches into one workspace are ordered by the stream they are enqueued on);
  *   - the calling thread's current device is the buffer's device when it registers.
- * (Stream capture: the persistent sweep kernels do not replay correctly from a HIP graph yet; the sweeps return
- *  SEMICRF_EINVAL on a capturing stream unless semicrf_set_impl(1) selects the row-sequential kernels.)
+ * (Stream capture: a sweep enqueued on a capturing stream takes the ordinary path -- its fill becomes a node of the graph --
+ *  whatever the workspace; every entry point of this library can be captured into a HIP graph and replayed.)
  * A change of (operation, T, B) costs one fill.  A launch that aborted (see below: NaN outputs / negative decode total)
  * raises a pinned host word; the next launch of ANY lease is preceded by a fill again.  semicrf_workspace_register may
  * synchronise the device (once per device); call it at set-up time.  (No counterpart in the reference: its

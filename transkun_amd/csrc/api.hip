@@ -117,13 +117,24 @@ static std::unordered_map<void*, Lease> g_leases;
 static unsigned* g_abort_word = nullptr;                 // pinned + mapped: the device address equals the host address
 
 // what the next sweep into `ws` has to do: 0 ordinary, 1 fill + self-clean, 2 clean already; tag = the lease's launch count
-static int lease_acquire(void* ws, int op, int T, int B, unsigned* tag)
+static int lease_acquire(void* ws, int op, int T, int B, unsigned* tag, hipStream_t stream)
 {
     *tag = 0;
     std::lock_guard<std::mutex> lk(g_lease_mu);
     if (g_leases.empty()) return 0;
     auto it = g_leases.find(ws);
     if (it == g_leases.end()) return 0;
+    {
+        // A launch that is being CAPTURED into a graph is replayed with the parameters of the capture -- the same granule tag
+        // every time, which a lease must never repeat (the rings would run ahead on the previous replay's partials and clear u
+        // under the panels).  Captured launches take the ordinary path: the fill is a node of the graph and resets everything
+        // on every replay; the lease no longer counts as clean.
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+            it->second.clean = false;
+            return 0;
+        }
+    }
     if (g_abort_word && __atomic_load_n(g_abort_word, __ATOMIC_RELAXED) != 0u) {
         __atomic_store_n(g_abort_word, 0u, __ATOMIC_RELAXED);
         for (auto& kv : g_leases) kv.second.clean = false;          // some launch gave up: its workspace is in an unknown state
@@ -202,19 +213,6 @@ size_t semicrf_workspace_bytes(int op, int T, int B)
     }
 }
 
-// The persistent sweeps do not survive being replayed from a HIP graph (measured: the second launch of an instantiated graph
-// times out in its hand-off waits or faults; plain kernels of this library -- evalPath, the row-sequential sweeps -- replay fine).
-// Until that is understood a capturing stream is refused instead of producing a graph that breaks on replay.
-static int refuse_capture(hipStream_t st, const char* what)
-{
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
-        set_error("%s: the persistent sweep kernels cannot be captured into a HIP graph (semicrf_set_impl(1) selects kernels that can)", what);
-        return SEMICRF_EINVAL;
-    }
-    return SEMICRF_OK;
-}
-
 static int check_common(const float* score, const float* noise, int T, int B)
 {
     SEMICRF_CHECK_ARG(T >= 1 && B >= 1, "T=%d, B=%d must be >= 1", T, B);
@@ -237,12 +235,11 @@ int semicrf_logz_fwd(const float* score, const float* noise, int T, int B, float
     if (!cv.ok || !ws) { set_error("workspace too small for logz_fwd"); return SEMICRF_EWORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     if (fast) {
-        if (int rc = refuse_capture(st, "semicrf_logz_fwd")) return rc;
         unsigned ltag = 0;
-        const int lease = lease_acquire(ws, SEMICRF_OP_LOGZ_FWD, T, B, &ltag);
+        const int lease = lease_acquire(ws, SEMICRF_OP_LOGZ_FWD, T, B, &ltag, st);
         if (launch_persist_sweep(0, 0, score, noise, T, B, vv, logZ, nullptr, pws, st, lease, ltag)) {
             lease_failed(ws);
-            set_error("persistent sweep could not be enqueued (hipMemsetAsync failed or too many chain chunks)"); return SEMICRF_ELAUNCH;
+            set_error("persistent sweep could not be enqueued (too many chain chunks for this device)"); return SEMICRF_ELAUNCH;
         }
     } else {
         launch_rowseq_sweep(0, 0, score, noise, T, B, vv, nullptr, logZ, st);
@@ -266,12 +263,11 @@ int semicrf_logz_bwd(const float* score, const float* noise, const float* v, con
     hipStream_t st = (hipStream_t)stream;
     if (fast) {
         // beta sweep fused with the marginals: score is read once, dScore written once
-        if (int rc = refuse_capture(st, "semicrf_logz_bwd")) return rc;
         unsigned ltag = 0;
-        const int lease = lease_acquire(ws, SEMICRF_OP_LOGZ_BWD, T, B, &ltag);
+        const int lease = lease_acquire(ws, SEMICRF_OP_LOGZ_BWD, T, B, &ltag, st);
         if (launch_persist_logz_bwd(score, noise, v, logZ, gout, T, B, dScore, dNoise, q, pws, st, lease, ltag)) {
             lease_failed(ws);
-            set_error("persistent sweep could not be enqueued (hipMemsetAsync failed or too many chain chunks)"); return SEMICRF_ELAUNCH;
+            set_error("persistent sweep could not be enqueued (too many chain chunks for this device)"); return SEMICRF_ELAUNCH;
         }
     } else {
         launch_rowseq_sweep(0, 1, score, noise, T, B, q, nullptr, nullptr, st);
@@ -292,12 +288,11 @@ int semicrf_beta(const float* score, const float* noise, int T, int B, float* be
     if (!cv.ok || (fast && !ws)) { set_error("workspace too small for beta"); return SEMICRF_EWORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     if (fast) {
-        if (int rc = refuse_capture(st, "semicrf_beta")) return rc;
         unsigned ltag = 0;
-        const int lease = lease_acquire(ws, SEMICRF_OP_LOGZ_FWD + 100, T, B, &ltag);
+        const int lease = lease_acquire(ws, SEMICRF_OP_LOGZ_FWD + 100, T, B, &ltag, st);
         if (launch_persist_sweep(0, 1, score, noise, T, B, beta, nullptr, nullptr, pws, st, lease, ltag)) {
             lease_failed(ws);
-            set_error("persistent sweep could not be enqueued (hipMemsetAsync failed or too many chain chunks)"); return SEMICRF_ELAUNCH;
+            set_error("persistent sweep could not be enqueued (too many chain chunks for this device)"); return SEMICRF_ELAUNCH;
         }
     } else {
         launch_rowseq_sweep(0, 1, score, noise, T, B, beta, nullptr, nullptr, st);
@@ -323,12 +318,11 @@ int semicrf_viterbi(const float* score, const float* noise, int T, int B, const 
     if (!cv.ok || !ws) { set_error("workspace too small for viterbi"); return SEMICRF_EWORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     if (fast) {
-        if (int rc = refuse_capture(st, "semicrf_viterbi")) return rc;
         unsigned ltag = 0;
-        const int lease = lease_acquire(ws, SEMICRF_OP_VITERBI, T, B, &ltag);
+        const int lease = lease_acquire(ws, SEMICRF_OP_VITERBI, T, B, &ltag, st);
         if (launch_persist_sweep(1, forward ? 0 : 1, score, noise, T, B, nullptr, nullptr, code, pws, st, lease, ltag)) {
             lease_failed(ws);
-            set_error("persistent sweep could not be enqueued (hipMemsetAsync failed or too many chain chunks)"); return SEMICRF_ELAUNCH;
+            set_error("persistent sweep could not be enqueued (too many chain chunks for this device)"); return SEMICRF_ELAUNCH;
         }
     } else {
         launch_rowseq_sweep(1, forward ? 0 : 1, score, noise, T, B, u, code, nullptr, st);

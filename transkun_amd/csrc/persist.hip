@@ -1942,6 +1942,13 @@ __global__ __launch_bounds__(256) void zero_upper_kernel(float* __restrict__ dSc
     }
 }
 
+// the workspace fill (see launch_persist_sweep_impl for why it is not hipMemsetAsync)
+__global__ __launch_bounds__(256) void fill_ff_kernel(v4u* __restrict__ p, size_t n16)
+{
+    const v4u e = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = e;
+}
+
 // exact zeros above the diagonal (begin > end) of a [T][T][B] tensor
 void launch_zero_upper(float* X, int T, int B, hipStream_t stream)
 {
@@ -2058,7 +2065,9 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
     // (probe build, flag 512: the u values of the previous launch in the same workspace stay -- panels alone on real values)
     const size_t fill_bytes = (SEMICRF_PANEL_PROBES && (P.dbg & 512u)) ? ug_off : persist_workspace_bytes(T, B);
     if (P.dbg != 0u) lease = lease ? 1 : 0;                       // timing ablations leave anything behind
-    if (lease != 2 && hipMemsetAsync(ws, 0xff, fill_bytes, stream) != hipSuccess) return 1;
+    // (a kernel of our own, not hipMemsetAsync: as fast, and a captured memset node of this size breaks the SECOND replay of an
+    // instantiated HIP graph -- wrong results or a memory fault -- while this kernel replays correctly)
+    if (lease != 2) hipLaunchKernelGGL(fill_ff_kernel, dim3(1024), dim3(256), 0, stream, (v4u*)ws, (fill_bytes + 15) / 16);
     P.selfclean = lease != 0 && P.dbg == 0u;
     static const Knobs knobs = read_knobs();                    // tuning knobs of the development tools: the environment is read ONCE
     const int xr_env = knobs.xr;
