@@ -42,7 +42,7 @@ __device__ __forceinline__ unsigned piece_soff(int e, int pattern)
     return (unsigned)((((size_t)(e >> 1) * T + 8 * (e & 1)) * B) * 4);
 }
 
-template <int METHOD, int S, int AUX>
+template <int METHOD, int S, int AUX, int WORK = 0, int BUBBLE = 0>
 __global__ __launch_bounds__(1024) void probe(Args A)
 {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -74,8 +74,24 @@ __global__ __launch_bounds__(1024) void probe(Args A)
                              : "v"(a));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc += o[e].x ^ o[e].y ^ o[e].z ^ o[e].w;
+                if (WORK) {
+                    // the panels' math, roughly: per tile 32 exponentials and ~80 plain instructions on dependent-ish data
+                    float f = __uint_as_float((acc & 0x007fffffu) | 0x3f800000u);
+#pragma unroll
+                    for (int w = 0; w < WORK; ++w) {
+                        f = __builtin_amdgcn_exp2f(f - 1.5f);
+                        f = __builtin_fmaf(f, 0.75f, 0.5f); f = __builtin_fmaf(f, 0.75f, 0.25f); f = __builtin_fmaf(f, 0.5f, 0.5f);
+                    }
+                    acc ^= __float_as_uint(f);
+                }
             }
-            if (issued < mine) { issue(issued); ++issued; }
+            if (BUBBLE && (done % 12) == 11) {
+                // a task boundary: nothing of the next task is requested before the current one is through, plus the
+                // reduction / queue draw (~2 us)
+                wait_vm<0>();
+                for (int w = 0; w < BUBBLE; ++w) __builtin_amdgcn_s_sleep(72);       // 72 x 64 cycles ~ 2 us
+            }
+            if (issued < mine && !(BUBBLE && issued > done + 1 && ((done + 1) / 12) != (issued / 12))) { issue(issued); ++issued; }
         }
     } else {
         const int mine = (A.ntiles - gw + nw - 1) / nw;
@@ -103,19 +119,19 @@ __global__ __launch_bounds__(1024) void probe(Args A)
     if (acc == 0x12345u) A.sink[0] = acc;
 }
 
-template <int METHOD, int S, int AUX>
+template <int METHOD, int S, int AUX, int WORK = 0, int BUBBLE = 0>
 static void run(const char* name, const float* x, unsigned* sink, int cus, int waves, int pattern, hipStream_t st)
 {
     Args A{x, sink, 80000, pattern};
     const size_t lds = METHOD <= 1 ? (size_t)waves * S * 8192 : 0;
     const size_t want = lds > 88 * 1024 ? lds : 88 * 1024;          // more than half a CU's LDS: one workgroup per CU
-    CK(hipFuncSetAttribute((const void*)probe<METHOD, S, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
+    CK(hipFuncSetAttribute((const void*)probe<METHOD, S, AUX, WORK, BUBBLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((probe<METHOD, S, AUX>), dim3(cus), dim3(waves * 64), want, st, A);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((probe<METHOD, S, AUX, WORK, BUBBLE>), dim3(cus), dim3(waves * 64), want, st, A);
     CK(hipEventRecord(e0, st));
     const int reps = 5;
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((probe<METHOD, S, AUX>), dim3(cus), dim3(waves * 64), want, st, A);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((probe<METHOD, S, AUX, WORK, BUBBLE>), dim3(cus), dim3(waves * 64), want, st, A);
     CK(hipEventRecord(e1, st));
     CK(hipEventSynchronize(e1));
     float ms = 0;
@@ -133,6 +149,22 @@ int main()
     CK(hipMalloc(&x, bytes)); CK(hipMalloc(&sink, 64));
     CK(hipMemset(x, 0, bytes));
     hipStream_t st; CK(hipStreamCreate(&st));
+    // second part (round 2): what do the panels' math and their task boundaries cost a compute unit?
+    if (getenv("STREAM_PROBE_PART2")) {
+        for (int cus : {168, 256}) {
+            run<1, 3, 2>("lds-dma 3 stages, read only", x, sink, cus, 4, 0, st);
+            run<1, 3, 2, 32>("  + math (32 exp + 96 fma per tile)", x, sink, cus, 4, 0, st);
+            run<1, 3, 2, 0, 1>("  + task boundary (drain + 2 us) every 12 tiles", x, sink, cus, 4, 0, st);
+            run<1, 3, 2, 32, 1>("  + math + task boundaries: 4 waves x 3 stages", x, sink, cus, 4, 0, st);
+            run<1, 3, 2, 32, 1>("  ... 5 waves x 3 stages", x, sink, cus, 5, 0, st);
+            run<1, 2, 2, 32, 1>("  ... 6 waves x 2 stages", x, sink, cus, 6, 0, st);
+            run<1, 2, 2, 32, 1>("  ... 8 waves x 2 stages", x, sink, cus, 8, 0, st);
+            run<1, 4, 2, 32, 1>("  ... 4 waves x 4 stages", x, sink, cus, 4, 0, st);
+            run<1, 2, 2, 32, 0>("  math, no boundaries: 8 waves x 2 stages", x, sink, cus, 8, 0, st);
+            run<1, 3, 2, 32, 0>("  math, no boundaries: 5 waves x 3 stages", x, sink, cus, 5, 0, st);
+        }
+        return 0;
+    }
     const int cus_list[] = {88, 168, 256};
     for (int pattern = 0; pattern < 2; ++pattern)
         for (int cus : cus_list) {

@@ -771,9 +771,9 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
 constexpr int PNS = SEMICRF_PNS;             // LDS stages per panel wave (tiles fetched ahead)
 constexpr int PSTAGE_BYTES = 10240;          // 8 KB of cells + 2 KB of u values
 #ifndef SEMICRF_PW_MAX
-#define SEMICRF_PW_MAX 4
+#define SEMICRF_PW_MAX 5
 #endif
-constexpr int PW_MAX = SEMICRF_PW_MAX;       // panel waves per workgroup (LDS: PW_MAX * PNS * PSTAGE_BYTES = 120 KB)
+constexpr int PW_MAX = SEMICRF_PW_MAX;       // panel waves per workgroup (LDS: PW_MAX * PNS * PSTAGE_BYTES = 150 KB; four of them run unless the sweep is throughput-bound)
 constexpr int LDS_PANEL_BYTES = PW_MAX * PNS * PSTAGE_BYTES;
 constexpr int LDS_HYBRID_PANEL = (LDS_SPINE_BYTES + 1023) / 1024 * 1024;     // stages of a spine workgroup's panel waves
 constexpr int HPW_MAX = (160 * 1024 - 512 - LDS_HYBRID_PANEL) / (PNS * PSTAGE_BYTES) < NT / 64 - RING - NLOADER - 1
@@ -2128,7 +2128,12 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         if (knobs.hybrid_start >= 0) hstart = knobs.hybrid_start;
         P.hybridStart = hstart;
         P.hybridPanelWaves = hpw;
-        int pw = PW_MAX;
+        // Five panel waves per workgroup where the sweep is bound by the far field's throughput (long sequences, many
+        // chains: T=2048, NBatch=352 forward 612 -> 562 us, gradient sweep 1620 -> 1550; T=1024: 185 -> 178), four where the
+        // hand-off chain sets the pace (T=691, 90 chains: 103 vs 115 us with five; T=1024, 88 chains: 151 vs 160).
+        // tools/stream_probe.hip shows the same per CU: with the panels' math and task boundaries 4 waves x 3 stages stream
+        // 22.7 GB/s, 5 x 3 24.8, 6 x 2 29.6, 8 x 2 35.3 -- more waves, not deeper stages, hide a wave's math and boundaries.
+        int pw = (T >= 1024 && nb >= 256) ? PW_MAX : (PW_MAX < 4 ? PW_MAX : 4);
         if (knobs.panel_waves > 0) pw = knobs.panel_waves;
         if (pw < 1) pw = 1;
         if (pw > PW_MAX) pw = PW_MAX;
