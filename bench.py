@@ -383,6 +383,8 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
         dd = synth.hash_normal(Cq * T, 7, dev).view(Cq, T)
         Sq, _ = _interval_score_raw(qq, kk, dd, T, Cq, Dq, 1.0 / 16, 0, False)
         extra["interval_score_fwd_ms"] = round(ev_time(lambda: _interval_score_raw(qq, kk, dd, T, Cq, Dq, 1.0 / 16, 0, False), 5), 3)
+        # (opt-in: three exact bf16 limbs per operand, six limb products on the bf16 matrix instructions -- fp32-grade, not bit-identical)
+        extra["interval_score_fwd_bf16x3_ms"] = round(ev_time(lambda: _interval_score_raw(qq, kk, dd, T, Cq, Dq, 1.0 / 16, 0, 4), 5), 3)
         dq = torch.empty_like(qq); dk2 = torch.empty_like(kk); ddg = torch.empty_like(dd)
         nws = int(lib.interval_score_bwd_workspace_bytes(Cq, T, Dq))
         wsq = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)
@@ -424,6 +426,10 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
             extra[tag + "_scorer_crf_logprob_fwd_bwd_ms_fused"] = round(ev_time(lambda: seg_step(True), 5), 3)
             extra[tag + "_scorer_crf_logprob_fwd_bwd_ms_unfused"] = round(ev_time(lambda: seg_step(False), 5), 3)
             extra[tag + "_scorer_decode_features_ms_device"] = round(ev_time(seg_decode, 5), 3)
+            m.contraction = "bf16x3"
+            extra[tag + "_scorer_crf_logprob_fwd_bwd_ms_fused_bf16x3"] = round(ev_time(lambda: seg_step(True), 5), 3)
+            extra[tag + "_scorer_decode_features_ms_device_bf16x3"] = round(ev_time(seg_decode, 5), 3)
+            m.contraction = "fp32"
             del ctx
         # ---- the transcription segment loop: decode -> heads -> events -> next forced start, F recordings in
         # lock step, incomplete-event merge on the host; the shipped geometry (16 s segments, 8 s hop: T = 691, 90 symbols) ----

@@ -48,6 +48,12 @@ extern "C" {
 #define SEMICRF_LEN_SQRT 1
 #define SEMICRF_LEN_NONE 2
 
+/* interval_score_fwd, full_square bit 2 (OR it to 0 / 1 / 2): opt-in contraction on the bf16 matrix instructions.  Default
+ * (bit clear) is the exact fp32 contraction.  With the bit every operand is split exactly into three bf16 limbs and six of
+ * the nine limb products are accumulated in fp32: |S - S_exact| <= 2^-21 * qscale * len * sum_d |q_d k_d| (measured
+ * <= 2^-23; tests/test_gpu_parity.py::test_scorer_bf16x3), i.e. fp32-grade but NOT bit-identical to the default, 2x faster. */
+#define SEMICRF_SCORE_BF16X3 4
+
 typedef void* semicrf_stream_t;
 
 int semicrf_abi_version(void);
@@ -159,6 +165,8 @@ int semicrf_eval_path_bwd(const float* gout, int T, int B, const int32_t* pairs,
  *   are set to zero (S needs no initialisation by the caller); 1 = the full square, as the reference materialises it;
  *   2 = e >= b only, the rest of S is left untouched -- for callers that hand S to the sweeps of this library only, which
  *   never read e < b (tests/test_gpu_parity.py::test_upper_triangle_is_never_read): saves the 2 T^2 C bytes of zeros.
+ *   | SEMICRF_SCORE_BF16X3: three-limb bf16 contraction (above); honoured where the LDS-tiled kernels run (16-byte
+ *   aligned rows, D % 64 == 0), the exact fp32 contraction otherwise.
  *   noise_out [T-1][C] is zero-filled when non-NULL (:436-437).
  */
 int interval_score_fwd(const float* q, const float* k, const float* diag, int C, int T, int D,

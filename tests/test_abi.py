@@ -42,6 +42,12 @@ def test_invalid_arguments_are_rejected_without_gpu():
     assert b"must be >= 1" in lib.semicrf_last_error()
     rc = lib.semicrf_logz_fwd(None, None, 8, 4, None, None, None, 0, None)
     assert rc == 1 and b"NULL" in lib.semicrf_last_error()
+    # full_square: triangle mode 0..2 in bits 0-1, SEMICRF_SCORE_BF16X3 (4) in bit 2, nothing else
+    import ctypes
+    fake = ctypes.c_void_p(4096)            # never dereferenced: the argument check comes first
+    for bad in (3, 7, 8, -1):
+        rc = lib.interval_score_fwd(fake, fake, fake, 2, 8, 64, 64, 64, 1, 0.125, 0, bad, fake, None, None)
+        assert rc == 1 and b"full_square" in lib.semicrf_last_error(), bad
 
 
 def test_python_surface_matches_reference():

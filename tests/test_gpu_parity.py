@@ -486,13 +486,20 @@ def test_leased_workspace_bitwise(gpu):
         T, B = sh
         s, nz = data[(sh, var)]
         lz = torch.empty(B, device=gpu); v = torch.empty(T, B, device=gpu)
+        none = torch.empty(0, device=gpu)
         if op == "fwd":
             _lib.ops().logz_fwd(s, nz, lz, v, True, ws)
             return (lz, v)
-        if op == "bwd":
-            _lib.ops().logz_fwd(s, nz, lz, v, True, ws)
+        if op == "fwd0":                                    # without the optional output (logProb without gradient)
+            _lib.ops().logz_fwd(s, nz, lz, none, False, ws)
+            return (lz,)
+        if op in ("bwd", "bwd0"):
+            _lib.ops().logz_fwd(s, nz, lz, v, True, scratch)   # (not in ws: consecutive gradient sweeps find their lease clean)
             g = synth.hash_normal(B, 5, gpu)
             ds = torch.empty(T, T, B, device=gpu); dn = torch.empty(max(T - 1, 0), B, device=gpu); q = torch.empty(T, B, device=gpu)
+            if op == "bwd0":
+                _lib.ops().logz_bwd(s, nz, v, lz, g, ds, dn, none, False, ws)
+                return (ds, dn)
             _lib.ops().logz_bwd(s, nz, v, lz, g, ds, dn, q, True, ws)
             return (ds, dn, q)
         pairs = torch.empty(B * 2 * T, 2, dtype=torch.int32, device=gpu); offs = torch.empty(B + 1, dtype=torch.int32, device=gpu)
@@ -501,7 +508,12 @@ def test_leased_workspace_bitwise(gpu):
         return (offs, pairs[:n])
 
     plain = torch.empty(nbytes, dtype=torch.uint8, device=gpu)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=gpu)
     want = {(sh, op, var): [t.clone() for t in run(plain, sh, op, var)] for sh in shapes for op in ("fwd", "bwd", "vit") for var in (0, 1)}
+    for sh in shapes:
+        for var in (0, 1):
+            want[(sh, "fwd0", var)] = want[(sh, "fwd", var)][:1]
+            want[(sh, "bwd0", var)] = want[(sh, "bwd", var)][:2]
     assert not torch.equal(want[((333, 46), "fwd", 0)][0], want[((333, 46), "fwd", 1)][0])
     leased = torch.empty(nbytes, dtype=torch.uint8, device=gpu)
     leased.random_(0, 256)                                  # arbitrary contents: the first launch fills
@@ -511,7 +523,11 @@ def test_leased_workspace_bitwise(gpu):
         seq = [((333, 46), "fwd")] * 4 + [((333, 46), "vit")] * 3 + [((333, 46), "bwd")] * 3 + \
               [((130, 600), "fwd")] * 3 + [((1024, 352), "fwd")] * 4 + [((1024, 352), "bwd")] * 3 + [((64, 12), "vit")] * 2 + \
               [((1024, 352), "vit")] * 3 + [((333, 46), "fwd"), ((130, 600), "bwd"), ((333, 46), "fwd"), ((333, 46), "fwd")] + \
-              [((200, 33), "fwd")] * 3 + [((200, 33), "bwd")] * 2 + [((200, 33), "vit")] * 2      # odd NBatch: 4-byte aligned clears
+              [((200, 33), "fwd")] * 3 + [((200, 33), "bwd")] * 2 + [((200, 33), "vit")] * 2 + \
+              [((333, 46), op) for op in ("fwd0", "fwd", "fwd", "fwd0", "fwd0", "fwd", "bwd0", "bwd", "bwd", "bwd0", "bwd0", "bwd")] + \
+              [((1024, 352), op) for op in ("fwd", "fwd0", "fwd", "bwd", "bwd0", "bwd")]
+        # (odd NBatch: 4-byte aligned clears.  fwd0 / bwd0: the optional outputs v / q are not passed -- the sweep's workspace must
+        # sit at the same place of the leased buffer either way: a forward without v followed by one with v used to return NaN)
         for i, (sh, op) in enumerate(seq):
             var = (i * 7 // 3) & 1                          # 0 0 0 1 1 0 0 1 1 1 ...: same and different data back to back
             got = run(leased, sh, op, var)
@@ -570,6 +586,82 @@ def test_scorer_lower_triangle_only(gpu):
         lower = torch.tril(torch.ones(T, T, dtype=torch.bool, device=gpu))
         assert torch.equal(S0[lower], S2[lower])
         assert bool((S2[~lower] == 7.5).all()) and bool((S0[~lower] == 0).all())
+
+
+BF3_SHAPES = [(20, 256, 64, 0, 0), (37, 300, 128, 1, 0), (33, 257, 256, 0, 1), (8, 128, 64, 2, 2), (90, 691, 256, 0, 2),
+              (64, 384, 256, 0, 0)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,T,D,mode,tri", BF3_SHAPES)
+def test_scorer_bf16x3(gpu, C, T, D, mode, tri):
+    """The opt-in contraction on the bf16 matrix instructions (full_square | SEMICRF_SCORE_BF16X3: three exact bf16 limbs per
+    operand, six limb products, fp32 accumulation) against an fp64 einsum.  Tolerance, stated in include/semicrf_hip.h:
+    |S - S64| <= 2^-21 * qscale * len * sum_d |q_d k_d| per cell (the exact fp32 kernel sits at 2^-21.2 on the same inputs).
+    The triangle modes behave as without the bit, the default path is untouched, and the bit is honoured (the result differs
+    from the fp32 kernel's in some cells: it is not a silent fallback)."""
+    from transkun_amd import _lib, synth
+    from transkun_amd.scorer import BF16X3, _interval_score_raw
+    _lib.set_impl(0)
+    q = synth.hash_normal(C * T * D, 71, "cpu").view(C, T, D).to(gpu)
+    k = synth.hash_normal(C * T * D, 72, "cpu").view(C, T, D).to(gpu)
+    dg = synth.hash_normal(C * T, 73, "cpu").view(C, T).to(gpu)
+    qs = 1.0 / D ** 0.5
+    fill = 7.5
+    def run(fs):
+        S = torch.full((T, T, C), fill, device=gpu)
+        nz = torch.empty(T - 1, C, device=gpu)
+        _lib.ops().interval_score_fwd(q, k, dg, C, T, D, q.stride(-2), k.stride(-2), dg.stride(-1), qs, mode, fs, S, nz)
+        return S
+    S3, S1 = run(tri | BF16X3), run(tri)
+    t = torch.arange(T, device=gpu)
+    ln = (t[:, None] - t[None, :]).abs().double()
+    ln = ln if mode == 0 else (ln.sqrt() if mode == 1 else torch.ones_like(ln))
+    lower = torch.ones(T, T, device=gpu).tril().bool()
+    worst = 0.0
+    for c0 in range(0, C, 16):                                     # fp64 reference in slabs of chains
+        qq, kk = q[c0:c0 + 16].double(), k[c0:c0 + 16].double()
+        ref = torch.einsum("ced,cbd->ebc", qq, kk) * qs * ln[:, :, None]
+        ref[t, t, :] += dg[c0:c0 + 16].double().t()
+        bound = torch.einsum("ced,cbd->ebc", qq.abs(), kk.abs()) * qs * ln[:, :, None] * 2.0 ** -21 + 1e-30
+        got = S3[:, :, c0:c0 + 16].double()
+        sel = lower if tri != 1 else torch.ones_like(lower)
+        sel = sel & (ln > 0)                                         # the diagonal is diag[c, t] exactly (len = 0)
+        worst = max(worst, float(((got - ref).abs() / bound)[sel].max()))
+        assert torch.equal(S3[t, t, c0:c0 + 16], dg[c0:c0 + 16].t()) or mode != 0
+    assert worst <= 1.0, worst
+    if tri == 0:
+        assert bool((S3[~lower] == 0).all())
+    elif tri == 2:
+        assert bool((S3[~lower] == fill).all())
+    sel3 = lower if tri != 1 else torch.ones_like(lower)
+    assert not torch.equal(S3[sel3], S1[sel3])                       # the bf16 kernel ran
+    assert float((S3[sel3] - S1[sel3]).abs().max()) <= 4e-6 * float(S1[sel3].abs().max())
+
+
+@pytest.mark.gpu
+def test_scorer_bf16x3_module_vs_reference(gpu):
+    """scorer.contraction = "bf16x3" at the model's real shape against the reference's own logProb and decode
+    (tests/golden/segment_T691_P90.npz): same tolerances as the exact fp32 contraction."""
+    from segment_common import SEGMENT_CASES, segment_inputs
+    from transkun_amd import CRF, _lib
+    from transkun_amd.scorer import ScaledInnerProductIntervalScorer
+    _lib.set_impl(0)
+    name = "T691_P90"
+    g = load_golden("segment_" + name)
+    N, P, T, D = SEGMENT_CASES[name][:4]
+    ctx, W, bias, iv, gout, starts = segment_inputs(name, gpu)
+    m = ScaledInnerProductIntervalScorer(D, 1).to(gpu)
+    m.contraction = "bf16x3"
+    with torch.no_grad():
+        m.map[0].weight.copy_(W); m.map[0].bias.copy_(bias)
+        S, b = m(ctx)
+    crf = CRF.NeuralSemiCRFInterval(S.flatten(-2, -1), b.flatten(-2, -1))
+    assert rel_err(crf.logProb(iv).cpu().numpy(), g["logProb"]) < 2e-5
+    assert crf.decode(forcedStartPos=starts, forward=False) == unpack_lists(g["decode_pairs"], g["decode_offsets"])
+    m.contraction = "tf32"
+    with pytest.raises(ValueError):
+        m(ctx)
 
 
 @pytest.mark.gpu

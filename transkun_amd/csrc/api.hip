@@ -69,7 +69,7 @@ bool launch_interval_score_bwd_packed(const float* dS, const float* q, const flo
                                       const float* const* fused);
 int launch_interval_score_mfma(const float* q, const float* k, const float* diag, int C, int T, int D,
                                 long long ldq, long long ldk, long long ldd, float qscale, int mode, int full,
-                                float* S, hipStream_t stream);
+                                float* S, hipStream_t stream, int prec);
 size_t persist_workspace_bytes(int T, int B);
 bool persist_supported(int T, int B);
 int launch_persist_sweep(int mode, int dir, const float* score, const float* noise, int T, int B, float* u_out,
@@ -229,9 +229,12 @@ int semicrf_logz_fwd(const float* score, const float* noise, int T, int B, float
     if (int rc = check_common(score, noise, T, B)) return rc;
     SEMICRF_CHECK_ARG(logZ != nullptr, "logZ is NULL");
     Carver cv(ws, ws_bytes);
-    float* vv = v ? v : cv.take<float>((size_t)T * B);
+    // the sweep's own workspace comes FIRST: a leased ws is only clean where the previous launch left it clean, so its place
+    // must not depend on which optional outputs the caller passes (v == NULL used to move it behind the scratch alpha: a
+    // logProb without gradient followed by one with, same lease -> NaN)
     const bool fast = use_persist(T, B);
     void* pws = fast ? cv.take<char>(persist_workspace_bytes(T, B)) : nullptr;
+    float* vv = v ? v : cv.take<float>((size_t)T * B);
     if (!cv.ok || !ws) { set_error("workspace too small for logz_fwd"); return SEMICRF_EWORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     if (fast) {
@@ -256,9 +259,9 @@ int semicrf_logz_bwd(const float* score, const float* noise, const float* v, con
     SEMICRF_CHECK_ARG(v && logZ && gout && dScore, "v/logZ/gout/dScore must be non-NULL");
     SEMICRF_CHECK_ARG(dNoise != nullptr || T == 1, "dNoise is NULL");
     Carver cv(ws, ws_bytes);
-    float* q = q_out ? q_out : cv.take<float>((size_t)T * B);
     const bool fast = use_persist(T, B);
-    void* pws = fast ? cv.take<char>(persist_workspace_bytes(T, B)) : nullptr;
+    void* pws = fast ? cv.take<char>(persist_workspace_bytes(T, B)) : nullptr;      // first: see semicrf_logz_fwd
+    float* q = q_out ? q_out : cv.take<float>((size_t)T * B);
     if (!cv.ok || !ws) { set_error("workspace too small for logz_bwd"); return SEMICRF_EWORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     if (fast) {
@@ -365,11 +368,14 @@ int interval_score_fwd(const float* q, const float* k, const float* diag, int C,
     SEMICRF_CHECK_ARG(q && k && diag && S, "q/k/diag/S must be non-NULL");
     SEMICRF_CHECK_ARG(ldq >= D && ldk >= D && ldd >= 1, "bad leading dimensions");
     SEMICRF_CHECK_ARG(length_scaling >= 0 && length_scaling <= 2, "bad length_scaling %d", length_scaling);
+    SEMICRF_CHECK_ARG(full_square >= 0 && (full_square & 3) <= 2 && (full_square & ~7) == 0, "bad full_square %d", full_square);
     hipStream_t st = (hipStream_t)stream;
+    const int prec = (full_square & SEMICRF_SCORE_BF16X3) ? 1 : 0;   // opt-in: three-limb bf16 contraction (scorer_mfma.hip)
+    full_square &= 3;
     if (full_square == 0) launch_zero_upper(S, T, C, st);      // begin > end: defined (zero), half the bytes of a full fill
     const int full_kernel = full_square == 1 ? 1 : 0;           // 2: lower triangle only, the rest of S is left as it is
     if (g_impl.load() == 0 && interval_score_mfma_supported(C, T, D)) {
-        if (launch_interval_score_mfma(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, length_scaling, full_kernel, S, st) != 0) {
+        if (launch_interval_score_mfma(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, length_scaling, full_kernel, S, st, prec) != 0) {
             set_error("interval_score_fwd: work list allocation failed");
             return SEMICRF_ELAUNCH;
         }

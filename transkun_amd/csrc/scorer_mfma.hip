@@ -16,6 +16,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <type_traits>
 #include <vector>
 
 namespace semicrf {
@@ -503,6 +504,56 @@ constexpr int XTB = 128;                   // tile columns (begin positions)
 #endif
 constexpr int XNS = SEMICRF_SCORE_XNS;     // LDS stages (4: measured no faster, profiles/r02_scorer.md)
 
+// Opt-in contraction on the bf16 matrix instructions (PREC = 1; interval_score_fwd, full_square bit 2).  Every fp32 operand
+// is split into three bf16 limbs, x = hi + mid + lo EXACTLY (round-to-nearest splits: 8 + 8 + 8 significant bits and the
+// signs of the remainders), and six of the nine limb products are accumulated in fp32 by v_mfma_f32_32x32x16_bf16, smallest
+// first: hi*lo, lo*hi, mid*mid, hi*mid, mid*hi, hi*hi.  Every limb product is exact (8 x 8 bits); what is dropped (mid*lo,
+// lo*mid, lo*lo) is below 2^-23 |q_d k_d| per term -- the size of the rounding of one fp32 fmaf of the default path.  Six
+// instructions of 8 passes replace eight fp32 instructions of 16 per 16 contraction values: 2.7x less matrix time; the
+// split costs ~5 vector instructions per operand value and is done by every wave for its own operands.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Limbs3 { bf16x8 h, m, l; };
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l)
+{
+    const bf16x2 hp = {(__bf16)a, (__bf16)b};                                    // v_cvt_pk_bf16_f32 (round to nearest even)
+    const unsigned hu = __builtin_bit_cast(unsigned, hp);
+    const f32x2 x = {a, b};
+    const f32x2 hf = {__builtin_bit_cast(float, hu << 16), __builtin_bit_cast(float, hu & 0xffff0000u)};
+    const f32x2 r1 = x - hf;                                                     // exact
+    const bf16x2 mp = {(__bf16)r1.x, (__bf16)r1.y};
+    const unsigned mu = __builtin_bit_cast(unsigned, mp);
+    const f32x2 mf = {__builtin_bit_cast(float, mu << 16), __builtin_bit_cast(float, mu & 0xffff0000u)};
+    const f32x2 r2 = r1 - mf;                                                    // exact, and fits 8 bits
+    const bf16x2 lp = {(__bf16)r2.x, (__bf16)r2.y};
+    h = hu; m = mu; l = __builtin_bit_cast(unsigned, lp);
+}
+__device__ __forceinline__ Limbs3 split8(const v4f a, const v4f b)
+{
+    unsigned h[4], m[4], l[4];
+    split_pair(a.x, a.y, h[0], m[0], l[0]);
+    split_pair(a.z, a.w, h[1], m[1], l[1]);
+    split_pair(b.x, b.y, h[2], m[2], l[2]);
+    split_pair(b.z, b.w, h[3], m[3], l[3]);
+    Limbs3 r;
+    r.h = __builtin_bit_cast(bf16x8, (u32x4){h[0], h[1], h[2], h[3]});
+    r.m = __builtin_bit_cast(bf16x8, (u32x4){m[0], m[1], m[2], m[3]});
+    r.l = __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]});
+    return r;
+}
+__device__ __forceinline__ f32x16 mma6(const Limbs3& A, const Limbs3& B, f32x16 acc)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.l, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l, B.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.m, B.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.m, B.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.h, acc, 0, 0, 0);
+    return acc;
+}
+
 // XTE = tile rows (end positions): 128 -> 8 waves, one workgroup per CU; 64 -> 4 waves, two (independent) workgroups
 // per CU whose barriers and operand reads fall into each other's matrix phases (24 instead of 32 flop per byte).
 template <int XTE>
@@ -795,9 +846,373 @@ static int launch_score_tile(const float* q, const float* k, const float* diag, 
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 128x128 tile kernel with the three-limb bf16 contraction (opt-in: interval_score_fwd, full_square | SEMICRF_SCORE_BF16X3)
+// ---------------------------------------------------------------------------------------------
+// Same items, schedule and epilogue as interval_score_tile_kernel<128>.  What differs is the operand path: the vector
+// work of the split (~5 instructions per value) would cost as much as the matrix instructions save if every wave split
+// its own operands (each value is used by 2 or 4 waves: measured 1.17 vs 1.23 ms).  So every value is split ONCE: the
+// 512 lanes fetch a chunk (256 rows x 32 contraction values) from global memory into registers, two chunks ahead, split
+// it and store the limbs to LDS ([stage][limb][row][4 pieces of 8 values], pieces swizzled by row so that writes and
+// reads are conflict-free); after one s_barrier per chunk the waves read bf16x8 operands and issue 24 instructions of
+// 8 passes (the fp32 kernel: 32 of 16).
+constexpr int W3_NS = 2;
+#ifndef SEMICRF_SCORE_SCHED3
+#define SEMICRF_SCORE_SCHED3 1
+#endif
+
+// XTE = 128: eight waves, one workgroup per CU (the one that is launched).  XTE = 64 -- four waves and 72 KB, two independent
+// workgroups per CU that could fall into each other's phases -- measured slower everywhere (1.28 vs 0.96 ms at T=1024, C=352;
+// 634 vs 552 us at T=691, C=360) and spills with the pinned instruction order.
+template <int XTE>
+__global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ diag, int C, int T, int D,
+    long long ldq, long long ldk, long long ldd, float qscale, int mode, int full, float* __restrict__ S,
+    int ntiles, int nquadp)
+{
+    constexpr int NTH = XTE * 4;                 // threads
+    constexpr int NR = XTE + XTB;                // rows per stage: q rows | k rows
+    constexpr int LIMB = NR * 64;                // bytes per limb plane: 32 values x 2 bytes per row
+    constexpr int STAGE = 3 * LIMB;
+    constexpr int NU = NR / XTE;                 // units (one row, 8 values) per lane and chunk: unit 0 is a q row, the others k rows
+    extern __shared__ __attribute__((aligned(16))) char xlds[];    // [W3_NS][STAGE]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int row = lane & 31, half = lane >> 5;
+    const int wer = wave >> 1, wh = wave & 1;                       // this wave: rows 32*wer.., columns 64*wh.. of the tile
+    const int dbg = mode >> 8;       // timing ablations (SEMICRF_SCORE_DEBUG, debug builds only; results are wrong when set):
+                                     // 1 no matrix instructions, 2 no operand fetch, 4 no stores
+    mode &= 0xff;
+    const int nchunk = D / ZCH;                                     // even (D % 64 == 0)
+    const int nbt = (T + XTB - 1) / XTB;
+    const int xcd = blockIdx.x % NXCD, slot0 = blockIdx.x / NXCD, nslots = gridDim.x / NXCD;
+    const long long nitems = (long long)ntiles * nquadp;
+
+    auto item_of = [&](int u, int& et, int& bt, int& c4) -> bool {
+        const long long n = (long long)(u >> 3) * (8 * NXCD) + xcd * 8 + (u & 7);
+        if (n >= nitems) return false;
+        // line group (32 chains = 8 quads) major: all tiles of a group before the next group, so that the group's q and k
+        // (64 MB at T=1024) come from HBM once and from the memory-side cache afterwards.  In tile-major order over all
+        // chains (the fp32 kernel's, which is bound by its matrix instructions) every operand tile is fetched again:
+        // 3.3 GB at T=1024, C=352 -- 1.09 ms instead of 0.86 here.
+        const long long v = n >> 3;
+        const int t = (int)(v % ntiles);
+        c4 = ((int)(v / ntiles) * 8 + (int)(n & 7)) * 4;
+        if (full) {
+            et = t / nbt; bt = t % nbt;
+        } else if (XTE == XTB) {
+            et = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            while (et * (et + 1) / 2 > t) --et;
+            while ((et + 1) * (et + 2) / 2 <= t) ++et;
+            bt = t - et * (et + 1) / 2;
+        } else {
+            // rows 2p and 2p+1 hold p+1 tiles each; p(p+1) tiles lie before the pair
+            int pp = (int)((sqrtf(4.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            while (pp * (pp + 1) > t) --pp;
+            while ((pp + 1) * (pp + 2) <= t) ++pp;
+            const int r = t - pp * (pp + 1);
+            et = r < pp + 1 ? 2 * pp : 2 * pp + 1;
+            bt = r < pp + 1 ? r : r - (pp + 1);
+        }
+        return true;
+    };
+
+    // reading lanes: lane = (row, half); the instruction of slab sl takes piece 2*half + sl of the row
+    unsigned rdA[2], rdB[2];
+    {
+        const int ra = 32 * wer + row, rb = XTE + 64 * wh + row;   // second column block: + 32 rows = + 2048 bytes, same swizzle
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            rdA[sl] = (unsigned)(ra * 64 + (((2 * half + sl) ^ ((ra >> 2) & 3)) * 16));
+            rdB[sl] = (unsigned)(rb * 64 + (((2 * half + sl) ^ ((rb >> 2) & 3)) * 16));
+        }
+    }
+    // loading lanes: unit j = (row j * XTE + tid / 4 of the stage, piece tid % 4)
+    const int oct = threadIdx.x & 3;
+    unsigned wof[NU];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        const int R = j * XTE + (int)(threadIdx.x >> 2);
+        wof[j] = (unsigned)(R * 64 + ((oct ^ ((R >> 2) & 3)) * 16));
+    }
+
+    // ---- request side (identical in all waves): (entry, chain of the quad, chunk) --------------------------------
+    int nx_u = slot0, nx_j = 0, nx_ch = 0, nx_c4 = 0;
+    bool nx_valid = false;
+    size_t nx_off[NU];
+    const float* nx_q = q;
+    const float* nx_k = k;
+    auto set_chain = [&]() {
+        const int c = nx_c4 + nx_j < C ? nx_c4 + nx_j : C - 1;
+        nx_q = q + (size_t)c * T * ldq;
+        nx_k = k + (size_t)c * T * ldk;
+    };
+    auto set_item = [&]() {
+        int et, bt;
+        nx_valid = item_of(nx_u, et, bt, nx_c4);
+        if (nx_valid) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                const int gr = (j == 0 ? et * XTE : bt * XTB + (j - 1) * XTE) + (int)(threadIdx.x >> 2);
+                const int cr = gr < T ? gr : T - 1;                          // clamped rows (masked at the write)
+                nx_off[j] = (size_t)cr * (size_t)(j == 0 ? ldq : ldk) + (size_t)(oct * 8);
+            }
+            nx_j = 0;
+            nx_ch = 0;
+            set_chain();
+        }
+    };
+    auto fetch = [&](v4f (&g)[NU][2]) {
+        if (!nx_valid) return;
+        if (!(dbg & 2))
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            const float* src = (j == 0 ? nx_q : nx_k) + nx_off[j] + (size_t)nx_ch * ZCH;
+            g[j][0] = *(const v4f*)src;
+            g[j][1] = *(const v4f*)(src + 4);
+        }
+        if (++nx_ch == nchunk) {
+            nx_ch = 0;
+            if (++nx_j == 4) {
+                nx_u += nslots;
+                set_item();
+            } else {
+                set_chain();
+            }
+        }
+    };
+    auto convert = [&](const v4f (&g)[NU][2], int stage) {
+        char* base = xlds + stage * STAGE;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            const Limbs3 L = split8(g[j][0], g[j][1]);
+            *(bf16x8*)(base + wof[j]) = L.h;
+            *(bf16x8*)(base + LIMB + wof[j]) = L.m;
+            *(bf16x8*)(base + 2 * LIMB + wof[j]) = L.l;
+        }
+    };
+
+    set_item();
+    if (!nx_valid) return;                      // uniform over the workgroup
+    int cur_u = slot0;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    float hold[3][2][16];
+
+    v4f g0[NU][2], g1[NU][2];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) { g0[j][0] = (v4f)(0.0f); g0[j][1] = (v4f)(0.0f); g1[j][0] = (v4f)(0.0f); g1[j][1] = (v4f)(0.0f); }
+    fetch(g0);
+    fetch(g1);
+    convert(g0, 0);
+    fetch(g0);
+
+    while (true) {
+        int et, bt, c4;
+        (void)item_of(cur_u, et, bt, c4);
+        const int erow = et * (XTE / 32) + wer, bcol = bt * (XTB / 32) + 2 * wh;
+        const bool on0 = full || bcol <= erow, on1 = full || bcol + 1 <= erow;
+        // (the blocks-above-the-diagonal cases are separate instantiations: a branch inside the half iteration would end the
+        // basic block the instruction order below is imposed on)
+        auto multiply = [&](int stage, auto ON0, auto ON1) {
+            const char* base = xlds + stage * STAGE;
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                Limbs3 A, B;
+                A.h = *(const bf16x8*)(base + rdA[sl]);
+                A.m = *(const bf16x8*)(base + LIMB + rdA[sl]);
+                A.l = *(const bf16x8*)(base + 2 * LIMB + rdA[sl]);
+                if constexpr (decltype(ON0)::value) {
+                    B.h = *(const bf16x8*)(base + rdB[sl]);
+                    B.m = *(const bf16x8*)(base + LIMB + rdB[sl]);
+                    B.l = *(const bf16x8*)(base + 2 * LIMB + rdB[sl]);
+                    acc0 = mma6(A, B, acc0);
+                }
+                if constexpr (decltype(ON1)::value) {
+                    B.h = *(const bf16x8*)(base + rdB[sl] + 2048);
+                    B.m = *(const bf16x8*)(base + LIMB + rdB[sl] + 2048);
+                    B.l = *(const bf16x8*)(base + 2 * LIMB + rdB[sl] + 2048);
+                    acc1 = mma6(A, B, acc1);
+                }
+            }
+        };
+        // Instruction order of a half iteration.  Inside a workgroup the barrier keeps every wave in the same phase, so whatever
+        // overlaps has to overlap inside a wave: the matrix pipe takes an instruction every 32 cycles, and the operand reads
+        // of the next slab, the split of the chunk after next (~90 vector instructions) and its limb stores go into those
+        // gaps, one piece per matrix instruction, the order pinned by scheduling barriers (in source order the compiler puts
+        // them behind the last matrix instruction: 1.09 ms, no better than fp32; sched_group_barrier hints were not followed).
+        auto half_full = [&](int srd, const v4f (&g)[NU][2], int swr) {
+            const char* rb = xlds + srd * STAGE;
+            char* wb = xlds + swr * STAGE;
+            Limbs3 A0, A1, B0, B1;
+            auto ld = [&](Limbs3& L, unsigned off) {
+                L.h = *(const bf16x8*)(rb + off);
+                L.m = *(const bf16x8*)(rb + LIMB + off);
+                L.l = *(const bf16x8*)(rb + 2 * LIMB + off);
+            };
+            unsigned ph[4], pm[4], pl[4];
+            auto piece = [&](int j, int pr) {
+                const v4f x = g[j][pr >> 1];
+                if (pr & 1) split_pair(x.z, x.w, ph[pr], pm[pr], pl[pr]);
+                else split_pair(x.x, x.y, ph[pr], pm[pr], pl[pr]);
+            };
+            auto store = [&](int j) {
+                *(u32x4*)(wb + wof[j]) = (u32x4){ph[0], ph[1], ph[2], ph[3]};
+                *(u32x4*)(wb + LIMB + wof[j]) = (u32x4){pm[0], pm[1], pm[2], pm[3]};
+                *(u32x4*)(wb + 2 * LIMB + wof[j]) = (u32x4){pl[0], pl[1], pl[2], pl[3]};
+            };
+            auto mma1 = [&](const Limbs3& A, const Limbs3& B, f32x16& acc, int p) {
+                switch (p) {
+                case 0: acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.l, acc, 0, 0, 0); break;
+                case 1: acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l, B.h, acc, 0, 0, 0); break;
+                case 2: acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.m, B.m, acc, 0, 0, 0); break;
+                case 3: acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.m, acc, 0, 0, 0); break;
+                case 4: acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.m, B.h, acc, 0, 0, 0); break;
+                default: acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.h, acc, 0, 0, 0); break;
+                }
+            };
+            ld(A0, rdA[0]);
+            ld(B0, rdB[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                // acc0 slab 0 (A0, B0) | acc1 slab 0 (A0, B1) | acc0 slab 1 (A1, B0) | acc1 slab 1 (A1, B1)
+                if (dbg & 1) {
+                    if (i == 0) acc0[0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, A0.h).x);
+                } else if (i < 6) mma1(A0, B0, acc0, i);
+                else if (i < 12) mma1(A0, B1, acc1, i - 6);
+                else if (i < 18) mma1(A1, B0, acc0, i - 12);
+                else mma1(A1, B1, acc1, i - 18);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i == 0) ld(B1, rdB[0] + 2048);
+                if (i >= 1 && i <= 4) piece(0, i - 1);
+                if (i == 5) store(0);
+                if (i == 6) ld(A1, rdA[1]);
+                if (i == 7) ld(B0, rdB[1]);
+                if (i >= 8 && i <= 11) piece(1, i - 8);
+                if (i == 12) store(1);
+                if (i == 13) ld(B1, rdB[1] + 2048);
+                if (NU > 2 && i >= 14 && i <= 17) piece(NU - 1, i - 14);
+                if (NU > 2 && i == 18) store(NU - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto chain_loop = [&](auto ON0, auto ON1) {
+            constexpr bool both = decltype(ON0)::value && decltype(ON1)::value;
+            for (int ch = 0; ch < nchunk; ch += 2) {
+                // the limbs of chunk ch are stored (mine: lgkmcnt, everybody's: the barrier) and everybody has read the
+                // other stage (no fence: the global prefetch stays in flight)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if constexpr (both && SEMICRF_SCORE_SCHED3) {
+                    half_full(0, g1, 1);
+                } else {
+                    multiply(0, ON0, ON1);
+                    convert(g1, 1);
+                }
+                fetch(g1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if constexpr (both && SEMICRF_SCORE_SCHED3) {
+                    half_full(1, g0, 0);
+                } else {
+                    multiply(1, ON0, ON1);
+                    convert(g0, 0);
+                }
+                fetch(g0);
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (on0 && on1) chain_loop(std::true_type{}, std::true_type{});
+            else if (on0) chain_loop(std::true_type{}, std::false_type{});
+            else chain_loop(std::false_type{}, std::false_type{});
+            if (j < 3) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    hold[j][0][r] = acc0[r]; hold[j][1][r] = acc1[r];
+                    acc0[r] = 0.0f; acc1[r] = 0.0f;
+                }
+            }
+        }
+        // ---- write the item's four chains: one 16-byte piece per cell (C/D layout: col = lane & 31,
+        //      row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) ----
+        {
+            const bool vec = (C & 3) == 0 && c4 + 3 < C;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int b = bt * XTB + 64 * wh + 32 * t + row;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int e = et * XTE + 32 * wer + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int len = e > b ? e - b : b - e;
+                    const float sc = qscale * len_scale_mfma(len, mode);
+                    const float last = t == 0 ? acc0[r] : acc1[r];
+                    float v[4] = {hold[0][t][r] * sc, hold[1][t][r] * sc, hold[2][t][r] * sc, last * sc};
+                    if (e < T && b < T && (full || b <= e) && c4 < C && !(dbg & 4)) {
+                        if (e == b) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (c4 + i < C) v[i] += diag[((size_t)(c4 + i) * T + e) * ldd];
+                        }
+                        float* dst = S + ((size_t)e * T + b) * C + c4;
+                        if (vec) {
+                            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (c4 + i < C) dst[i] = v[i];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+        }
+        cur_u += nslots;
+        int e2, b2, c2;
+        if (!item_of(cur_u, e2, b2, c2)) break;
+    }
+}
+
+template <int XTE>
+static int launch_score_tile3(const float* q, const float* k, const float* diag, int C, int T, int D, long long ldq,
+                              long long ldk, long long ldd, float qscale, int mode, int full, float* S, hipStream_t stream)
+{
+    const int net = (T + XTE - 1) / XTE, nbt = (T + XTB - 1) / XTB;
+    int ntiles = 0;
+    if (full) ntiles = net * nbt;
+    else
+        for (int et = 0; et < net; ++et) ntiles += (et * XTE + XTE - 1) / XTB + 1 < nbt ? (et * XTE + XTE - 1) / XTB + 1 : nbt;
+    const int nquadp = ((C + 3) / 4 + 7) / 8 * 8;
+    const size_t lds = (size_t)W3_NS * 3 * (XTE + XTB) * 64;
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
+        (void)hipFuncSetAttribute((const void*)interval_score_tile3_kernel<XTE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    int ncu = 256, dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+        ncu = v;
+    int grid = ncu * (128 / XTE) / (8 * NXCD) * (8 * NXCD);       // persistent workgroups (128 / XTE per CU); per XCD a multiple of 8 slots
+    if (grid < 8 * NXCD) grid = 8 * NXCD;
+    const long long nitems = (long long)ntiles * nquadp;
+    const long long need = (nitems + 8 * NXCD - 1) / (8 * NXCD) * (8 * NXCD);
+    if (grid > need) grid = (int)need;
+    int dbg = 0;
+#ifdef SEMICRF_DEBUG_BUILD
+    if (const char* e = getenv("SEMICRF_SCORE_DEBUG")) dbg = atoi(e) & 0xff;      // timing ablations (wrong results): debug builds only
+#endif
+    hipLaunchKernelGGL(interval_score_tile3_kernel<XTE>, dim3(grid), dim3(XTE * 4), lds, stream, q, k, diag, C, T, D, ldq, ldk, ldd, qscale,
+                       mode | (dbg << 8), full, S, ntiles, nquadp);
+    return 0;
+}
+
 int launch_interval_score_mfma(const float* q, const float* k, const float* diag, int C, int T, int D,
                                 long long ldq, long long ldk, long long ldd, float qscale, int mode, int full,
-                                float* S, hipStream_t stream)
+                                float* S, hipStream_t stream, int prec)
 {
     const int nt = (T + ST - 1) / ST;
     const size_t lds = (size_t)ST * ST * SPAD * sizeof(float);
@@ -811,6 +1226,8 @@ int launch_interval_score_mfma(const float* q, const float* k, const float* diag
         // 64-row tiles when they waste less of the last tile row (e.g. T=691: 704 vs 768 rows) -- measured 779 vs 814 us
         int variant = T < 256 ? 32 : ((T + 63) / 64 * 64 < (T + 127) / 128 * 128 ? 64 : 128);
         if (const char* e = getenv("SEMICRF_SCORE_VARIANT")) variant = atoi(e);      // tuning knob: 0 = register-load kernel
+        if (prec == 1 && T >= 128)
+            return launch_score_tile3<128>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream);
         if (variant == 128)
             return launch_score_tile<128>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream);
         if (variant == 64)

@@ -27,7 +27,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .scorer import QPAD, ScaledInnerProductIntervalScorer, _interval_score_raw, bwd_workspace, qd_weights
+from .scorer import BF16X3, QPAD, ScaledInnerProductIntervalScorer, _interval_score_raw, bwd_workspace, qd_weights
 
 _nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
 
@@ -42,12 +42,12 @@ def _beta_raw(score, noise):
 
 class _ScorerCRFLogProb(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qd, k, pairs, offsets, N, P, T, D, mode):
+    def forward(ctx, qd, k, pairs, offsets, N, P, T, D, mode, fs=2):
         # qd: [N,P,T,D+QPAD] = [q | diag | zeros] (one GEMM, see scorer.py); k: [N,P,T,D]
         C = N * P
         qd3, k3 = qd.reshape(C, T, D + QPAD), k.reshape(C, T, D)
         qs = 1.0 / math.sqrt(D)
-        S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qs, mode, 2)      # S never leaves this node
+        S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qs, mode, fs)     # S never leaves this node (fs: 2 | BF16X3)
         logz, v = _nsci._logz_fwd_raw(S, noise, True)
         path = _nsci._eval_path_raw(S, noise, pairs, offsets)
         ctx.save_for_backward(qd3, k3, S, noise, v, logz, pairs, offsets)
@@ -78,7 +78,7 @@ class _ScorerCRFLogProb(torch.autograd.Function):
             # + g on the path cells: dq[c,e] += g qs len(e-b) k[c,b], dk[c,b] += g qs len(e-b) q[c,e], ddiag[c,t] += g (b == e)
             ops.interval_score_path_bwd(g, pairs, int(K), offsets, q, k, C, T, D, q.stride(-2), k.stride(-2), qs, mode, dq, dk, dd,
                                         dq.stride(-2), D, dd.stride(-1))
-        return (dqd.view(N, P, T, D + QPAD), dk.view(N, P, T, D), None, None, None, None, None, None, None)
+        return (dqd.view(N, P, T, D + QPAD), dk.view(N, P, T, D), None, None, None, None, None, None, None, None)
 
 
 def scorer_crf_logprob(scorer: ScaledInnerProductIntervalScorer, ctx: torch.Tensor, intervals) -> torch.Tensor:
@@ -100,4 +100,5 @@ def scorer_crf_logprob(scorer: ScaledInnerProductIntervalScorer, ctx: torch.Tens
     qd = F.linear(x, Wqd, bqd)
     k = F.linear(x, W[D:2 * D], bias[D:2 * D])
     pairs, offsets = _nsci.pack_intervals(intervals, T, N * P, ctx.device)
-    return _ScorerCRFLogProb.apply(qd, k, pairs, offsets, N, P, T, D, _lib.LEN_MODES[scorer.lengthScaling])
+    fs = 2 | (BF16X3 if getattr(scorer, "contraction", "fp32") == "bf16x3" else 0)
+    return _ScorerCRFLogProb.apply(qd, k, pairs, offsets, N, P, T, D, _lib.LEN_MODES[scorer.lengthScaling], fs)

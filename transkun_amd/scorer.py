@@ -22,12 +22,13 @@ from . import _lib
 def _interval_score_raw(q, k, diag, T: int, C: int, D: int, qscale: float, mode: int, full_square):
     """q,k: [C,T,D] views with unit stride in d; diag: [C,T] view.  Returns S [T,T,C], noise [T-1,C].
     full_square: False/0 lower triangle + zeros above, True/1 the full square, 2 lower triangle only (the cells with
-    begin > end stay uninitialised: for S that only this library's CRF kernels read)."""
+    begin > end stay uninitialised: for S that only this library's CRF kernels read); | BF16X3 (4): the opt-in three-limb
+    bf16 contraction (include/semicrf_hip.h: SEMICRF_SCORE_BF16X3)."""
     dev = q.device
     assert q.stride(-1) == 1 and k.stride(-1) == 1
     # full_square=False: the library computes e >= b and zero-fills the rest itself (half the bytes of torch.zeros)
     S = torch.empty(T, T, C, dtype=torch.float32, device=dev)
-    if int(full_square) == 2 and os.environ.get("SEMICRF_POISON_UNWRITTEN"):
+    if (int(full_square) & 3) == 2 and os.environ.get("SEMICRF_POISON_UNWRITTEN"):
         S.fill_(float("nan"))           # test hook: whatever reads begin > end of a lower-triangle-only S shows up as NaN
     noise = torch.empty(max(T - 1, 0), C, dtype=torch.float32, device=dev)
     _lib.ops().interval_score_fwd(q, k, diag, C, T, D, q.stride(-2), k.stride(-2), diag.stride(-1), float(qscale), int(mode),
@@ -45,6 +46,9 @@ def bwd_workspace(C: int, T: int, D: int, device) -> torch.Tensor:
     if n is None:
         n = _BWD_WS[key] = int(_lib.load().interval_score_bwd_workspace_bytes(C, T, D))
     return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+BF16X3 = 4      # SEMICRF_SCORE_BF16X3: OR into full_square
 
 
 QPAD = 4        # [q | diag | 3 zero columns]: one GEMM instead of a D-wide and a 1-wide one, rows stay 16-byte aligned
@@ -70,7 +74,7 @@ class _IntervalScore(torch.autograd.Function):
         qscale = 1.0 / math.sqrt(D)
         S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qscale, mode, full_square)
         ctx.save_for_backward(qd3, k3)
-        ctx.meta = (N, P, T, D, mode, int(full_square) == 1)
+        ctx.meta = (N, P, T, D, mode, (int(full_square) & 3) == 1)
         return S.view(T, T, N, P), noise.view(max(T - 1, 0), N, P)
 
     @staticmethod
@@ -139,6 +143,10 @@ class ScaledInnerProductIntervalScorer(nn.Module):
         self.withScoreEps = withScoreEps
         self.fullSquare = False   # True: also materialise e<b like the reference (the CRF never reads it); 2: leave e<b
                                   # uninitialised (only for S that goes straight into this package's CRF)
+        self.contraction = "fp32"  # "bf16x3": opt-in forward contraction on the bf16 matrix instructions -- operands split
+                                  # exactly into three bf16 limbs, six limb products, fp32 accumulation: fp32-grade scores
+                                  # (|error| <= 2^-21 * sum_d |q_d k_d| * scale), not bit-identical to "fp32"; the
+                                  # backward is the exact fp32 one either way
 
     def forward(self, ctx):
         # ctx: [N, P, T, size]
@@ -155,5 +163,8 @@ class ScaledInnerProductIntervalScorer(nn.Module):
         Wqd, bqd = qd_weights(W, bias, D)
         qd = F.linear(x, Wqd, bqd)
         k = F.linear(x, W[D:2 * D], bias[D:2 * D])
-        S, b = _IntervalScore.apply(qd, k, N, P, T, D, _lib.LEN_MODES[self.lengthScaling], self.fullSquare)
+        if self.contraction not in ("fp32", "bf16x3"):
+            raise ValueError(f"contraction must be 'fp32' or 'bf16x3', not {self.contraction!r}")
+        fs = int(self.fullSquare) | (BF16X3 if self.contraction == "bf16x3" else 0)
+        S, b = _IntervalScore.apply(qd, k, N, P, T, D, _lib.LEN_MODES[self.lengthScaling], fs)
         return S, b
