@@ -27,7 +27,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .scorer import BF16X3, QPAD, ScaledInnerProductIntervalScorer, _interval_score_raw, bwd_workspace, qd_weights
+from .scorer import BF16X3, QPAD, ScaledInnerProductIntervalScorer, _ScorerLinear, _interval_score_raw, bwd_workspace, qd_weights
 
 _nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
 
@@ -97,8 +97,7 @@ def scorer_crf_logprob(scorer: ScaledInnerProductIntervalScorer, ctx: torch.Tens
     W, bias = lin.weight, lin.bias
     x = ctx.float()
     Wqd, bqd = qd_weights(W, bias, D)
-    qd = F.linear(x, Wqd, bqd)
-    k = F.linear(x, W[D:2 * D], bias[D:2 * D])
+    qd, k = _ScorerLinear.apply(x, Wqd, bqd, W[D:2 * D], bias[D:2 * D])
     pairs, offsets = _nsci.pack_intervals(intervals, T, N * P, ctx.device)
     fs = 2 | (BF16X3 if getattr(scorer, "contraction", "fp32") == "bf16x3" else 0)
     return _ScorerCRFLogProb.apply(qd, k, pairs, offsets, N, P, T, D, _lib.LEN_MODES[scorer.lengthScaling], fs)
