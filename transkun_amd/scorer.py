@@ -3,7 +3,8 @@
 
 Same constructor arguments, same parameter names (`map.0.weight`, `map.0.bias`) so reference
 checkpoints load, same outputs: S [T, T, N, P] and the all-zero noise score [T-1, N, P].
-The Linear map stays a stock GEMM (hipBLASLt through torch); everything after it --
+The Linear map stays stock GEMMs (hipBLASLt through torch) with a backward of its own (_ScorerLinear: the weight
+gradients as batched GEMMs over row chunks); everything after it --
 scaling, the per-chain q.k^T contraction, length scaling, diagonal, and the permute to the
 CRF layout -- is one kernel that writes the chain-contiguous layout directly.
 """
