@@ -24,3 +24,8 @@ def test_scorer_linear_backward_matches_autograd(monkeypatch):
     qd, k = sc._ScorerLinear.apply(x0, Wq, bq, Wk.detach(), bk)
     (qd.sum() + k.sum()).backward()
     assert Wq.grad is not None and bk.grad is not None
+    # one of the two outputs unused
+    x1 = x.detach().requires_grad_()
+    qd, k = sc._ScorerLinear.apply(x1, Wq, bq, Wk, bk)
+    (gx,) = torch.autograd.grad(k.sum(), [x1])
+    assert torch.allclose(gx, torch.autograd.grad(F.linear(x1, Wk, bk).sum(), [x1])[0])

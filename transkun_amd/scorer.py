@@ -97,15 +97,19 @@ class _ScorerLinear(torch.autograd.Function):
         x, Wqd, Wk = ctx.saved_tensors
         K = x.shape[-1]
         x2 = x.reshape(-1, K)
-        g1, g2 = dqd.reshape(-1, Wqd.shape[0]), dk.reshape(-1, Wk.shape[0])
+        # (an output nobody differentiated arrives as None)
+        g1 = dqd.reshape(-1, Wqd.shape[0]) if dqd is not None else None
+        g2 = dk.reshape(-1, Wk.shape[0]) if dk is not None else None
         need = ctx.needs_input_grad
         dx = None
         if need[0]:
-            dx = g1.mm(Wqd)
-            dx.addmm_(g2, Wk)
-            dx = dx.view(x.shape)
-        return (dx, _tn_splitk(g1, x2) if need[1] else None, g1.sum(0) if need[2] else None,
-                _tn_splitk(g2, x2) if need[3] else None, g2.sum(0) if need[4] else None)
+            dx = g1.mm(Wqd) if g1 is not None else None
+            if g2 is not None:
+                dx = g2.mm(Wk) if dx is None else dx.addmm_(g2, Wk)
+            dx = dx.view(x.shape) if dx is not None else None
+        return (dx,
+                _tn_splitk(g1, x2) if need[1] and g1 is not None else None, g1.sum(0) if need[2] and g1 is not None else None,
+                _tn_splitk(g2, x2) if need[3] and g2 is not None else None, g2.sum(0) if need[4] and g2 is not None else None)
 
 
 class _IntervalScore(torch.autograd.Function):
