@@ -516,19 +516,22 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct Limbs3 { bf16x8 h, m, l; };
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b)
+{
+    unsigned r;                                          // {bf16(a) in bits 15:0, bf16(b) in bits 31:16}, round to nearest even
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));      // (written out: from `(__bf16)x` the compiler converts
+    return r;                                            // the first element a second time, alone, for the shift below)
+}
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l)
 {
-    const bf16x2 hp = {(__bf16)a, (__bf16)b};                                    // v_cvt_pk_bf16_f32 (round to nearest even)
-    const unsigned hu = __builtin_bit_cast(unsigned, hp);
+    const unsigned hu = cvt_pk_bf16(a, b);
     const f32x2 x = {a, b};
     const f32x2 hf = {__builtin_bit_cast(float, hu << 16), __builtin_bit_cast(float, hu & 0xffff0000u)};
     const f32x2 r1 = x - hf;                                                     // exact
-    const bf16x2 mp = {(__bf16)r1.x, (__bf16)r1.y};
-    const unsigned mu = __builtin_bit_cast(unsigned, mp);
+    const unsigned mu = cvt_pk_bf16(r1.x, r1.y);
     const f32x2 mf = {__builtin_bit_cast(float, mu << 16), __builtin_bit_cast(float, mu & 0xffff0000u)};
     const f32x2 r2 = r1 - mf;                                                    // exact, and fits 8 bits
-    const bf16x2 lp = {(__bf16)r2.x, (__bf16)r2.y};
-    h = hu; m = mu; l = __builtin_bit_cast(unsigned, lp);
+    h = hu; m = mu; l = cvt_pk_bf16(r2.x, r2.y);
 }
 __device__ __forceinline__ Limbs3 split8(const v4f a, const v4f b)
 {
@@ -879,8 +882,14 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int row = lane & 31, half = lane >> 5;
     const int wer = wave >> 1, wh = wave & 1;                       // this wave: rows 32*wer.., columns 64*wh.. of the tile
-    const int dbg = mode >> 8;       // timing ablations (SEMICRF_SCORE_DEBUG, debug builds only; results are wrong when set):
-                                     // 1 no matrix instructions, 2 no operand fetch, 4 no stores
+    // timing ablations (SEMICRF_SCORE_DEBUG, debug builds only; results are wrong when set): 1 no matrix instructions, 2 no
+    // operand fetch, 4 no stores.  A constant 0 in release builds: a run-time test in front of every matrix instruction costs
+    // two scalar instructions and ends its basic block
+#ifdef SEMICRF_DEBUG_BUILD
+    const int dbg = mode >> 8;
+#else
+    constexpr int dbg = 0;
+#endif
     mode &= 0xff;
     const int nchunk = D / ZCH;                                     // even (D % 64 == 0)
     const int nbt = (T + XTB - 1) / XTB;
@@ -994,6 +1003,15 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
     set_item();
     if (!nx_valid) return;                      // uniform over the workgroup
     int cur_u = slot0;
+#ifdef SEMICRF_SCORE_PROBE
+    // cycle accounting of one wave (probe build; tools/score_probe.py): [0] waiting at the barrier, [1] operand reads + matrix
+    // instructions + split + limb stores, [2] the fetch of the chunk after next, [3] the epilogue; written over the (unused)
+    // cells S[0, 1.., :] of a lower-triangle-only launch
+    unsigned long long pc[4] = {0, 0, 0, 0}, pt = __builtin_readcyclecounter();
+#define SCORE_PROBE(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); pc[i] += now_ - pt; pt = now_; } while (0)
+#else
+#define SCORE_PROBE(i) do { } while (0)
+#endif
 
     f32x16 acc0, acc1;
 #pragma unroll
@@ -1106,23 +1124,29 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                SCORE_PROBE(0);
                 if constexpr (both && SEMICRF_SCORE_SCHED3) {
                     half_full(0, g1, 1);
                 } else {
                     multiply(0, ON0, ON1);
                     convert(g1, 1);
                 }
+                SCORE_PROBE(1);
                 fetch(g1);
+                SCORE_PROBE(2);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                SCORE_PROBE(0);
                 if constexpr (both && SEMICRF_SCORE_SCHED3) {
                     half_full(1, g0, 0);
                 } else {
                     multiply(1, ON0, ON1);
                     convert(g0, 0);
                 }
+                SCORE_PROBE(1);
                 fetch(g0);
+                SCORE_PROBE(2);
             }
         };
 #pragma unroll
@@ -1172,10 +1196,16 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
         }
+        SCORE_PROBE(3);
         cur_u += nslots;
         int e2, b2, c2;
         if (!item_of(cur_u, e2, b2, c2)) break;
     }
+#ifdef SEMICRF_SCORE_PROBE
+    if (lane == 0 && !full)
+        for (int i = 0; i < 4; ++i) S[(size_t)C + (size_t)((blockIdx.x * (XTE / 16) + wave) * 4 + i)] = (float)pc[i];
+#endif
+#undef SCORE_PROBE
 }
 
 template <int XTE>
