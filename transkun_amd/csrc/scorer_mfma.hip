@@ -573,8 +573,13 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
     const int row = lane & 31, half = lane >> 5;
     const int wer = wave >> 1, wh = wave & 1;                       // this wave: rows 32*wer.., columns 64*wh.. of the tile
     const unsigned lds0 = z_lds_addr(xlds);
-    const int dbg = mode >> 8;       // timing ablations (SEMICRF_SCORE_DEBUG; results are wrong when set): 1 no matrix
-                                     // instructions, 2 no operand requests, 4 no stores, 8 no LDS reads
+    // timing ablations (SEMICRF_SCORE_DEBUG, debug builds only; results are wrong when set): 1 no matrix instructions, 2 no
+    // operand requests, 4 no stores, 8 no LDS reads; a constant 0 in release builds
+#ifdef SEMICRF_DEBUG_BUILD
+    const int dbg = mode >> 8;
+#else
+    constexpr int dbg = 0;
+#endif
     mode &= 0xff;
     const int nchunk = D / ZCH;
     const int nbt = (T + XTB - 1) / XTB;                            // column tiles
