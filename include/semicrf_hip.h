@@ -51,7 +51,9 @@ extern "C" {
 /* interval_score_fwd, full_square bit 2 (OR it to 0 / 1 / 2): opt-in contraction on the bf16 matrix instructions.  Default
  * (bit clear) is the exact fp32 contraction.  With the bit every operand is split exactly into three bf16 limbs and six of
  * the nine limb products are accumulated in fp32: |S - S_exact| <= 2^-21 * qscale * len * sum_d |q_d k_d| (measured
- * <= 2^-23; tests/test_gpu_parity.py::test_scorer_bf16x3), i.e. fp32-grade but NOT bit-identical to the default, 2x faster. */
+ * <= 2^-22; tests/test_gpu_parity.py::test_scorer_bf16x3), i.e. fp32-grade but NOT bit-identical to the default, 1.3-1.4x
+ * faster.  Operands must be finite with |x| < 2^127 (the first limb rounds to nearest: larger values round to infinity);
+ * limbs below the bf16 normal range (|x| < 2^-110) may be flushed to zero by the matrix instruction. */
 #define SEMICRF_SCORE_BF16X3 4
 
 typedef void* semicrf_stream_t;
