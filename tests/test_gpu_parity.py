@@ -589,7 +589,7 @@ def test_scorer_lower_triangle_only(gpu):
 
 
 BF3_SHAPES = [(20, 256, 64, 0, 0), (37, 300, 128, 1, 0), (33, 257, 256, 0, 1), (8, 128, 64, 2, 2), (90, 691, 256, 0, 2),
-              (64, 384, 256, 0, 0)]
+              (64, 384, 256, 0, 0), (12, 200, 192, 0, 2), (3, 129, 64, 0, 1)]
 
 
 @pytest.mark.gpu
