@@ -98,6 +98,10 @@ int semicrf_debug_device_status(void);
  * 4-chain group); the eight rings of a 32-chain panel group get workgroup indices that are equal modulo 8 (one XCD). */
 int semicrf_debug_wg_ticket(int n_spine, int grid, int block);
 
+/* Test hook, process-wide: force one of interval_score_fwd's kernels where it applies (0 = register loads, 32 = streaming,
+ * 64 / 128 = shared-operand tiles); -1 = automatic choice (the default).  The library reads no environment variables. */
+void semicrf_debug_score_variant(int variant);
+
 /*
  * Log-partition, forward (alpha) sweep.
  * Replaces: computeLogZ (NeuralSemiCRFInterval.py:207-246) and the un-flipped half of

@@ -66,13 +66,16 @@ def test_python_surface_matches_reference():
     assert crf.score.shape == (3, 3, 2) and crf.noiseScore.shape == (2, 2)
 
 
-def test_no_cpu_fallback():
-    from transkun_amd import CRF
-    crf = CRF.NeuralSemiCRFInterval(torch.zeros(4, 4, 2), torch.zeros(3, 2))
-    for call in (lambda: crf.decode(), lambda: crf.computeLogZ(), lambda: crf.logProb([[], []]),
-                 lambda: crf.evalPath([[], []])):
-        with pytest.raises(RuntimeError, match="no CPU fallback"):
-            call()
+def test_gpu_only_entry_points_refuse_cpu_tensors():
+    """CPU tensors are dispatched to the shim's host kernels for the CRF ops (tests/test_cpu_dispatch.py); the GPU-only entry
+    points say so instead of computing anything elsewhere, and no op has a fallback from one device to another."""
+    from transkun_amd import _lib
+    with pytest.raises(RuntimeError, match="only runs on an AMD GPU"):
+        _lib.require_gpu(torch.zeros(1), "ctx")
+    ops = _lib.ops()
+    with pytest.raises((NotImplementedError, RuntimeError)):        # no CPU kernel registered for the segment loop
+        ops.segment_onset_filter(torch.zeros(1, 2, dtype=torch.int32), torch.zeros(2, dtype=torch.int32), 1, 4,
+                                 torch.zeros(1, 2, dtype=torch.int32), torch.zeros(2, dtype=torch.int32), torch.zeros(1, dtype=torch.int32))
 
 
 def test_shape_asserts_like_reference():
@@ -149,7 +152,8 @@ def test_scorer_regrouped_linear_rows():
 
 def test_torch_ops_shim_registers_every_op():
     """libsemicrf_torch.so (LibTorch stable ABI, csrc/torch_ops.cpp) registers the compute entry points of the C ABI as
-    torch.ops.semicrf.*; there is no CPU kernel behind them (a CPU tensor must fail in the dispatcher, not fall back)."""
+    torch.ops.semicrf.*: the CRF ops for the dispatch keys CUDA (HIP kernels) and CPU (the shim's own host kernels), the
+    scorer / gather / segment ops for CUDA only (a CPU tensor fails in the dispatcher; nothing falls back across devices)."""
     import torch
     from transkun_amd import _lib
     ops = _lib.ops()
@@ -158,8 +162,13 @@ def test_torch_ops_shim_registers_every_op():
                  "interval_features_gather", "interval_features_gather_bwd"):
         assert hasattr(ops, name), name
     s = torch.zeros(4, 4, 2); n = torch.zeros(3, 2)
+    lz = torch.full((2,), float("nan"))
+    ops.logz_fwd(s, n, lz, torch.zeros(4, 2), True, torch.zeros(0, dtype=torch.uint8))
+    # all-zero scores: logZ = log(number of segmentations weighted by 2 per frame) -- finite, equal for both chains
+    assert bool(torch.isfinite(lz).all()) and float(lz[0]) == float(lz[1])
     with pytest.raises(NotImplementedError):
-        ops.logz_fwd(s, n, torch.zeros(2), torch.zeros(4, 2), True, torch.zeros(256, dtype=torch.uint8))
+        ops.interval_score_fwd(torch.zeros(2, 4, 8), torch.zeros(2, 4, 8), torch.zeros(2, 4), 2, 4, 8, 8, 8, 1, 1.0, 0, 0,
+                               torch.zeros(4, 4, 2), torch.zeros(3, 2))
 
 
 def test_workgroup_role_map_is_a_permutation():

@@ -290,7 +290,18 @@ def test_scorer_forward_kernels(gpu, variant, C, T, D, mode, full, monkeypatch):
     an fp64 einsum of the same definition (LayersTransformer.py:406-441)."""
     from transkun_amd import synth
     from transkun_amd.scorer import _interval_score_raw
-    monkeypatch.setenv("SEMICRF_SCORE_VARIANT", str(variant))
+    from transkun_amd import _lib
+    lib = _lib.load()
+    lib.semicrf_debug_score_variant(variant)            # process-wide test hook (the library reads no environment)
+    try:
+        _scorer_forward_case(gpu, C, T, D, mode, full)
+    finally:
+        lib.semicrf_debug_score_variant(-1)
+
+
+def _scorer_forward_case(gpu, C, T, D, mode, full):
+    from transkun_amd import synth
+    from transkun_amd.scorer import _interval_score_raw
     q = synth.hash_normal(C * T * D, 71, "cpu").view(C, T, D).to(gpu)
     k = synth.hash_normal(C * T * D, 72, "cpu").view(C, T, D).to(gpu)
     dg = synth.hash_normal(C * T, 73, "cpu").view(C, T).to(gpu)
@@ -964,6 +975,58 @@ def test_two_node_pattern_both_orders_and_dtype(gpu):
     d = grads(lambda c: c.logProb(iv), torch.float64)
     assert d[0].dtype == torch.float64 and d[1].dtype == torch.float64 and d[2].dtype == torch.float64
     assert float((d[0].float() - ref[0]).abs().max()) <= 1e-5 * float(ref[0].abs().max())
+
+
+@pytest.mark.gpu
+def test_two_node_pattern_with_more_consumers(gpu):
+    """The advisor's case (round 2): `score` has MORE consumers than the two CRF nodes -- a regulariser on the score tensor
+    created before / after the CRF calls, a second computeLogZ(), a second backward through a retained graph.  The hub owns
+    the pass's dense gradient, so nothing depends on which gradient reaches autograd's buffers first."""
+    from transkun_amd import CRF, synth
+    T, B = 96, 10
+    score, noise = synth.crf_inputs(T, B, 19, gpu)
+    iv = synth.synthetic_intervals(T, B, seed=19)
+    w = synth.hash_normal(B, 20, gpu)
+    r = synth.hash_normal(T * T * B, 21, gpu).view(T, T, B)
+
+    def run(build):
+        s = score.clone().requires_grad_(); n = noise.clone().requires_grad_()
+        loss = build(s, n)
+        loss.backward()
+        return s.grad.clone(), n.grad.clone()
+
+    def ref(s, n):
+        c = CRF.NeuralSemiCRFInterval(s, n)
+        return (c.logProb(iv) * w).sum() + (s * r).sum()
+    want = run(ref)
+
+    def reg_after(s, n):
+        c = CRF.NeuralSemiCRFInterval(s, n)
+        lp = c.evalPath(iv) - c.computeLogZ()
+        return (lp * w).sum() + (s * r).sum()                   # third consumer created AFTER computeLogZ: its gradient arrives first
+    def reg_before(s, n):
+        reg = (s * r).sum()
+        c = CRF.NeuralSemiCRFInterval(s, n)
+        return (c.evalPath(iv) * w).sum() - (c.computeLogZ() * w).sum() + reg
+    def two_logz(s, n):
+        c = CRF.NeuralSemiCRFInterval(s, n)
+        return ((c.evalPath(iv) - 0.25 * c.computeLogZ() - 0.75 * c.computeLogZ(noBackward=True)) * w).sum() + (s * r).sum()
+    def mixed(s, n):
+        c = CRF.NeuralSemiCRFInterval(s, n)
+        return ((0.5 * c.logProb(iv) + 0.5 * (c.evalPath(iv) - c.computeLogZ())) * w).sum() + (s * r).sum()
+    for build in (reg_after, reg_before, two_logz, mixed):
+        got = run(build)
+        for x, y in zip(got, want):
+            assert float((x - y).abs().max()) <= 2e-5 * float(y.abs().max()), build.__name__
+    # a retained graph, differentiated twice: the second pass must not see anything of the first
+    s = score.clone().requires_grad_(); n = noise.clone().requires_grad_()
+    c = CRF.NeuralSemiCRFInterval(s, n)
+    loss = ((c.evalPath(iv) - c.computeLogZ()) * w).sum() + (s * r).sum()
+    g1 = torch.autograd.grad(loss, [s, n], retain_graph=True)
+    g2 = torch.autograd.grad(loss, [s, n])
+    for x, y, z in zip(g1, g2, want):
+        assert torch.equal(x, y)
+        assert float((x - z).abs().max()) <= 2e-5 * float(z.abs().max())
 
 
 # ---- transcription segment loop (SURVEY 8f rank 3) -----------------------------------------------------------------

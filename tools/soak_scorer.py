@@ -18,15 +18,15 @@ for it in range(n_cases):
     k = synth.hash_normal(C * T * D, 2000 + it, dev).view(C, T, D)
     dg = synth.hash_normal(C * T, 3000 + it, dev).view(C, T)
     qs = 1.0 / D ** 0.5
-    os.environ["SEMICRF_SCORE_VARIANT"] = "0"
+    lib.semicrf_debug_score_variant(0)
     ref, _ = _interval_score_raw(q, k, dg, T, C, D, qs, mode, full)
-    for v in ("32", "64", "128"):
-        os.environ["SEMICRF_SCORE_VARIANT"] = v
+    for v in (32, 64, 128):
+        lib.semicrf_debug_score_variant(v)
         got, _ = _interval_score_raw(q, k, dg, T, C, D, qs, mode, full)
         err = float((got - ref).abs().max()) / float(ref.abs().max())
         worst_f = max(worst_f, err)
         assert err < 3e-6, (T, C, D, mode, full, v, err)
-    os.environ.pop("SEMICRF_SCORE_VARIANT")
+    lib.semicrf_debug_score_variant(-1)
     dS = synth.hash_normal(T * T * C, 4000 + it, dev).view(T, T, C)
     nws = int(lib.interval_score_bwd_workspace_bytes(C, T, D)); assert nws > 0
     ws = torch.full((nws,), 0xFF, dtype=torch.uint8, device=dev)

@@ -4,7 +4,8 @@ Drop-in for /root/reference/transkun/CRF/NeuralSemiCRFInterval.py (class at :553
 constructor, method names, defaults, argument meaning and result types.  All arithmetic runs
 in hand-written gfx950 HIP kernels behind the C ABI of include/semicrf_hip.h; this file only
 validates shapes, marshals the Python interval lists to/from packed int32 buffers and wires the
-kernels into autograd.  There is no CPU path: CPU tensors raise RuntimeError.
+kernels into autograd.  CPU tensors are dispatched to the shim's own host kernels (csrc/cpu_ops.cpp; config #1,
+crfMinimalExample on the CPU); a GPU tensor is never computed anywhere but in the HIP kernels.
 
 Arithmetic is fp32 (the reference's callers are fp32 throughout); other floating dtypes are computed in fp32 and the
 results and gradients are cast back to the input dtype, as the reference preserves it.
@@ -41,8 +42,9 @@ def _check_inputs(score: torch.Tensor, noiseScore: torch.Tensor):
     T, B = score.shape[0], score.shape[2]
     assert noiseScore.shape[0] == T - 1
     assert noiseScore.shape[1] == B
-    _lib.require_gpu(score, "score")
-    _lib.require_gpu(noiseScore, "noiseScore")
+    _lib.require_device(score, "score")
+    _lib.require_device(noiseScore, "noiseScore")
+    assert score.device == noiseScore.device
     return T, B
 
 
@@ -135,7 +137,7 @@ def _odd_pad(score) -> bool:
     """The persistent kernels take any NBatch >= 2 (an odd one natively since round 2: 4-byte aligned 16-byte accesses).
     A single chain is run with one all-zero ghost chain appended instead of on the ~100x slower row-sequential kernels;
     the ghost chain's outputs are dropped."""
-    return score.shape[2] == 1 and score.shape[0] >= 2 and _lib.get_impl() == 0
+    return score.is_cuda and score.shape[2] == 1 and score.shape[0] >= 2 and _lib.get_impl() == 0
 
 
 def _pad1(t):
@@ -206,15 +208,18 @@ def _gout(grad_output: torch.Tensor, B: int) -> torch.Tensor:
 # autograd nodes
 # --------------------------------------------------------------------------------------
 
-# The reference's own call pattern is evalPath(...) - computeLogZ() as TWO autograd nodes (ModelTransformer.py:263-265).
+# The reference's own call pattern is crf.evalPath(...) - crf.computeLogZ() as TWO autograd nodes (ModelTransformer.py:263-265).
 # Differentiated naively, the evalPath node returns a dense zero [T,T,B] tensor with a few thousand cells set and autograd
-# adds it to the dense gradient of the logZ node: two more passes over 1.48 GB at T=1024, NBatch=352.  Both nodes belong
-# to the same backward pass and the logZ node (created later) runs first; it leaves the ADDRESS of its dense gradient here
-# (no reference: autograd must stay the only owner, or it would copy the buffer), keyed by the autograd graph-task id and
-# the identity of the score tensor object, and the evalPath node of the same pass and the same tensor scatters its cells
-# INTO that buffer (same stream; the engine holds the buffer until both nodes have run) and contributes no tensor of its
-# own.  Any other order or combination falls back to the dense gradient.
-_SHARED_GRAD = {"task": -1, "key": None, "dscore": 0, "dnoise": 0}
+# adds it to the dense gradient of the logZ node: two more passes over 1.48 GB at T=1024, NBatch=352.
+#
+# The methods of one NeuralSemiCRFInterval object therefore hang their nodes on a private HUB node (_Hub: an identity on
+# (score, noiseScore) that only this object knows).  In backward the children do not hand dense gradients to the engine: they
+# DEPOSIT them in the hub's accumulator of the running graph task -- the first dense gradient becomes the buffer, later dense
+# ones are added in place, an evalPath node scatters its +-gout cells straight into it (or is parked until a dense gradient
+# arrives) -- and return None; the hub's own backward, which the engine runs after every child of the pass, hands the
+# buffer on.  The accumulator OWNS the tensor (a strong reference, no raw addresses), so any number of consumers of `score`
+# in any order is safe: consumers outside this object meet the hub's result one level up, in the engine's own buffers.
+# The module-level functions (no object, no hub) differentiate the plain way.
 
 
 def _graph_task_id() -> int:
@@ -222,18 +227,103 @@ def _graph_task_id() -> int:
     return int(fn()) if fn is not None else -1
 
 
+class _HubState:
+    """Gradient accumulators of one CRF object's hub, one per graph task in flight."""
+
+    def __init__(self):
+        self.acc = {}
+
+    def _slot(self, tid):
+        a = self.acc.get(tid)
+        if a is None:
+            a = self.acc[tid] = {"ds": None, "dn": None, "paths": [], "shape": None, "dev": None}
+            if len(self.acc) > 8:                       # passes that never reached the hub (an error mid-backward)
+                for k in list(self.acc)[:-8]:
+                    del self.acc[k]
+        return a
+
+    @staticmethod
+    def _scatter(a, path):
+        g, pairs, offsets, K, T, B = path
+        _eval_path_bwd_raw(g, T, B, pairs, offsets, a["ds"], a["dn"], K)
+
+    def deposit_dense(self, tid, dscore, dnoise):
+        a = self._slot(tid)
+        if a["ds"] is None:
+            a["ds"], a["dn"] = dscore, dnoise
+            for p in a["paths"]:
+                self._scatter(a, p)
+            a["paths"] = []
+        else:
+            a["ds"].add_(dscore)
+            if dnoise is not None and a["dn"] is not None:
+                a["dn"].add_(dnoise)
+
+    def deposit_path(self, tid, g, pairs, offsets, K, T, B):
+        a = self._slot(tid)
+        a["shape"], a["dev"] = (T, B), g.device
+        if a["ds"] is not None:
+            self._scatter(a, (g, pairs, offsets, K, T, B))
+        else:
+            a["paths"].append((g, pairs, offsets, K, T, B))
+
+    def collect(self, tid):
+        a = self.acc.pop(tid, None)
+        if a is None:
+            return None, None
+        if a["ds"] is None and a["paths"]:              # only evalPath nodes were reached: the dense zero tensor after all
+            T, B = a["shape"]
+            a["ds"] = torch.zeros(T, T, B, dtype=torch.float32, device=a["dev"])
+            a["dn"] = torch.zeros(max(T - 1, 0), B, dtype=torch.float32, device=a["dev"])
+            for p in a["paths"]:
+                self._scatter(a, p)
+        return a["ds"], a["dn"]
+
+
+class _Hub(torch.autograd.Function):
+    """Identity on (score, noiseScore), private to one NeuralSemiCRFInterval object: collects its children's gradients."""
+
+    @staticmethod
+    def forward(ctx, score, noiseScore, state):
+        ctx.state = state
+        ctx.set_materialize_grads(False)
+        ctx.in_dtypes = (score.dtype, noiseScore.dtype)
+        ctx.shapes = (score.shape, noiseScore.shape)
+        return score.detach(), noiseScore.detach()
+
+    @staticmethod
+    def backward(ctx, gs, gn):
+        ds, dn = ctx.state.collect(_graph_task_id())
+        if gs is not None:                              # a child that returned its gradient the plain way
+            ds = gs.float() if ds is None else ds.add_(gs)
+        if gn is not None:
+            dn = gn.float() if dn is None else dn.add_(gn)
+        if ds is not None:
+            ds = ds.reshape(ctx.shapes[0]).to(ctx.in_dtypes[0])
+        if dn is not None:
+            dn = dn.reshape(ctx.shapes[1]).to(ctx.in_dtypes[1])
+        return ds, dn, None
+
+
+def _hub_of(state):
+    """The state to deposit in during this backward pass, or None (no hub / no graph task id: return gradients plainly)."""
+    if state is None or torch.is_grad_enabled() or _graph_task_id() < 0:
+        return None
+    return state
+
+
 class ComputeLogZFasterGrad(torch.autograd.Function):
     """logZ with a hand-written gradient (reference :459-475), recompute-in-backward flavour."""
 
     @staticmethod
-    def forward(ctx, score, noiseScore):
+    def forward(ctx, score, noiseScore, hub=None):
         score_c, noise_c = _prep(score), _prep(noiseScore)
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         logz, v = _logz_fwd_raw(score_c, noise_c, want_v=need)
         if need:
             ctx.save_for_backward(score_c, noise_c, v, logz)
         ctx.in_dtypes = (score.dtype, noiseScore.dtype)
-        ctx.key = (id(score), id(noiseScore), score_c.data_ptr(), tuple(score_c.shape))
+        ctx.hub = hub
         return logz.to(score.dtype)
 
     @staticmethod
@@ -241,24 +331,26 @@ class ComputeLogZFasterGrad(torch.autograd.Function):
         score, noise, v, logz = ctx.saved_tensors
         B = score.shape[2]
         dscore, dnoise, _ = _logz_bwd_raw(score, noise, v, logz, _gout(grad_output, B))
-        tid = _graph_task_id()
-        if tid >= 0 and ctx.in_dtypes == (torch.float32, torch.float32) and _odd_pad(score) is False:
-            _SHARED_GRAD.update(task=tid, key=ctx.key, dscore=dscore.data_ptr(), dnoise=dnoise.data_ptr())
-        return dscore.to(ctx.in_dtypes[0]), dnoise.to(ctx.in_dtypes[1])
+        hub = _hub_of(ctx.hub)
+        if hub is not None:
+            hub.deposit_dense(_graph_task_id(), dscore, dnoise)
+            return None, None, None
+        return dscore.to(ctx.in_dtypes[0]), dnoise.to(ctx.in_dtypes[1]), None
 
 
-computeLogZFasterGrad = ComputeLogZFasterGrad.apply
+def computeLogZFasterGrad(score, noiseScore):
+    return ComputeLogZFasterGrad.apply(score, noiseScore)
 
 
 class _EvalPath(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, score, noiseScore, pairs, offsets):
+    def forward(ctx, score, noiseScore, pairs, offsets, hub=None):
         score_c, noise_c = _prep(score), _prep(noiseScore)
         ctx.save_for_backward(pairs, offsets)
         ctx.shape = (score_c.shape[0], score_c.shape[2])
-        ctx.key = (id(score), id(noiseScore), score_c.data_ptr(), tuple(score_c.shape))
         ctx.K = getattr(pairs, "_semicrf_K", pairs.shape[0])
         ctx.in_dtypes = (score.dtype, noiseScore.dtype)
+        ctx.hub = hub
         return _eval_path_raw(score_c, noise_c, pairs, offsets).to(score.dtype)
 
     @staticmethod
@@ -266,25 +358,16 @@ class _EvalPath(torch.autograd.Function):
         pairs, offsets = ctx.saved_tensors
         T, B = ctx.shape
         g = _gout(grad_output, B)
-        sh = _SHARED_GRAD
-        if (sh["dscore"] and sh["task"] == _graph_task_id() and sh["key"] == ctx.key
-                and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]):
-            # the logZ node of this pass has already produced the dense gradient of the same score tensor: add the path
-            # cells to it in place (raw C ABI call on the buffer's address); this node contributes nothing of its own
-            ds_ptr, dn_ptr = sh["dscore"], sh["dnoise"]
-            sh.update(task=-1, key=None, dscore=0, dnoise=0)
-            lib = _lib.load()
-            with torch.cuda.device(g.device):
-                rc = lib.semicrf_eval_path_bwd(_lib.ptr(g), T, B, _lib.ptr(pairs), int(ctx.K), _lib.ptr(offsets),
-                                               _lib._vp(ds_ptr), _lib._vp(dn_ptr) if dn_ptr else None, _lib.stream_of(g))
-            _lib.check(rc, "semicrf_eval_path_bwd")
-            return None, None, None, None
-        sh.update(task=-1, key=None, dscore=0, dnoise=0)
+        hub = _hub_of(ctx.hub)
+        if hub is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            # the path cells go straight into the pass's dense gradient (owned by the hub); nothing of its own
+            hub.deposit_path(_graph_task_id(), g, pairs, offsets, ctx.K, T, B)
+            return None, None, None, None, None
         dscore = torch.zeros(T, T, B, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
         dnoise = torch.zeros(max(T - 1, 0), B, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1] else None
         _eval_path_bwd_raw(g, T, B, pairs, offsets, dscore, dnoise, ctx.K)
         return (dscore.to(ctx.in_dtypes[0]) if dscore is not None else None,
-                dnoise.to(ctx.in_dtypes[1]) if dnoise is not None else None, None, None)
+                dnoise.to(ctx.in_dtypes[1]) if dnoise is not None else None, None, None, None)
 
 
 class _LogProb(torch.autograd.Function):
@@ -402,6 +485,20 @@ class NeuralSemiCRFInterval:
         """
         self.score = score
         self.noiseScore = noiseScore
+        self._hub = None            # (id(score), id(noiseScore), score alias, noise alias, _HubState)
+
+    def _hubbed(self):
+        """(score, noiseScore, hub state) for the differentiable methods: aliases behind this object's private hub node when a
+        gradient can flow, the tensors themselves (hub None) otherwise."""
+        s, n = self.score, self.noiseScore
+        if not (torch.is_grad_enabled() and (s.requires_grad or n.requires_grad)) :
+            return s, n, None
+        h = self._hub
+        if h is None or h[0] is not s or h[1] is not n:
+            state = _HubState()
+            hs, hn = _Hub.apply(s, n, state)
+            h = self._hub = (s, n, hs, hn, state)
+        return h[2], h[3], h[4]
 
     def decode(self, forcedStartPos=None, forward=False):
         if forward:
@@ -411,15 +508,16 @@ class NeuralSemiCRFInterval:
 
     def evalPath(self, intervals):
         """compute the unnormalized score"""
-        return evalPath(intervals, self.score, self.noiseScore)
+        T, B = _check_inputs(self.score, self.noiseScore)
+        pairs, offsets = pack_intervals(intervals, T, B, self.score.device)
+        s, n, hub = self._hubbed()
+        return _EvalPath.apply(s, n, pairs, offsets, hub)
 
     def computeLogZ(self, noBackward=False):
         """compute the log normalization factor"""
-        if noBackward:
-            return computeLogZ(self.score, self.noiseScore)
-        else:
-            _check_inputs(self.score, self.noiseScore)
-            return computeLogZFasterGrad(self.score, self.noiseScore)
+        _check_inputs(self.score, self.noiseScore)
+        s, n, hub = self._hubbed()
+        return ComputeLogZFasterGrad.apply(s, n, hub)
 
     def logProb(self, intervals, noBackward=False):
         T, B = _check_inputs(self.score, self.noiseScore)

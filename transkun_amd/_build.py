@@ -91,14 +91,15 @@ def build_torch_shim(force: bool = False, verbose: bool = False) -> str:
     has loaded anyway).  No hipify, no torch.utils.cpp_extension."""
     import torch
     src = os.path.join(CSRC, "torch_ops.cpp")
-    hdr = os.path.join(HERE, "..", "include", "semicrf_hip.h")
-    if (not force and os.path.exists(TORCH_LIB)
-            and os.path.getmtime(TORCH_LIB) > max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(LIB))):
+    cpu_src = os.path.join(CSRC, "cpu_ops.cpp")           # the CPU dispatch key's host kernels (plain C++, OpenMP)
+    deps = [src, cpu_src, os.path.join(CSRC, "cpu_ops.h"), os.path.join(HERE, "..", "include", "semicrf_hip.h"), LIB]
+    if not force and os.path.exists(TORCH_LIB) and os.path.getmtime(TORCH_LIB) > max(os.path.getmtime(d) for d in deps):
         return TORCH_LIB
     troot = os.path.dirname(torch.__file__)
     cxx = os.environ.get("CXX") or shutil.which("g++") or "c++"
     tmp = TORCH_LIB + ".tmp"
-    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(troot, "include"), src, "-o", tmp,
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-fno-fast-math", "-I" + os.path.join(troot, "include"), src, cpu_src,
+           "-o", tmp,
            "-L" + HERE, "-l:libsemicrf_hip.so", "-L" + os.path.join(troot, "lib"), "-ltorch_cpu", "-ltorch_hip", "-lc10",
            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(troot, "lib")]
     if verbose:

@@ -7,7 +7,9 @@ to libsemicrf_hip.so itself -- workspace sizes, the implementation switch, the d
 
 torch is imported first on purpose: the library needs libamdhip64.so.7 and must bind to the
 HIP runtime torch has already loaded (one runtime per process), not to a second copy.
-There is NO fallback: a missing library or a non-GPU tensor raises.
+There is NO fallback: a missing library raises, and a GPU tensor is only ever computed by the HIP kernels.  CPU tensors are
+dispatched (by torch's dispatcher, on the tensors' device) to the product's own host kernels in the same shim
+(csrc/cpu_ops.cpp) -- the reference class runs wherever its tensors live (crfMinimalExample, BASELINE config #1).
 """
 from __future__ import annotations
 
@@ -39,6 +41,7 @@ _SIGS = {
     "semicrf_get_impl": (ctypes.c_int, []),
     "semicrf_debug_device_status": (ctypes.c_int, []),
     "semicrf_debug_wg_ticket": (_i, [_i, _i, _i]),
+    "semicrf_debug_score_variant": (None, [_i]),
     "semicrf_logz_fwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "semicrf_logz_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "semicrf_viterbi": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i64, _vp, _vp, _sz, _vp]),
@@ -73,7 +76,7 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise SemiCRFLibraryError(
                 f"{LIB_PATH} not found: build it with `python -m transkun_amd._build` "
-                "(hipcc --offload-arch=gfx950).  transkun_amd has no CPU fallback.")
+                "(hipcc --offload-arch=gfx950).  transkun_amd never falls back to another implementation.")
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
@@ -130,16 +133,23 @@ def stream_of(t: torch.Tensor):
 
 
 def require_gpu(t: torch.Tensor, name: str) -> None:
+    """For the entry points that exist on the GPU only (interval scorer kernels, attribute gather, segment loop)."""
     if not t.is_cuda:
-        raise RuntimeError(
-            f"transkun_amd: `{name}` is on {t.device}; this layer only runs on an AMD GPU through its "
-            "HIP kernels (there is deliberately no CPU fallback)")
+        raise RuntimeError(f"transkun_amd: `{name}` is on {t.device}; this entry point only runs on an AMD GPU through its HIP kernels")
+
+
+def require_device(t: torch.Tensor, name: str) -> None:
+    """The CRF entry points take GPU tensors (HIP kernels) or CPU tensors (the shim's host kernels); nothing else."""
+    if not (t.is_cuda or t.device.type == "cpu"):
+        raise RuntimeError(f"transkun_amd: `{name}` is on {t.device}; supported: an AMD GPU (HIP kernels) or the CPU (host kernels)")
 
 
 _WS_BYTES = {}
 
 
 def workspace(op: int, T: int, B: int, device) -> torch.Tensor:
+    if torch.device(device).type == "cpu":
+        return torch.empty(0, dtype=torch.uint8)          # the host kernels allocate their own scratch
     key = (op, T, B)
     n = _WS_BYTES.get(key)
     if n is None:
@@ -156,7 +166,8 @@ def leased_workspace(op: int, T: int, B: int, device, kind: str = "") -> torch.T
     T, B), kept alive here, filled once -- every launch leaves it clean for the next one on the same stream.
     SEMICRF_NO_LEASE=1 falls back to a fresh buffer per call (filled by every launch)."""
     global _LEASES
-    if os.environ.get("SEMICRF_NO_LEASE") or os.environ.get("SEMICRF_DEBUG_KEEP_WS"):
+    device = torch.device(device)
+    if device.type == "cpu" or os.environ.get("SEMICRF_NO_LEASE") or os.environ.get("SEMICRF_DEBUG_KEEP_WS"):
         return workspace(op, T, B, device)
     if _LEASES is None:
         _LEASES = collections.OrderedDict()

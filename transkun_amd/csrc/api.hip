@@ -76,6 +76,7 @@ int launch_persist_sweep(int mode, int dir, const float* score, const float* noi
                          float* last_out, int* code, void* ws, hipStream_t stream, int lease, unsigned lease_tag);
 int persist_set_host_abort_word(unsigned* devptr);
 int persist_wg_ticket(int nSpine, int grid, int b);
+void set_score_variant(int v);
 
 int read_and_clear_device_status();
 
@@ -146,7 +147,8 @@ static int lease_acquire(void* ws, int op, int T, int B, unsigned* tag, hipStrea
     if (L.count == 0u) *tag = ++L.count;
     return clean ? 2 : 1;
 }
-// a sweep that could not be enqueued leaves nothing behind: the lease does not count as clean
+// a sweep that could not be enqueued leaves nothing behind, and a launch of the row-sequential kernels (impl 1) carves its
+// scratch out of the same buffer: either way the lease no longer counts as clean
 static void lease_failed(void* ws)
 {
     std::lock_guard<std::mutex> lk(g_lease_mu);
@@ -166,6 +168,7 @@ void semicrf_set_impl(int impl) { g_impl.store(impl); }
 int semicrf_get_impl(void) { return g_impl.load(); }
 int semicrf_debug_device_status(void) { return read_and_clear_device_status(); }
 int semicrf_debug_wg_ticket(int n_spine, int grid, int block) { return persist_wg_ticket(n_spine, grid, block); }
+void semicrf_debug_score_variant(int variant) { set_score_variant(variant); }
 
 int semicrf_workspace_register(void* ws, size_t ws_bytes)
 {
@@ -245,6 +248,7 @@ int semicrf_logz_fwd(const float* score, const float* noise, int T, int B, float
             set_error("persistent sweep could not be enqueued (too many chain chunks for this device)"); return SEMICRF_ELAUNCH;
         }
     } else {
+        lease_failed(ws);
         launch_rowseq_sweep(0, 0, score, noise, T, B, vv, nullptr, logZ, st);
     }
     SEMICRF_CHECK_LAUNCH("semicrf_logz_fwd");
@@ -273,6 +277,7 @@ int semicrf_logz_bwd(const float* score, const float* noise, const float* v, con
             set_error("persistent sweep could not be enqueued (too many chain chunks for this device)"); return SEMICRF_ELAUNCH;
         }
     } else {
+        lease_failed(ws);
         launch_rowseq_sweep(0, 1, score, noise, T, B, q, nullptr, nullptr, st);
         launch_marginals(score, noise, v, q, logZ, gout, T, B, dScore, dNoise, st);
     }
@@ -298,6 +303,7 @@ int semicrf_beta(const float* score, const float* noise, int T, int B, float* be
             set_error("persistent sweep could not be enqueued (too many chain chunks for this device)"); return SEMICRF_ELAUNCH;
         }
     } else {
+        lease_failed(ws);
         launch_rowseq_sweep(0, 1, score, noise, T, B, beta, nullptr, nullptr, st);
     }
     SEMICRF_CHECK_LAUNCH("semicrf_beta");
@@ -328,6 +334,7 @@ int semicrf_viterbi(const float* score, const float* noise, int T, int B, const 
             set_error("persistent sweep could not be enqueued (too many chain chunks for this device)"); return SEMICRF_ELAUNCH;
         }
     } else {
+        lease_failed(ws);
         launch_rowseq_sweep(1, forward ? 0 : 1, score, noise, T, B, u, code, nullptr, st);
     }
     int nerr = 0, estride = 0;

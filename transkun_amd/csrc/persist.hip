@@ -47,10 +47,7 @@
 namespace semicrf {
 
 constexpr int PB = 16;             // positions per block
-#ifndef SEMICRF_RING
-#define SEMICRF_RING 4
-#endif
-constexpr int RING = SEMICRF_RING;            // waves per ring; band = RING-1 off-diagonal blocks + the diagonal block
+constexpr int RING = 4;            // waves per ring; band = RING-1 off-diagonal blocks + the diagonal block (5 / 6 measured slower)
 constexpr int RS = 4;              // chains per ring (one per lane)
 constexpr int GS = RS;              // chains per spine workgroup
 constexpr int GP = 32;             // chains per panel task (4 per lane)
@@ -58,12 +55,6 @@ constexpr int GP = 32;             // chains per panel task (4 per lane)
 #define SEMICRF_TPT 12            // 12 tiles per task and a last part of at least 4: 184-186 us vs 188-190 with 16 / 1 (T=1024, NBatch=352)
 #endif
 constexpr int TPT = SEMICRF_TPT;   // tiles (column blocks) per panel task
-#ifndef SEMICRF_TICKET_ATOMIC
-#define SEMICRF_TICKET_ATOMIC 0
-#endif
-#ifndef SEMICRF_STATIC_FIRST
-#define SEMICRF_STATIC_FIRST 1
-#endif
 #ifndef SEMICRF_LEADT
 #define SEMICRF_LEADT 4
 #endif
@@ -81,7 +72,7 @@ __host__ __device__ inline void part_tiles(int q, int part, int& m0, int& m1)
 #ifndef SEMICRF_NT
 #define SEMICRF_NT 640
 #endif
-constexpr int NT = SEMICRF_NT;     // threads per workgroup (10 waves: a spine workgroup = 4 ring + loader + far + 2 recent + 2 streaming waves)
+constexpr int NT = SEMICRF_NT;     // threads per workgroup (10 waves: a spine workgroup = 4 ring + loader + far + 4 streaming waves)
 constexpr int MAX_CHUNKS = 16;     // chain chunks (launches) per call
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
@@ -100,32 +91,11 @@ constexpr float RESC_LIFT = 96.0f, RESC_HI = 108.0f, RESC_EARLY = 56.0f;
 constexpr unsigned CTRL_INIT = 0xffffffffu;  // initial value of every workspace word (one 0xff fill per launch)
 constexpr unsigned U_EMPTY = 0xffffffffu;  // not-yet-published u (a NaN pattern the spine never stores): the value is its own flag
 
-#ifndef SEMICRF_LOADER_PACE
-#define SEMICRF_LOADER_PACE 0      // s_sleep argument after every second band load of the loader wave (0: back to back)
-#endif
-#ifndef SEMICRF_DIET
-#define SEMICRF_DIET 1             // 1: forward-sweep panel math on packed fp32 pairs, exponent argument formed by one fma
-#endif
-#ifndef SEMICRF_EARLY_REFILL
-#define SEMICRF_EARLY_REFILL 0     // 1: a stage is refilled as soon as its tile sits in registers (before the math), not after it
-#endif
-#ifndef SEMICRF_LDS_REDUCE
-#define SEMICRF_LDS_REDUCE 1      // 1: the panels' final reduction over the column slots goes through LDS (see panel_role)
-#endif
-#ifndef SEMICRF_TASK_PREFETCH
-#define SEMICRF_TASK_PREFETCH 0     // (measured slower: 220 vs 206 us at T=1024, 720 vs 633 at T=2048) 1: a panel wave that is behind the ring takes its next task while the last tiles of the current one are in flight
-#endif
-#ifndef SEMICRF_SCHED
-#define SEMICRF_SCHED 0            // 0: one task queue in (block, part) order; 1: per-part queues, earliest block first among the
-#endif                             //    parts whose columns the ring has already published (see panel_next_task)
-// control words of a launch (all start at 0xffffffff).  Three separate 128-byte lines: counters that take atomics must
+// control words of a launch (all start at 0xffffffff).  Separate 128-byte lines: counters that take atomics must
 // not share a line with words that are polled (hundreds of idle waves reading a line that others update atomically
 // slow every dequeue down to tens of microseconds).
 constexpr size_t CTRL_WORDS = 256;   // control words per chain chunk
 constexpr int CTRL_EXIT = 64;         // [64]: workgroups that have left (leased workspaces: the last one resets the control words)
-constexpr int CTRL_QHEAD = 32;        // [32 + i]: next task of scheduler queue i (atomic counters only)
-constexpr int CTRL_PROG = 128;        // [128]: block the first spine has published; [129 + i]: block queue i hands out
-constexpr int MAX_QUEUES = 63;        // one lane per queue in the peek (T <= 16 * (RING + 63 * TPT))
 
 typedef unsigned long long u64;
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -145,19 +115,13 @@ struct SweepParams {
     int hybridPanelWaves;  // panel waves of a spine workgroup (0..2)
     int hybridStart;       // ... which start once the ring has reached this row block
     int zeroWaves;         // GRAD: waves per panel workgroup that write the zero upper triangle of dScore (0: separate kernel)
-    int xr;                // the newest xr far tiles of every block are left to the RECENT waves of the spine workgroups (0: none)
-    int recentWaves;       // recent waves per spine workgroup
-    int rpart;             // index of the recent waves' slab in farg
-    int fullLead;          // full column parts enter the task queue this many blocks before the last part of their block
-    int runAhead;          // EDF scheduler: a last-part task of block k may be taken once the ring has published block k-4-runAhead
     unsigned tag;          // nonzero launch epoch
     int selfclean;         // leased workspace (semicrf_workspace_register): the launch leaves u and its control words as the fill would
     unsigned dbg;          // SEMICRF_DEBUG_FLAGS (timing experiments only; results are wrong when set):
                            // 1 spine ignores far partials, 2 panels exit at once, 4 panels do not wait for u,
                            // 8 spine exits at once, 16 spine 0 records per-block timestamps,
                            // 32 panels only stream their cells (no granules, no math)
-    unsigned* ctrl;        // [0] (ticket: unused unless SEMICRF_TICKET_ATOMIC), [1] error, [2] panel task queue head, [3] zero-fill row queue head,
-                           // [32..] scheduler queues (SEMICRF_SCHED=1), [64] workgroups that have left (leases), [128..] scheduling hints
+    unsigned* ctrl;        // [1] error, [2] panel task queue head, [3] zero-fill row queue head, [64] workgroups that have left (leases)
     u64* ts;               // [2T] debug timestamps of spine 0, ring 0 (dbg & 16)
     unsigned* ug;          // [T][B] u as float bits (position-major: index p*B + c); U_EMPTY until the spine publishes it
     u64* farg;             // [parts][T][B] granules of far-field partials (part = column range of TPT tiles)
@@ -293,14 +257,8 @@ __device__ __forceinline__ bool spin_abort(unsigned* ctrl, int& spins, int limit
 //     next broadcast simply reads the lanes of the next row,
 //   * row jj+1 receives its last term through logaddexp2(Vp, u + W) where Vp (everything but that term)
 //     is refreshed one step ahead by the (M,S) push that runs beside it.
-#ifndef SEMICRF_NRBUF
-#define SEMICRF_NRBUF 4
-#endif
-#ifndef SEMICRF_NLOADER
-#define SEMICRF_NLOADER (RING >= 5 ? 2 : 1)
-#endif
-constexpr int NLOADER = SEMICRF_NLOADER;          // loader waves per ring (a row block is RING tiles)
-constexpr int NRBUF = SEMICRF_NRBUF;                  // row-block buffers between the loader and the ring
+constexpr int NLOADER = 1;                            // loader waves per ring (a row block is RING tiles)
+constexpr int NRBUF = 4;                              // row-block buffers between the loader and the ring
 constexpr int TILE_BYTES = PB * PB * RS * 4;          // 4096: [column u][row r][chain] floats
 constexpr int NCONST = 3;                             // per-row constants: diagonal cell, noise, alpha (GRAD)
 constexpr int LDS_TILES = 0;
@@ -380,7 +338,6 @@ __device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* 
                 off = off < last4 ? off : last4;
                 __builtin_amdgcn_global_load_lds((gbl_void_t*)(score + off),
                                                  (lds_void_t*)(lds + LDS_TILES + (slot * RING + i) * TILE_BYTES + q * 1024), 16, 0, 0);
-                if (SEMICRF_LOADER_PACE > 0 && (q & 1)) __builtin_amdgcn_s_sleep(SEMICRF_LOADER_PACE);
             }
         }
         const int prow_c = kr * PB + cr < T ? kr * PB + cr : T - 1;
@@ -441,9 +398,8 @@ __device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds
     for (int k = RING; k < K; ++k) {
         const int prow = k * PB + r;
         const bool rvalid = cvalid && prow < T;
-        // parts of block k: the panels' column parts of its far tiles 0 .. k-RING-xr, plus the recent waves' partial
-        const int npanel = k >= RING + P.xr ? nparts_of(k - RING - P.xr) : 0;
-        const int nparts = npanel + (P.xr > 0 ? 1 : 0);
+        // parts of block k: the panels' column parts of its far tiles 0 .. k-RING
+        const int nparts = nparts_of(k - RING);
         float aM = SEMICRF_NEG_INF, aS = 0.f;
         int aK = 0x7fffffff;
         if (rvalid) {
@@ -457,7 +413,7 @@ __device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         if (i < np && !have[i])
-                            gq[i] = load_granule(farg + ((size_t)(p0 + i < npanel ? p0 + i : P.rpart) * T + prow) * Bs + c);
+                            gq[i] = load_granule(farg + ((size_t)(p0 + i) * T + prow) * Bs + c);
                     bool all = true;
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
@@ -750,8 +706,6 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
                 dScore[((size_t)frow * T + frow) * Bs + c] = gz * fexp2(arow + mine + draw - 2.0f * sp);
             if (MODE == 1) code[(size_t)c * T + frow] = (mykey + 1) | (sp > 0.0f ? 0x40000000 : 0);
         }
-        if (SEMICRF_SCHED != 0 && sg == 0 && lane == 0)      // scheduling hint for the panels: block k is out
-            atomicMax((int*)(ctrl + CTRL_PROG), k);
         if (SEMICRF_PANEL_PROBES && trace) ts[k] = __builtin_amdgcn_s_memrealtime();                 // chain probe: u published
     }
 }
@@ -759,12 +713,8 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
 // ---------------------------------------------------------------------------------------------
 // PANEL role (per wave)
 // ---------------------------------------------------------------------------------------------
-#ifndef SEMICRF_GRAD_AUX
-#define SEMICRF_GRAD_AUX 2      // nt: the gradient is written once
-#endif
-#ifndef SEMICRF_CELL_AUX
-#define SEMICRF_CELL_AUX 2      // nt: every cell is read once -- keep the stream from evicting the (re-read) u granules from L2
-#endif
+constexpr int GRAD_AUX = 2;                  // nt: the gradient is written once
+constexpr int CELL_AUX = 2;                  // nt: every cell is read once -- keep the stream from evicting the (re-read) u values from L2
 #ifndef SEMICRF_PNS
 #define SEMICRF_PNS 3
 #endif
@@ -851,7 +801,7 @@ __device__ __forceinline__ void panel_fetch_cells(const float* score, const Pane
     for (int e = 0; e < 8; ++e) {
         const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(
             (int)(DIR == 0 ? panel_soff<DIR>(G, e >> 1, e & 1, T, Bs) : (unsigned)(((size_t)(14 - 2 * e) * T * Bs) * 4)));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(stage + e * 1024), 16, G.fvoff, so, 0, SEMICRF_CELL_AUX);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(stage + e * 1024), 16, G.fvoff, so, 0, CELL_AUX);
     }
 }
 __device__ __forceinline__ void panel_read_gran(unsigned addr, v4u& g0, v4u& g1)
@@ -885,122 +835,37 @@ __device__ __forceinline__ void panel_wait_younger(int y)
 }
 
 // ---- task selection -----------------------------------------------------------------------------------------------
-// Block k = RING + q has q + 1 far tiles, cut at fixed columns into parts of TPT tiles: the FULL parts p < q / TPT and
-// the LAST part q / TPT (1..TPT tiles, it ends with the newest tile, whose u the ring publishes four blocks before it
-// needs the result).  One queue in (block, part) order makes the waves run ahead of the ring by (#waves / tasks per
-// block) blocks and wait there, while most of the far field -- the full parts of all later blocks -- could already be
-// streamed: at T=1024, NBatch=352 the panels idle through the first 20 blocks and the sweep is bound by their
-// throughput afterwards.  Instead: queue 0 holds the last parts in block order, queue 1 + p the full parts p in block
-// order; a full part is AVAILABLE once the ring has published its last column block, a last part is ELIGIBLE
-// `runAhead` blocks before its newest tile (those waves wait at the frontier, as before).  A wave takes the eligible
-// head of the earliest block (earliest deadline first; the last part wins a tie).  `prog` (the block spine 0 has
-// published) is only a hint: every tile still checks its u values, so a stale or early hint costs time, not results.
-
+// Block k = RING + q has q + 1 far tiles, cut at fixed columns into FULL parts of TPT tiles and one LAST part (see
+// part_tiles), each split in four row quarters and 32-chain groups.  ONE queue in (block, part, chain group, row
+// quarter) order: an atomic counter.  (Per-part earliest-deadline queues, full parts handed out early, next-task
+// prefetch and "recent-tile" waves on the spine CUs were all measured slower, DESIGN.md section 3 "Round 2".)
 struct PanelTask { int k, part, g, q4; };
 
-// queue position -> task (single queue in (block, part, chain group, row quarter) order)
+// queue position -> task
 __device__ __forceinline__ void panel_task_decode(const SweepParams& P, int task, PanelTask& t)
 {
     t.q4 = task & 3;
     const int t2 = task >> 2;
     t.g = t2 % P.nPanelGroups;
     int tt = t2 / P.nPanelGroups;
-    if (tt < LEADT - 1) { t.part = 0; t.k = RING + P.xr + tt; return; }      // the first LEADT - 1 blocks: one part
+    if (tt < LEADT - 1) { t.part = 0; t.k = RING + tt; return; }      // the first LEADT - 1 blocks: one part
     tt -= LEADT - 1;
     int a = 0;
     while (tt >= TPT * (a + 1) * (a + 2) / 2) ++a;          // group a: blocks with a+1 parts
     tt -= TPT * a * (a + 1) / 2;
     const int q = a * TPT + tt / (a + 1) + LEADT - 1;
     t.part = tt % (a + 1);
-    t.k = RING + P.xr + q;
+    t.k = RING + q;
 }
 
 __device__ __forceinline__ bool panel_next_task(const SweepParams& P, PanelTask& t)
 {
-    unsigned* const ctrl = P.ctrl;
-    const int lane = threadIdx.x & 63;
-    const int G4 = P.nPanelGroups * 4;
-    if (SEMICRF_SCHED == 0) {
-        int task = 0;
-        if (lane == 0) task = (int)(atomicAdd(ctrl + 2, 1u) + 1u);        // counters start at 0xffffffff (one 0xff fill)
-        task = __builtin_amdgcn_readfirstlane(task) + P.taskBase;
-        if (task >= P.nTasks) return false;
-        if (P.fullLead > 0) {
-            // One queue, but the FULL parts of block k (16 tiles: ~20 us of streaming, all of their columns published long
-            // before) are handed out fullLead blocks earlier than the block's last part (a few tiles that end with the newest
-            // one).  In plain (block, part) order the waves reach block k only 4-8 blocks ahead of the ring once a block has
-            // several parts, the full parts finish after the last part, and the ring waits for them (chain trace: the far
-            // wave has everything 6 us after the slowest last-part task stored).  Key kappa holds: the full parts of block
-            // kappa + fullLead, then the last part of block kappa.
-            const int FQ = RING + P.xr;
-            const int rem = task % G4;
-            int tt = task / G4;
-            t.q4 = rem & 3;
-            t.g = rem >> 2;
-            for (int kappa = FQ - P.fullLead; kappa < P.K; ++kappa) {
-                const int kf = kappa + P.fullLead;
-                const int nfull = kf < P.K ? nfull_of(kf - FQ) : 0;             // kf >= FQ always
-                if (tt < nfull) { t.k = kf; t.part = tt; return true; }
-                tt -= nfull;
-                if (kappa >= FQ) {
-                    if (tt == 0) { t.k = kappa; t.part = nfull_of(kappa - FQ); return true; }
-                    --tt;
-                }
-            }
-            return false;
-        }
-        panel_task_decode(P, task, t);
-        return true;
-    }
-    const int FQ = RING + P.xr;                                 // first block with panel tiles
-    int nq = nparts_of(P.K - 1 - FQ);                           // queue i >= 1 exists when some block has a full part i - 1
-    if (nq > MAX_QUEUES) nq = MAX_QUEUES;
-    int spins = 0;
-    u64 dead = 0;                                               // queues this wave has seen run out
-    while (true) {
-        // peek: the block every queue is handing out (raised once per block by the wave that opens it: a read-mostly line)
-        unsigned v = 0;
-        if (lane <= nq) v = __hip_atomic_load(ctrl + CTRL_PROG + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int prog = (int)__builtin_amdgcn_readlane(v, 0);              // -1: nothing published yet
-        int best = -1, bestk = 0x7fffffff;
-        bool left = false;
-        for (int i = 0; i < nq; ++i) {
-            const int k0 = i == 0 ? FQ : FQ + i * TPT + LEADT - 1;          // first block of queue i
-            if (P.K <= k0) continue;
-            const unsigned hv = (unsigned)__builtin_amdgcn_readlane(v, 1 + i);
-            const int kq = hv == CTRL_INIT ? k0 : (int)hv;
-            if (kq >= P.K || ((dead >> i) & 1)) continue;                   // handed out completely
-            left = true;
-            const bool ok = i == 0 ? kq <= prog + FQ + P.runAhead : prog >= i * TPT - 1;
-            if (ok && kq < bestk) { bestk = kq; best = i; }
-        }
-        if (!left) return false;
-        if (best < 0) {
-            if (SEMICRF_PANEL_PROBES && lane == 0) atomicAdd(ctrl + 80, 1u);      // probe: idle peeks
-            __builtin_amdgcn_s_sleep(64);
-            if (spin_abort(ctrl, spins, SPIN_LIMIT, 11)) return false;
-            continue;
-        }
-        int idx = 0;
-        if (lane == 0) idx = (int)(atomicAdd(ctrl + CTRL_QHEAD + best, 1u) + 1u);
-        idx = __builtin_amdgcn_readfirstlane(idx);
-        const int k0 = best == 0 ? FQ : FQ + best * TPT + LEADT - 1;
-        const int size = (P.K - k0) * G4;
-        if (idx >= size) {
-            // past the end: the queue is empty (the summary only ever grows: a late "opened block k" cannot undo this)
-            if (lane == 0) atomicMax((int*)(ctrl + CTRL_PROG + 1 + best), P.K);
-            dead |= (u64)1 << best;
-            continue;
-        }
-        t.k = k0 + idx / G4;
-        const int rem = idx % G4;
-        if (rem == 0 && lane == 0) atomicMax((int*)(ctrl + CTRL_PROG + 1 + best), t.k);      // this wave opens block t.k of the queue
-        t.q4 = rem & 3;
-        t.g = rem >> 2;
-        t.part = best == 0 ? nfull_of(t.k - FQ) : best - 1;
-        if (SEMICRF_PANEL_PROBES && lane == 0) atomicAdd(ctrl + (best == 0 ? 81 : 82), 1u);   // probe: tasks by kind
-        return true;
-    }
+    int task = 0;
+    if ((threadIdx.x & 63) == 0) task = (int)(atomicAdd(P.ctrl + 2, 1u) + 1u);        // counters start at 0xffffffff (one 0xff fill)
+    task = __builtin_amdgcn_readfirstlane(task) + P.taskBase;
+    if (task >= P.nTasks) return false;
+    panel_task_decode(P, task, t);
+    return true;
 }
 
 template <int MODE, int DIR, bool GRAD>
@@ -1038,14 +903,6 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
     // vector-memory operations issued so far by this wave (a lower bound: the waits below may only under-count the operations
     // younger than the fetch they wait for), and its value right after each stage's fetch.  They run on across tasks.
     int issued = 0, mark0 = 0, mark1 = 0, mark2 = 0;
-    // Task prefetch: a wave whose previous task never had to wait for the ring is BEHIND it (the sweep is bound by the far
-    // field, every task is late): it takes its next task while the last tiles of the current one are still in flight and
-    // fills the stages they leave with the first tiles of the next one, so that dequeue and pipeline fill (3-4 us of a
-    // ~20 us task) overlap with streaming.  A wave that does wait for the ring must not hold a second task: the task would
-    // start late, and at that point of the sweep it is on the critical path.
-    bool late_mode = false, have_next = false;
-    PanelTask nxt;
-    int nxt_fetched = 0, s_first = 0;
     // task timeline probe (probe build, dbg & 256; tools/task_trace.py): the wave that drew task 0 stamps 5 words per task at ts[3T/2 + 5n]
     bool tracer = false;
     int tn = 0;
@@ -1053,19 +910,14 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
     while (true) {
         // ---- next task: (k, part, g, q4); a task only waits on spine progress below k-3 ----
         PanelTask tk;
-        int pre = 0;                                                // tiles of this task that are already in flight
-        if (have_next) { tk = nxt; pre = nxt_fetched; have_next = false; nxt_fetched = 0; }
-        else {
-            if (first_task >= 0 && first_task < P.nTasks) { panel_task_decode(P, first_task, tk); first_task = -1; }
-            else if (!panel_next_task(P, tk)) break;
-            first_task = -1;
-            s_first = 0;
-            if (SEMICRF_PROBE_TASKS && (dbg & 256u) && tk.k == RING + P.xr && tk.part == 0 && tk.g == 0 && tk.q4 == 0) tracer = true;
-        }
+        if (first_task >= 0 && first_task < P.nTasks) panel_task_decode(P, first_task, tk);
+        else if (!panel_next_task(P, tk)) break;
+        first_task = -1;
+        if (SEMICRF_PROBE_TASKS && (dbg & 256u) && tk.k == RING && tk.part == 0 && tk.g == 0 && tk.q4 == 0) tracer = true;
         u64* const tsp = P.ts + (3 * T) / 2 + 5 * tn;
         const bool tr = SEMICRF_PROBE_TASKS && tracer && lane == 0 && 5 * tn + 5 <= T / 2;
         if (tr) tsp[0] = __builtin_amdgcn_s_memrealtime();
-        const int q = tk.k - RING - P.xr;                           // the newest tile the panels have of this block
+        const int q = tk.k - RING;                                  // the newest far tile of this block
         int m0, m1;
         part_tiles(q, tk.part, m0, m1);                             // tiles m0 .. m1-1 of the q+1 panel tiles of block k
         const int k = tk.k, part = tk.part, g = tk.g, q4 = tk.q4;
@@ -1123,24 +975,16 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
         // are stale by construction.  From then on it fetches the NEXT tile's u again (device scope) while it works on
         // the current tile, so that a published value is found on the first look instead of two round trips later.
         bool frontier = false;
-        bool tried_next = false;
-        PanelGeom Gn;
-        int nm0 = 0, nm1 = 0;
-        {
-            int si = s_first;
-            for (int i = 0; i < pre; ++i) si = si + 1 == PNS ? 0 : si + 1;
 #pragma unroll
-            for (int i = 0; i < PNS; ++i)
-                if (i >= pre && m0 + i < m1) {
-                    panel_fetch_cells<DIR>(score, G, stage0 + si * PSTAGE_BYTES, m0 + i, T, Bs);
-                    if (!probe_stream && !probe_nou) panel_fetch_gran<false>(ursrc, stage0 + si * PSTAGE_BYTES, G.gvoff, m0 + i, B);
-                    issued += 10;
-                    if (si == 0) mark0 = issued; else if (si == 1) mark1 = issued; else mark2 = issued;
-                    si = si + 1 == PNS ? 0 : si + 1;
-                }
-        }
+        for (int i = 0; i < PNS; ++i)
+            if (m0 + i < m1) {
+                panel_fetch_cells<DIR>(score, G, stage0 + i * PSTAGE_BYTES, m0 + i, T, Bs);
+                if (!probe_stream && !probe_nou) panel_fetch_gran<false>(ursrc, stage0 + i * PSTAGE_BYTES, G.gvoff, m0 + i, B);
+                issued += 10;
+                if (i == 0) mark0 = issued; else if (i == 1) mark1 = issued; else mark2 = issued;
+            }
 
-        for (int m = m0, s = s_first; m < m1; ++m, s = (s + 1 == PNS ? 0 : s + 1)) {
+        for (int m = m0, s = 0; m < m1; ++m, s = (s + 1 == PNS ? 0 : s + 1)) {
             char* const stage = stage0 + s * PSTAGE_BYTES;
             // ---- wait for the stage, move it to registers ------------------------------------------------
             panel_wait_younger(issued - (s == 0 ? mark0 : (s == 1 ? mark1 : mark2)));
@@ -1157,14 +1001,6 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
             v4u xo[8];
             panel_read_cells<DIR>(rdbase + (unsigned)(s * PSTAGE_BYTES), xo);
             const bool refill = m + PNS < m1;
-            if (SEMICRF_EARLY_REFILL && refill) {
-                // the tile is in registers: its stage can take the cells of tile m + PNS right away, so that PNS tiles
-                // stay in flight while this one is processed (the u part follows once this tile's u has been read)
-                asm volatile("" ::: "memory");          // the LDS reads above come first
-                panel_fetch_cells<DIR>(score, G, stage, m + PNS, T, Bs);
-                issued += 8;
-                if (probe_stream) { if (s == 0) mark0 = issued; else if (s == 1) mark1 = issued; else mark2 = issued; }
-            }
             if (probe_stream) {          // streaming probe: touch the data, nothing else
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
@@ -1204,18 +1040,13 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                         panel_read_gran(grbase + (unsigned)(s * PSTAGE_BYTES), g0, g1);
                     }
                 }
-                if (SEMICRF_EARLY_REFILL && refill && !probe_nou) {
-                    panel_fetch_gran<false>(ursrc, stage, G.gvoff, m + PNS, B);
-                    issued += 2;
-                    if (s == 0) mark0 = issued; else if (s == 1) mark1 = issued; else mark2 = issued;
-                }
                 if (frontier && m + 1 < m1) {
                     const int sn = s + 1 == PNS ? 0 : s + 1;
                     panel_fetch_gran<true>(ursrc, stage0 + sn * PSTAGE_BYTES, G.gvoff, m + 1, B);
                     issued += 2;
                     if (sn == 0) mark0 = issued; else if (sn == 1) mark1 = issued; else mark2 = issued;
                 }
-                if (SEMICRF_PANEL_PROBES && (dbg & 16u) && P.xr == 0 && g == 0 && q4 == 0 && m == q && lane == 0) P.ts[192 + k] = __builtin_amdgcn_s_memrealtime();   // chain probe: newest tile's u seen
+                if (SEMICRF_PANEL_PROBES && (dbg & 16u) && g == 0 && q4 == 0 && m == q && lane == 0) P.ts[192 + k] = __builtin_amdgcn_s_memrealtime();   // chain probe: newest tile's u seen
                 // chains past the end of the batch (a ragged last quad reads the NEXT position's first chains there, published or
                 // not; a quad that lies past the end altogether reads the first chains, waited for or not): their u is set to 0,
                 // so that what they contribute to the wave-wide rescale test -- and with it the other chains' reference points
@@ -1227,7 +1058,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                 const float uv[2][4] = {{__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z), __uint_as_float(g0.w)},
                                         {__uint_as_float(g1.x), __uint_as_float(g1.y), __uint_as_float(g1.z), __uint_as_float(g1.w)}};
 
-                if (MODE == 0 && !GRAD && SEMICRF_DIET) {
+                if (MODE == 0 && !GRAD) {
                     // The same accumulation with half the vector instructions (the panels are issue- and power-bound next
                     // to their loads): the exponent argument t - M = cell*log2e + (u - M) is ONE packed fma per two chains
                     // on top of one packed subtract, the overflow test is a max3 tree over those arguments, the sums are
@@ -1301,7 +1132,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                                     gv.y = __float_as_uint(gz[1] * fexp2(t[h][1] + arow[rr][1]));
                                     gv.z = __float_as_uint(gz[2] * fexp2(t[h][2] + arow[rr][2]));
                                     gv.w = __float_as_uint(gz[3] * fexp2(t[h][3] + arow[rr][3]));
-                                    if (c + 3 < c1) __builtin_amdgcn_raw_buffer_store_b128(gv, gs, G.voff, so, SEMICRF_GRAD_AUX);
+                                    if (c + 3 < c1) __builtin_amdgcn_raw_buffer_store_b128(gv, gs, G.voff, so, GRAD_AUX);
                                     else {                                  // ragged tail of the chain range
                                         __builtin_amdgcn_raw_buffer_store_b32(gv.x, gs, G.voff, so, 0);
                                         if (c + 1 < c1) __builtin_amdgcn_raw_buffer_store_b32(gv.y, gs, G.voff + 4, so, 0);
@@ -1336,52 +1167,27 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                 }
             }
             // ---- refill the stage PNS tiles ahead ----------------------------------------------------------
-            if (!SEMICRF_EARLY_REFILL && refill) {
+            if (refill) {
                 panel_fetch_cells<DIR>(score, G, stage, m + PNS, T, Bs);
                 if (!probe_stream && !probe_nou) panel_fetch_gran<false>(ursrc, stage, G.gvoff, m + PNS, B);
                 issued += 10;
                 if (s == 0) mark0 = issued; else if (s == 1) mark1 = issued; else mark2 = issued;
-            } else if (SEMICRF_TASK_PREFETCH && !refill && late_mode && !frontier && !probe_stream && !probe_nou) {
-                // nothing of this task is left to request: this stage takes a tile of the wave's NEXT task
-                if (!tried_next) {
-                    tried_next = true;
-                    have_next = panel_next_task(P, nxt);
-                    if (have_next) {
-                        const int nq = nxt.k - RING - P.xr;
-                        part_tiles(nq, nxt.part, nm0, nm1);
-                        if (nxt.k * PB + nxt.q4 * 4 >= T) nm1 = nm0;          // rows past the end: nothing to fetch
-                        geom_of(nxt, Gn);
-                        nxt_fetched = 0;
-                        // its first tile goes into THIS stage: the stage cursor of the next task starts here
-                        s_first = s;
-                    }
-                }
-                if (have_next && nm0 + nxt_fetched < nm1) {
-                    panel_fetch_cells<DIR>(score, Gn, stage, nm0 + nxt_fetched, T, Bs);
-                    panel_fetch_gran<false>(ursrc, stage, Gn.gvoff, nm0 + nxt_fetched, B);
-                    issued += 10;
-                    if (s == 0) mark0 = issued; else if (s == 1) mark1 = issued; else mark2 = issued;
-                    ++nxt_fetched;
-                }
             }
         }
         if (tr) { tsp[2] = __builtin_amdgcn_s_memrealtime(); tsp[4] = (u64)(m1 - m0) | ((u64)k << 8) | ((u64)(frontier ? 1 : 0) << 16) | ((u64)part << 20); }
-        if (!have_next) wait_vmcnt<0>();      // nothing of this task is in flight when its stages are reused
-        late_mode = !frontier;
+        wait_vmcnt<0>();      // nothing of this task is in flight when its stages are reused
+        (void)frontier;
 
         // ---- reduce over the 8 column slots (lane bits 3..5) --------------------------------------------------------------
         // The task's last tile is the newest one: what follows sits on the ring's critical path (16 hand-off rounds per
-        // sweep at T=1024: a microsecond here is 16 in the total).  SEMICRF_LDS_REDUCE: the 16 accumulators of every lane go
+        // sweep at T=1024: a microsecond here is 16 in the total).  The 16 accumulators of every lane go
         // through LDS once (the wave's stages are idle now) and each lane merges the 8 slot values of its two results with
         // ONE exact maximum and 8 independent exps, instead of a 3-stage shuffle tree with two dependent exps per stage.
         const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
         u64* fbase = farg + (size_t)part * T * Bs;
         const int pi = pbase + (b5 ? 2 : 0) + (b4 ? 1 : 0);
-#if SEMICRF_LDS_REDUCE
-        if (!SEMICRF_TASK_PREFETCH) {
+        {
             constexpr int RSTR = 65 * 8;                                  // bytes between accumulators (65 lanes: spreads the banks)
-            float2* const red = (float2*)stage0;
-            (void)red;
             char* const rb = stage0;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
@@ -1416,313 +1222,12 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                 }
                 if (pi < T && cc < c1 && !(SEMICRF_PANEL_PROBES && (dbg & 32u))) store_granule(fbase + (size_t)pi * Bs + cc, gr);
             }
-        } else
-#endif
-        {
-        auto xmerge = [&](float& kM, float& kS, int& kK, float sM, float sS, int sK, int off) {
-            const float oM = __shfl_xor(sM, off);
-            if (MODE == 0) {
-                const float oS = __shfl_xor(sS, off);
-                acc_merge(kM, kS, oM, oS);
-            } else {
-                const int oK = __shfl_xor(sK, off);
-                max_push(kM, kK, oM, oK);
-            }
-        };
-        float M1[2][4], S1[2][4];
-        int K1[2][4];
-#pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float kM = b5 ? aM[r2 + 2][i] : aM[r2][i], kS = b5 ? aS[r2 + 2][i] : aS[r2][i];
-                int kK = b5 ? aK[r2 + 2][i] : aK[r2][i];
-                xmerge(kM, kS, kK, b5 ? aM[r2][i] : aM[r2 + 2][i], b5 ? aS[r2][i] : aS[r2 + 2][i],
-                       b5 ? aK[r2][i] : aK[r2 + 2][i], 32);
-                M1[r2][i] = kM; S1[r2][i] = kS; K1[r2][i] = kK;
-            }
-        float M2[4], S2[4];
-        int K2[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float kM = b4 ? M1[1][i] : M1[0][i], kS = b4 ? S1[1][i] : S1[0][i];
-            int kK = b4 ? K1[1][i] : K1[0][i];
-            xmerge(kM, kS, kK, b4 ? M1[0][i] : M1[1][i], b4 ? S1[0][i] : S1[1][i], b4 ? K1[0][i] : K1[1][i], 16);
-            M2[i] = kM; S2[i] = kS; K2[i] = kK;
         }
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            float kM = b3 ? M2[2 + e] : M2[e], kS = b3 ? S2[2 + e] : S2[e];
-            int kK = b3 ? K2[2 + e] : K2[e];
-            xmerge(kM, kS, kK, b3 ? M2[e] : M2[2 + e], b3 ? S2[e] : S2[2 + e], b3 ? K2[e] : K2[2 + e], 8);
-            const int cc = c + (b3 ? 2 : 0) + e;
-            if (pi < T && cc < c1 && !(SEMICRF_PANEL_PROBES && (dbg & 32u))) {
-                const u64 gr = MODE == 0 ? make_granule(tag, kM + flog2(kS)) : make_granule_key(tag, kM, kK);
-                store_granule(fbase + (size_t)pi * Bs + cc, gr);
-            }
-        }
-        }
-        if (SEMICRF_PANEL_PROBES && (dbg & 16u) && P.xr == 0 && g == 0 && m1 == q + 1 && lane == 0 && k < 64)
+        if (SEMICRF_PANEL_PROBES && (dbg & 16u) && g == 0 && m1 == q + 1 && lane == 0 && k < 64)
             P.ts[256 + 64 * q4 + k] = __builtin_amdgcn_s_memrealtime();     // chain probe: partial stored (per row quarter)
         if (tr) tsp[3] = __builtin_amdgcn_s_memrealtime();
         ++tn;
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// RECENT role (per wave, in the spine workgroups)
-// ---------------------------------------------------------------------------------------------
-// The ring needs the far-field result of block k four blocks after it published the u of that field's newest tile, and
-// every microsecond of that hand-off beyond the 3-block slack stalls all eight rings of a chain group.  In a panel task
-// the newest tile waits for a free wave behind the bulk of the far field, is polled from a compute unit with deep
-// memory queues, and ends in a 14-exchange reduction.  The recent waves take the newest xr tiles of every block out of
-// that path: two waves per spine workgroup (compute units that stream little), a FIXED share of the (block, chain group,
-// row quarter) triples each -- triple i belongs to recent wave i mod #waves, no queue -- and a lane mapping without any
-// cross-lane reduction: lane = (row of the quarter, PAIR of chains), the 16 columns of a tile are walked serially from
-// the LDS stage, so that a lane ends with the finished partial of its two (row, chain) cells and stores them itself.
-// The cells of the next tiles are prefetched (they do not depend on u); u is polled tile by tile.
-constexpr int RNS = 3;                        // LDS stages of a recent wave (PSTAGE_BYTES each, the panels' layout)
-
-template <int DIR>
-__device__ __forceinline__ unsigned recent_cell_off(int rr, int col, int cp)
-{
-    const int h = col >> 3, s8 = col & 7;
-    return DIR == 0 ? (unsigned)((rr * 2 + h) * 1024 + s8 * 128 + cp * 8)
-                    : (unsigned)(((s8 >> 1) + 4 * h) * 1024 + rr * 256 + (s8 & 1) * 128 + cp * 8);
-}
-
-// 16 ds_read_b64 in flight, one wait: value c comes from (c even ? base_even : base_odd) + off[c]
-typedef float v2f_t __attribute__((ext_vector_type(2)));
-template <int O0, int O1, int O2, int O3, int O4, int O5, int O6, int O7, int O8, int O9, int O10, int O11, int O12, int O13, int O14, int O15>
-__device__ __forceinline__ void lds_read16_b64(unsigned be, unsigned bo, v2f_t (&o)[16])
-{
-    asm volatile("ds_read_b64 %0, %16 offset:%18\n\tds_read_b64 %1, %17 offset:%19\n\t"
-                 "ds_read_b64 %2, %16 offset:%20\n\tds_read_b64 %3, %17 offset:%21\n\t"
-                 "ds_read_b64 %4, %16 offset:%22\n\tds_read_b64 %5, %17 offset:%23\n\t"
-                 "ds_read_b64 %6, %16 offset:%24\n\tds_read_b64 %7, %17 offset:%25\n\t"
-                 "ds_read_b64 %8, %16 offset:%26\n\tds_read_b64 %9, %17 offset:%27\n\t"
-                 "ds_read_b64 %10, %16 offset:%28\n\tds_read_b64 %11, %17 offset:%29\n\t"
-                 "ds_read_b64 %12, %16 offset:%30\n\tds_read_b64 %13, %17 offset:%31\n\t"
-                 "ds_read_b64 %14, %16 offset:%32\n\tds_read_b64 %15, %17 offset:%33\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
-                   "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15])
-                 : "v"(be), "v"(bo), "n"(O0), "n"(O1), "n"(O2), "n"(O3), "n"(O4), "n"(O5), "n"(O6), "n"(O7), "n"(O8), "n"(O9),
-                   "n"(O10), "n"(O11), "n"(O12), "n"(O13), "n"(O14), "n"(O15));
-}
-// byte offset of column c (before the per-lane swap of column pairs) in the u part / the cell part of a stage
-constexpr int r_uoff(int c) { return (c >> 3) * 1024 + (c & 7) * 128; }
-template <int DIR>
-constexpr int r_coff(int c) { return DIR == 0 ? (c >> 3) * 1024 + (c & 7) * 128 : (((c & 7) >> 1) + 4 * (c >> 3)) * 1024 + (c & 1) * 128; }
-
-template <int MODE, int DIR, bool GRAD>
-__device__ __forceinline__ void recent_role(const SweepParams& P, char* lds, int rid, int nrecent)
-{
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    const int T = P.T, B = P.B, K = P.K;
-    const int c0 = P.c0, c1 = P.c1;
-    unsigned* const ctrl = P.ctrl;
-    const size_t Bs = (size_t)B;
-    const float* __restrict__ score = P.score;
-    float* const dScore = P.dScore;
-    const int lane = threadIdx.x & 63;
-    const int rr = lane >> 4, cp = lane & 15;              // processing mapping: (row of the quarter, chain pair)
-    const int fslot = lane >> 3, fq8 = lane & 7;           // fetch mapping of the panels' stage layout
-    const int G4 = P.nPanelGroups * 4;
-    const int ntask = (K - RING) * G4;
-    const auto ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.ug, 0, (int)((size_t)T * Bs * 4), 0x00020000);
-    const unsigned tag = P.tag;
-    u64* const fbase = P.farg + (size_t)P.rpart * T * Bs;
-    const v2f l2e = {LOG2E, LOG2E};
-
-    // the wave's tiles as one sequence: task i = rid + n * nrecent -> (k, g, q4), tiles mlo(k) .. k - RING
-    struct Cur { int task, k, m; };
-    auto task_k = [&](int task) { return RING + task / G4; };
-    auto mlo = [&](int k) { const int lo = k - RING + 1 - P.xr; return lo > 0 ? lo : 0; };
-    auto geom = [&](int task, PanelGeom& G, int& pbase, int& cl) {
-        const int k = task_k(task);
-        const int rem = task % G4;
-        const int q4 = rem & 3, g = rem >> 2;
-        pbase = k * PB + q4 * 4;
-        const int c = c0 + g * GP + fq8 * 4;
-        cl = c < c1 ? c : c0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) G.pirow[i] = pbase + i < T ? pbase + i : T - 1;
-        G.voff = DIR == 0 ? (unsigned)((fslot * B + cl) * 4) : (unsigned)(((size_t)(7 - fslot) * T * Bs + cl) * 4);
-        const int f_pisub = lane >> 4, f_pjsub = (lane >> 3) & 1;
-        const int f_pirow = pbase + f_pisub < T ? pbase + f_pisub : T - 1;
-        G.fvoff = DIR == 0 ? G.voff : (unsigned)((((size_t)(1 - f_pjsub) * T + (G.pirow[3] - f_pirow)) * Bs + cl) * 4);
-        G.gvoff = (unsigned)((fslot * B + cl) * 4);
-    };
-    auto advance = [&](Cur& c) {
-        if (c.m < c.k - RING) { ++c.m; return; }
-        c.task += nrecent;
-        c.k = c.task < ntask ? task_k(c.task) : K;
-        c.m = c.task < ntask ? mlo(c.k) : 0;
-    };
-    // cells AND u of a tile (10 loads): the u copy is checked when the tile's turn comes and fetched again while it is
-    // not complete (the newest tile of a triple is usually not published yet when it is prefetched)
-    auto fetch_cells = [&](const Cur& c, int stage) {
-        PanelGeom G; int pbase, cl;
-        geom(c.task, G, pbase, cl);
-        panel_fetch_cells<DIR>(score, G, lds + stage * PSTAGE_BYTES, c.m, T, Bs);
-        panel_fetch_gran<true>(ursrc, lds + stage * PSTAGE_BYTES, G.gvoff, c.m, B);
-    };
-
-    Cur cur{rid, 0, 0};
-    if (cur.task >= ntask) return;
-    cur.k = task_k(cur.task); cur.m = mlo(cur.k);
-    Cur pre = cur;                                          // prefetch cursor: RNS - 1 tiles ahead of `cur`
-    int pstage = 0;
-#pragma unroll
-    for (int i = 0; i < RNS - 1; ++i)
-        if (pre.task < ntask) { fetch_cells(pre, pstage); pstage = pstage + 1 == RNS ? 0 : pstage + 1; advance(pre); }
-
-    float aM[2] = {SEMICRF_NEG_INF, SEMICRF_NEG_INF}, aS[2] = {0.f, 0.f};
-    int aK[2] = {0x7fffffff, 0x7fffffff};
-    int stage = 0;
-    float gzA = 0.f, gzB = 0.f, garA = 0.f, garB = 0.f;
-    bool pre_inflight = false;          // the prefetch issued during the previous tile (the tile after this one)
-    {
-        // start-up: RNS - 1 tiles were requested together; the second of them is the one "in flight" behind the first
-        Cur t2 = cur; advance(t2);
-        pre_inflight = t2.task < ntask;
-    }
-    while (cur.task < ntask) {
-        PanelGeom G; int pbase, cl;
-        geom(cur.task, G, pbase, cl);
-        const int k = cur.k, m = cur.m;
-        const int rem = cur.task % G4;
-        const int g = rem >> 2;
-        const int cA = c0 + g * GP + cp * 2;                // this lane's two chains
-        const bool vA = cA < c1, vB = cA + 1 < c1;
-        const int pi = pbase + rr;
-        const bool rvalid = pi < T;
-        if (GRAD && m == mlo(k)) {      // first tile of the triple: its row constants (before anything of this tile is in flight)
-            const bool rv = rvalid;
-            const float lzA = vA ? P.logZ[cA] : 0.f, lzB = vB ? P.logZ[cA + 1] : 0.f;
-            gzA = vA ? P.gout[cA] : 0.f; gzB = vB ? P.gout[cA + 1] : 0.f;
-            const size_t fr = (size_t)frame_of<DIR>(rv ? pi : T - 1, T) * Bs;
-            garA = ((vA ? P.vfwd[fr + cA] : 0.f) - lzA) * LOG2E;
-            garB = ((vB ? P.vfwd[fr + cA + 1] : 0.f) - lzB) * LOG2E;
-        }
-        char* const st = lds + stage * PSTAGE_BYTES;
-        const unsigned ubase = lds_addr(st) + 8192u;
-        const unsigned cbase = lds_addr(st);
-        // ---- u of tile m: poll until the rings of this chain group have published block m ----------------------
-        // a lane with an odd row walks the columns in swapped pairs (c ^ 1): its 8-byte reads then fall into the other half of
-        // the banks than those of the even row that shares its half-wave.  The swap toggles address bit 7 of every read.
-        const int bsw = (rr & 1) * 128;
-        v2f uu[PB];
-        {
-            const unsigned ue = ubase + (unsigned)(cp * 8 + bsw), uo = ubase + (unsigned)(cp * 8 - bsw);
-            int spins = 0;
-            // this tile's loads are older than the (at most one) prefetch that is still in flight
-            if (pre_inflight) wait_vmcnt<10>(); else wait_vmcnt<0>();
-            while (true) {
-                lds_read16_b64<r_uoff(0), r_uoff(1), r_uoff(2), r_uoff(3), r_uoff(4), r_uoff(5), r_uoff(6), r_uoff(7), r_uoff(8), r_uoff(9),
-                               r_uoff(10), r_uoff(11), r_uoff(12), r_uoff(13), r_uoff(14), r_uoff(15)>(ue, uo, uu);
-                bool ok = true;
-#pragma unroll
-                for (int c = 0; c < PB; ++c)
-                    ok = ok && (__float_as_uint(uu[c].x) != U_EMPTY || !vA) && (__float_as_uint(uu[c].y) != U_EMPTY || !vB);
-                if (__all(ok)) break;
-                if (spins > 0) __builtin_amdgcn_s_sleep(2);
-                if (spin_abort(ctrl, spins, SPIN_LIMIT, 12)) break;
-                panel_fetch_gran<true>(ursrc, st, G.gvoff, m, B);
-                wait_vmcnt<0>();
-            }
-        }
-        if (SEMICRF_PANEL_PROBES && (P.dbg & 16u) && rem == 0 && m == k - RING && lane == 0) P.ts[192 + k] = __builtin_amdgcn_s_memrealtime();   // chain probe: newest tile's u seen
-        // ---- the stage that tile m - 1 left: cells of the tile RNS - 1 ahead ------------------------------------
-        pre_inflight = pre.task < ntask;
-        if (pre_inflight) { fetch_cells(pre, pstage); pstage = pstage + 1 == RNS ? 0 : pstage + 1; advance(pre); }
-        // cells of this tile: landed together with its u (loads return in order)
-        v2f xx[PB];
-        {
-            const unsigned rb = cbase + (unsigned)(cp * 8) + (DIR == 0 ? (unsigned)(rr * 2048) : (unsigned)(rr * 256));
-            lds_read16_b64<r_coff<DIR>(0), r_coff<DIR>(1), r_coff<DIR>(2), r_coff<DIR>(3), r_coff<DIR>(4), r_coff<DIR>(5), r_coff<DIR>(6),
-                           r_coff<DIR>(7), r_coff<DIR>(8), r_coff<DIR>(9), r_coff<DIR>(10), r_coff<DIR>(11), r_coff<DIR>(12), r_coff<DIR>(13),
-                           r_coff<DIR>(14), r_coff<DIR>(15)>(rb + (unsigned)bsw, rb - (unsigned)bsw, xx);
-        }
-        if (rvalid) {
-            if (MODE == 0) {
-                v2f mref = {aM[0], aM[1]};
-                v2f e[PB];
-                float emax = SEMICRF_NEG_INF;
-#pragma unroll
-                for (int c = 0; c < PB; ++c) {
-                    e[c] = __builtin_elementwise_fma(xx[c], l2e, uu[c] - mref);
-                    emax = fmaxf(emax, fmaxf(e[c].x, e[c].y));
-                }
-                if (emax > RESCALE_THR) {                    // per lane: no cross-lane dependence in this mapping
-                    float tx = SEMICRF_NEG_INF, ty = SEMICRF_NEG_INF;
-#pragma unroll
-                    for (int c = 0; c < PB; ++c) {
-                        tx = fmaxf(tx, fmaf(xx[c].x, LOG2E, uu[c].x));
-                        ty = fmaxf(ty, fmaf(xx[c].y, LOG2E, uu[c].y));
-                    }
-                    const float mx = fmaxf(aM[0], tx), my = fmaxf(aM[1], ty);
-                    aS[0] = aS[0] * fexp2(aM[0] - mx); aS[1] = aS[1] * fexp2(aM[1] - my);      // -inf - m -> 0
-                    aM[0] = mx; aM[1] = my;
-                    mref.x = mx; mref.y = my;
-#pragma unroll
-                    for (int c = 0; c < PB; ++c) {
-                        e[c].x = fmaf(xx[c].x, LOG2E, uu[c].x) - mx;
-                        e[c].y = fmaf(xx[c].y, LOG2E, uu[c].y) - my;
-                    }
-                }
-                if (GRAD) {
-                    // marginal(pi, pj) = gz * exp2(t + arow), t = e + M
-                    const float arA = garA + aM[0], arB = garB + aM[1];
-                    const auto gs = __builtin_amdgcn_make_buffer_rsrc((void*)(dScore + panel_tile_off<DIR>(G, m, T, Bs)), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-                    for (int c = 0; c < PB; ++c) {
-                        const int col = c ^ (rr & 1);
-                        const int h = col >> 3, s8 = col & 7;
-                        const unsigned so = panel_soff<DIR>(G, rr, h, T, Bs);
-                        const unsigned vo = (DIR == 0 ? (unsigned)(s8 * B * 4) : (unsigned)((size_t)(7 - s8) * T * Bs * 4)) + (unsigned)(cA * 4);
-                        const float ga = gzA * fexp2(e[c].x + arA), gb = gzB * fexp2(e[c].y + arB);
-                        if (vA) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ga), gs, vo, so, SEMICRF_GRAD_AUX);
-                        if (vB) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gb), gs, vo + 4, so, SEMICRF_GRAD_AUX);
-                    }
-                }
-                v2f sacc = {aS[0], aS[1]};
-#pragma unroll
-                for (int c = 0; c < PB; ++c) {
-                    const v2f pe = {fexp2(e[c].x), fexp2(e[c].y)};
-                    sacc += pe;
-                }
-                aS[0] = sacc.x; aS[1] = sacc.y;
-            } else {
-#pragma unroll
-                for (int c = 0; c < PB; ++c) {
-                    const int col = c ^ (rr & 1);
-                    const int key = frame_of<DIR>(m * PB + col, T);
-                    max_push(aM[0], aK[0], uu[c].x + xx[c].x, key);
-                    max_push(aM[1], aK[1], uu[c].y + xx[c].y, key);
-                }
-            }
-        }
-        // ---- last tile of the triple: the lane's two partials are complete ----------------------------------------
-        if (m == k - RING) {
-            if (rvalid) {
-                u64* fp = fbase + (size_t)pi * Bs + cA;
-                if (MODE == 0) {
-                    if (vA) store_granule(fp, make_granule(tag, aM[0] + flog2(aS[0])));
-                    if (vB) store_granule(fp + 1, make_granule(tag, aM[1] + flog2(aS[1])));
-                } else {
-                    if (vA) store_granule(fp, make_granule_key(tag, aM[0], aK[0]));
-                    if (vB) store_granule(fp + 1, make_granule_key(tag, aM[1], aK[1]));
-                }
-            }
-            if (SEMICRF_PANEL_PROBES && (P.dbg & 16u) && rem == 0 && lane == 0) P.ts[256 + k] = __builtin_amdgcn_s_memrealtime();     // chain probe: partial stored
-            aM[0] = aM[1] = SEMICRF_NEG_INF; aS[0] = aS[1] = 0.f; aK[0] = aK[1] = 0x7fffffff;
-        }
-        stage = stage + 1 == RNS ? 0 : stage + 1;
-        advance(cur);
-    }
-    wait_vmcnt<0>();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1812,11 +1317,13 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
 {
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];
     __shared__ int s_exit;
-#if SEMICRF_TICKET_ATOMIC
-    __shared__ int s_ticket;
-    if (threadIdx.x == 0) s_ticket = (int)(atomicAdd(P.ctrl, 1u) + 1u);
-#endif
-    if (threadIdx.x == 0) { s_abort = 0; s_exit = 0; }
+    // A leased workspace that an earlier launch left with its error word up (the host fills it again as soon as it has seen the
+    // pinned abort word, but launches it had already enqueued arrive first): this launch gives up at once -- its waits see the
+    // word within a few polls, its outputs are poisoned like the aborted launch's own.
+    if (threadIdx.x == 0) {
+        s_abort = __hip_atomic_load(P.ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != CTRL_INIT ? 1 : 0;
+        s_exit = 0;
+    }
     // flags and sequence numbers start at 0
     for (int i = threadIdx.x; i < (LDS_DUMMY - LDS_FAR) / 4; i += NT) ((int*)(s_dyn + LDS_FAR))[i] = 0;
     __syncthreads();
@@ -1824,11 +1331,7 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
     // the dispatcher starts them in index order, so a workgroup still only waits on earlier ones.  (An atomic ticket cost
     // every workgroup a device-scope round trip before it could do anything, on a line that hundreds of waves hit with
     // their first task draws at the same moment.)
-#if SEMICRF_TICKET_ATOMIC
-    const int ticket = s_ticket;
-#else
     const int ticket = wg_ticket(P.nSpine, (int)gridDim.x, (int)blockIdx.x);
-#endif
     const int wave = (int)(threadIdx.x >> 6);
     // clock probe (probe build, debug flag 128): shader cycles and 100 MHz ticks of one panel workgroup over the launch
     const bool clk = SEMICRF_PANEL_PROBES && (P.dbg & 128u) && ticket == P.nSpine + 3 && threadIdx.x == 0;
@@ -1870,11 +1373,7 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
             if (!(P.dbg & 8u)) loader_role<DIR, GRAD>(P, sg, s_dyn, wave - RING);
         } else if (wave == RING + NLOADER) {
             if (!(P.dbg & 9u)) far_role<MODE, DIR>(P, sg, s_dyn);
-        } else if (wave - (RING + NLOADER + 1) < P.recentWaves) {
-            const int wr = wave - (RING + NLOADER + 1);
-            if (!(P.dbg & 2u))
-                recent_role<MODE, DIR, GRAD>(P, s_dyn + LDS_HYBRID_PANEL + wr * (PNS * PSTAGE_BYTES), sg * P.recentWaves + wr, P.nSpine * P.recentWaves);
-        } else if (!(P.dbg & 2u) && wave - (RING + NLOADER + 1) < P.recentWaves + P.hybridPanelWaves) {
+        } else if (!(P.dbg & 2u) && wave - (RING + NLOADER + 1) < P.hybridPanelWaves) {
             // Spare waves stream tiles like the panel workgroups do (their stages lie behind the spine's LDS) -- but only
             // once the sweep is bound by the far field: during the first blocks the ring sets the pace and a streaming
             // wave on its CU only slows it down.  They wait until the ring has taken row block hybridStart.
@@ -1920,7 +1419,7 @@ constexpr size_t CTRL_BYTES = MAX_CHUNKS * CTRL_WORDS * sizeof(unsigned);
 static int max_parts(int T)
 {
     const int K = (T + PB - 1) / PB;
-    return (K > RING ? (K - 1 - RING) / TPT + 1 : 1) + 1;          // + the recent waves' slab
+    return K > RING ? nparts_of(K - 1 - RING) : 1;
 }
 
 // writes the exact zeros of the upper triangle (begin > end) of the dense gradient: row e, columns e+1..T-1
@@ -1994,8 +1493,7 @@ size_t persist_workspace_bytes(int T, int B)
 bool persist_supported(int T, int B)
 {
     return B >= 2 && T >= 2 && T < 65535 && (long long)T * B * 64 < (1ll << 31) &&      // 32-bit buffer offsets
-           (B + GS - 1) / GS <= MAX_CHUNKS * (device_cus() / 2 > 0 ? device_cus() / 2 : 1) &&      // chain chunks of at most half the CUs' worth of rings
-           max_parts(T) <= MAX_QUEUES;                   // one scheduler queue per column part
+           (B + GS - 1) / GS <= MAX_CHUNKS * (device_cus() / 2 > 0 ? device_cus() / 2 : 1);      // chain chunks of at most half the CUs' worth of rings
 }
 
 static unsigned next_tag()
@@ -2005,16 +1503,17 @@ static unsigned next_tag()
     return (lo << 16) | lo;                                      // both 16-bit halves nonzero
 }
 
-static int g_run_ahead_max = 6;
-static int g_full_lead = 0;          // off: measured slower at T=1024/2048 (the waves are the bottleneck: a lead only moves the wait), -5 % at T=691
-static int g_recent_tiles = 0;      // recent waves off by default: measured slower, kept for the next attempt
-
-struct Knobs { int xr, run_ahead, hybrid_waves, hybrid_start, panel_waves, zero_waves, full_lead; };
+// Launch-geometry knobs of the development tools (tools/bench_sweep.py): the environment is read only by a library built
+// with -DSEMICRF_DEBUG_BUILD=1 (once, at the first launch); the release library ignores it (-1 = the built-in choice).
+struct Knobs { int hybrid_waves, hybrid_start, panel_waves, zero_waves; };
 static Knobs read_knobs()
 {
+#if defined(SEMICRF_DEBUG_BUILD) && SEMICRF_DEBUG_BUILD
     auto get = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : -1; };
-    return Knobs{get("SEMICRF_XR"), get("SEMICRF_RUN_AHEAD"), get("SEMICRF_HYBRID_PANEL_WAVES"), get("SEMICRF_HYBRID_START"),
-                 get("SEMICRF_PANEL_WAVES"), get("SEMICRF_ZERO_WAVES"), get("SEMICRF_FULL_LEAD")};
+    return Knobs{get("SEMICRF_HYBRID_PANEL_WAVES"), get("SEMICRF_HYBRID_START"), get("SEMICRF_PANEL_WAVES"), get("SEMICRF_ZERO_WAVES")};
+#else
+    return Knobs{-1, -1, -1, -1};
+#endif
 }
 
 struct GradArgs {
@@ -2069,8 +1568,7 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
     // instantiated HIP graph -- wrong results or a memory fault -- while this kernel replays correctly)
     if (lease != 2) hipLaunchKernelGGL(fill_ff_kernel, dim3(1024), dim3(256), 0, stream, (v4u*)ws, (fill_bytes + 15) / 16);
     P.selfclean = lease != 0 && P.dbg == 0u;
-    static const Knobs knobs = read_knobs();                    // tuning knobs of the development tools: the environment is read ONCE
-    const int xr_env = knobs.xr;
+    static const Knobs knobs = read_knobs();
 
     // Chain chunks: at most a quarter of the CUs host spines in one launch (every workgroup must be resident
     // and the panels need the rest of the chip).
@@ -2091,16 +1589,9 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         const int nb = P.c1 - P.c0;
         P.nSpine = (nb + GS - 1) / GS;
         P.nPanelGroups = (nb + GP - 1) / GP;
-        // The newest xr far tiles of every block go to the recent waves (two per spine workgroup, static shares): only when
-        // there are enough of them to give every (block, chain group, row quarter) triple a wave for three block times.
-        int rw = HPW_MAX < 2 ? (HPW_MAX > 0 ? HPW_MAX : 0) : 2;
-        int xr = xr_env >= 0 ? xr_env : g_recent_tiles;
-        if (xr > P.K - RING) xr = P.K - RING > 0 ? P.K - RING : 0;
-        if (P.nSpine * rw < 3 * P.nPanelGroups * 4 || xr <= 0) { xr = 0; rw = 0; }
-        P.xr = xr; P.recentWaves = rw; P.rpart = max_parts(T) - 1;
-        // panel tasks per chain group: block k = RING + xr + q has q/TPT + 1 column parts, each split in 4 row quarters
+        // panel tasks per chain group: block k = RING + q has nparts_of(q) column parts, each split in 4 row quarters
         long long ntask = 0;
-        for (int q = 0; q < P.K - RING - xr; ++q) ntask += nparts_of(q);
+        for (int q = 0; q < P.K - RING; ++q) ntask += nparts_of(q);
         ntask *= 4;
         P.nTasks = (int)(ntask * P.nPanelGroups);
         P.ctrl = (unsigned*)w + (size_t)ci * CTRL_WORDS;
@@ -2111,16 +1602,13 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         // the gradient sweep (which also stores a tile per tile loaded) a few more.
         int nPanelWG = ncu - P.nSpine;
         if (nPanelWG < 0) nPanelWG = 0;
-        float per_cu = (float)T / 1024.0f;
-        per_cu = per_cu < 0.75f ? 0.75f : (per_cu > 2.0f ? 2.0f : per_cu);
-        if (grad) per_cu *= 1.25f;
         // The spine workgroups' two spare waves stream tiles too, from row block hybridStart on: while the ring sets
         // the pace (the first third of the blocks) a streaming wave on its CU only slows it down; afterwards the sweep is
         // bound by the far field and every CU helps.  Forward, T=1024: 205 us (start at 24-32) vs 214 (from the start)
         // vs 217 (never); T=691, NBatch=360: 158 vs 177 vs 173; T=2048: 651 vs 677 (from the start) vs 788 (never).
         // The gradient sweep is bandwidth-bound almost from the start.
-        int hpw = HPW_MAX - rw > 0 ? HPW_MAX - rw : 0;
-        if (knobs.hybrid_waves >= 0 && knobs.hybrid_waves <= HPW_MAX - rw) hpw = knobs.hybrid_waves;
+        int hpw = HPW_MAX > 0 ? HPW_MAX : 0;
+        if (knobs.hybrid_waves >= 0 && knobs.hybrid_waves <= HPW_MAX) hpw = knobs.hybrid_waves;
         // (round 2, after the panel math got cheaper: later is better -- T=691: 143-150 us from block 28 vs 160 from 16;
         // T=512: 89 from 20 vs 92 from 12; T=1024: 185 from 40 vs 188 from 32; T=2048: 583-598 from 32-48 vs 602-617 from 64-80)
         int hstart = grad ? 12 : P.K * 5 / 8;
@@ -2137,27 +1625,7 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         if (knobs.panel_waves > 0) pw = knobs.panel_waves;
         if (pw < 1) pw = 1;
         if (pw > PW_MAX) pw = PW_MAX;
-        (void)per_cu;
         P.panelWaves = pw;
-        {
-            // full parts may wait for columns whose blocks need tasks that come later in the queue: at most (lead - 5) blocks'
-            // worth of them can be blocked at a time, which must stay well below the number of panel waves
-            int lead = knobs.full_lead >= 0 ? knobs.full_lead : g_full_lead;
-            const int g4 = P.nPanelGroups * 4;
-            while (lead > 5 && (lead - 5) * g4 > nPanelWG * pw / 2) --lead;
-            if (nPanelWG * pw < 2 * g4) lead = 0;
-            P.fullLead = lead;
-        }
-        {
-            // waves that may sit on last-part tasks whose newest u is not out yet: at most half of the panel waves, so
-            // that the full parts of earlier blocks always find a free wave (see panel_next_task)
-            const int g4 = P.nPanelGroups * 4;
-            int ra = g4 > 0 ? (nPanelWG * pw / 2) / g4 : 0;
-            const int ra_max = knobs.run_ahead >= 0 ? knobs.run_ahead : g_run_ahead_max;
-            ra = ra < 0 ? 0 : (ra > ra_max ? ra_max : ra);
-            if (knobs.run_ahead >= 0) ra = knobs.run_ahead;          // development knob: taken as given
-            P.runAhead = ra;
-        }
         // the zero upper triangle of the gradient: by spare waves of the first chunk's panel workgroups, or (no
         // panel workgroups: short sequences) by its own kernel
         int zw = 0;
@@ -2174,7 +1642,7 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         if (P.nTasks == 0) nPanelWG = 0;
         const int grid = P.nSpine + nPanelWG;
         // the panel workgroups' waves know their first task (the first draws of ~700 waves all hit one counter at the start)
-        P.taskBase = (SEMICRF_STATIC_FIRST && SEMICRF_SCHED == 0 && P.fullLead == 0 && !SEMICRF_TASK_PREFETCH) ? nPanelWG * P.panelWaves : 0;
+        P.taskBase = nPanelWG * P.panelWaves;
         if (P.taskBase > P.nTasks) P.taskBase = P.nTasks;
         if (grad) launch_one<0, 1, true>(P, grid, stream);
         else if (mode == 0 && dir == 0) launch_one<0, 0, false>(P, grid, stream);

@@ -10,6 +10,7 @@
 // the two half-waves take the two halves of the d axis -- any d permutation applied to both operands is
 // legal), results are scaled, transposed through a padded LDS tile and written chain-contiguous (64-byte
 // segments), lower triangle only unless the caller asks for the full square.
+#include <atomic>
 #include "common.h"
 
 #include <cstdlib>
@@ -1245,6 +1246,10 @@ static int launch_score_tile3(const float* q, const float* k, const float* diag,
     return 0;
 }
 
+// test hook: force one of the forward kernels (0 register loads, 32 streaming, 64 / 128 shared-operand tiles; -1 = auto)
+static std::atomic<int> g_score_variant{-1};
+void set_score_variant(int v) { g_score_variant.store(v, std::memory_order_relaxed); }
+
 int launch_interval_score_mfma(const float* q, const float* k, const float* diag, int C, int T, int D,
                                 long long ldq, long long ldk, long long ldd, float qscale, int mode, int full,
                                 float* S, hipStream_t stream, int prec)
@@ -1253,14 +1258,13 @@ int launch_interval_score_mfma(const float* q, const float* k, const float* diag
     const size_t lds = (size_t)ST * ST * SPAD * sizeof(float);
     const bool aligned = ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ldq % 4 == 0 && ldk % 4 == 0;
     const int nch = (D / 64 <= 4) ? D / 64 : 0;
-    int band = 4;
-    static const int band_env = [] { const char* e = getenv("SEMICRF_SCORE_BAND"); return e ? atoi(e) : 0; }();     // tuning knob, read once
-    if (band_env >= 1 && band_env <= 64) band = band_env;
+    const int band = 4;
     // 16-byte aligned rows: the LDS-staged kernel (T*ld*4 < 2^31: 32-bit buffer offsets)
     if (aligned && D % 64 == 0 && (long long)T * ldq * 4 < (1ll << 31) && (long long)T * ldk * 4 < (1ll << 31)) {
         // 64-row tiles when they waste less of the last tile row (e.g. T=691: 704 vs 768 rows) -- measured 779 vs 814 us
         int variant = T < 256 ? 32 : ((T + 63) / 64 * 64 < (T + 127) / 128 * 128 ? 64 : 128);
-        if (const char* e = getenv("SEMICRF_SCORE_VARIANT")) variant = atoi(e);      // tuning knob: 0 = register-load kernel
+        const int forced = g_score_variant.load(std::memory_order_relaxed);     // test hook (semicrf_debug_score_variant), -1 = auto
+        if (forced >= 0) variant = forced;
         if (prec == 1 && T >= 128)
             return launch_score_tile3<128>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream);
         if (variant == 128)

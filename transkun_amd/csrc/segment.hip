@@ -46,7 +46,10 @@ __global__ __launch_bounds__(256) void onset_pack_kernel(const int* __restrict__
         }
 }
 
-__global__ __launch_bounds__(256) void offsets_scan_kernel(const int* __restrict__ counts, int B, int* __restrict__ offsets)
+// src_total: the total of the offsets the counts were derived from (or null): a negative one is semicrf_viterbi's "a wait timed
+// out" marker and is handed on instead of the sum
+__global__ __launch_bounds__(256) void offsets_scan_kernel(const int* __restrict__ counts, int B, int* __restrict__ offsets,
+                                                           const int* __restrict__ src_total)
 {
     __shared__ int part[256];
     __shared__ int carry;
@@ -68,14 +71,14 @@ __global__ __launch_bounds__(256) void offsets_scan_kernel(const int* __restrict
         if (threadIdx.x == 255) carry += part[255];
         __syncthreads();
     }
-    if (threadIdx.x == 0) offsets[B] = carry;
+    if (threadIdx.x == 0) offsets[B] = (src_total && *src_total < 0) ? *src_total : carry;
 }
 
 void launch_onset_filter(const int* pairs, const int* offsets, int B, int bound, int* pairs_out, long long cap, int* offsets_out,
                          int* counts, hipStream_t stream)
 {
     hipLaunchKernelGGL(onset_count_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, pairs, offsets, B, bound, counts);
-    hipLaunchKernelGGL(offsets_scan_kernel, dim3(1), dim3(256), 0, stream, counts, B, offsets_out);
+    hipLaunchKernelGGL(offsets_scan_kernel, dim3(1), dim3(256), 0, stream, counts, B, offsets_out, offsets + B);
     hipLaunchKernelGGL(onset_pack_kernel, dim3(B), dim3(64), 0, stream, pairs, offsets, counts, offsets_out, B, pairs_out, cap);
 }
 

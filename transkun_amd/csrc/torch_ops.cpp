@@ -12,25 +12,70 @@
 #include <torch/csrc/stable/tensor.h>
 
 #include "../../include/semicrf_hip.h"
+#include "cpu_ops.h"
+
+#include <vector>
 
 using torch::stable::Tensor;
+using torch::headeronly::ScalarType;
 
 namespace {
+
+// Every op is dispatcher-visible: arguments are checked here (dtype, contiguity, element counts against T / B / K), not only
+// in the Python mirror -- a wrong dtype or a short buffer is an error, never an out-of-bounds access.
+inline void want(const Tensor& t, ScalarType st, int64_t min_numel, const char* name)
+{
+    STD_TORCH_CHECK(t.defined(), "semicrf: `", name, "` is undefined");
+    STD_TORCH_CHECK(t.scalar_type() == st, "semicrf: `", name, "` has the wrong dtype");
+    STD_TORCH_CHECK(t.is_contiguous(), "semicrf: `", name, "` must be contiguous");
+    STD_TORCH_CHECK(t.numel() >= min_numel, "semicrf: `", name, "` holds ", t.numel(), " elements, the call needs ", min_numel);
+}
+inline const float* f32(const Tensor& t, int64_t n, const char* name) { want(t, ScalarType::Float, n, name); return n > 0 || t.numel() > 0 ? (const float*)t.data_ptr() : nullptr; }
+inline float* f32w(const Tensor& t, int64_t n, const char* name) { return (float*)f32(t, n, name); }
+inline int32_t* i32(const Tensor& t, int64_t n, const char* name) { want(t, ScalarType::Int, n, name); return n > 0 || t.numel() > 0 ? (int32_t*)t.data_ptr() : nullptr; }
+inline void* bytes(const Tensor& t, const char* name) { want(t, ScalarType::Byte, 0, name); return t.numel() > 0 ? t.data_ptr() : nullptr; }
+
+struct Dims { int T, B; };
+inline Dims crf_dims(const Tensor& score, const Tensor& noise)
+{
+    STD_TORCH_CHECK(score.dim() == 3 && score.size(0) == score.size(1), "semicrf: score must be [T, T, B]");
+    const int64_t T = score.size(0), B = score.size(2);
+    STD_TORCH_CHECK(T >= 1 && B >= 1 && T < (1 << 29) && B < (1ll << 31), "semicrf: bad score shape");
+    want(score, ScalarType::Float, T * T * B, "score");
+    want(noise, ScalarType::Float, (T - 1) * B, "noise");
+    return Dims{(int)T, (int)B};
+}
 
 struct Ctx {
     torch::stable::accelerator::DeviceGuard guard;
     void* stream = nullptr;
-    explicit Ctx(const Tensor& t) : guard(t.get_device_index())
+    static int32_t index_of(const Tensor& t)
     {
-        STD_TORCH_CHECK(t.is_cuda(), "semicrf: tensors must live on the GPU (there is no CPU path)");
+        STD_TORCH_CHECK(t.is_cuda(), "semicrf: this overload takes GPU tensors");
+        return t.get_device_index();
+    }
+    explicit Ctx(const Tensor& t) : guard(index_of(t))          // is_cuda is checked BEFORE the guard is built
+    {
         TORCH_ERROR_CODE_CHECK(aoti_torch_get_current_cuda_stream(t.get_device_index(), &stream));
     }
+    // every tensor of a call lives on the device of the first one
+    template <typename... Ts>
+    void same(const Tensor& a, const Ts&... rest) const
+    {
+        const Tensor* ts[] = {&rest...};
+        for (const Tensor* t : ts)
+            STD_TORCH_CHECK(!t->defined() || t->numel() == 0 || (t->is_cuda() && t->get_device_index() == a.get_device_index()),
+                            "semicrf: all tensors of a call must share one device");
+    }
 };
-
-inline void same_device(const Tensor& a, const Tensor& b)
+template <typename... Ts>
+inline void all_cpu(const Ts&... ts)
 {
-    STD_TORCH_CHECK(b.is_cuda() && a.get_device_index() == b.get_device_index(), "semicrf: all tensors of a call must share one device");
+    const Tensor* a[] = {&ts...};
+    for (const Tensor* t : a)
+        STD_TORCH_CHECK(!t->defined() || t->numel() == 0 || t->is_cpu(), "semicrf: all tensors of a call must share one device");
 }
+
 inline void check(int rc, const char* what)
 {
     STD_TORCH_CHECK(rc == SEMICRF_OK, what, " failed (code ", rc, "): ", semicrf_last_error());
@@ -39,87 +84,194 @@ inline float* fp(const Tensor& t) { return t.defined() && t.numel() > 0 ? (float
 inline const float* cfp(const Tensor& t) { return t.defined() && t.numel() > 0 ? (const float*)t.data_ptr() : nullptr; }
 inline int32_t* ip(const Tensor& t) { return t.defined() && t.numel() > 0 ? (int32_t*)t.data_ptr() : nullptr; }
 
-// ---- semi-CRF --------------------------------------------------------------------------------------------------------
+// ---- semi-CRF, GPU (dispatch key CUDA = HIP tensors) ------------------------------------------------------------------
 void logz_fwd(Tensor score, Tensor noise, Tensor logZ, Tensor v, bool want_v, Tensor ws)
 {
-    Ctx c(score); same_device(score, noise); same_device(score, logZ); same_device(score, ws);
-    const int T = (int)score.size(0), B = (int)score.size(2);
-    check(semicrf_logz_fwd(cfp(score), cfp(noise), T, B, fp(logZ), want_v ? fp(v) : nullptr, ws.data_ptr(), (size_t)ws.numel(), c.stream),
+    Ctx c(score); c.same(score, noise, logZ, v, ws);
+    const Dims d = crf_dims(score, noise);
+    const int64_t TB = (int64_t)d.T * d.B;
+    check(semicrf_logz_fwd(cfp(score), cfp(noise), d.T, d.B, f32w(logZ, d.B, "logZ"), want_v ? f32w(v, TB, "v") : nullptr, bytes(ws, "ws"),
+                           (size_t)ws.numel(), c.stream),
           "semicrf_logz_fwd");
 }
 void logz_bwd(Tensor score, Tensor noise, Tensor v, Tensor logZ, Tensor gout, Tensor dScore, Tensor dNoise, Tensor q, bool want_q,
               Tensor ws)
 {
-    Ctx c(score); same_device(score, noise); same_device(score, dScore); same_device(score, ws);
-    const int T = (int)score.size(0), B = (int)score.size(2);
-    check(semicrf_logz_bwd(cfp(score), cfp(noise), cfp(v), cfp(logZ), cfp(gout), T, B, fp(dScore), fp(dNoise), want_q ? fp(q) : nullptr,
-                           ws.data_ptr(), (size_t)ws.numel(), c.stream),
+    Ctx c(score); c.same(score, noise, v, logZ, gout, dScore, dNoise, q, ws);
+    const Dims d = crf_dims(score, noise);
+    const int64_t TB = (int64_t)d.T * d.B;
+    check(semicrf_logz_bwd(cfp(score), cfp(noise), f32(v, TB, "v"), f32(logZ, d.B, "logZ"), f32(gout, d.B, "gout"), d.T, d.B,
+                           f32w(dScore, TB * d.T, "dScore"), f32w(dNoise, TB - d.B, "dNoise"), want_q ? f32w(q, TB, "q") : nullptr,
+                           bytes(ws, "ws"), (size_t)ws.numel(), c.stream),
           "semicrf_logz_bwd");
 }
 void beta(Tensor score, Tensor noise, Tensor out, Tensor ws)
 {
-    Ctx c(score); same_device(score, noise); same_device(score, out);
-    const int T = (int)score.size(0), B = (int)score.size(2);
-    check(semicrf_beta(cfp(score), cfp(noise), T, B, fp(out), ws.data_ptr(), (size_t)ws.numel(), c.stream), "semicrf_beta");
+    Ctx c(score); c.same(score, noise, out, ws);
+    const Dims d = crf_dims(score, noise);
+    check(semicrf_beta(cfp(score), cfp(noise), d.T, d.B, f32w(out, (int64_t)d.T * d.B, "beta"), bytes(ws, "ws"), (size_t)ws.numel(), c.stream),
+          "semicrf_beta");
 }
 void viterbi(Tensor score, Tensor noise, Tensor start, bool has_start, bool forward, Tensor pairs, Tensor offsets, Tensor ws)
 {
-    Ctx c(score); same_device(score, noise); same_device(score, pairs); same_device(score, offsets);
-    const int T = (int)score.size(0), B = (int)score.size(2);
-    check(semicrf_viterbi(cfp(score), cfp(noise), T, B, has_start ? ip(start) : nullptr, forward ? 1 : 0, ip(pairs),
-                          (int64_t)pairs.size(0), ip(offsets), ws.data_ptr(), (size_t)ws.numel(), c.stream),
+    Ctx c(score); c.same(score, noise, pairs, offsets, ws);
+    if (has_start) c.same(score, start);
+    const Dims d = crf_dims(score, noise);
+    STD_TORCH_CHECK(pairs.dim() == 2 && pairs.size(1) == 2, "semicrf: pairs must be [cap, 2]");
+    check(semicrf_viterbi(cfp(score), cfp(noise), d.T, d.B, has_start ? i32(start, d.B, "start") : nullptr, forward ? 1 : 0,
+                          i32(pairs, 0, "pairs"), (int64_t)pairs.size(0), i32(offsets, d.B + 1, "offsets"), bytes(ws, "ws"),
+                          (size_t)ws.numel(), c.stream),
           "semicrf_viterbi");
 }
 void eval_path(Tensor score, Tensor noise, Tensor pairs, int64_t K, Tensor offsets, Tensor out, Tensor ws)
 {
-    Ctx c(score); same_device(score, noise); same_device(score, pairs); same_device(score, out);
-    const int T = (int)score.size(0), B = (int)score.size(2);
-    check(semicrf_eval_path(cfp(score), cfp(noise), T, B, ip(pairs), K, ip(offsets), fp(out), ws.data_ptr(), (size_t)ws.numel(), c.stream),
+    Ctx c(score); c.same(score, noise, pairs, offsets, out);
+    const Dims d = crf_dims(score, noise);
+    STD_TORCH_CHECK(K >= 0, "semicrf: negative interval count");
+    check(semicrf_eval_path(cfp(score), cfp(noise), d.T, d.B, i32(pairs, 2 * K, "pairs"), K, i32(offsets, d.B + 1, "offsets"),
+                            f32w(out, d.B, "out"), ws.numel() > 0 ? ws.data_ptr() : nullptr, (size_t)ws.numel(), c.stream),
           "semicrf_eval_path");
 }
 void eval_path_bwd(Tensor gout, int64_t T, int64_t B, Tensor pairs, int64_t K, Tensor offsets, Tensor dScore, bool has_ds, Tensor dNoise,
                    bool has_dn)
 {
-    Ctx c(gout); same_device(gout, pairs);
-    check(semicrf_eval_path_bwd(cfp(gout), (int)T, (int)B, ip(pairs), K, ip(offsets), has_ds ? fp(dScore) : nullptr,
-                                has_dn ? fp(dNoise) : nullptr, c.stream),
+    Ctx c(gout); c.same(gout, pairs, offsets);
+    if (has_ds) c.same(gout, dScore);
+    if (has_dn) c.same(gout, dNoise);
+    STD_TORCH_CHECK(T >= 1 && B >= 1 && K >= 0 && T < (1 << 29) && B < (1ll << 31), "semicrf: bad sizes");
+    check(semicrf_eval_path_bwd(f32(gout, B, "gout"), (int)T, (int)B, i32(pairs, 2 * K, "pairs"), K, i32(offsets, B + 1, "offsets"),
+                                has_ds ? f32w(dScore, T * T * B, "dScore") : nullptr, has_dn ? f32w(dNoise, (T - 1) * B, "dNoise") : nullptr,
+                                c.stream),
           "semicrf_eval_path_bwd");
 }
 
+// ---- semi-CRF, CPU (dispatch key CPU): the product's own host kernels (cpu_ops.cpp) -- selected by the tensors' device, never
+// a fallback for GPU tensors.  The workspace argument is ignored (pass an empty tensor).
+void logz_fwd_cpu(Tensor score, Tensor noise, Tensor logZ, Tensor v, bool want_v, Tensor ws)
+{
+    all_cpu(score, noise, logZ, v);
+    const Dims d = crf_dims(score, noise);
+    const int64_t TB = (int64_t)d.T * d.B;
+    std::vector<float> scratch;
+    float* vv;
+    if (want_v) vv = f32w(v, TB, "v");
+    else { scratch.resize((size_t)TB); vv = scratch.data(); }
+    semicrf_cpu::logz_fwd(cfp(score), cfp(noise), d.T, d.B, f32w(logZ, d.B, "logZ"), vv);
+}
+void logz_bwd_cpu(Tensor score, Tensor noise, Tensor v, Tensor logZ, Tensor gout, Tensor dScore, Tensor dNoise, Tensor q, bool want_q,
+                  Tensor ws)
+{
+    all_cpu(score, noise, v, logZ, gout, dScore, dNoise, q);
+    const Dims d = crf_dims(score, noise);
+    const int64_t TB = (int64_t)d.T * d.B;
+    std::vector<float> scratch;
+    float* qq;
+    if (want_q) qq = f32w(q, TB, "q");
+    else { scratch.resize((size_t)TB); qq = scratch.data(); }
+    semicrf_cpu::logz_bwd(cfp(score), cfp(noise), f32(v, TB, "v"), f32(logZ, d.B, "logZ"), f32(gout, d.B, "gout"), d.T, d.B,
+                          f32w(dScore, TB * d.T, "dScore"), f32w(dNoise, TB - d.B, "dNoise"), qq);
+}
+void beta_cpu(Tensor score, Tensor noise, Tensor out, Tensor ws)
+{
+    all_cpu(score, noise, out);
+    const Dims d = crf_dims(score, noise);
+    semicrf_cpu::logz_bwd(cfp(score), cfp(noise), nullptr, nullptr, nullptr, d.T, d.B, nullptr, nullptr, f32w(out, (int64_t)d.T * d.B, "beta"));
+}
+void viterbi_cpu(Tensor score, Tensor noise, Tensor start, bool has_start, bool forward, Tensor pairs, Tensor offsets, Tensor ws)
+{
+    all_cpu(score, noise, pairs, offsets);
+    if (has_start) all_cpu(start);
+    const Dims d = crf_dims(score, noise);
+    STD_TORCH_CHECK(pairs.dim() == 2 && pairs.size(1) == 2, "semicrf: pairs must be [cap, 2]");
+    const int32_t* st = has_start ? i32(start, d.B, "start") : nullptr;
+    if (st)
+        for (int c = 0; c < d.B; ++c) STD_TORCH_CHECK(st[c] >= 0 && st[c] < d.T, "semicrf: forcedStartPos out of range");
+    semicrf_cpu::viterbi(cfp(score), cfp(noise), d.T, d.B, st, forward ? 1 : 0, i32(pairs, 0, "pairs"), (int64_t)pairs.size(0),
+                         i32(offsets, d.B + 1, "offsets"));
+}
+inline void check_path(const int32_t* pairs, int64_t K, const int32_t* offsets, int T, int B)
+{
+    STD_TORCH_CHECK(offsets[0] == 0 && offsets[B] == K, "semicrf: offsets do not match the interval count");
+    for (int c = 0; c < B; ++c) STD_TORCH_CHECK(offsets[c] <= offsets[c + 1], "semicrf: offsets must ascend");
+    for (int64_t i = 0; i < K; ++i)
+        STD_TORCH_CHECK(pairs[2 * i] >= 0 && pairs[2 * i] <= pairs[2 * i + 1] && pairs[2 * i + 1] < T, "semicrf: interval out of range");
+}
+void eval_path_cpu(Tensor score, Tensor noise, Tensor pairs, int64_t K, Tensor offsets, Tensor out, Tensor ws)
+{
+    all_cpu(score, noise, pairs, offsets, out);
+    const Dims d = crf_dims(score, noise);
+    STD_TORCH_CHECK(K >= 0, "semicrf: negative interval count");
+    const int32_t* pp = i32(pairs, 2 * K, "pairs");
+    const int32_t* oo = i32(offsets, d.B + 1, "offsets");
+    check_path(pp, K, oo, d.T, d.B);
+    semicrf_cpu::eval_path(cfp(score), cfp(noise), d.T, d.B, pp, oo, f32w(out, d.B, "out"));
+}
+void eval_path_bwd_cpu(Tensor gout, int64_t T, int64_t B, Tensor pairs, int64_t K, Tensor offsets, Tensor dScore, bool has_ds, Tensor dNoise,
+                       bool has_dn)
+{
+    all_cpu(gout, pairs, offsets);
+    STD_TORCH_CHECK(T >= 1 && B >= 1 && K >= 0 && T < (1 << 29) && B < (1ll << 31), "semicrf: bad sizes");
+    const int32_t* pp = i32(pairs, 2 * K, "pairs");
+    const int32_t* oo = i32(offsets, B + 1, "offsets");
+    check_path(pp, K, oo, (int)T, (int)B);
+    semicrf_cpu::eval_path_bwd(f32(gout, B, "gout"), (int)T, (int)B, pp, oo, has_ds ? f32w(dScore, T * T * B, "dScore") : nullptr,
+                               has_dn ? f32w(dNoise, (T - 1) * B, "dNoise") : nullptr);
+}
+
 // ---- interval scorer ---------------------------------------------------------------------------------------------------
+// q / k / diag (and their gradients) are strided views ([C][T][D] rows of ld floats): dtype and the device are checked, the
+// strides are the caller's statement; everything dense is checked for its element count.
+inline const float* f32s(const Tensor& t, const char* name)
+{
+    STD_TORCH_CHECK(t.defined() && t.scalar_type() == ScalarType::Float, "semicrf: `", name, "` must be a float32 tensor");
+    return t.numel() > 0 ? (const float*)t.data_ptr() : nullptr;
+}
+inline float* f32so(const Tensor& t, const char* name) { return t.defined() && t.numel() > 0 ? (float*)f32s(t, name) : nullptr; }
+inline void score_dims(int64_t C, int64_t T, int64_t D)
+{
+    STD_TORCH_CHECK(C >= 1 && T >= 1 && D >= 1 && C < (1ll << 31) && T < (1 << 29) && D < (1 << 20), "semicrf: bad C / T / D");
+}
 void interval_score_fwd_op(Tensor q, Tensor k, Tensor diag, int64_t C, int64_t T, int64_t D, int64_t ldq, int64_t ldk, int64_t ldd,
                            double qscale, int64_t mode, int64_t full, Tensor S, Tensor noise)
 {
-    Ctx c(q); same_device(q, k); same_device(q, diag); same_device(q, S);
-    check(interval_score_fwd(cfp(q), cfp(k), cfp(diag), (int)C, (int)T, (int)D, ldq, ldk, ldd, (float)qscale, (int)mode, (int)full, fp(S),
-                             fp(noise), c.stream),
+    Ctx c(q); c.same(q, k, diag, S, noise);
+    score_dims(C, T, D);
+    check(interval_score_fwd(f32s(q, "q"), f32s(k, "k"), f32s(diag, "diag"), (int)C, (int)T, (int)D, ldq, ldk, ldd, (float)qscale, (int)mode,
+                             (int)full, f32w(S, T * T * C, "S"), noise.numel() > 0 ? f32w(noise, (T - 1) * C, "noise") : nullptr, c.stream),
           "interval_score_fwd");
 }
 void interval_score_bwd_ws_op(Tensor dS, Tensor q, Tensor k, int64_t C, int64_t T, int64_t D, int64_t ldq, int64_t ldk, double qscale,
                               int64_t mode, Tensor dq, Tensor dk, Tensor ddiag, int64_t lddq, int64_t lddk, int64_t lddd, Tensor ws)
 {
-    Ctx c(dS); same_device(dS, q); same_device(dS, k); same_device(dS, dq);
-    check(interval_score_bwd_ws(cfp(dS), cfp(q), cfp(k), (int)C, (int)T, (int)D, ldq, ldk, (float)qscale, (int)mode, fp(dq), fp(dk), fp(ddiag),
-                                lddq, lddk, lddd, ws.numel() > 0 ? ws.data_ptr() : nullptr, (size_t)ws.numel(), c.stream),
+    Ctx c(dS); c.same(dS, q, k, dq, dk, ddiag, ws);
+    score_dims(C, T, D);
+    check(interval_score_bwd_ws(f32(dS, T * T * C, "dS"), f32s(q, "q"), f32s(k, "k"), (int)C, (int)T, (int)D, ldq, ldk, (float)qscale, (int)mode,
+                                f32so(dq, "dq"), f32so(dk, "dk"), f32so(ddiag, "ddiag"), lddq, lddk, lddd, bytes(ws, "ws"), (size_t)ws.numel(),
+                                c.stream),
           "interval_score_bwd_ws");
 }
 void interval_score_bwd_fused_ws_op(Tensor S, Tensor alpha, Tensor beta_, Tensor logZ, Tensor gout, Tensor q, Tensor k, int64_t C, int64_t T,
                                     int64_t D, int64_t ldq, int64_t ldk, double qscale, int64_t mode, Tensor dq, Tensor dk, Tensor ddiag,
                                     int64_t lddq, int64_t lddk, int64_t lddd, Tensor ws)
 {
-    Ctx c(S); same_device(S, q); same_device(S, k); same_device(S, dq);
-    check(interval_score_bwd_fused_ws(cfp(S), cfp(alpha), cfp(beta_), cfp(logZ), cfp(gout), cfp(q), cfp(k), (int)C, (int)T, (int)D, ldq, ldk,
-                                      (float)qscale, (int)mode, fp(dq), fp(dk), fp(ddiag), lddq, lddk, lddd,
-                                      ws.numel() > 0 ? ws.data_ptr() : nullptr, (size_t)ws.numel(), c.stream),
+    Ctx c(S); c.same(S, alpha, beta_, logZ, gout, q, k, dq, dk, ddiag, ws);
+    score_dims(C, T, D);
+    check(interval_score_bwd_fused_ws(f32(S, T * T * C, "S"), f32(alpha, T * C, "alpha"), f32(beta_, T * C, "beta"), f32(logZ, C, "logZ"),
+                                      f32(gout, C, "gout"), f32s(q, "q"), f32s(k, "k"), (int)C, (int)T, (int)D, ldq, ldk, (float)qscale,
+                                      (int)mode, f32so(dq, "dq"), f32so(dk, "dk"), f32so(ddiag, "ddiag"), lddq, lddk, lddd, bytes(ws, "ws"),
+                                      (size_t)ws.numel(), c.stream),
           "interval_score_bwd_fused_ws");
 }
 void interval_score_path_bwd_op(Tensor gout, Tensor pairs, int64_t K, Tensor offsets, Tensor q, Tensor k, int64_t C, int64_t T, int64_t D,
                                 int64_t ldq, int64_t ldk, double qscale, int64_t mode, Tensor dq, Tensor dk, Tensor ddiag, int64_t lddq,
                                 int64_t lddk, int64_t lddd)
 {
-    Ctx c(gout); same_device(gout, q); same_device(gout, dq);
-    check(interval_score_path_bwd(cfp(gout), ip(pairs), K, ip(offsets), cfp(q), cfp(k), (int)C, (int)T, (int)D, ldq, ldk, (float)qscale,
-                                  (int)mode, fp(dq), fp(dk), fp(ddiag), lddq, lddk, lddd, c.stream),
+    Ctx c(gout); c.same(gout, pairs, offsets, q, k, dq, dk, ddiag);
+    score_dims(C, T, D);
+    STD_TORCH_CHECK(K >= 0, "semicrf: negative interval count");
+    check(interval_score_path_bwd(f32(gout, C, "gout"), i32(pairs, 2 * K, "pairs"), K, i32(offsets, C + 1, "offsets"), f32s(q, "q"),
+                                  f32s(k, "k"), (int)C, (int)T, (int)D, ldq, ldk, (float)qscale, (int)mode, f32so(dq, "dq"), f32so(dk, "dk"),
+                                  f32so(ddiag, "ddiag"), lddq, lddk, lddd, c.stream),
           "interval_score_path_bwd");
 }
 
@@ -127,36 +279,47 @@ void interval_score_path_bwd_op(Tensor gout, Tensor pairs, int64_t K, Tensor off
 void interval_features_gather_op(Tensor ctx, int64_t C, int64_t T, int64_t D, int64_t ldc, Tensor pairs, int64_t K, Tensor offsets,
                                  int64_t nSym, Tensor out, Tensor symIdx, Tensor scatterIdx)
 {
-    Ctx c(ctx); same_device(ctx, pairs); same_device(ctx, out);
-    check(interval_features_gather(cfp(ctx), (int)C, (int)T, (int)D, ldc, ip(pairs), K, ip(offsets), (int)nSym, fp(out),
-                                   (int64_t*)symIdx.data_ptr(), (int64_t*)scatterIdx.data_ptr(), c.stream),
+    Ctx c(ctx); c.same(ctx, pairs, offsets, out, symIdx, scatterIdx);
+    score_dims(C, T, D);
+    STD_TORCH_CHECK(K >= 0, "semicrf: negative interval count");
+    want(symIdx, ScalarType::Long, K, "symIdx"); want(scatterIdx, ScalarType::Long, K, "scatterIdx");
+    check(interval_features_gather(f32s(ctx, "ctx"), (int)C, (int)T, (int)D, ldc, i32(pairs, 2 * K, "pairs"), K, i32(offsets, C + 1, "offsets"),
+                                   (int)nSym, f32w(out, K * 3 * D, "out"), K > 0 ? (int64_t*)symIdx.data_ptr() : nullptr,
+                                   K > 0 ? (int64_t*)scatterIdx.data_ptr() : nullptr, c.stream),
           "interval_features_gather");
 }
 void interval_features_gather_bwd_op(Tensor gout, Tensor ctx, int64_t C, int64_t T, int64_t D, int64_t ldc, Tensor pairs, int64_t K,
                                      Tensor offsets, Tensor dctx, int64_t lddc)
 {
-    Ctx c(gout); same_device(gout, ctx); same_device(gout, dctx);
-    check(interval_features_gather_bwd(cfp(gout), cfp(ctx), (int)C, (int)T, (int)D, ldc, ip(pairs), K, ip(offsets), fp(dctx), lddc, c.stream),
+    Ctx c(gout); c.same(gout, ctx, pairs, offsets, dctx);
+    score_dims(C, T, D);
+    STD_TORCH_CHECK(K >= 0, "semicrf: negative interval count");
+    check(interval_features_gather_bwd(f32(gout, K * 3 * D, "gout"), f32s(ctx, "ctx"), (int)C, (int)T, (int)D, ldc, i32(pairs, 2 * K, "pairs"),
+                                       K, i32(offsets, C + 1, "offsets"), (float*)f32s(dctx, "dctx"), lddc, c.stream),
           "interval_features_gather_bwd");
 }
 
 // ---- transcription segment loop ----------------------------------------------------------------------------------------
 void segment_onset_filter_op(Tensor pairs, Tensor offsets, int64_t B, int64_t bound, Tensor pairs_out, Tensor offsets_out, Tensor counts_ws)
 {
-    Ctx c(offsets); same_device(offsets, pairs_out); same_device(offsets, offsets_out);
-    check(segment_onset_filter(ip(pairs), ip(offsets), (int)B, (int)bound, ip(pairs_out), pairs_out.numel() / 2, ip(offsets_out),
-                               ip(counts_ws), c.stream),
+    Ctx c(offsets); c.same(offsets, pairs, pairs_out, offsets_out, counts_ws);
+    STD_TORCH_CHECK(B >= 1 && B < (1ll << 31), "semicrf: bad B");
+    check(segment_onset_filter(i32(pairs, 0, "pairs"), i32(offsets, B + 1, "offsets"), (int)B, (int)bound, i32(pairs_out, 0, "pairs_out"),
+                               pairs_out.numel() / 2, i32(offsets_out, B + 1, "offsets_out"), i32(counts_ws, B, "counts_ws"), c.stream),
           "segment_onset_filter");
 }
 void segment_events_op(Tensor pairs, int64_t K, Tensor offsets, int64_t B, int64_t nSym, Tensor ofValue, Tensor ofPresence,
                        int64_t lastFrameIdx, double frameDur, Tensor beginTime, int64_t stepFrames, Tensor times, Tensor flags, Tensor lastP,
                        Tensor nextStart)
 {
-    Ctx c(offsets); same_device(offsets, beginTime); same_device(offsets, lastP); same_device(offsets, nextStart);
-    check(segment_events(ip(pairs), K, ip(offsets), (int)B, (int)nSym, cfp(ofValue),
+    Ctx c(offsets); c.same(offsets, pairs, ofValue, ofPresence, beginTime, times, flags, lastP, nextStart);
+    STD_TORCH_CHECK(B >= 1 && B < (1ll << 31) && nSym >= 1 && K >= 0, "semicrf: bad B / nSym / K");
+    want(ofPresence, ScalarType::Byte, 2 * K, "ofPresence"); want(flags, ScalarType::Byte, 2 * K, "flags");
+    want(beginTime, ScalarType::Double, B / nSym, "beginTime"); want(times, ScalarType::Double, 2 * K, "times");
+    check(segment_events(i32(pairs, 2 * K, "pairs"), K, i32(offsets, B + 1, "offsets"), (int)B, (int)nSym, f32(ofValue, 2 * K, "ofValue"),
                          K > 0 ? (const unsigned char*)ofPresence.data_ptr() : nullptr, (int)lastFrameIdx, frameDur,
                          (const double*)beginTime.data_ptr(), (int)stepFrames, K > 0 ? (double*)times.data_ptr() : nullptr,
-                         K > 0 ? (unsigned char*)flags.data_ptr() : nullptr, ip(lastP), ip(nextStart), c.stream),
+                         K > 0 ? (unsigned char*)flags.data_ptr() : nullptr, i32(lastP, B, "lastP"), i32(nextStart, B, "nextStart"), c.stream),
           "segment_events");
 }
 
@@ -190,6 +353,16 @@ STABLE_TORCH_LIBRARY(semicrf, m)
           "Tensor(c!) counts_ws) -> ()");
     m.def("segment_events(Tensor pairs, int K, Tensor offsets, int B, int nSym, Tensor ofValue, Tensor ofPresence, int lastFrameIdx, "
           "float frameDur, Tensor beginTime, int stepFrames, Tensor(a!) times, Tensor(b!) flags, Tensor(c!) lastP, Tensor(d!) nextStart) -> ()");
+}
+
+STABLE_TORCH_LIBRARY_IMPL(semicrf, CPU, m)
+{
+    m.impl("logz_fwd", TORCH_BOX(&logz_fwd_cpu));
+    m.impl("logz_bwd", TORCH_BOX(&logz_bwd_cpu));
+    m.impl("beta", TORCH_BOX(&beta_cpu));
+    m.impl("viterbi", TORCH_BOX(&viterbi_cpu));
+    m.impl("eval_path", TORCH_BOX(&eval_path_cpu));
+    m.impl("eval_path_bwd", TORCH_BOX(&eval_path_bwd_cpu));
 }
 
 STABLE_TORCH_LIBRARY_IMPL(semicrf, CUDA, m)

@@ -204,8 +204,11 @@ class SegmentTranscriber(nn.Module):
         seg = packed[:, 6].astype(np.int64) // P
         pitch = np.asarray(self.targetMIDIPitch, dtype=np.int64)[packed[:, 5].astype(np.int64)]
         order = np.lexsort((pitch, packed[:, 1], packed[:, 0], seg))             # by recording, then (start, end, pitch)
+        # velocity: class indices for 'hamming' / 'match' / 'mae', the float expectation for 'mse' (ModelTransformer.py:597: its
+        # .tolist() yields floats there)
+        vel = packed[order, 4] if step["velocity"].is_floating_point() else packed[order, 4].astype(np.int64)
         cols = (seg[order].tolist(), packed[order, 0].tolist(), packed[order, 1].tolist(), pitch[order].tolist(),
-                packed[order, 4].astype(np.int64).tolist(), (packed[order, 2] != 0).tolist(), (packed[order, 3] != 0).tolist())
+                vel.tolist(), (packed[order, 2] != 0).tolist(), (packed[order, 3] != 0).tolist())
         for sg, a, b, p, v, f0, f1 in zip(*cols):
             out[sg].append(Note(a, b, p, v, f0, f1))
         return out
