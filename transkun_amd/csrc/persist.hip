@@ -78,7 +78,6 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr int SPIN_LIMIT = 1 << 20;       // global-memory polls (with s_sleep): ~0.3 s
 constexpr int SPIN_LIMIT_LDS = 1 << 24;   // LDS polls (s_sleep 1): ~0.5 s
-constexpr float RESCALE_THR = 64.0f;
 // Panel accumulators (reference M, sum S of exp2(t - M)).  u grows by ~45 log2 units per tile of 16 positions on N(0,1)
 // scores, so the old rule -- "move M when a term exceeds M + 64, to exactly that term" -- moved every accumulator every
 // 1.4 tiles, each at its own time; the test is a wave-wide __any over 32 chains x 8 columns, so the slow path ran on EVERY
@@ -277,6 +276,11 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 struct SpineBlk { float v[PB]; };
 
+// lane -> (row of the block, chain of the ring) in the spine workgroup's ring, far and loader-constant code: a chain's 16 rows
+// are one DPP row (lanes 16 ch .. 16 ch + 15), so that "row j of my chain" is a row_newbcast operand
+__device__ __forceinline__ int spine_row(int lane) { return lane & 15; }
+__device__ __forceinline__ int spine_chain(int lane) { return lane >> 4; }
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N)); }
 
@@ -299,6 +303,27 @@ __device__ __forceinline__ void lds_flag_store_asm(int* p, int v)
 {
     asm volatile("ds_write_b32 %0, %1" ::"v"(lds_addr(p)), "v"(v) : "memory");
 }
+// hand-off entries that carry their own sequence number: the whole entry in ONE access, always a fresh read
+__device__ __forceinline__ u64 lds_load64(const void* p)
+{
+    return __hip_atomic_load((const u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store64(void* p, float value, int seq)
+{
+    __hip_atomic_store((u64*)p, ((u64)(unsigned)seq << 32) | (u64)__float_as_uint(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_store128(void* p, float4 v)
+{
+    const f32x4_t w = {v.x, v.y, v.z, v.w};
+    asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr(p)), "v"(w) : "memory");
+}
+__device__ __forceinline__ float4 lds_load128(const void* p)
+{
+    f32x4_t w;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(lds_addr(p)) : "memory");
+    return make_float4(w.x, w.y, w.z, w.w);
+}
 
 // ---- loader wave ---------------------------------------------------------------------------------------
 template <int DIR, bool GRAD>
@@ -316,7 +341,7 @@ __device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* 
     // tile loads: instruction q covers columns 4q..4q+3, lane = (column within the group, row)
     const int tu = lane >> 4, tr = lane & 15;
     // constants: lane = (row, chain) like the ring waves
-    const int cr = lane >> 2, cch = lane & 3;
+    const int cr = spine_row(lane), cch = spine_chain(lane);
     const int cc = cbase + cch < P.c1 ? cbase + cch : cbase;
     int* const ready = (int*)(lds + LDS_CTL);
     int* const cons = ready + NRBUF;
@@ -390,7 +415,7 @@ __device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds
     const unsigned tag = P.tag;
     const size_t Bs = (size_t)B;
     const int lane = threadIdx.x & 63;
-    const int r = lane >> 2, ch = lane & 3;
+    const int r = spine_row(lane), ch = spine_chain(lane);
     const int c = P.c0 + sg * GS + ch;
     const bool cvalid = c < P.c1;
     float4* const far = (float4*)(lds + LDS_FAR);
@@ -437,12 +462,39 @@ __device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds
             }
         }
         const float val = MODE == 0 ? aM + flog2(aS) : aM;
-        far[(k % NFAR) * 64 + lane] = make_float4(val, __int_as_float(aK), __int_as_float(k + 1), 0.0f);   // one DS write: data + seq
+        lds_store128(far + (k % NFAR) * 64 + lane, make_float4(val, __int_as_float(aK), __int_as_float(k + 1), 0.0f));   // one DS write: data + seq
         if (SEMICRF_PANEL_PROBES && (P.dbg & 16u) && cbase_is_first && lane == 0) P.ts[128 + k] = __builtin_amdgcn_s_memrealtime();   // chain probe
     }
 }
 
 // ---- ring waves -----------------------------------------------------------------------------------------
+// The diagonal phase of the LSE sweeps (round 3).  Rows p = own0 .. own0+15 of the owner's block satisfy
+//     y[r] = log2( 2^V[r] + sum_{j<r} 2^(y[j] + d[r][j]) ),   u[r] = y[r] + sp[r],
+// V[r] = everything outside the block (shadow pushes + far partial, known when the phase starts), d[r][j] = log2 cell
+// (r, j) + sp[j] (for j = r-1 the cell with the skip folded in, `wl`).  Walked in the log domain this is 16 dependent
+// logaddexp steps of ~240 cycles each for a lone wave (two transcendentals and a cross-lane broadcast per step): 1.6 us per
+// block, the pace of the whole head of the sweep.  Now:
+//   1. a (max,+) pass over the block gives every row an exponent e[r] = max(Vmax[r], max_j e[j] + d[r][j]): the weight of the
+//      best single path into row r, so y[r] - e[r] lies in [0, 16 log2 17];
+//   2. with Y[r] = 2^(y[r] - e[r]) the recurrence is LINEAR with coefficients m[r][j] = 2^(e[j] + d[r][j] - e[r]) <= 1
+//      (sixteen independent exponentials per lane): Y[r] = a[r] + sum_j Y[j] m[r][j], a[r] = S[r] 2^(Vmax[r] - e[r]) <= #terms;
+//      nothing can overflow, what underflows is below 2^-24 of a term of size >= 1;
+//   3. y[r] = e[r] + log2 Y[r].
+// Both passes are 15 steps of TWO dependent vector instructions: a lane is (row r, chain) with the chain's 16 rows in one DPP
+// row, so "the value of row j" is a row_newbcast operand (v_add_f32_dpp / v_mov_b32_dpp), no LDS round trip.
+// tools/dpp_probe.hip measures the chains on their own.  The (max,+) sweeps keep their stepwise form (one add and one
+// compare per step, bit-exact candidates).
+template <int J>
+__device__ __forceinline__ float row_bcast(float x)       // lane J of this lane's DPP row: row J of the block, same chain
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + J, 0xf, 0xf, false));
+}
+template <int J, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (J < N) { f(IC<J>{}); static_for<J + 1, N>(f); }
+}
+
 template <int MODE, int DIR, bool GRAD>
 __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int ring_pos, char* lds)
 {
@@ -460,7 +512,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
     float* const dNoise = P.dNoise;
     const int rw = __builtin_amdgcn_readfirstlane(ring_pos);                // position of the wave in the ring
     const int lane = threadIdx.x & 63;
-    const int r = lane >> 2, ch = lane & 3;
+    const int r = spine_row(lane), ch = spine_chain(lane);
     const int c = P.c0 + sg * GS + ch;
     const bool cvalid = c < P.c1;
     const int cc = cvalid ? c : P.c0;
@@ -469,7 +521,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
     float* const ring = (float*)(lds + LDS_RING);
     float* const dummy = (float*)(lds + LDS_DUMMY);
     const float* rd_base = ring + ch * 2;                                   // + (j % NPOS) * 8 floats
-    const int bp_addr = ch << 2;                                            // ds_bpermute byte address of lane ch
+    const int bp_row0 = ch << 6;                                            // ds_bpermute byte address of this chain's row 0; row jj: + 4 jj
     const int* const ready = (const int*)(lds + LDS_CTL);
     int* const cons = (int*)(lds + LDS_CTL) + NRBUF;
     const float4* const far = (const float4*)(lds + LDS_FAR);
@@ -541,39 +593,47 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
                 }
             }
         }
-        // LSE: W = wl + sp of every row of the block, in every lane (the value chain is carried redundantly)
-        float Wb[PB];
-        if (MODE == 0) {
-#pragma unroll
-            for (int jj = 1; jj < PB; ++jj)
-                Wb[jj] = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + (jj << 4), __float_as_int(wl + sp)));
-            Wb[0] = 0.0f;
-        }
         // GRAD: marginal(prow, j) = gz * exp2(t + arow) with t = u[j] + cell*log2e, arow = (alpha[frame] - logZ)*log2e
         const float arow = (GRAD && rvalid) ? (vfl - lzc) * LOG2E : 0.f;
+        // LSE: the block's own triangle as log2 coefficients d[j] = cell(r, j) + sp[j] (column r-1: the cell with the skip
+        // folded in; columns >= r: none) -- known at the start of the iteration, long before the phase that needs them
+        float d[PB - 1];
+        if (MODE == 0) {
+            static_for<0, PB - 1>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const float cj = r > j + 1 ? X[RING - 1].v[j] * LOG2E : (r == j + 1 ? wl : SEMICRF_NEG_INF);
+                d[j] = (rvalid ? cj : SEMICRF_NEG_INF) + row_bcast<j>(sp);
+            });
+        }
         if (trace) ev[1] = __builtin_readcyclecounter();
 
         float aM = SEMICRF_NEG_INF, aS = 0.f;
         int aK = 0x7fffffff;
 
-        // wait for positions j .. j+3 in the ring and return this lane's chain (one check per four positions:
-        // a wave that lags behind its ring mate catches up at the cost of the pushes alone)
+        // wait for positions j .. j+3 in the ring and return this lane's chain (one check per four positions: a wave that
+        // lags behind its ring mate catches up at the cost of the pushes alone).  Every entry is ONE 8-byte word {u, seq},
+        // written with one DS store and read with ONE 64-bit load (lds_load64: the compiler splits a plain float2 load into
+        // separate loads of value and seq when they are used apart -- the value read BEFORE its seq is a torn read);
+        // the LSE owner writes all 16 positions of a block with one instruction, so each entry's own seq is checked.
         auto ring_get4 = [&](int j, float (&uo)[4]) {
-            const float2* e = (const float2*)(rd_base + (j % NPOS) * 8);       // j % 4 == 0: no wrap inside the group
-            float2 v0 = e[0], v1 = e[RS], v2 = e[2 * RS], v3 = e[3 * RS];
-            if (!__all(__float_as_int(v3.y) == j + 4)) {
+            const float* e = rd_base + (j % NPOS) * 8;                         // j % 4 == 0: no wrap inside the group
+            u64 w0, w1, w2, w3;
+            auto fetch = [&]() { w0 = lds_load64(e); w1 = lds_load64(e + 2 * RS); w2 = lds_load64(e + 4 * RS); w3 = lds_load64(e + 6 * RS); };
+            auto ok = [&]() {
+                return (int)(w0 >> 32) == j + 1 && (int)(w1 >> 32) == j + 2 && (int)(w2 >> 32) == j + 3 && (int)(w3 >> 32) == j + 4;
+            };
+            fetch();
+            if (!__all(ok())) {
                 int spins = 0;
                 while (true) {
                     __builtin_amdgcn_s_sleep(1);
-                    asm volatile("" ::: "memory");           // force a fresh LDS read
-                    v3 = e[3 * RS];
-                    if (__all(__float_as_int(v3.y) == j + 4)) break;
+                    fetch();
+                    if (__all(ok())) break;
                     if (spin_abort(ctrl, spins, SPIN_LIMIT_LDS, 2)) break;
                 }
-                asm volatile("" ::: "memory");
-                v0 = e[0]; v1 = e[RS]; v2 = e[2 * RS];       // published in order: all there once the last one is
             }
-            uo[0] = v0.x; uo[1] = v1.x; uo[2] = v2.x; uo[3] = v3.x;
+            uo[0] = __uint_as_float((unsigned)w0); uo[1] = __uint_as_float((unsigned)w1);
+            uo[2] = __uint_as_float((unsigned)w2); uo[3] = __uint_as_float((unsigned)w3);
         };
 
         // ---------------- shadow phase: apply a block published by a ring mate ---------------------
@@ -617,13 +677,12 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
         if (k >= RING && !(dbg & 1u)) {
             // combined far-field partial of this (row, chain), left in LDS by the far wave
             const float4* fe = far + (k % NFAR) * 64 + lane;
-            float4 f = *fe;
+            float4 f = lds_load128(fe);                          // one 16-byte read: data and seq together
             if (!__all(__float_as_int(f.z) == k + 1)) {
                 int spins = 0;
                 while (true) {
                     __builtin_amdgcn_s_sleep(1);
-                    asm volatile("" ::: "memory");
-                    f = *fe;
+                    f = lds_load128(fe);
                     if (__all(__float_as_int(f.z) == k + 1)) break;
                     if (spin_abort(ctrl, spins, SPIN_LIMIT_LDS, 8)) break;
                 }
@@ -634,41 +693,45 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
             }
         }
 
-        // ring entry of position own0 (+8 floats per step); writers: the four lanes of row 0, the other lanes' stores go to a sink
         if (SEMICRF_PANEL_PROBES && trace) ts[64 + k] = __builtin_amdgcn_s_memrealtime();            // chain probe: far partial in hand
-        float* const wr = r == 0 ? ring + ch * 2 + (own0 % NPOS) * 8 : dummy + lane * 2;
         int mykey = -1;
+        float mine = 0.f;                    // this lane's finished u (log2 units for LSE)
         if (MODE == 0) {
-            // Every lane carries the value chain of its chain redundantly, so the dependent chain u[j] -> u[j+1]
-            // = logaddexp2(VpB, u[j] + W[j+1]) contains no cross-lane step: W of every row was broadcast at the
-            // start of the iteration, and VpB (row j+1's sum of everything but its last term) is broadcast one
-            // step ahead, right after the push of u[j-1].
-            float Vp = aM + flog2(aS) + sp;
-            float ucur = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(prow == 0 ? sp : Vp)));   // row 0
-            float VpB = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + (1 << 4), __float_as_int(Vp)));           // row 1
-#pragma unroll
-            for (int jj = 0; jj < PB; ++jj) {
-                const int j = own0 + jj;
-                const float u = ucur;
-                *(float2*)(wr + jj * 8) = make_float2(u, __int_as_float(j + 1));    // one DS write: data + seq
-                // critical chain: value of row jj+1
-                if (jj + 1 < PB) {
-                    const float t = u + Wb[jj + 1 < PB ? jj + 1 : 0];
-                    ucur = fmaxf(VpB, t) + flog2(1.0f + fexp2(-fabsf(VpB - t)));
-                }
-                // push for the rows further down, refresh Vp, send row jj+2's ahead
-                const float p = fmaf(X[RING - 1].v[jj], LOG2E, u);
-                if (GRAD) {
-                    if (rvalid && r > jj) grad_store(j, gz * fexp2(p + arow));
-                    if (rvalid && r == jj + 1)
-                        dNoise[(size_t)gap_of<DIR>(prow, T) * Bs + c] = gz * fexp2(u + nz * LOG2E + arow);
-                }
-                acc_push1(aM, aS, p);
-                Vp = aM + flog2(aS) + sp;
-                if (jj + 2 < PB) VpB = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + ((jj + 2) << 4), __float_as_int(Vp)));
+            // everything outside the block: S terms relative to their maximum mx (the first position has the empty path, weight 1;
+            // rows past the end and ghost chains run on finite stand-ins, nobody reads them)
+            float mx = aM, S = aS;
+            if (prow == 0 || !rvalid) { mx = 0.0f; S = 1.0f; }
+            // 1. exponents: the best single path into every row
+            float e = mx;
+            static_for<0, PB - 1>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                e = fmaxf(e, row_bcast<j>(e) + d[j]);      // lane j's e is final: it only ever took terms of rows < j
+            });
+            // 2. linear solve in units of 2^e.  The coefficient's exponent is formed as (e[j] - e[r]) + d[j]: the difference of
+            // the two large numbers first (exact or nearly so), then the small one -- one rounding at the magnitude of d, where
+            // the log-domain step rounded every term at the magnitude of u (ulp(1000) ~ 6e-5: 4e-5 relative in the sum)
+            float acc = S * fexp2(mx - e);
+            static_for<0, PB - 1>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                acc = fmaf(row_bcast<j>(acc), fexp2((row_bcast<j>(e) - e) + d[j]), acc);
+            });
+            // 3. back to the log domain; one 8-byte DS write per lane publishes the whole block to the ring mates
+            mine = e + flog2(acc) + sp;
+            lds_store64(ring + ch * 2 + ((own0 + r) % NPOS) * 8, mine, own0 + r + 1);
+            __builtin_amdgcn_s_setprio(1);
+            if (GRAD) {
+                // marginals of the block's own triangle and of its gaps (off the critical path: the block is out)
+                static_for<0, PB - 1>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const float uj = row_bcast<j>(mine);
+                    if (rvalid && r > j) grad_store(own0 + j, gz * fexp2(fmaf(X[RING - 1].v[j], LOG2E, uj) + arow));
+                    if (rvalid && r == j + 1) dNoise[(size_t)gap_of<DIR>(prow, T) * Bs + c] = gz * fexp2(uj + nz * LOG2E + arow);
+                });
             }
         } else {
-            // (max,+): after the push of u[jj] the accumulator of row jj+1 is complete
+            // (max,+): after the push of u[jj] the accumulator of row jj+1 is complete.  Ring entry of position own0 (+8 floats per
+            // step); writers: the four lanes of row 0, the other lanes' stores go to a sink
+            float* const wr = r == 0 ? ring + ch * 2 + (own0 % NPOS) * 8 : dummy + lane * 2;
             float cv;
             {
                 const float b0 = prow == 0 ? 0.0f : aM;
@@ -678,21 +741,21 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
 #pragma unroll
             for (int jj = 0; jj < PB; ++jj) {
                 const int j = own0 + jj;
-                const float u = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr + (jj << 4), __float_as_int(cv)));
-                *(float2*)(wr + jj * 8) = make_float2(u, __int_as_float(j + 1));
+                const float u = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_row0 + (jj << 2), __float_as_int(cv)));
+                lds_store64(wr + jj * 8, u, j + 1);
                 const int key = frame_of<DIR>(j < T ? j : T - 1, T);
                 if (r == jj + 1) max_push(aM, aK, u + nz, -1);                  // the skip candidate goes first (key -1)
                 max_push(aM, aK, u + X[RING - 1].v[jj], key);
                 cv = sp > 0.0f ? aM + sp : aM;
                 if (r == jj + 1) mykey = aK;
             }
+            __builtin_amdgcn_s_setprio(1);
+            mine = __uint_as_float((unsigned)lds_load64(rd_base + (prow_c % NPOS) * 8));
         }
-        __builtin_amdgcn_s_setprio(1);
         if (trace) ev[7] = __builtin_readcyclecounter();
 
         // ---- once per block: publish the 16 finished positions to HBM -----------------------------
         if (rvalid) {
-            float mine = rd_base[(prow % NPOS) * 8];
             if (k == K - 1 && lds_flag_load(&s_abort) != 0) mine = __uint_as_float(0x7fc00000u);     // a wait timed out: poison the results
             if (k < K - RING) {                                 // the far field of block k' ends at block k' - RING: nobody reads the last RING blocks' u
                 unsigned ub = __float_as_uint(mine);
