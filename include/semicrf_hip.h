@@ -206,6 +206,41 @@ int interval_score_bwd_ws(const float* dS, const float* q, const float* k, int C
                           int64_t lddq, int64_t lddk, int64_t lddd, void* ws, size_t ws_bytes, semicrf_stream_t stream);
 
 /*
+ * SLOT LAYOUT of the chain axis (the *_p entry points): a private layout between this library's scorer and its CRF kernels.
+ *
+ * The model's chains come in groups of `group` symbols per segment (90: ModelTransformer.py:97); the CRF kernels stream the
+ * score tensor in 32-chain pieces of 128 bytes, and a chain count that is not a multiple of 32 makes most pieces straddle two
+ * lines (T=691: 90 / 360 chains run 22 - 32 % slower than 96 / 384).  With the slot layout every group owns `pitch` >= group
+ * SLOTS of the chain axis: chain c = g * group + p lives in slot g * pitch + p; the slots p = group .. pitch-1 are ghosts.
+ *   - S (and dS) is [T][T][Cs], Cs = (C / group) * pitch; the scorer multiplies only the C real chains and writes exact zeros
+ *     into the ghost slots (cells e >= b; with full_square == 0 also the zeros above the diagonal);
+ *   - the CRF entry points are called with B = Cs: a ghost slot is an ordinary chain of all-zero scores whose results the
+ *     caller drops; noise, alpha, beta, logZ, gout and the interval offsets ([Cs + 1], ghost slots empty) are slot-indexed;
+ *   - q, k, diag and their gradients stay chain-indexed ([C][T][..]).
+ * group == pitch (== any divisor layout) is the plain contiguous layout; a padded pitch must be a multiple of 4 and needs the
+ * LDS-tiled kernels (16-byte aligned rows, D % 64 == 0, T >= 128; backward: the workspace path) -- SEMICRF_EINVAL otherwise.
+ * The reference has no counterpart: its scorer ends with permute(2,3,0,1).contiguous() (LayersTransformer.py:439) and the
+ * glue flattens (N, P) (ModelTransformer.py:215-216); transkun_amd/fused.py and transcribe.py use the slot layout inside and
+ * hand out chain-indexed results.
+ */
+int interval_score_fwd_p(const float* q, const float* k, const float* diag, int C, int T, int D,
+                         int64_t ldq, int64_t ldk, int64_t ldd, float qscale, int length_scaling,
+                         int full_square, int group, int pitch, float* S, float* noise_out, semicrf_stream_t stream);
+int interval_score_bwd_ws_p(const float* dS, const float* q, const float* k, int C, int T, int D, int64_t ldq,
+                            int64_t ldk, float qscale, int length_scaling, int group, int pitch, float* dq, float* dk,
+                            float* ddiag, int64_t lddq, int64_t lddk, int64_t lddd, void* ws, size_t ws_bytes,
+                            semicrf_stream_t stream);
+int interval_score_bwd_fused_ws_p(const float* S, const float* alpha, const float* beta, const float* logZ,
+                                  const float* gout, const float* q, const float* k, int C, int T, int D, int64_t ldq,
+                                  int64_t ldk, float qscale, int length_scaling, int group, int pitch, float* dq, float* dk,
+                                  float* ddiag, int64_t lddq, int64_t lddk, int64_t lddd, void* ws, size_t ws_bytes,
+                                  semicrf_stream_t stream);
+int interval_score_path_bwd_p(const float* gout, const int32_t* pairs, int64_t K, const int32_t* offsets, const float* q,
+                              const float* k, int C, int T, int D, int64_t ldq, int64_t ldk, float qscale, int length_scaling,
+                              int group, int pitch, float* dq, float* dk, float* ddiag, int64_t lddq, int64_t lddk,
+                              int64_t lddd, semicrf_stream_t stream);
+
+/*
  * Backward-direction values only (the beta half of forward_backward, NeuralSemiCRFInterval.py:386-414, without the
  * marginals): beta[t][c] by frame, natural log.  Workspace: semicrf_workspace_bytes(SEMICRF_OP_LOGZ_FWD, T, B).
  * Used by interval_score_bwd_fused, which rebuilds the marginals tile by tile instead of reading a dense gradient.

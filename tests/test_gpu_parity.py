@@ -593,7 +593,7 @@ def test_scorer_lower_triangle_only(gpu):
         S0 = torch.empty(T, T, C, device=gpu); S2 = torch.full((T, T, C), 7.5, device=gpu)
         nz = torch.empty(T - 1, C, device=gpu)
         for full, S in ((0, S0), (2, S2)):
-            _lib.ops().interval_score_fwd(q, k, dg, C, T, D, q.stride(-2), k.stride(-2), dg.stride(-1), 1.0 / 8, 0, full, S, nz)
+            _lib.ops().interval_score_fwd(q, k, dg, C, T, D, q.stride(-2), k.stride(-2), dg.stride(-1), 1.0 / 8, 0, full, C, C, S, nz)
         lower = torch.tril(torch.ones(T, T, dtype=torch.bool, device=gpu))
         assert torch.equal(S0[lower], S2[lower])
         assert bool((S2[~lower] == 7.5).all()) and bool((S0[~lower] == 0).all())
@@ -622,7 +622,7 @@ def test_scorer_bf16x3(gpu, C, T, D, mode, tri):
     def run(fs):
         S = torch.full((T, T, C), fill, device=gpu)
         nz = torch.empty(T - 1, C, device=gpu)
-        _lib.ops().interval_score_fwd(q, k, dg, C, T, D, q.stride(-2), k.stride(-2), dg.stride(-1), qs, mode, fs, S, nz)
+        _lib.ops().interval_score_fwd(q, k, dg, C, T, D, q.stride(-2), k.stride(-2), dg.stride(-1), qs, mode, fs, C, C, S, nz)
         return S
     S3, S1 = run(tri | BF16X3), run(tri)
     t = torch.arange(T, device=gpu)
@@ -1152,3 +1152,66 @@ def test_transcribe_many_equals_one_by_one(gpu):
     together = m.transcribe_many([fn_a, fn_b, fn_b], [n_full, n_short, n_full])
     for x, y in zip(alone, together):
         assert [e.astuple() for e in x] == [e.astuple() for e in y]
+
+
+# ---- slot layout of the chain axis (include/semicrf_hip.h "SLOT LAYOUT") ------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,P,pitch,T,D,bf16x3", [(1, 90, 96, 200, 64, False), (2, 90, 96, 300, 128, False), (3, 10, 32, 130, 256, False),
+                                                   (2, 90, 128, 257, 64, True), (4, 90, 96, 691, 256, False)])
+def test_scorer_slot_layout(gpu, N, P, pitch, T, D, bf16x3):
+    """interval_score_fwd with a slot layout: the real slots hold bit for bit what the contiguous layout holds, the ghost slots
+    exact zeros (lower triangle and, with full_square == 0, above it); the backward through the slot layout (plain and fused
+    with the CRF's marginals) equals the contiguous one."""
+    from transkun_amd import synth
+    from transkun_amd.scorer import BF16X3, _interval_score_raw, bwd_workspace, slot_maps
+    C = N * P
+    q = synth.hash_normal(C * T * D, 171, "cpu").view(C, T, D).to(gpu)
+    k = synth.hash_normal(C * T * D, 172, "cpu").view(C, T, D).to(gpu)
+    dg = synth.hash_normal(C * T, 173, "cpu").view(C, T).to(gpu)
+    qs = 1.0 / D ** 0.5
+    fs = 0 | (BF16X3 if bf16x3 else 0)
+    from transkun_amd import _lib
+    _lib.load().semicrf_debug_score_variant(128)       # the slot layout lives in the tile kernels: the same kernel for the reference
+    try:
+        ref, _ = _interval_score_raw(q, k, dg, T, C, D, qs, 0, fs)
+    finally:
+        _lib.load().semicrf_debug_score_variant(-1)
+    got, nz = _interval_score_raw(q, k, dg, T, C, D, qs, 0, fs, P, pitch)
+    assert got.shape == (T, T, N * pitch) and nz.shape == (T - 1, N * pitch) and float(nz.abs().max()) == 0.0
+    g4 = got.view(T, T, N, pitch)
+    assert torch.equal(g4[..., :P].reshape(T, T, C), ref)
+    assert float(g4[..., P:].abs().max()) == 0.0
+    if bf16x3:
+        return
+    # backward: a lower-triangular cotangent in slot layout (ghost slots carry garbage that must not matter)
+    real, _ = slot_maps(N, P, pitch, gpu)
+    cot = synth.hash_normal(T * T * C, 174, gpu).view(T, T, C)
+    cot_s = synth.hash_normal(T * T * N * pitch, 175, gpu).view(T, T, N * pitch)
+    cot_s[:, :, real] = cot
+    ops = _lib_ops()
+    outs = []
+    for (dS, grp, pit) in ((cot, C, C), (cot_s, P, pitch)):
+        dq = torch.full((C, T, D), float("nan"), device=gpu); dk = torch.full((C, T, D), float("nan"), device=gpu)
+        dd = torch.full((C, T), float("nan"), device=gpu)
+        ws = bwd_workspace(C, T, D, gpu)
+        ops.interval_score_bwd_ws(dS.contiguous(), q, k, C, T, D, D, D, qs, 0, grp, pit, dq, dk, dd, D, D, 1, ws)
+        outs.append((dq, dk, dd))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def _lib_ops():
+    from transkun_amd import _lib
+    return _lib.ops()
+
+
+def test_slot_layout_offsets_maps():
+    from transkun_amd.scorer import slot_maps
+    real, off = slot_maps(2, 3, 4, "cpu")
+    assert real.tolist() == [0, 1, 2, 4, 5, 6]
+    assert off.tolist() == [0, 1, 2, 3, 3, 4, 5, 6, 6]
+    offsets = torch.tensor([0, 2, 2, 5, 6, 6, 9])                     # by chain (6 chains)
+    by_slot = offsets[off]
+    assert by_slot.tolist() == [0, 2, 2, 5, 5, 6, 6, 9, 9]
+    assert torch.cat([by_slot[real], by_slot[-1:]]).tolist() == offsets.tolist()

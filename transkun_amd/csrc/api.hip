@@ -61,15 +61,18 @@ void launch_interval_features_bwd(const float* gout, const float* ctx, int C, in
 void launch_interval_score_path_bwd(const float* gout, const int* pairs, int K, const int* offsets, const float* q,
                                     const float* k, int C, int T, int D, long long ldq, long long ldk, float qscale, int mode,
                                     float* dq, float* dk, float* ddiag, long long lddq, long long lddk, long long lddd,
-                                    hipStream_t stream);
+                                    hipStream_t stream, int group, int pitch);
+void launch_interval_score_bwd_diag(const float* dS, const float* const* fused, float* ddiag, int C, int T, long long lddd,
+                                    int group, int pitch, hipStream_t stream);
+bool interval_score_slots_supported(int C, int T, int D, const float* q, const float* k, long long ldq, long long ldk);
 size_t interval_score_bwd_ws_bytes(int C, int T, int D);
 bool launch_interval_score_bwd_packed(const float* dS, const float* q, const float* k, int C, int T, int D, long long ldq,
                                       long long ldk, float qscale, int mode, float* dq, float* dk, long long lddq,
                                       long long lddk, void* ws, size_t ws_bytes, hipStream_t stream,
-                                      const float* const* fused);
+                                      const float* const* fused, int group, int pitch);
 int launch_interval_score_mfma(const float* q, const float* k, const float* diag, int C, int T, int D,
                                 long long ldq, long long ldk, long long ldd, float qscale, int mode, int full,
-                                float* S, hipStream_t stream, int prec);
+                                float* S, hipStream_t stream, int prec, int group, int pitch);
 size_t persist_workspace_bytes(int T, int B);
 bool persist_supported(int T, int B);
 int launch_persist_sweep(int mode, int dir, const float* score, const float* noise, int T, int B, float* u_out,
@@ -367,35 +370,60 @@ int semicrf_eval_path_bwd(const float* gout, int T, int B, const int32_t* pairs,
     return SEMICRF_OK;
 }
 
-int interval_score_fwd(const float* q, const float* k, const float* diag, int C, int T, int D, int64_t ldq,
-                       int64_t ldk, int64_t ldd, float qscale, int length_scaling, int full_square, float* S,
-                       float* noise_out, semicrf_stream_t stream)
+static int check_slots(int C, int group, int pitch)
+{
+    SEMICRF_CHECK_ARG(group >= 1 && pitch >= group && C % group == 0, "bad slot layout: C=%d group=%d pitch=%d", C, group, pitch);
+    SEMICRF_CHECK_ARG(pitch == group || pitch % 4 == 0, "a padded slot pitch must be a multiple of 4 (pitch=%d)", pitch);
+    SEMICRF_CHECK_ARG((long long)(C / group) * pitch < (1ll << 31), "too many slots");
+    return SEMICRF_OK;
+}
+
+int interval_score_fwd_p(const float* q, const float* k, const float* diag, int C, int T, int D, int64_t ldq,
+                         int64_t ldk, int64_t ldd, float qscale, int length_scaling, int full_square, int group, int pitch,
+                         float* S, float* noise_out, semicrf_stream_t stream)
 {
     SEMICRF_CHECK_ARG(C >= 1 && T >= 1 && D >= 1, "C=%d T=%d D=%d must be >= 1", C, T, D);
     SEMICRF_CHECK_ARG(q && k && diag && S, "q/k/diag/S must be non-NULL");
     SEMICRF_CHECK_ARG(ldq >= D && ldk >= D && ldd >= 1, "bad leading dimensions");
     SEMICRF_CHECK_ARG(length_scaling >= 0 && length_scaling <= 2, "bad length_scaling %d", length_scaling);
     SEMICRF_CHECK_ARG(full_square >= 0 && (full_square & 3) <= 2 && (full_square & ~7) == 0, "bad full_square %d", full_square);
+    if (int rc = check_slots(C, group, pitch)) return rc;
+    if (pitch == group) group = pitch = C;                     // no ghosts: ONE group (quads must not straddle a group's end)
+    const bool slots = pitch != group;
+    const int Cs = (C / group) * pitch;
+    if (slots)
+        SEMICRF_CHECK_ARG(g_impl.load() == 0 && interval_score_slots_supported(C, T, D, q, k, ldq, ldk),
+                          "a padded slot layout needs the shared-operand kernels: 16-byte aligned rows, D %% 64 == 0, T >= 128");
     hipStream_t st = (hipStream_t)stream;
     const int prec = (full_square & SEMICRF_SCORE_BF16X3) ? 1 : 0;   // opt-in: three-limb bf16 contraction (scorer_mfma.hip)
     full_square &= 3;
-    if (full_square == 0) launch_zero_upper(S, T, C, st);      // begin > end: defined (zero), half the bytes of a full fill
+    if (full_square == 0) launch_zero_upper(S, T, Cs, st);     // begin > end: defined (zero), half the bytes of a full fill
     const int full_kernel = full_square == 1 ? 1 : 0;           // 2: lower triangle only, the rest of S is left as it is
     if (g_impl.load() == 0 && interval_score_mfma_supported(C, T, D)) {
-        if (launch_interval_score_mfma(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, length_scaling, full_kernel, S, st, prec) != 0) {
+        if (launch_interval_score_mfma(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, length_scaling, full_kernel, S, st, prec, group, pitch) != 0) {
             set_error("interval_score_fwd: work list allocation failed");
             return SEMICRF_ELAUNCH;
         }
-    } else
+    } else {
+        SEMICRF_CHECK_ARG(!slots, "a padded slot layout needs the shared-operand kernels");
         launch_interval_score_naive(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, length_scaling, full_kernel, S, st);
+    }
     if (noise_out && T > 1) {
-        if (hipMemsetAsync(noise_out, 0, (size_t)(T - 1) * C * sizeof(float), st) != hipSuccess) {
+        if (hipMemsetAsync(noise_out, 0, (size_t)(T - 1) * Cs * sizeof(float), st) != hipSuccess) {
             set_error("hipMemsetAsync failed");
             return SEMICRF_ELAUNCH;
         }
     }
     SEMICRF_CHECK_LAUNCH("interval_score_fwd");
     return SEMICRF_OK;
+}
+
+int interval_score_fwd(const float* q, const float* k, const float* diag, int C, int T, int D, int64_t ldq,
+                       int64_t ldk, int64_t ldd, float qscale, int length_scaling, int full_square, float* S,
+                       float* noise_out, semicrf_stream_t stream)
+{
+    return interval_score_fwd_p(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, length_scaling, full_square, C > 0 ? C : 1, C > 0 ? C : 1, S,
+                                noise_out, stream);
 }
 
 int interval_score_bwd(const float* dS, const float* q, const float* k, int C, int T, int D, int64_t ldq, int64_t ldk,
@@ -416,9 +444,9 @@ int interval_score_bwd(const float* dS, const float* q, const float* k, int C, i
 
 size_t interval_score_bwd_workspace_bytes(int C, int T, int D) { return interval_score_bwd_ws_bytes(C, T, D); }
 
-int interval_score_bwd_ws(const float* dS, const float* q, const float* k, int C, int T, int D, int64_t ldq, int64_t ldk,
-                          float qscale, int length_scaling, float* dq, float* dk, float* ddiag, int64_t lddq,
-                          int64_t lddk, int64_t lddd, void* ws, size_t ws_bytes, semicrf_stream_t stream)
+int interval_score_bwd_ws_p(const float* dS, const float* q, const float* k, int C, int T, int D, int64_t ldq, int64_t ldk,
+                            float qscale, int length_scaling, int group, int pitch, float* dq, float* dk, float* ddiag, int64_t lddq,
+                            int64_t lddk, int64_t lddd, void* ws, size_t ws_bytes, semicrf_stream_t stream)
 {
     SEMICRF_CHECK_ARG(C >= 1 && T >= 1 && D >= 1, "C=%d T=%d D=%d must be >= 1", C, T, D);
     SEMICRF_CHECK_ARG(dS && q && k, "dS/q/k must be non-NULL");
@@ -426,15 +454,28 @@ int interval_score_bwd_ws(const float* dS, const float* q, const float* k, int C
                       "bad leading dimensions");
     SEMICRF_CHECK_ARG(length_scaling >= 0 && length_scaling <= 2, "bad length_scaling %d", length_scaling);
     SEMICRF_CHECK_ARG(interval_score_bwd_supported(C, T, D), "interval_score_bwd needs D %% 32 == 0 and D <= 256 (D=%d)", D);
+    if (int rc = check_slots(C, group, pitch)) return rc;
+    if (pitch == group) group = pitch = C;                     // no ghosts: ONE group (quads must not straddle a group's end)
+    const bool slots = pitch != group;
     hipStream_t st = (hipStream_t)stream;
     if (g_impl.load() == 0 && (dq || dk) &&
-        launch_interval_score_bwd_packed(dS, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, lddq, lddk, ws, ws_bytes, st, nullptr)) {
-        if (ddiag) launch_interval_score_bwd(dS, q, k, C, T, D, ldq, ldk, qscale, length_scaling, nullptr, nullptr, ddiag, lddq, lddk, lddd, st);
+        launch_interval_score_bwd_packed(dS, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, lddq, lddk, ws, ws_bytes, st, nullptr,
+                                         group, pitch)) {
+        if (ddiag) launch_interval_score_bwd_diag(dS, nullptr, ddiag, C, T, lddd, group, pitch, st);
     } else {
+        SEMICRF_CHECK_ARG(!slots, "a padded slot layout needs the packed path (workspace, D in {64,128,256}, T >= 64, aligned rows)");
         launch_interval_score_bwd(dS, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, ddiag, lddq, lddk, lddd, st);
     }
     SEMICRF_CHECK_LAUNCH("interval_score_bwd_ws");
     return SEMICRF_OK;
+}
+
+int interval_score_bwd_ws(const float* dS, const float* q, const float* k, int C, int T, int D, int64_t ldq, int64_t ldk,
+                          float qscale, int length_scaling, float* dq, float* dk, float* ddiag, int64_t lddq,
+                          int64_t lddk, int64_t lddd, void* ws, size_t ws_bytes, semicrf_stream_t stream)
+{
+    return interval_score_bwd_ws_p(dS, q, k, C, T, D, ldq, ldk, qscale, length_scaling, C > 0 ? C : 1, C > 0 ? C : 1, dq, dk, ddiag, lddq, lddk,
+                                   lddd, ws, ws_bytes, stream);
 }
 
 int interval_score_bwd_fused(const float* S, const float* alpha, const float* beta, const float* logZ,
@@ -454,10 +495,10 @@ int interval_score_bwd_fused(const float* S, const float* alpha, const float* be
     return SEMICRF_OK;
 }
 
-int interval_score_bwd_fused_ws(const float* S, const float* alpha, const float* beta, const float* logZ,
-                                const float* gout, const float* q, const float* k, int C, int T, int D, int64_t ldq,
-                                int64_t ldk, float qscale, int length_scaling, float* dq, float* dk, float* ddiag,
-                                int64_t lddq, int64_t lddk, int64_t lddd, void* ws, size_t ws_bytes, semicrf_stream_t stream)
+int interval_score_bwd_fused_ws_p(const float* S, const float* alpha, const float* beta, const float* logZ,
+                                  const float* gout, const float* q, const float* k, int C, int T, int D, int64_t ldq,
+                                  int64_t ldk, float qscale, int length_scaling, int group, int pitch, float* dq, float* dk, float* ddiag,
+                                  int64_t lddq, int64_t lddk, int64_t lddd, void* ws, size_t ws_bytes, semicrf_stream_t stream)
 {
     SEMICRF_CHECK_ARG(C >= 1 && T >= 1 && D >= 1, "C=%d T=%d D=%d must be >= 1", C, T, D);
     SEMICRF_CHECK_ARG(S && alpha && beta && logZ && gout && q && k, "S/alpha/beta/logZ/gout/q/k must be non-NULL");
@@ -465,17 +506,49 @@ int interval_score_bwd_fused_ws(const float* S, const float* alpha, const float*
                       "bad leading dimensions");
     SEMICRF_CHECK_ARG(length_scaling >= 0 && length_scaling <= 2, "bad length_scaling %d", length_scaling);
     SEMICRF_CHECK_ARG(interval_score_bwd_supported(C, T, D), "interval_score_bwd_fused needs D %% 32 == 0 and D <= 256 (D=%d)", D);
+    if (int rc = check_slots(C, group, pitch)) return rc;
+    if (pitch == group) group = pitch = C;                     // no ghosts: ONE group (quads must not straddle a group's end)
+    const bool slots = pitch != group;
     hipStream_t st = (hipStream_t)stream;
     const float* fused[4] = {alpha, beta, logZ, gout};
     if (g_impl.load() == 0 && (dq || dk) &&
-        launch_interval_score_bwd_packed(S, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, lddq, lddk, ws, ws_bytes, st, fused)) {
-        if (ddiag) launch_interval_score_bwd_fused(S, alpha, beta, logZ, gout, q, k, C, T, D, ldq, ldk, qscale, length_scaling, nullptr,
-                                                   nullptr, ddiag, lddq, lddk, lddd, st);
+        launch_interval_score_bwd_packed(S, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, lddq, lddk, ws, ws_bytes, st, fused,
+                                         group, pitch)) {
+        if (ddiag) launch_interval_score_bwd_diag(S, fused, ddiag, C, T, lddd, group, pitch, st);
     } else {
+        SEMICRF_CHECK_ARG(!slots, "a padded slot layout needs the packed path (workspace, D in {64,128,256}, T >= 64, aligned rows)");
         launch_interval_score_bwd_fused(S, alpha, beta, logZ, gout, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, ddiag, lddq,
                                         lddk, lddd, st);
     }
     SEMICRF_CHECK_LAUNCH("interval_score_bwd_fused_ws");
+    return SEMICRF_OK;
+}
+
+int interval_score_bwd_fused_ws(const float* S, const float* alpha, const float* beta, const float* logZ,
+                                const float* gout, const float* q, const float* k, int C, int T, int D, int64_t ldq,
+                                int64_t ldk, float qscale, int length_scaling, float* dq, float* dk, float* ddiag,
+                                int64_t lddq, int64_t lddk, int64_t lddd, void* ws, size_t ws_bytes, semicrf_stream_t stream)
+{
+    return interval_score_bwd_fused_ws_p(S, alpha, beta, logZ, gout, q, k, C, T, D, ldq, ldk, qscale, length_scaling, C > 0 ? C : 1,
+                                         C > 0 ? C : 1, dq, dk, ddiag, lddq, lddk, lddd, ws, ws_bytes, stream);
+}
+
+int interval_score_path_bwd_p(const float* gout, const int32_t* pairs, int64_t K, const int32_t* offsets, const float* q,
+                              const float* k, int C, int T, int D, int64_t ldq, int64_t ldk, float qscale, int length_scaling,
+                              int group, int pitch, float* dq, float* dk, float* ddiag, int64_t lddq, int64_t lddk, int64_t lddd,
+                              semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(C >= 1 && T >= 1 && D >= 1, "C=%d T=%d D=%d must be >= 1", C, T, D);
+    SEMICRF_CHECK_ARG(gout && offsets && q && k, "gout/offsets/q/k must be non-NULL");
+    SEMICRF_CHECK_ARG(K >= 0 && K < (1ll << 31) && (K == 0 || pairs), "bad interval count");
+    SEMICRF_CHECK_ARG(ldq >= D && ldk >= D && (!dq || lddq >= D) && (!dk || lddk >= D) && (!ddiag || lddd >= 1),
+                      "bad leading dimensions");
+    SEMICRF_CHECK_ARG(length_scaling >= 0 && length_scaling <= 2, "bad length_scaling %d", length_scaling);
+    if (int rc = check_slots(C, group, pitch)) return rc;
+    if (pitch == group) group = pitch = C;
+    launch_interval_score_path_bwd(gout, pairs, (int)K, offsets, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, ddiag,
+                                   lddq, lddk, lddd, (hipStream_t)stream, group, pitch);
+    SEMICRF_CHECK_LAUNCH("interval_score_path_bwd");
     return SEMICRF_OK;
 }
 
@@ -484,16 +557,8 @@ int interval_score_path_bwd(const float* gout, const int32_t* pairs, int64_t K, 
                             float* dq, float* dk, float* ddiag, int64_t lddq, int64_t lddk, int64_t lddd,
                             semicrf_stream_t stream)
 {
-    SEMICRF_CHECK_ARG(C >= 1 && T >= 1 && D >= 1, "C=%d T=%d D=%d must be >= 1", C, T, D);
-    SEMICRF_CHECK_ARG(gout && offsets && q && k, "gout/offsets/q/k must be non-NULL");
-    SEMICRF_CHECK_ARG(K >= 0 && K < (1ll << 31) && (K == 0 || pairs), "bad interval count");
-    SEMICRF_CHECK_ARG(ldq >= D && ldk >= D && (!dq || lddq >= D) && (!dk || lddk >= D) && (!ddiag || lddd >= 1),
-                      "bad leading dimensions");
-    SEMICRF_CHECK_ARG(length_scaling >= 0 && length_scaling <= 2, "bad length_scaling %d", length_scaling);
-    launch_interval_score_path_bwd(gout, pairs, (int)K, offsets, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, ddiag,
-                                   lddq, lddk, lddd, (hipStream_t)stream);
-    SEMICRF_CHECK_LAUNCH("interval_score_path_bwd");
-    return SEMICRF_OK;
+    return interval_score_path_bwd_p(gout, pairs, K, offsets, q, k, C, T, D, ldq, ldk, qscale, length_scaling, C > 0 ? C : 1, C > 0 ? C : 1,
+                                     dq, dk, ddiag, lddq, lddk, lddd, stream);
 }
 
 int interval_features_gather(const float* ctx, int C, int T, int D, int64_t ldc, const int32_t* pairs, int64_t K,

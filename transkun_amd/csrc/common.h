@@ -46,6 +46,18 @@ struct PerDeviceOnce {
     }
 };
 
+// ---- slot layout of the chain axis (interval_score_*_p, include/semicrf_hip.h) ---------------------------------
+// The C chains come in groups of `group` (the symbols of one segment); every group owns `pitch` >= group slots of the
+// chain axis of S / dS / alpha / beta / logZ / gout / interval offsets; q, k, diag and their gradients are indexed by chain.
+// group == pitch: slots and chains coincide.
+struct ChainSlots { int group, pitch; };
+__host__ __device__ inline int slot_of_chain(ChainSlots s, int c) { return (c / s.group) * s.pitch + c % s.group; }
+__host__ __device__ inline int chain_of_slot(ChainSlots s, int slot)      // -1: a ghost slot
+{
+    const int p = slot % s.pitch;
+    return p < s.group ? (slot / s.pitch) * s.group + p : -1;
+}
+
 // ---- device math ---------------------------------------------------------------------------
 // F.softplus(beta=1, threshold=20): NeuralSemiCRFInterval.py:218,232,395,427
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }

@@ -206,24 +206,27 @@ __global__ __launch_bounds__(64 * BC) void interval_score_bwd_kernel(
 }
 
 // ddiag[c][t] = dS[t][t][c]
+// (Cs, SL: the slot layout of dS's chain axis, common.h; Cs == C and group == pitch: chains and slots coincide)
 __global__ __launch_bounds__(256) void interval_score_bwd_diag_kernel(const float* __restrict__ dS, float* __restrict__ ddiag,
-                                                                       int C, int T, long long ldd)
+                                                                       int C, int T, long long ldd, int Cs, ChainSlots SL)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)T * C) return;
     const int t = (int)(i / C), c = (int)(i % C);
-    ddiag[(size_t)c * T * ldd + (size_t)t * ldd] = dS[((size_t)t * T + t) * C + c];
+    ddiag[(size_t)c * T * ldd + (size_t)t * ldd] = dS[((size_t)t * T + t) * Cs + slot_of_chain(SL, c)];
 }
 
 // FUSED ddiag[c][t] = gout[c] * marginal[t,t,c]
 __global__ __launch_bounds__(256) void interval_score_bwd_diag_fused_kernel(const float* __restrict__ S, FusedArgs F,
-                                                                             float* __restrict__ ddiag, int C, int T, long long ldd)
+                                                                             float* __restrict__ ddiag, int C, int T, long long ldd,
+                                                                             int Cs, ChainSlots SL)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)T * C) return;
     const int t = (int)(i / C), c = (int)(i % C);
-    const float s = S[((size_t)t * T + t) * C + c];
-    ddiag[((size_t)c * T + t) * ldd] = F.gout[c] * marginal_of(s, F.alpha[(size_t)t * C + c], F.beta[(size_t)t * C + c], F.logZ[c], true);
+    const int sl = slot_of_chain(SL, c);
+    const float s = S[((size_t)t * T + t) * Cs + sl];
+    ddiag[((size_t)c * T + t) * ldd] = F.gout[sl] * marginal_of(s, F.alpha[(size_t)t * Cs + sl], F.beta[(size_t)t * Cs + sl], F.logZ[sl], true);
 }
 
 // The evalPath part of logProb's gradient pushed through the scorer: every interval (b, e) of chain c contributes
@@ -232,18 +235,19 @@ __global__ __launch_bounds__(256) void interval_score_bwd_diag_fused_kernel(cons
 __global__ __launch_bounds__(256) void interval_score_path_bwd_kernel(
     const float* __restrict__ gout, const int* __restrict__ pairs, int K, const int* __restrict__ offsets,
     const float* __restrict__ q, const float* __restrict__ k, int C, int T, int D, long long ldq, long long ldk, float qscale,
-    int mode, float* dq, float* dk, float* ddiag, long long lddq, long long lddk, long long lddd)
+    int mode, float* dq, float* dk, float* ddiag, long long lddq, long long lddk, long long lddd, int Cs, ChainSlots SL)
 {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= K) return;
-    int lo = 0, hi = C;                       // chain of interval i: largest c with offsets[c] <= i
+    int lo = 0, hi = Cs;                      // slot of interval i: largest s with offsets[s] <= i (ghost slots hold no interval)
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (offsets[mid] <= i) lo = mid; else hi = mid;
     }
-    const int c = lo;
+    const int c = chain_of_slot(SL, lo);
+    if (c < 0) return;                        // an interval filed under a ghost slot (a caller error): ignored
     const int b = pairs[2 * i], e = pairs[2 * i + 1];
-    const float g = gout[c];
+    const float g = gout[lo];
     const float w = g * qscale * len_scale_bwd(e - b, mode);
     const float* qe = q + ((size_t)c * T + e) * ldq;
     const float* kb = k + ((size_t)c * T + b) * ldk;
@@ -257,11 +261,28 @@ __global__ __launch_bounds__(256) void interval_score_path_bwd_kernel(
 void launch_interval_score_path_bwd(const float* gout, const int* pairs, int K, const int* offsets, const float* q,
                                     const float* k, int C, int T, int D, long long ldq, long long ldk, float qscale, int mode,
                                     float* dq, float* dk, float* ddiag, long long lddq, long long lddk, long long lddd,
-                                    hipStream_t stream)
+                                    hipStream_t stream, int group, int pitch)
 {
     if (K <= 0) return;
     hipLaunchKernelGGL(interval_score_path_bwd_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, gout, pairs, K, offsets, q, k, C,
-                       T, D, ldq, ldk, qscale, mode, dq, dk, ddiag, lddq, lddk, lddd);
+                       T, D, ldq, ldk, qscale, mode, dq, dk, ddiag, lddq, lddk, lddd, (C / group) * pitch, ChainSlots{group, pitch});
+}
+
+// ddiag alone, for the packed path (which produces dq and dk): plain (F == nullptr) or fused
+void launch_interval_score_bwd_diag(const float* dS, const float* const* fused, float* ddiag, int C, int T, long long lddd,
+                                    int group, int pitch, hipStream_t stream)
+{
+    const size_t n = (size_t)T * C;
+    const int Cs = (C / group) * pitch;
+    const ChainSlots SL{group, pitch};
+    if (fused) {
+        const FusedArgs F{fused[0], fused[1], fused[2], fused[3]};
+        hipLaunchKernelGGL(interval_score_bwd_diag_fused_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dS, F, ddiag,
+                           C, T, lddd, Cs, SL);
+    } else {
+        hipLaunchKernelGGL(interval_score_bwd_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dS, ddiag, C, T,
+                           lddd, Cs, SL);
+    }
 }
 
 bool interval_score_bwd_supported(int C, int T, int D) { return D % 32 == 0 && D >= 32 && D <= 32 * BND_MAX && T >= 1 && C >= 1; }
@@ -300,7 +321,7 @@ void launch_interval_score_bwd(const float* dS, const float* q, const float* k, 
     if (ddiag) {
         const size_t n = (size_t)T * C;
         hipLaunchKernelGGL(interval_score_bwd_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dS, ddiag,
-                           C, T, lddd);
+                           C, T, lddd, C, ChainSlots{C, C});
     }
 }
 
@@ -315,7 +336,7 @@ void launch_interval_score_bwd_fused(const float* S, const float* alpha, const f
     if (ddiag) {
         const size_t n = (size_t)T * C;
         hipLaunchKernelGGL(interval_score_bwd_diag_fused_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, S, F,
-                           ddiag, C, T, lddd);
+                           ddiag, C, T, lddd, C, ChainSlots{C, C});
     }
 }
 

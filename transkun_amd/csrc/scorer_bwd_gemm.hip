@@ -86,9 +86,11 @@ struct PackFused {
     const float* gout;    // [C]
 };
 
+// C here is the number of SLOTS (the chain pitch of dS, alpha, beta, logZ, gout); a slot's matrix goes to its chain's slab,
+// ghost slots are skipped (SL: common.h).
 template <bool FUSED>
 __global__ __launch_bounds__(256) void score_bwd_pack_kernel(const float* __restrict__ dS, float* __restrict__ Gt, int C,
-                                                             int T, int Tp, float qscale, int mode, PackFused F)
+                                                             int T, int Tp, float qscale, int mode, PackFused F, ChainSlots SL)
 {
     __shared__ __attribute__((aligned(16))) float L[PK_CH * PK_CHS];
     const int b0 = blockIdx.x * PK_B, e0 = blockIdx.y * PK_E, cg = blockIdx.z * PK_CH;
@@ -155,8 +157,8 @@ __global__ __launch_bounds__(256) void score_bwd_pack_kernel(const float* __rest
         const int idx = tid + it * 256;
         const int j4 = idx & 7, rowid = idx >> 3;
         const int el = rowid & 7, ch = rowid >> 3;
-        const int c = cg + ch;
-        if (c < C) {
+        const int c = cg + ch < C ? chain_of_slot(SL, cg + ch) : -1;
+        if (c >= 0) {
             const float4 v = *(const float4*)(L + ch * PK_CHS + el * PK_ROW + 4 * j4);
             const int blk = e0 / GM;                          // the 8 rows of a block lie in one 128-row block
             float* row = Gt + (size_t)c * gt_chain_floats(Tp) + gt_block_off(blk) + (size_t)(e0 + el - blk * GM) * gt_row_len(blk, Tp);
@@ -433,21 +435,23 @@ static void launch_gemm(const float* Gt, int Tp, const float* other, long long l
 bool launch_interval_score_bwd_packed(const float* dS, const float* q, const float* k, int C, int T, int D, long long ldq,
                                       long long ldk, float qscale, int mode, float* dq, float* dk, long long lddq,
                                       long long lddk, void* ws, size_t ws_bytes, hipStream_t stream,
-                                      const float* const* fused)
+                                      const float* const* fused, int group, int pitch)
 {
+    const ChainSlots SL{group, pitch};
+    const int Cs = (C / group) * pitch;                       // slots: the chain pitch of dS and of the CRF-side vectors
     const size_t need = interval_score_bwd_ws_bytes(C, T, D);
     if (need == 0 || !ws || ws_bytes < need) return false;
     if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ldq % 4 || ldk % 4 || ((uintptr_t)ws & 15)) return false;
     if ((long long)T * ldq * 4 >= (1ll << 31) || (long long)T * ldk * 4 >= (1ll << 31)) return false;
     const int Tp = round_up32(T);
     float* Gt = (float*)ws;
-    const dim3 pgrid(Tp / PK_B, Tp / PK_E, (C + PK_CH - 1) / PK_CH);
+    const dim3 pgrid(Tp / PK_B, Tp / PK_E, (Cs + PK_CH - 1) / PK_CH);
     if (fused) {
         const PackFused F{fused[0], fused[1], fused[2], fused[3]};
-        hipLaunchKernelGGL(score_bwd_pack_kernel<true>, pgrid, dim3(256), 0, stream, dS, Gt, C, T, Tp, qscale, mode, F);
+        hipLaunchKernelGGL(score_bwd_pack_kernel<true>, pgrid, dim3(256), 0, stream, dS, Gt, Cs, T, Tp, qscale, mode, F, SL);
     } else {
         const PackFused F{nullptr, nullptr, nullptr, nullptr};
-        hipLaunchKernelGGL(score_bwd_pack_kernel<false>, pgrid, dim3(256), 0, stream, dS, Gt, C, T, Tp, qscale, mode, F);
+        hipLaunchKernelGGL(score_bwd_pack_kernel<false>, pgrid, dim3(256), 0, stream, dS, Gt, Cs, T, Tp, qscale, mode, F, SL);
     }
 #define SEMICRF_GEMM_DISPATCH(AT_, OTHER, LDO, OUT, LDOUT)                                                              \
     switch (D) {                                                                                                        \

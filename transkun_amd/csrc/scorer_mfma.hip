@@ -558,13 +558,51 @@ __device__ __forceinline__ f32x16 mma6(const Limbs3& A, const Limbs3& B, f32x16 
     return acc;
 }
 
+// Slot layout of the chain axis (interval_score_fwd_p, include/semicrf_hip.h): the C chains come in groups of `group`
+// (the symbols of one segment), each group owns `pitch` >= group SLOTS of S's chain axis; the slots group..pitch-1 of
+// every group are ghosts and read zero.  With pitch a multiple of 32 every 32-slot piece of a cell is one aligned 128-byte
+// line -- what the CRF kernels want (T=691: 90 symbols at pitch 96 run 22 % faster than at pitch 90) -- while the scorer
+// only multiplies the real chains.  Items are quads of REAL chains (ceil(group / 4) per group: no all-ghost items, the
+// static schedule stays balanced); the last quad of a group also writes the zeros of the group's ghost tail.
+// group == pitch == C: the plain contiguous layout.
+struct SlotGeom {
+    int group, pitch, qps, nrq;          // quads per group, real quads in total
+};
+__host__ __device__ inline SlotGeom slot_geom(int C, int group, int pitch)
+{
+    SlotGeom g;
+    g.group = group; g.pitch = pitch;
+    g.qps = (group + 3) / 4;
+    g.nrq = (C / group) * g.qps;
+    return g;
+}
+struct QuadInfo {
+    int c4;      // first slot of the quad (S's chain index)
+    int ck;      // its first chain (q / k / diag index)
+    int nr;      // real chains in it (0: padding item, nothing to do)
+    int tz;      // ghost slots behind it that this item zero-fills (a multiple of 4)
+};
+__device__ __forceinline__ QuadInfo quad_info(const SlotGeom& g, int rq)
+{
+    QuadInfo o;
+    if (rq >= g.nrq) { o.c4 = 0; o.ck = 0; o.nr = 0; o.tz = 0; return o; }
+    const int seg = rq / g.qps, qd = rq - seg * g.qps;
+    o.c4 = seg * g.pitch + qd * 4;
+    o.ck = seg * g.group + qd * 4;
+    o.nr = g.group - qd * 4 < 4 ? g.group - qd * 4 : 4;
+    const int tail = g.pitch - g.qps * 4;
+    o.tz = (qd == g.qps - 1 && tail > 0) ? tail : 0;
+    return o;
+}
+
 // XTE = tile rows (end positions): 128 -> 8 waves, one workgroup per CU; 64 -> 4 waves, two (independent) workgroups
 // per CU whose barriers and operand reads fall into each other's matrix phases (24 instead of 32 flop per byte).
+// C = real chains; Cs = slots (the chain pitch of S); see SlotGeom.
 template <int XTE>
 __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ diag, int C, int T, int D,
     long long ldq, long long ldk, long long ldd, float qscale, int mode, int full, float* __restrict__ S,
-    int ntiles, int nquadp)
+    int ntiles, int nquadp, int Cs, SlotGeom G)
 {
     constexpr int XW = XTE / 16;                   // waves: (row block of 32, column half of 64)
     constexpr int KP = 16 / XW;                    // k pieces (8 rows x 128 bytes) per wave and chunk; q pieces: 2
@@ -588,11 +626,11 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
     const long long nitems = (long long)ntiles * nquadp;            // nquadp: chain quads, padded to a multiple of 8
 
     // entry u of this XCD's list -> global item n: 8 consecutive entries = the 8 quads of one 128-byte line group
-    auto item_of = [&](int u, int& et, int& bt, int& c4) -> bool {
+    auto item_of = [&](int u, int& et, int& bt, QuadInfo& qi) -> bool {
         const long long n = (long long)(u >> 3) * (8 * NXCD) + xcd * 8 + (u & 7);
         if (n >= nitems) return false;
         const int t = (int)(n / nquadp);
-        c4 = (int)(n % nquadp) * 4;
+        qi = quad_info(G, (int)(n % nquadp));
         if (full) {
             et = t / nbt; bt = t % nbt;
         } else if (XTE == XTB) {
@@ -623,19 +661,21 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
     }
 
     // ---- request side (identical in all waves): (entry, chain of the quad, chunk, stage) ----------------------
-    int nx_u = slot0, nx_j = 0, nx_ch = 0, nx_stage = 0, nx_c4 = 0;
+    int nx_u = slot0, nx_j = 0, nx_ch = 0, nx_stage = 0;
+    QuadInfo nx_q4 = {0, 0, 0, 0};
     bool nx_valid = false;
     unsigned voq[2], vok[4];      // (a [KP] array captured by the lambdas below trips the host compiler)
     const float* nx_q = q;
     const float* nx_k = k;
     auto set_chain = [&]() {
-        const int c = nx_c4 + nx_j < C ? nx_c4 + nx_j : C - 1;
+        const int c = nx_q4.ck + nx_j;                                       // nx_j < nx_q4.nr: a real chain
         nx_q = q + (size_t)c * T * ldq;
         nx_k = k + (size_t)c * T * ldk;
     };
     auto set_item = [&]() {
-        int et, bt;
-        nx_valid = item_of(nx_u, et, bt, nx_c4);
+        int et = 0, bt = 0;
+        // padding items (no real chain) request nothing: the consuming side skips them the same way
+        while ((nx_valid = item_of(nx_u, et, bt, nx_q4)) && nx_q4.nr == 0) nx_u += nslots;
         if (nx_valid) {
             // loading lanes: a piece is 8 rows x 128 bytes; this wave's q pieces 2*wave.. and k pieces KP*wave..
 #pragma unroll
@@ -675,7 +715,7 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
         nx_stage = nx_stage + 1 == XNS ? 0 : nx_stage + 1;
         if (++nx_ch == nchunk) {
             nx_ch = 0;
-            if (++nx_j == 4) {
+            if (++nx_j == nx_q4.nr) {
                 nx_u += nslots;
                 set_item();
             } else {
@@ -685,8 +725,11 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
     };
 
     set_item();
-    if (!nx_valid) return;                      // uniform over the workgroup
     int cur_u = slot0;
+    {
+        int e0_, b0_; QuadInfo q0_;
+        if (!item_of(cur_u, e0_, b0_, q0_)) return;                 // uniform over the workgroup
+    }
 
     f32x16 acc0, acc1;
 #pragma unroll
@@ -701,14 +744,16 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
     int rd_stage = 0;
 
     while (true) {
-        int et, bt, c4;
-        (void)item_of(cur_u, et, bt, c4);
+        int et, bt;
+        QuadInfo qi;
+        (void)item_of(cur_u, et, bt, qi);
+        const int c4 = qi.c4;
         // 32x32 blocks of this wave that lie entirely above the diagonal are not multiplied (nor written)
         const int erow = et * (XTE / 32) + wer, bcol = bt * (XTB / 32) + 2 * wh;
         const bool on0 = full || bcol <= erow, on1 = full || bcol + 1 <= erow;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            for (int ch = 0; ch < nchunk; ++ch) {
+            for (int ch = 0; ch < (j < qi.nr ? nchunk : 0); ++ch) {
                 // this wave's pieces of the current chunk have landed (a younger request may stay in flight) ...
                 if (XNS >= 4 && inflight >= 3) {
                     if (KP == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -784,7 +829,7 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
         // ---- write the item's four chains: one 16-byte piece per cell (C/D layout: col = lane & 31,
         //      row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) ----
         {
-            const bool vec = (C & 3) == 0 && c4 + 3 < C;
+            const bool vec = (Cs & 3) == 0 && c4 + 3 < Cs;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int b = bt * XTB + 64 * wh + 32 * t + row;
@@ -795,20 +840,21 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
                     const float sc = qscale * len_scale_mfma(len, mode);
                     const float last = t == 0 ? acc0[r] : acc1[r];
                     float v[4] = {hold[0][t][r] * sc, hold[1][t][r] * sc, hold[2][t][r] * sc, last * sc};
-                    if (e < T && b < T && (full || b <= e) && c4 < C && !(dbg & 4)) {
+                    if (e < T && b < T && (full || b <= e) && qi.nr > 0 && !(dbg & 4)) {
                         if (e == b) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
-                                if (c4 + i < C) v[i] += diag[((size_t)(c4 + i) * T + e) * ldd];
+                                if (i < qi.nr) v[i] += diag[((size_t)(qi.ck + i) * T + e) * ldd];
                         }
-                        float* dst = S + ((size_t)e * T + b) * C + c4;
+                        float* dst = S + ((size_t)e * T + b) * Cs + c4;
                         if (vec) {
                             // (plain stores: L2 merges the eight 16-byte pieces of a line; nontemporal ones do not -- 2.4 ms)
-                            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);      // ghost slots of the quad: exact zeros (hold = 0)
+                            for (int z = 4; z <= qi.tz; z += 4) *(float4*)(dst + z) = make_float4(0.f, 0.f, 0.f, 0.f);   // the group's ghost tail
                         } else {
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
-                                if (c4 + i < C) dst[i] = v[i];
+                                if (i < qi.nr) dst[i] = v[i];
                         }
                     }
                 }
@@ -817,21 +863,25 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
         }
         cur_u += nslots;
-        int e2, b2, c2;
-        if (!item_of(cur_u, e2, b2, c2)) break;
+        int e2, b2;
+        QuadInfo q2;
+        if (!item_of(cur_u, e2, b2, q2)) break;
     }
 }
 
 template <int XTE>
 static int launch_score_tile(const float* q, const float* k, const float* diag, int C, int T, int D, long long ldq,
-                             long long ldk, long long ldd, float qscale, int mode, int full, float* S, hipStream_t stream)
+                             long long ldk, long long ldd, float qscale, int mode, int full, float* S, hipStream_t stream,
+                             int group, int pitch)
 {
+    const SlotGeom G = slot_geom(C, group, pitch);
+    const int Cs = (C / group) * pitch;
     const int net = (T + XTE - 1) / XTE, nbt = (T + XTB - 1) / XTB;
     int ntiles = 0;
     if (full) ntiles = net * nbt;
     else
         for (int et = 0; et < net; ++et) ntiles += (et * XTE + XTE - 1) / XTB + 1 < nbt ? (et * XTE + XTE - 1) / XTB + 1 : nbt;
-    const int nquadp = ((C + 3) / 4 + 7) / 8 * 8;
+    const int nquadp = (G.nrq + 7) / 8 * 8;
     const size_t lds = (size_t)XNS * (XTE + XTB) * 128;
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
@@ -851,7 +901,7 @@ static int launch_score_tile(const float* q, const float* k, const float* diag, 
     if (const char* e = getenv("SEMICRF_SCORE_DEBUG")) dbg = atoi(e) & 0xff;      // timing ablations (wrong results): debug builds only
 #endif
     hipLaunchKernelGGL(interval_score_tile_kernel<XTE>, dim3(grid), dim3(XTE * 4), lds, stream, q, k, diag, C, T, D, ldq, ldk, ldd,
-                       qscale, mode | (dbg << 8), full, S, ntiles, nquadp);
+                       qscale, mode | (dbg << 8), full, S, ntiles, nquadp, Cs, G);
     return 0;
 }
 
@@ -877,7 +927,7 @@ template <int XTE>
 __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ diag, int C, int T, int D,
     long long ldq, long long ldk, long long ldd, float qscale, int mode, int full, float* __restrict__ S,
-    int ntiles, int nquadp)
+    int ntiles, int nquadp, int Cs, SlotGeom G)
 {
     constexpr int NTH = XTE * 4;                 // threads
     constexpr int NR = XTE + XTB;                // rows per stage: q rows | k rows
@@ -902,7 +952,7 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
     const int xcd = blockIdx.x % NXCD, slot0 = blockIdx.x / NXCD, nslots = gridDim.x / NXCD;
     const long long nitems = (long long)ntiles * nquadp;
 
-    auto item_of = [&](int u, int& et, int& bt, int& c4) -> bool {
+    auto item_of = [&](int u, int& et, int& bt, QuadInfo& qi) -> bool {
         const long long n = (long long)(u >> 3) * (8 * NXCD) + xcd * 8 + (u & 7);
         if (n >= nitems) return false;
         // line group (32 chains = 8 quads) major: all tiles of a group before the next group, so that the group's q and k
@@ -911,7 +961,7 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
         // 3.3 GB at T=1024, C=352 -- 1.09 ms instead of 0.86 here.
         const long long v = n >> 3;
         const int t = (int)(v % ntiles);
-        c4 = ((int)(v / ntiles) * 8 + (int)(n & 7)) * 4;
+        qi = quad_info(G, (int)(v / ntiles) * 8 + (int)(n & 7));
         if (full) {
             et = t / nbt; bt = t % nbt;
         } else if (XTE == XTB) {
@@ -951,19 +1001,21 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
     }
 
     // ---- request side (identical in all waves): (entry, chain of the quad, chunk) --------------------------------
-    int nx_u = slot0, nx_j = 0, nx_ch = 0, nx_c4 = 0;
+    int nx_u = slot0, nx_j = 0, nx_ch = 0;
+    QuadInfo nx_q4 = {0, 0, 0, 0};
     bool nx_valid = false;
     size_t nx_off[NU];
     const float* nx_q = q;
     const float* nx_k = k;
     auto set_chain = [&]() {
-        const int c = nx_c4 + nx_j < C ? nx_c4 + nx_j : C - 1;
+        const int c = nx_q4.ck + nx_j;                                       // nx_j < nx_q4.nr: a real chain
         nx_q = q + (size_t)c * T * ldq;
         nx_k = k + (size_t)c * T * ldk;
     };
     auto set_item = [&]() {
-        int et, bt;
-        nx_valid = item_of(nx_u, et, bt, nx_c4);
+        int et = 0, bt = 0;
+        // padding items (no real chain) request nothing: the consuming side skips them the same way
+        while ((nx_valid = item_of(nx_u, et, bt, nx_q4)) && nx_q4.nr == 0) nx_u += nslots;
         if (nx_valid) {
 #pragma unroll
             for (int j = 0; j < NU; ++j) {
@@ -987,7 +1039,7 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
         }
         if (++nx_ch == nchunk) {
             nx_ch = 0;
-            if (++nx_j == 4) {
+            if (++nx_j == nx_q4.nr) {
                 nx_u += nslots;
                 set_item();
             } else {
@@ -1007,8 +1059,11 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
     };
 
     set_item();
-    if (!nx_valid) return;                      // uniform over the workgroup
     int cur_u = slot0;
+    {
+        int e0_, b0_; QuadInfo q0_;
+        if (!item_of(cur_u, e0_, b0_, q0_)) return;                 // uniform over the workgroup
+    }
 #ifdef SEMICRF_SCORE_PROBE
     // cycle accounting of one wave (probe build; tools/score_probe.py): [0] waiting at the barrier, [1] operand reads + matrix
     // instructions + split + limb stores, [2] the fetch of the chunk after next, [3] the epilogue; written over the (unused)
@@ -1033,8 +1088,10 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
     fetch(g0);
 
     while (true) {
-        int et, bt, c4;
-        (void)item_of(cur_u, et, bt, c4);
+        int et, bt;
+        QuadInfo qi;
+        (void)item_of(cur_u, et, bt, qi);
+        const int c4 = qi.c4;
         const int erow = et * (XTE / 32) + wer, bcol = bt * (XTB / 32) + 2 * wh;
         const bool on0 = full || bcol <= erow, on1 = full || bcol + 1 <= erow;
         // (the blocks-above-the-diagonal cases are separate instantiations: a branch inside the half iteration would end the
@@ -1157,7 +1214,8 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
         };
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (on0 && on1) chain_loop(std::true_type{}, std::true_type{});
+            if (j >= qi.nr) { }                                       // a ghost slot of the quad: nothing was requested for it
+            else if (on0 && on1) chain_loop(std::true_type{}, std::true_type{});
             else if (on0) chain_loop(std::true_type{}, std::false_type{});
             else chain_loop(std::false_type{}, std::false_type{});
             if (j < 3) {
@@ -1171,7 +1229,7 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
         // ---- write the item's four chains: one 16-byte piece per cell (C/D layout: col = lane & 31,
         //      row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) ----
         {
-            const bool vec = (C & 3) == 0 && c4 + 3 < C;
+            const bool vec = (Cs & 3) == 0 && c4 + 3 < Cs;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int b = bt * XTB + 64 * wh + 32 * t + row;
@@ -1182,19 +1240,20 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
                     const float sc = qscale * len_scale_mfma(len, mode);
                     const float last = t == 0 ? acc0[r] : acc1[r];
                     float v[4] = {hold[0][t][r] * sc, hold[1][t][r] * sc, hold[2][t][r] * sc, last * sc};
-                    if (e < T && b < T && (full || b <= e) && c4 < C && !(dbg & 4)) {
+                    if (e < T && b < T && (full || b <= e) && qi.nr > 0 && !(dbg & 4)) {
                         if (e == b) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
-                                if (c4 + i < C) v[i] += diag[((size_t)(c4 + i) * T + e) * ldd];
+                                if (i < qi.nr) v[i] += diag[((size_t)(qi.ck + i) * T + e) * ldd];
                         }
-                        float* dst = S + ((size_t)e * T + b) * C + c4;
+                        float* dst = S + ((size_t)e * T + b) * Cs + c4;
                         if (vec) {
-                            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);      // ghost slots of the quad: exact zeros (hold = 0)
+                            for (int z = 4; z <= qi.tz; z += 4) *(float4*)(dst + z) = make_float4(0.f, 0.f, 0.f, 0.f);   // the group's ghost tail
                         } else {
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
-                                if (c4 + i < C) dst[i] = v[i];
+                                if (i < qi.nr) dst[i] = v[i];
                         }
                     }
                 }
@@ -1204,26 +1263,30 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
         }
         SCORE_PROBE(3);
         cur_u += nslots;
-        int e2, b2, c2;
-        if (!item_of(cur_u, e2, b2, c2)) break;
+        int e2, b2;
+        QuadInfo q2;
+        if (!item_of(cur_u, e2, b2, q2)) break;
     }
 #ifdef SEMICRF_SCORE_PROBE
     if (lane == 0 && !full)
-        for (int i = 0; i < 4; ++i) S[(size_t)C + (size_t)((blockIdx.x * (XTE / 16) + wave) * 4 + i)] = (float)pc[i];
+        for (int i = 0; i < 4; ++i) S[(size_t)Cs + (size_t)((blockIdx.x * (XTE / 16) + wave) * 4 + i)] = (float)pc[i];
 #endif
 #undef SCORE_PROBE
 }
 
 template <int XTE>
 static int launch_score_tile3(const float* q, const float* k, const float* diag, int C, int T, int D, long long ldq,
-                              long long ldk, long long ldd, float qscale, int mode, int full, float* S, hipStream_t stream)
+                              long long ldk, long long ldd, float qscale, int mode, int full, float* S, hipStream_t stream,
+                              int group, int pitch)
 {
+    const SlotGeom G = slot_geom(C, group, pitch);
+    const int Cs = (C / group) * pitch;
     const int net = (T + XTE - 1) / XTE, nbt = (T + XTB - 1) / XTB;
     int ntiles = 0;
     if (full) ntiles = net * nbt;
     else
         for (int et = 0; et < net; ++et) ntiles += (et * XTE + XTE - 1) / XTB + 1 < nbt ? (et * XTE + XTE - 1) / XTB + 1 : nbt;
-    const int nquadp = ((C + 3) / 4 + 7) / 8 * 8;
+    const int nquadp = (G.nrq + 7) / 8 * 8;
     const size_t lds = (size_t)W3_NS * 3 * (XTE + XTB) * 64;
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
@@ -1242,7 +1305,7 @@ static int launch_score_tile3(const float* q, const float* k, const float* diag,
     if (const char* e = getenv("SEMICRF_SCORE_DEBUG")) dbg = atoi(e) & 0xff;      // timing ablations (wrong results): debug builds only
 #endif
     hipLaunchKernelGGL(interval_score_tile3_kernel<XTE>, dim3(grid), dim3(XTE * 4), lds, stream, q, k, diag, C, T, D, ldq, ldk, ldd, qscale,
-                       mode | (dbg << 8), full, S, ntiles, nquadp);
+                       mode | (dbg << 8), full, S, ntiles, nquadp, Cs, G);
     return 0;
 }
 
@@ -1250,10 +1313,20 @@ static int launch_score_tile3(const float* q, const float* k, const float* diag,
 static std::atomic<int> g_score_variant{-1};
 void set_score_variant(int v) { g_score_variant.store(v, std::memory_order_relaxed); }
 
+// group / pitch: the slot layout of S's chain axis (SlotGeom); group == pitch == C is the contiguous layout.  Returns 2 when a
+// slot layout is asked for and the shared-operand tile kernels do not apply (the caller reports SEMICRF_EINVAL).
+bool interval_score_slots_supported(int C, int T, int D, const float* q, const float* k, long long ldq, long long ldk)
+{
+    const bool aligned = ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ldq % 4 == 0 && ldk % 4 == 0;
+    return aligned && D % 64 == 0 && T >= 128 && (long long)T * ldq * 4 < (1ll << 31) && (long long)T * ldk * 4 < (1ll << 31);
+}
+
 int launch_interval_score_mfma(const float* q, const float* k, const float* diag, int C, int T, int D,
                                 long long ldq, long long ldk, long long ldd, float qscale, int mode, int full,
-                                float* S, hipStream_t stream, int prec)
+                                float* S, hipStream_t stream, int prec, int group, int pitch)
 {
+    const bool slots = !(group == C && pitch == C);
+    if (slots && !interval_score_slots_supported(C, T, D, q, k, ldq, ldk)) return 2;
     const int nt = (T + ST - 1) / ST;
     const size_t lds = (size_t)ST * ST * SPAD * sizeof(float);
     const bool aligned = ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ldq % 4 == 0 && ldk % 4 == 0;
@@ -1265,12 +1338,13 @@ int launch_interval_score_mfma(const float* q, const float* k, const float* diag
         int variant = T < 256 ? 32 : ((T + 63) / 64 * 64 < (T + 127) / 128 * 128 ? 64 : 128);
         const int forced = g_score_variant.load(std::memory_order_relaxed);     // test hook (semicrf_debug_score_variant), -1 = auto
         if (forced >= 0) variant = forced;
+        if (slots && variant != 64) variant = 128;                 // the slot layout lives in the tile kernels
         if (prec == 1 && T >= 128)
-            return launch_score_tile3<128>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream);
+            return launch_score_tile3<128>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream, group, pitch);
         if (variant == 128)
-            return launch_score_tile<128>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream);
+            return launch_score_tile<128>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream, group, pitch);
         if (variant == 64)
-            return launch_score_tile<64>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream);
+            return launch_score_tile<64>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream, group, pitch);
         if (variant == 32)
             return launch_score_stream(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, band, stream);
     }

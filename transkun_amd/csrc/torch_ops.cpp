@@ -231,47 +231,58 @@ inline void score_dims(int64_t C, int64_t T, int64_t D)
 {
     STD_TORCH_CHECK(C >= 1 && T >= 1 && D >= 1 && C < (1ll << 31) && T < (1 << 29) && D < (1 << 20), "semicrf: bad C / T / D");
 }
+inline int64_t slots_of(int64_t C, int64_t group, int64_t pitch)
+{
+    STD_TORCH_CHECK(group >= 1 && pitch >= group && C % group == 0 && group < (1ll << 31) && pitch < (1ll << 31), "semicrf: bad slot layout");
+    return C / group * pitch;
+}
 void interval_score_fwd_op(Tensor q, Tensor k, Tensor diag, int64_t C, int64_t T, int64_t D, int64_t ldq, int64_t ldk, int64_t ldd,
-                           double qscale, int64_t mode, int64_t full, Tensor S, Tensor noise)
+                           double qscale, int64_t mode, int64_t full, int64_t group, int64_t pitch, Tensor S, Tensor noise)
 {
     Ctx c(q); c.same(q, k, diag, S, noise);
     score_dims(C, T, D);
-    check(interval_score_fwd(f32s(q, "q"), f32s(k, "k"), f32s(diag, "diag"), (int)C, (int)T, (int)D, ldq, ldk, ldd, (float)qscale, (int)mode,
-                             (int)full, f32w(S, T * T * C, "S"), noise.numel() > 0 ? f32w(noise, (T - 1) * C, "noise") : nullptr, c.stream),
+    const int64_t Cs = slots_of(C, group, pitch);
+    check(interval_score_fwd_p(f32s(q, "q"), f32s(k, "k"), f32s(diag, "diag"), (int)C, (int)T, (int)D, ldq, ldk, ldd, (float)qscale, (int)mode,
+                               (int)full, (int)group, (int)pitch, f32w(S, T * T * Cs, "S"),
+                               noise.numel() > 0 ? f32w(noise, (T - 1) * Cs, "noise") : nullptr, c.stream),
           "interval_score_fwd");
 }
 void interval_score_bwd_ws_op(Tensor dS, Tensor q, Tensor k, int64_t C, int64_t T, int64_t D, int64_t ldq, int64_t ldk, double qscale,
-                              int64_t mode, Tensor dq, Tensor dk, Tensor ddiag, int64_t lddq, int64_t lddk, int64_t lddd, Tensor ws)
+                              int64_t mode, int64_t group, int64_t pitch, Tensor dq, Tensor dk, Tensor ddiag, int64_t lddq, int64_t lddk,
+                              int64_t lddd, Tensor ws)
 {
     Ctx c(dS); c.same(dS, q, k, dq, dk, ddiag, ws);
     score_dims(C, T, D);
-    check(interval_score_bwd_ws(f32(dS, T * T * C, "dS"), f32s(q, "q"), f32s(k, "k"), (int)C, (int)T, (int)D, ldq, ldk, (float)qscale, (int)mode,
-                                f32so(dq, "dq"), f32so(dk, "dk"), f32so(ddiag, "ddiag"), lddq, lddk, lddd, bytes(ws, "ws"), (size_t)ws.numel(),
-                                c.stream),
+    const int64_t Cs = slots_of(C, group, pitch);
+    check(interval_score_bwd_ws_p(f32(dS, T * T * Cs, "dS"), f32s(q, "q"), f32s(k, "k"), (int)C, (int)T, (int)D, ldq, ldk, (float)qscale,
+                                  (int)mode, (int)group, (int)pitch, f32so(dq, "dq"), f32so(dk, "dk"), f32so(ddiag, "ddiag"), lddq, lddk, lddd,
+                                  bytes(ws, "ws"), (size_t)ws.numel(), c.stream),
           "interval_score_bwd_ws");
 }
 void interval_score_bwd_fused_ws_op(Tensor S, Tensor alpha, Tensor beta_, Tensor logZ, Tensor gout, Tensor q, Tensor k, int64_t C, int64_t T,
-                                    int64_t D, int64_t ldq, int64_t ldk, double qscale, int64_t mode, Tensor dq, Tensor dk, Tensor ddiag,
-                                    int64_t lddq, int64_t lddk, int64_t lddd, Tensor ws)
+                                    int64_t D, int64_t ldq, int64_t ldk, double qscale, int64_t mode, int64_t group, int64_t pitch, Tensor dq,
+                                    Tensor dk, Tensor ddiag, int64_t lddq, int64_t lddk, int64_t lddd, Tensor ws)
 {
     Ctx c(S); c.same(S, alpha, beta_, logZ, gout, q, k, dq, dk, ddiag, ws);
     score_dims(C, T, D);
-    check(interval_score_bwd_fused_ws(f32(S, T * T * C, "S"), f32(alpha, T * C, "alpha"), f32(beta_, T * C, "beta"), f32(logZ, C, "logZ"),
-                                      f32(gout, C, "gout"), f32s(q, "q"), f32s(k, "k"), (int)C, (int)T, (int)D, ldq, ldk, (float)qscale,
-                                      (int)mode, f32so(dq, "dq"), f32so(dk, "dk"), f32so(ddiag, "ddiag"), lddq, lddk, lddd, bytes(ws, "ws"),
-                                      (size_t)ws.numel(), c.stream),
+    const int64_t Cs = slots_of(C, group, pitch);
+    check(interval_score_bwd_fused_ws_p(f32(S, T * T * Cs, "S"), f32(alpha, T * Cs, "alpha"), f32(beta_, T * Cs, "beta"),
+                                        f32(logZ, Cs, "logZ"), f32(gout, Cs, "gout"), f32s(q, "q"), f32s(k, "k"), (int)C, (int)T, (int)D, ldq,
+                                        ldk, (float)qscale, (int)mode, (int)group, (int)pitch, f32so(dq, "dq"), f32so(dk, "dk"),
+                                        f32so(ddiag, "ddiag"), lddq, lddk, lddd, bytes(ws, "ws"), (size_t)ws.numel(), c.stream),
           "interval_score_bwd_fused_ws");
 }
 void interval_score_path_bwd_op(Tensor gout, Tensor pairs, int64_t K, Tensor offsets, Tensor q, Tensor k, int64_t C, int64_t T, int64_t D,
-                                int64_t ldq, int64_t ldk, double qscale, int64_t mode, Tensor dq, Tensor dk, Tensor ddiag, int64_t lddq,
-                                int64_t lddk, int64_t lddd)
+                                int64_t ldq, int64_t ldk, double qscale, int64_t mode, int64_t group, int64_t pitch, Tensor dq, Tensor dk,
+                                Tensor ddiag, int64_t lddq, int64_t lddk, int64_t lddd)
 {
     Ctx c(gout); c.same(gout, pairs, offsets, q, k, dq, dk, ddiag);
     score_dims(C, T, D);
     STD_TORCH_CHECK(K >= 0, "semicrf: negative interval count");
-    check(interval_score_path_bwd(f32(gout, C, "gout"), i32(pairs, 2 * K, "pairs"), K, i32(offsets, C + 1, "offsets"), f32s(q, "q"),
-                                  f32s(k, "k"), (int)C, (int)T, (int)D, ldq, ldk, (float)qscale, (int)mode, f32so(dq, "dq"), f32so(dk, "dk"),
-                                  f32so(ddiag, "ddiag"), lddq, lddk, lddd, c.stream),
+    const int64_t Cs = slots_of(C, group, pitch);
+    check(interval_score_path_bwd_p(f32(gout, Cs, "gout"), i32(pairs, 2 * K, "pairs"), K, i32(offsets, Cs + 1, "offsets"), f32s(q, "q"),
+                                    f32s(k, "k"), (int)C, (int)T, (int)D, ldq, ldk, (float)qscale, (int)mode, (int)group, (int)pitch,
+                                    f32so(dq, "dq"), f32so(dk, "dk"), f32so(ddiag, "ddiag"), lddq, lddk, lddd, c.stream),
           "interval_score_path_bwd");
 }
 
@@ -336,15 +347,16 @@ STABLE_TORCH_LIBRARY(semicrf, m)
     m.def("eval_path(Tensor score, Tensor noise, Tensor pairs, int K, Tensor offsets, Tensor(a!) out, Tensor(b!) ws) -> ()");
     m.def("eval_path_bwd(Tensor gout, int T, int B, Tensor pairs, int K, Tensor offsets, Tensor(a!) dScore, bool has_ds, Tensor(b!) dNoise, "
           "bool has_dn) -> ()");
+    // (group, pitch): the slot layout of the chain axis (include/semicrf_hip.h, *_p entry points); group == pitch: contiguous
     m.def("interval_score_fwd(Tensor q, Tensor k, Tensor diag, int C, int T, int D, int ldq, int ldk, int ldd, float qscale, int mode, "
-          "int full, Tensor(a!) S, Tensor(b!) noise) -> ()");
-    m.def("interval_score_bwd_ws(Tensor dS, Tensor q, Tensor k, int C, int T, int D, int ldq, int ldk, float qscale, int mode, Tensor(a!) dq, "
-          "Tensor(b!) dk, Tensor(c!) ddiag, int lddq, int lddk, int lddd, Tensor(d!) ws) -> ()");
+          "int full, int group, int pitch, Tensor(a!) S, Tensor(b!) noise) -> ()");
+    m.def("interval_score_bwd_ws(Tensor dS, Tensor q, Tensor k, int C, int T, int D, int ldq, int ldk, float qscale, int mode, int group, "
+          "int pitch, Tensor(a!) dq, Tensor(b!) dk, Tensor(c!) ddiag, int lddq, int lddk, int lddd, Tensor(d!) ws) -> ()");
     m.def("interval_score_bwd_fused_ws(Tensor S, Tensor alpha, Tensor beta, Tensor logZ, Tensor gout, Tensor q, Tensor k, int C, int T, int D, "
-          "int ldq, int ldk, float qscale, int mode, Tensor(a!) dq, Tensor(b!) dk, Tensor(c!) ddiag, int lddq, int lddk, int lddd, "
-          "Tensor(d!) ws) -> ()");
+          "int ldq, int ldk, float qscale, int mode, int group, int pitch, Tensor(a!) dq, Tensor(b!) dk, Tensor(c!) ddiag, int lddq, int lddk, "
+          "int lddd, Tensor(d!) ws) -> ()");
     m.def("interval_score_path_bwd(Tensor gout, Tensor pairs, int K, Tensor offsets, Tensor q, Tensor k, int C, int T, int D, int ldq, int ldk, "
-          "float qscale, int mode, Tensor(a!) dq, Tensor(b!) dk, Tensor(c!) ddiag, int lddq, int lddk, int lddd) -> ()");
+          "float qscale, int mode, int group, int pitch, Tensor(a!) dq, Tensor(b!) dk, Tensor(c!) ddiag, int lddq, int lddk, int lddd) -> ()");
     m.def("interval_features_gather(Tensor ctx, int C, int T, int D, int ldc, Tensor pairs, int K, Tensor offsets, int nSym, Tensor(a!) out, "
           "Tensor(b!) symIdx, Tensor(c!) scatterIdx) -> ()");
     m.def("interval_features_gather_bwd(Tensor gout, Tensor ctx, int C, int T, int D, int ldc, Tensor pairs, int K, Tensor offsets, "

@@ -27,7 +27,8 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .scorer import BF16X3, QPAD, ScaledInnerProductIntervalScorer, _ScorerLinear, _interval_score_raw, bwd_workspace, qd_weights
+from .scorer import (BF16X3, QPAD, ScaledInnerProductIntervalScorer, _ScorerLinear, _interval_score_raw, bwd_workspace, qd_weights,
+                     slot_maps, slot_pitch)
 
 _nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
 
@@ -41,26 +42,42 @@ def _beta_raw(score, noise):
 
 
 class _ScorerCRFLogProb(torch.autograd.Function):
+    """S never leaves this node, so its chain axis uses the SLOT layout (include/semicrf_hip.h): every segment's P symbols sit
+    in `pitch` slots (96 for the model's 90), the CRF kernels see N*pitch chains of which the ghosts are all-zero and their
+    results dropped; intervals, logProb and the cotangent are chain-indexed at the node's boundary."""
+
     @staticmethod
     def forward(ctx, qd, k, pairs, offsets, N, P, T, D, mode, fs=2):
         # qd: [N,P,T,D+QPAD] = [q | diag | zeros] (one GEMM, see scorer.py); k: [N,P,T,D]
         C = N * P
+        pitch = slot_pitch(P, T, D, N)
         qd3, k3 = qd.reshape(C, T, D + QPAD), k.reshape(C, T, D)
         qs = 1.0 / math.sqrt(D)
-        S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qs, mode, fs)     # S never leaves this node (fs: 2 | BF16X3)
+        S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qs, mode, fs, P, pitch)     # fs: 2 | BF16X3
+        if pitch != P:
+            real, offmap = slot_maps(N, P, pitch, S.device)
+            offsets_s = offsets.index_select(0, offmap)
+        else:
+            real, offsets_s = None, offsets
         logz, v = _nsci._logz_fwd_raw(S, noise, True)
-        path = _nsci._eval_path_raw(S, noise, pairs, offsets)
-        ctx.save_for_backward(qd3, k3, S, noise, v, logz, pairs, offsets)
-        ctx.meta = (N, P, T, D, mode, getattr(pairs, "_semicrf_K", pairs.shape[0]))
-        return path - logz
+        K = getattr(pairs, "_semicrf_K", pairs.shape[0])
+        pairs._semicrf_K = K
+        path = _nsci._eval_path_raw(S, noise, pairs, offsets_s)
+        ctx.save_for_backward(qd3, k3, S, noise, v, logz, pairs, offsets_s)
+        ctx.meta = (N, P, T, D, mode, K, pitch)
+        lp = path - logz
+        return lp if real is None else lp.index_select(0, real)
 
     @staticmethod
     def backward(ctx, g):
-        qd3, k, S, noise, v, logz, pairs, offsets = ctx.saved_tensors
-        N, P, T, D, mode, K = ctx.meta
+        qd3, k, S, noise, v, logz, pairs, offsets_s = ctx.saved_tensors
+        N, P, T, D, mode, K, pitch = ctx.meta
         C = N * P
         qs = 1.0 / math.sqrt(D)
         g = g.reshape(C).to(torch.float32).contiguous()
+        if pitch != P:
+            real, _ = slot_maps(N, P, pitch, S.device)
+            g = torch.zeros(N * pitch, dtype=torch.float32, device=S.device).index_copy_(0, real, g)      # ghost slots: 0
         ops = _lib.ops()
         beta = _beta_raw(S, noise)
         gneg = (-g).contiguous()                                   # d logProb / d logZ = -1
@@ -71,13 +88,13 @@ class _ScorerCRFLogProb(torch.autograd.Function):
         dk = torch.empty(C, T, D, dtype=torch.float32, device=S.device)
         # with a workspace: marginals evaluated by the repack kernel + two tiled GEMMs (scorer_bwd_gemm.hip)
         ws = bwd_workspace(C, T, D, S.device)
-        ops.interval_score_bwd_fused_ws(S, v, beta, logz, gneg, q, k, C, T, D, q.stride(-2), k.stride(-2), qs, mode, dq, dk, dd,
+        ops.interval_score_bwd_fused_ws(S, v, beta, logz, gneg, q, k, C, T, D, q.stride(-2), k.stride(-2), qs, mode, P, pitch, dq, dk, dd,
                                         dq.stride(-2), D, dd.stride(-1), ws)
         del ws
         if K > 0:
             # + g on the path cells: dq[c,e] += g qs len(e-b) k[c,b], dk[c,b] += g qs len(e-b) q[c,e], ddiag[c,t] += g (b == e)
-            ops.interval_score_path_bwd(g, pairs, int(K), offsets, q, k, C, T, D, q.stride(-2), k.stride(-2), qs, mode, dq, dk, dd,
-                                        dq.stride(-2), D, dd.stride(-1))
+            ops.interval_score_path_bwd(g, pairs, int(K), offsets_s, q, k, C, T, D, q.stride(-2), k.stride(-2), qs, mode, P, pitch, dq, dk,
+                                        dd, dq.stride(-2), D, dd.stride(-1))
         return (dqd.view(N, P, T, D + QPAD), dk.view(N, P, T, D), None, None, None, None, None, None, None, None)
 
 

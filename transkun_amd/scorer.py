@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import math
 import os
+import warnings
 
 import torch
 import torch.nn as nn
@@ -20,20 +21,53 @@ import torch.nn.functional as F
 from . import _lib
 
 
-def _interval_score_raw(q, k, diag, T: int, C: int, D: int, qscale: float, mode: int, full_square):
-    """q,k: [C,T,D] views with unit stride in d; diag: [C,T] view.  Returns S [T,T,C], noise [T-1,C].
+def slot_pitch(P: int, T: int, D: int, N: int = 1) -> int:
+    """The chain pitch this package's own glue gives N groups of P symbols (include/semicrf_hip.h, "SLOT LAYOUT"): the CRF
+    kernels stream 32-chain pieces of the flattened chain axis, which are whole 128-byte lines when the total slot count
+    N * pitch is a multiple of 32 (T=691, 90 symbols: 22 % faster at pitch 96).  The smallest such pitch >= P (a multiple
+    of 4) where the LDS-tiled scorer kernels and the packed backward apply; P itself (the contiguous layout) otherwise."""
+    if (N * P) % 32 == 0 or T < 128 or D not in (64, 128, 256) or _lib.get_impl() != 0:
+        return P
+    step = max(4, 32 // math.gcd(N, 32))
+    return (P + step - 1) // step * step
+
+
+_SLOT_MAPS = {}
+
+
+def slot_maps(N: int, P: int, pitch: int, device):
+    """(slot of every chain [N*P], offsets gather map [N*pitch + 1]) for chain c = n*P + p <-> slot n*pitch + p: interval
+    offsets by slot are offsets_by_chain[map] (a ghost slot is empty: it starts and ends where the next group starts)."""
+    key = (N, P, pitch, str(device))
+    m = _SLOT_MAPS.get(key)
+    if m is None:
+        n = torch.arange(N).view(N, 1)
+        p = torch.arange(pitch).view(1, pitch)
+        real = (n * pitch + torch.arange(P).view(1, P)).reshape(-1)
+        off = torch.where(p < P, n * P + p, (n + 1) * P).reshape(-1)
+        off = torch.cat([off, torch.tensor([N * P])])
+        m = _SLOT_MAPS[key] = (real.to(device), off.to(device))
+    return m
+
+
+def _interval_score_raw(q, k, diag, T: int, C: int, D: int, qscale: float, mode: int, full_square, group: int = 0, pitch: int = 0):
+    """q,k: [C,T,D] views with unit stride in d; diag: [C,T] view.  Returns S [T,T,Cs], noise [T-1,Cs]; Cs = C, or with a
+    slot layout (group, pitch: include/semicrf_hip.h) C / group * pitch with exact zeros in the ghost slots.
     full_square: False/0 lower triangle + zeros above, True/1 the full square, 2 lower triangle only (the cells with
     begin > end stay uninitialised: for S that only this library's CRF kernels read); | BF16X3 (4): the opt-in three-limb
     bf16 contraction (include/semicrf_hip.h: SEMICRF_SCORE_BF16X3)."""
     dev = q.device
     assert q.stride(-1) == 1 and k.stride(-1) == 1
+    if not group:
+        group = pitch = C
+    Cs = C // group * pitch
     # full_square=False: the library computes e >= b and zero-fills the rest itself (half the bytes of torch.zeros)
-    S = torch.empty(T, T, C, dtype=torch.float32, device=dev)
+    S = torch.empty(T, T, Cs, dtype=torch.float32, device=dev)
     if (int(full_square) & 3) == 2 and os.environ.get("SEMICRF_POISON_UNWRITTEN"):
         S.fill_(float("nan"))           # test hook: whatever reads begin > end of a lower-triangle-only S shows up as NaN
-    noise = torch.empty(max(T - 1, 0), C, dtype=torch.float32, device=dev)
+    noise = torch.empty(max(T - 1, 0), Cs, dtype=torch.float32, device=dev)
     _lib.ops().interval_score_fwd(q, k, diag, C, T, D, q.stride(-2), k.stride(-2), diag.stride(-1), float(qscale), int(mode),
-                                  int(full_square), S, noise)
+                                  int(full_square), int(group), int(pitch), S, noise)
     return S, noise
 
 
@@ -118,26 +152,30 @@ class _IntervalScore(torch.autograd.Function):
     qd: [N,P,T,D+QPAD] = [q | diag | zeros]; k: [N,P,T,D]."""
 
     @staticmethod
-    def forward(ctx, qd, k, N, P, T, D, mode, full_square):
+    def forward(ctx, qd, k, N, P, T, D, mode, full_square, pitch=0):
+        # pitch > P: the slot layout -- S comes back as [T, T, N, pitch] (zeros in the slots P.. of every segment)
         C = N * P
+        pitch = pitch or P
         qd3, k3 = qd.reshape(C, T, D + QPAD), k.reshape(C, T, D)
         qscale = 1.0 / math.sqrt(D)
-        S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qscale, mode, full_square)
+        S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qscale, mode, full_square, P, pitch)
         ctx.save_for_backward(qd3, k3)
-        ctx.meta = (N, P, T, D, mode, (int(full_square) & 3) == 1)
-        return S.view(T, T, N, P), noise.view(max(T - 1, 0), N, P)
+        ctx.meta = (N, P, T, D, mode, (int(full_square) & 3) == 1, pitch)
+        return S.view(T, T, N, pitch), noise.view(max(T - 1, 0), N, pitch)
+
+    _warned_torch_backward = False
 
     @staticmethod
     def backward(ctx, dS, dnoise):
         qd3, k = ctx.saved_tensors
-        N, P, T, D, mode, full = ctx.meta
+        N, P, T, D, mode, full, pitch = ctx.meta
         C = N * P
         qs = 1.0 / math.sqrt(D)
         q = qd3[..., :D]
         if D % 32 == 0 and D <= 256 and dS.is_cuda and not full:
             # HIP kernels: dq/dk from dS in its native [T,T,C] layout on the matrix cores (exact fp32), written straight
             # into the gradient of [q | diag | pad]
-            g = dS.reshape(T, T, C)
+            g = dS.reshape(T, T, N * pitch)
             if not g.is_contiguous():
                 g = g.contiguous()
             dqd = torch.empty(C, T, D + QPAD, dtype=torch.float32, device=g.device)
@@ -147,12 +185,18 @@ class _IntervalScore(torch.autograd.Function):
             # with a workspace the library repacks dS per chain and runs two LDS-tiled GEMMs (scorer_bwd_gemm.hip);
             # 0 bytes: shapes it does not take -- the direct kernels run
             ws = bwd_workspace(C, T, D, g.device)
-            _lib.ops().interval_score_bwd_ws(g, q, k, C, T, D, q.stride(-2), k.stride(-2), qs, mode, dq, dk, dd, dq.stride(-2), D,
-                                             dd.stride(-1), ws)
-            return (dqd.view(N, P, T, D + QPAD), dk.view(N, P, T, D), None, None, None, None, None, None)
+            _lib.ops().interval_score_bwd_ws(g, q, k, C, T, D, q.stride(-2), k.stride(-2), qs, mode, P, pitch, dq, dk, dd,
+                                             dq.stride(-2), D, dd.stride(-1), ws)
+            return (dqd.view(N, P, T, D + QPAD), dk.view(N, P, T, D), None, None, None, None, None, None, None)
+        if not _IntervalScore._warned_torch_backward:
+            _IntervalScore._warned_torch_backward = True
+            warnings.warn("transkun_amd.scorer: the interval-score backward runs as plain torch ops (contraction size D=%d not a "
+                          "multiple of 32 or > 256, or the full square was requested): about 10x slower than the HIP kernels" % D)
+        if pitch != P:
+            dS = dS[..., :P]
         dq, dk, dd = _IntervalScore._backward_torch(dS, q, k, N, P, T, D, mode, full)[:3]
         dqd = torch.cat([dq.reshape(C, T, D), dd.reshape(C, T, 1), dq.new_zeros(C, T, QPAD - 1)], dim=-1)
-        return (dqd.view(N, P, T, D + QPAD), dk, None, None, None, None, None, None)
+        return (dqd.view(N, P, T, D + QPAD), dk, None, None, None, None, None, None, None)
 
     @staticmethod
     def _backward_torch(dS, q, k, N, P, T, D, mode, full=False):
@@ -193,6 +237,10 @@ class ScaledInnerProductIntervalScorer(nn.Module):
         self.withScoreEps = withScoreEps
         self.fullSquare = False   # True: also materialise e<b like the reference (the CRF never reads it); 2: leave e<b
                                   # uninitialised (only for S that goes straight into this package's CRF)
+        self.slotPitch = None      # an int > P (a multiple of 4): forward() returns S as [T, T, N, slotPitch] and the noise score as
+                                  # [T-1, N, slotPitch] with zeros in the slots P.. of every segment (include/semicrf_hip.h, "SLOT
+                                  # LAYOUT") -- for callers that hand flatten(-2, -1) of both straight to NeuralSemiCRFInterval and
+                                  # drop the ghost chains' results; None: the reference's [T, T, N, P]
         self.contraction = "fp32"  # "bf16x3": opt-in forward contraction on the bf16 matrix instructions -- operands split
                                   # exactly into three bf16 limbs, six limb products, fp32 accumulation: fp32-grade scores
                                   # (|error| <= 2^-21 * sum_d |q_d k_d| * scale), not bit-identical to "fp32"; the
@@ -215,5 +263,5 @@ class ScaledInnerProductIntervalScorer(nn.Module):
         if self.contraction not in ("fp32", "bf16x3"):
             raise ValueError(f"contraction must be 'fp32' or 'bf16x3', not {self.contraction!r}")
         fs = int(self.fullSquare) | (BF16X3 if self.contraction == "bf16x3" else 0)
-        S, b = _IntervalScore.apply(qd, k, N, P, T, D, _lib.LEN_MODES[self.lengthScaling], fs)
+        S, b = _IntervalScore.apply(qd, k, N, P, T, D, _lib.LEN_MODES[self.lengthScaling], fs, int(self.slotPitch or 0))
         return S, b

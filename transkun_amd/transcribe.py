@@ -31,7 +31,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib, attributes
-from .scorer import ScaledInnerProductIntervalScorer
+from .scorer import ScaledInnerProductIntervalScorer, slot_maps, slot_pitch
 
 _nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
 
@@ -139,9 +139,26 @@ class SegmentTranscriber(nn.Module):
         B = Fn * P
         dev = ctxBatch.device
         ops = _lib.ops()
-        S, b = self.scorer(ctxBatch)                                                     # processFramesBatch :199-222
+        # processFramesBatch :199-222.  S stays inside this step, so its chain axis uses the slot layout (include/semicrf_hip.h):
+        # the P symbols of a segment in `pitch` slots (96 for 90) -- whole 128-byte lines for the CRF kernels -- with all-zero
+        # ghost chains that decode to nothing; the packed result is chain-indexed again before anything else sees it
+        pitch = slot_pitch(P, T, D, Fn)
+        self.scorer.slotPitch = pitch if pitch != P else None
+        try:
+            S, b = self.scorer(ctxBatch)
+        finally:
+            self.scorer.slotPitch = None
         score, noise = S.flatten(-2, -1), b.flatten(-2, -1)
-        pairs, offsets = _nsci._viterbi_raw(score, noise, start, False)                  # transcribeFrames :549
+        if pitch != P:
+            real, _ = slot_maps(Fn, P, pitch, dev)
+            start_s = None
+            if start is not None:
+                start_s = torch.zeros(Fn * pitch, dtype=torch.int32, device=dev).index_copy_(0, real, start)
+            pairs, offsets_s = _nsci._viterbi_raw(score, noise, start_s, False)          # transcribeFrames :549
+            # offsets by chain: chain c starts where its slot starts; the total (and the time-out marker) is the last entry
+            offsets = torch.cat([offsets_s.index_select(0, real), offsets_s[-1:]])
+        else:
+            pairs, offsets = _nsci._viterbi_raw(score, noise, start, False)              # transcribeFrames :549
         if onsetBound is not None:                                                       # :554-555
             pairs2 = torch.empty_like(pairs)
             offsets2 = torch.empty_like(offsets)
