@@ -463,9 +463,11 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
     ctx = synth.hash_normal(N * P * Ts * D, 21 + rank, dev).view(N, P, Ts, D) * 0.5
     iv = synth.synthetic_intervals(Ts, N * P, seed=21 + rank)
     ncoll = [0]
+    from transkun_amd.dist import FlatGradBucket
+    bucket = FlatGradBucket(model.parameters())      # gradients live in one persistent flat buffer; reduce-scatter + all-gather
 
     def tstep():
-        _, ncoll[0] = train_step(model, ctx.requires_grad_(), iv)
+        _, ncoll[0] = train_step(model, ctx.requires_grad_(), iv, bucket=bucket)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -486,8 +488,12 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
     extra["train_step_ms"] = round(dt * 1e3, 3)
     extra["train_step_segments_per_s"] = round(world * N / dt, 2)
     extra["train_step_config"] = (f"per rank: 4 segments x 90 symbols x T=691, D=256: Linear + interval scorer + fused CRF log_prob, "
-                                  f"(loss/50).backward(), one [3] all-reduce, {ncoll[0]} flat gradient all-reduce(s) of "
-                                  f"{sum(p.numel() for p in model.parameters()) / 1e6:.2f} M fp32 parameters; backbone out of scope (ctx is the input)")
+                                  f"(loss/50).backward(), one [3] all-reduce, gradient exchange of "
+                                  f"{sum(p.numel() for p in model.parameters()) / 1e6:.2f} M fp32 parameters from a persistent flat bucket: "
+                                  f"{ncoll[0]} collective(s) per step (reduce-scatter + all-gather over RCCL, started by the backward pass "
+                                  f"on a side stream), {bucket.bytes_per_rank / 1e6:.1f} MB sent per rank; backbone out of scope (ctx is the input)")
+    extra["train_step_collectives"] = int(ncoll[0])
+    extra["train_step_exchange_bytes_per_rank"] = int(bucket.bytes_per_rank)
 
 
 def _cpu_model() -> str:

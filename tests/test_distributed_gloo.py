@@ -161,3 +161,45 @@ def test_train_shaped_step_two_ranks(tmp_path):
         for i, g in enumerate(p["grads"]):
             want = sum(q["local"][i] for q in parts)
             assert torch.allclose(g, want, rtol=1e-6, atol=1e-9)
+
+
+def _bucket_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from transkun_amd import synth
+    from transkun_amd.dist import FlatGradBucket
+    from transkun_amd.trainstep import SegmentModel, train_step
+    torch.manual_seed(0)
+    model = SegmentModel(size=8, total_params=5000)
+    bucket = FlatGradBucket(model.parameters())
+    ptrs = [p.grad.data_ptr() for p in model.parameters()]
+    N, P, T = 2, 3, 10
+    out = []
+    for step in range(2):                                     # twice: the buffer persists, zero() replaces grad = None
+        ctx = synth.hash_normal(N * P * T * 8, 50 + rank + 10 * step, "cpu").view(N, P, T, 8)
+        stats, ncoll = train_step(model, ctx, None, log_prob=_cpu_log_prob, bucket=bucket)
+        local = SegmentModel(size=8, total_params=5000)
+        local.load_state_dict(model.state_dict())
+        logp = _cpu_log_prob(local.scorer, ctx, None).view(N, -1)
+        (-logp.sum(-1).mean() / 50).backward()
+        out.append({"ncoll": ncoll, "grads": [p.grad.clone() for p in model.parameters()],
+                    "local": [(p.grad.clone() if p.grad is not None else torch.full_like(p, 1e-3)) for p in local.parameters()],
+                    "same_storage": [p.grad.data_ptr() for p in model.parameters()] == ptrs})
+    torch.save(out, os.path.join(out_dir, f"b{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_grad_bucket_two_ranks(tmp_path):
+    """FlatGradBucket: .grad of every parameter is a view of one persistent buffer (same storage step after step), the
+    hook-started exchange sums over the ranks (one all_reduce over gloo; reduce-scatter + all-gather over RCCL, covered by
+    tests/test_gpu_parity.py::test_rccl_world1_train_step on the GPU)."""
+    world = 2
+    mp.spawn(_bucket_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(tmp_path, f"b{r}.pt"), weights_only=False) for r in range(world)]
+    for step in range(2):
+        for p in parts:
+            assert p[step]["ncoll"] == 1 and p[step]["same_storage"]
+            for i, g in enumerate(p[step]["grads"]):
+                want = sum(q[step]["local"][i] for q in parts)
+                assert torch.allclose(g, want, rtol=1e-6, atol=1e-9)

@@ -1215,3 +1215,95 @@ def test_slot_layout_offsets_maps():
     by_slot = offsets[off]
     assert by_slot.tolist() == [0, 2, 2, 5, 5, 6, 6, 9, 9]
     assert torch.cat([by_slot[real], by_slot[-1:]]).tolist() == offsets.tolist()
+
+
+# ---- RCCL on the hardware: a group of ONE rank on the leased GPU -----------------------------------
+
+@pytest.fixture(scope="module")
+def rccl_world1(gpu):
+    """init_process_group("nccl") IS RCCL on ROCm; one rank is all a 1-GPU box can host, and enough to execute the RCCL
+    code path of this package (communicator set-up, reduce-scatter / all-gather / all-reduce kernels on the GPU)."""
+    import socket
+    import torch.distributed as dist
+    if dist.is_initialized():
+        yield dist
+        return
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(gpu)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    yield dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_world1_train_step(gpu, rccl_world1):
+    """train.py:186-189 + :214-229 on the real HIP path (Linear + scorer + fused CRF log_prob at the model's segment shape) with
+    the exchange running over RCCL: the [3] loss all-reduce, the gradient reduce-scatter + all-gather out of the persistent
+    flat bucket (started by the backward pass on a side stream), and the round-1 flat all-reduce.  One rank: every sum is the
+    rank's own value, so the gradients must equal those of the same step without any exchange."""
+    from transkun_amd import _lib, synth
+    from transkun_amd.dist import FlatGradBucket, allreduce_gradients_flat, fused_loss_allreduce
+    from transkun_amd.trainstep import SegmentModel, train_step
+    dist = rccl_world1
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    N, P, T, D = 2, 90, 691, 256
+    torch.manual_seed(0)
+    model = SegmentModel(D, total_params=2_000_000).to(gpu)
+    ctx = synth.hash_normal(N * P * T * D, 61, gpu).view(N, P, T, D) * 0.5
+    iv = synth.synthetic_intervals(T, N * P, seed=61)
+    # reference: the step without a process-group exchange
+    stats0, n0 = train_step(model, ctx, iv)
+    want = [p.grad.clone() for p in model.parameters()]
+    assert n0 == 0
+    bucket = FlatGradBucket(model.parameters(), always=True)           # always: issue the collectives in a group of one
+    for _ in range(2):
+        stats, ncoll = train_step(model, ctx, iv, bucket=bucket)
+        torch.cuda.synchronize()
+        assert ncoll == 2 and bucket.collectives == 2                  # reduce-scatter + all-gather
+        assert float(stats[0]) == pytest.approx(float(stats0[0]), rel=1e-6) and float(stats[2]) == 1.0
+        for p, w in zip(model.parameters(), want):
+            assert p.grad.data_ptr() >= bucket.flat.data_ptr() and p.grad.data_ptr() < bucket.flat.data_ptr() + bucket.flat.numel() * 4
+            assert float((p.grad - w).abs().max()) <= 1e-6 * float(w.abs().max() + 1e-30)
+    # the [3] loss message and the concatenating exchange through RCCL as well (world 1: forced)
+    t = torch.ones(3, device=gpu)
+    dist.all_reduce(t)
+    assert t.tolist() == [1.0, 1.0, 1.0]
+    flat = bucket.flat.clone()
+    shard = flat.view(1, -1)[0]
+    dist.reduce_scatter_tensor(shard, flat)
+    dist.all_gather_into_tensor(flat, shard)
+    assert torch.equal(flat, bucket.flat)
+    assert _lib.device_status() == 0
+
+
+@pytest.mark.gpu
+def test_sweep_while_collective_in_flight(gpu, rccl_world1):
+    """The persistent sweeps need every workgroup of a launch resident (one per CU); an RCCL kernel on another stream holds
+    compute units while it runs.  Forward sweep, gradient sweep and decode while all-reduces of a 54.5 MB buffer are in
+    flight on a side stream: results equal the quiet run's bit for bit and no bounded wait gives up."""
+    import importlib
+    from transkun_amd import _lib, synth
+    nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
+    dist = rccl_world1
+    T, B = 691, 360
+    s, n = synth.crf_inputs(T, B, 71, gpu)
+    g = torch.ones(B, device=gpu)
+    lz0, v0 = nsci._logz_fwd_raw(s, n, True)
+    ds0, dn0, _ = nsci._logz_bwd_raw(s, n, v0, lz0, g)
+    p0, o0 = nsci._viterbi_raw(s, n, None, False)
+    torch.cuda.synchronize()
+    buf = torch.ones(13_610_000, device=gpu)
+    side = torch.cuda.Stream(device=gpu)
+    for rep in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                dist.all_reduce(buf)
+        lz, v = nsci._logz_fwd_raw(s, n, True)
+        ds, dn, _ = nsci._logz_bwd_raw(s, n, v, lz, g)
+        p, o = nsci._viterbi_raw(s, n, None, False)
+        torch.cuda.synchronize()
+        assert torch.equal(lz, lz0) and torch.equal(v, v0), rep
+        assert torch.equal(ds, ds0) and torch.equal(dn, dn0), rep
+        assert torch.equal(o, o0) and torch.equal(p[:int(o[-1])], p0[:int(o0[-1])]), rep
+    assert _lib.device_status() == 0

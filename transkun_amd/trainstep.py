@@ -20,7 +20,7 @@ from typing import Callable, Optional
 import torch
 import torch.nn as nn
 
-from .dist import allreduce_gradients_flat, fused_loss_allreduce
+from .dist import FlatGradBucket, allreduce_gradients_flat, fused_loss_allreduce
 from .scorer import ScaledInnerProductIntervalScorer
 
 MODEL_PARAMS = 13_610_000        # the shipped 2.0.conf model (13.61 M fp32 = 54.5 MB)
@@ -45,19 +45,37 @@ def default_log_prob(scorer, ctx, intervals):
 
 
 def train_step(model: SegmentModel, ctx: torch.Tensor, intervals, seconds_per_segment: float = 16.0, group=None,
-               log_prob: Optional[Callable] = None, bucket_bytes: int = 64 << 20):
+               log_prob: Optional[Callable] = None, bucket_bytes: int = 64 << 20, bucket: Optional[FlatGradBucket] = None):
     """One train.py-shaped step on this rank's segments.  ctx: [N, P, T, size]; intervals: N*P lists (chain n*P + p).
-    Returns (stats [3] = summed loss / seconds / batch count over ranks, number of gradient collectives issued)."""
+    Returns (stats [3] = summed loss / seconds / batch count over ranks, number of gradient collectives issued).
+
+    bucket: a FlatGradBucket over model.parameters() (make it once, pass it every step): gradients live in its persistent
+    flat buffer, the exchange is a reduce-scatter + all-gather that the backward pass starts itself on a side stream and
+    that overlaps the loss bookkeeping; without it the gradients are concatenated and all-reduced after the backward
+    (allreduce_gradients_flat, the round-1 exchange)."""
     N = ctx.shape[0]
     fn = log_prob or default_log_prob
-    for p in model.parameters():
-        p.grad = None
+    if bucket is not None:
+        bucket.zero()
+        bucket.arm()
+    else:
+        for p in model.parameters():
+            p.grad = None
     logp = fn(model.scorer, ctx, intervals).view(N, -1)            # ModelTransformer.py:266
     loss = -logp.sum(-1).mean()                                    # train.py:187
+    # The backbone's backward is not part of this path: its gradient is a stand-in of the right size.  In the model it is
+    # the LAST gradient to arrive (the backbone sits upstream of the scorer), so it is written after the backward pass here
+    # as well -- the exchange starts when it lands, not earlier.
     (loss / 50).backward()                                         # train.py:189
-    if model.rest.grad is None:
-        # the backbone's backward is not part of this path: its gradient is a stand-in of the right size
+    if bucket is not None:
+        with torch.no_grad():
+            model.rest.grad.fill_(1e-3)
+        bucket._on_grad(model.rest)                                # the stand-in's "hook": the bucket is complete now
+    elif model.rest.grad is None:
         model.rest.grad = torch.full_like(model.rest, 1e-3)
     stats = fused_loss_allreduce(loss, seconds_per_segment * N, 1.0, group=group)       # train.py:215-217
-    ncoll = allreduce_gradients_flat(model.parameters(), group=group, bucket_bytes=bucket_bytes)   # train.py:229
+    if bucket is not None:
+        ncoll = bucket.wait()                                                           # train.py:229
+    else:
+        ncoll = allreduce_gradients_flat(model.parameters(), group=group, bucket_bytes=bucket_bytes)
     return stats, ncoll
