@@ -431,6 +431,23 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
             extra[tag + "_scorer_decode_features_ms_device_bf16x3"] = round(ev_time(seg_decode, 5), 3)
             m.contraction = "fp32"
             del ctx
+        # ---- BASELINE configs[3] end to end: 16 s of audio -> frames (T = 691) -> log-mel (fp32) -> backbone in bf16 (a stand-in
+        # with the reference Backbone's interface; the real one is out of scope) -> fp32 ctx -> scorer + CRF logProb (fused route)
+        from transkun_amd.frontend import MelSpectrum, makeFrame, normalize_gain
+        audio = synth.hash_normal(2 * 705600, 41, dev).view(1, 2, 705600) * 0.1
+        mel = MelSpectrum(4096, 30, 8000, 229, 44100, nExtraWins=5, log=True, toMono=True).to(dev)
+        backbone = synth.StandInBackbone().to(dev).to(torch.bfloat16)
+        iv1 = synth.synthetic_intervals(Ts, P, seed=12)
+
+        def full_forward():
+            with torch.no_grad():
+                feat = mel(normalize_gain(makeFrame(audio, 1024, 4096)))
+                c = backbone(feat.to(torch.bfloat16)).float()
+                return scorer_crf_logprob(m, c, iv1)
+        extra["segment_full_forward_ms"] = round(ev_time(full_forward, 5), 3)
+        extra["segment_full_forward_config"] = ("16 s @ 44.1 kHz stereo -> makeFrame (T=691) -> 6-window log-mel (229 bands, fp32) -> stand-in "
+                                                "backbone in bf16 -> fp32 ctx [1,90,691,256] -> Linear + interval scorer + CRF logProb (forward only)")
+        del audio, mel, backbone
         # ---- the transcription segment loop: decode -> heads -> events -> next forced start, F recordings in
         # lock step, incomplete-event merge on the host; the shipped geometry (16 s segments, 8 s hop: T = 691, 90 symbols) ----
         from transkun_amd.transcribe import SegmentTranscriber

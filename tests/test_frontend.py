@@ -1,32 +1,47 @@
 """Audio front-end restatement (transkun_amd/frontend.py) against the reference's own makeFrame / GaussianWindows / Spectrum
-(tests/golden/frontend.npz, tools/make_golden.py:case_frontend).  The mel filterbank is parity-unpinned (torchaudio is not
-installed in the build container): structural checks only.  CPU."""
+(tests/golden/frontend.npz, tools/make_golden.py:case_frontend), on the CPU and -- marked gpu -- on cuda:0 (rocFFT /
+hipBLASLt behind the same torch ops).  The mel filterbank is pinned to the formula torchaudio documents by an independent
+float64 derivation (tests/golden/mel_fbank.npz, tools/make_mel_fixture.py); torchaudio itself is not installed in the build
+container, so its binary output stays unpinned.  The last test is BASELINE configs[3] end to end on the GPU."""
+import math
+
 import numpy as np
+import pytest
 import torch
 
 from conftest import load_golden, rel_err
 
 
 def test_framing_windows_and_spectrum_match_reference():
+    _framing_windows_spectrum("cpu")
+
+
+@pytest.mark.gpu
+def test_framing_windows_and_spectrum_match_reference_on_gpu(gpu):
+    _framing_windows_spectrum(gpu)
+
+
+def _framing_windows_spectrum(dev):
     from transkun_amd import synth
     from transkun_amd.frontend import GaussianWindows, Spectrum, makeFrame
     g = load_golden("frontend")
-    x = synth.hash_normal(2 * 20000, 950, "cpu").view(2, 20000)
+    x = synth.hash_normal(2 * 20000, 950, "cpu").view(2, 20000).to(dev)
     for hop, win in ((1024, 4096), (160, 400)):
         fr = makeFrame(x, hop, win)
         assert list(fr.shape) == list(g[f"frames_{hop}_shape"])
-        assert np.array_equal(fr.double().sum(-1).numpy(), g[f"frames_{hop}_rowsum"])          # framing is a copy: exact
-        assert np.array_equal(fr[0, :2, :8].numpy(), g[f"frames_{hop}_first"]) and np.array_equal(fr[1, -2:, -8:].numpy(), g[f"frames_{hop}_last"])
-    gw = GaussianWindows(5, 4096)
+        assert np.array_equal(fr.double().sum(-1).cpu().numpy(), g[f"frames_{hop}_rowsum"])          # framing is a copy: exact
+        assert np.array_equal(fr[0, :2, :8].cpu().numpy(), g[f"frames_{hop}_first"]) and np.array_equal(fr[1, -2:, -8:].cpu().numpy(), g[f"frames_{hop}_last"])
+    gw = GaussianWindows(5, 4096).to(dev)
     with torch.no_grad():
         gw.sigma.copy_(torch.from_numpy(g["gw_sigma"])); gw.center.copy_(torch.from_numpy(g["gw_center"]))
-    Y = gw.get().detach()
+    Y = gw.get().detach().cpu()
     assert rel_err(Y.double().sum(0).numpy(), g["gw_colsum"]) < 1e-6
     assert np.allclose(Y[[0, 1000, 2048, 4095]].numpy(), g["gw_rows"], rtol=1e-5, atol=1e-7)
-    sp = Spectrum(4096, nExtraWins=5)
+    sp = Spectrum(4096, nExtraWins=5).to(dev)
     with torch.no_grad():
         sp.winGen.sigma.copy_(gw.sigma); sp.winGen.center.copy_(gw.center)
         S = sp(makeFrame(x, 1024, 4096))
+    S = S.cpu()
     assert list(S.shape) == list(g["spec_shape"])
     P = S.abs().pow(2)
     assert rel_err(P.double().sum(dim=(0, 1, 2)).numpy(), g["spec_power_sum"]) < 1e-5
@@ -34,8 +49,26 @@ def test_framing_windows_and_spectrum_match_reference():
     assert np.allclose(torch.view_as_real(S[1, 5, [2, 300], :]).numpy(), g["spec_re_im"], rtol=1e-4, atol=1e-5)
 
 
+def test_mel_filterbank_matches_independent_fp64_derivation():
+    """melscale_fbanks (fp32 torch ops) against tests/golden/mel_fbank.npz: the same filterbank derived band by band in
+    float64 from torchaudio's documented definition (HTK mel scale, triangles of height 1, no area normalisation) by
+    tools/make_mel_fixture.py, which shares no code with the product."""
+    from transkun_amd.frontend import melscale_fbanks
+    g = load_golden("mel_fbank")
+    n_freqs, f_min, f_max, n_mels, fs = (float(x) for x in g["meta"])
+    fb = melscale_fbanks(int(n_freqs), f_min, f_max, int(n_mels), int(fs)).double().numpy()
+    want = np.zeros_like(fb)
+    want[g["rows"], g["cols"]] = g["vals"]
+    assert fb.shape == want.shape == (2049, 229)
+    assert float(np.abs(fb - want).max()) < 5e-5            # fp32 linspace / pow of the product against float64 (measured 2.1e-5)
+    assert np.array_equal(fb > 1e-4, want > 1e-4)           # the same support (up to bins that touch a corner)
+    # every band peaks next to its centre frequency
+    bins = np.arange(2049) * (22050 / 2048)
+    assert float(np.abs(bins[fb.argmax(0)] - g["corners"][:, 1]).max()) <= 22050 / 2048
+
+
 def test_mel_filterbank_structure_and_log_mel_range():
-    """melscale_fbanks (parity unpinned): non-negative triangles with peak <= 1, one peak per band at increasing
+    """melscale_fbanks: non-negative triangles with peak <= 1, one peak per band at increasing
     frequencies inside [f_min, f_max], zero outside; MelSpectrum(log=True) maps into [0, ~1]."""
     from transkun_amd import synth
     from transkun_amd.frontend import MelSpectrum, makeFrame, melscale_fbanks, normalize_gain
@@ -51,3 +84,43 @@ def test_mel_filterbank_structure_and_log_mel_range():
     feat = m(frames)
     assert feat.shape == (1, 1, frames.shape[-2], 229, 6)
     assert float(feat.min()) >= 0.0 and torch.isfinite(feat).all()
+
+
+@pytest.mark.gpu
+def test_full_segment_forward_config3(gpu):
+    """BASELINE configs[3] on the GPU: 16 s of audio at 44.1 kHz -> makeFrame (T = 691) -> gain normalisation -> log-mel
+    (six windows, 229 bands) -> a backbone in bf16 (a stand-in with the reference Backbone's interface: the real one is
+    out of scope) -> fp32 ctx -> interval scorer + CRF logProb (fused route, slot layout) and decode.  Checks the data
+    flow's shapes and dtypes, the bf16 -> fp32 hand-off (ctx holds bf16-representable fp32 values), that logProb of the
+    decoded path is the best one (>= logProb of the synthetic path, <= 0) and that fused and unfused routes agree."""
+    from transkun_amd import CRF, _lib, synth
+    from transkun_amd.frontend import MelSpectrum, makeFrame, normalize_gain
+    from transkun_amd.fused import scorer_crf_logprob
+    from transkun_amd.scorer import ScaledInnerProductIntervalScorer
+    fs, hop, win, seg = 44100, 1024, 4096, 16.0
+    nS = int(seg * fs)
+    audio = synth.hash_normal(2 * nS, 970, gpu).view(1, 2, nS) * 0.1                 # [nBatch, nAudioChannel, nSample]
+    frames = makeFrame(audio, hop, win)
+    T = frames.shape[-2]
+    assert T == math.ceil(nS / hop) + 1 == 691
+    mel = MelSpectrum(win, 30, 8000, 229, fs, nExtraWins=5, log=True, toMono=True).to(gpu)
+    feat = mel(normalize_gain(frames))
+    assert feat.shape == (1, 1, T, 229, 6) and feat.dtype == torch.float32 and bool(torch.isfinite(feat).all())
+    backbone = synth.StandInBackbone().to(gpu).to(torch.bfloat16)
+    with torch.no_grad():
+        ctx_bf = backbone(feat.to(torch.bfloat16))
+    assert ctx_bf.dtype == torch.bfloat16 and ctx_bf.shape == (1, 90, T, 256)
+    ctx = ctx_bf.float()                                                               # the fp32 hand-off into the scorer
+    assert torch.equal(ctx.to(torch.bfloat16).float(), ctx)
+    scorer = ScaledInnerProductIntervalScorer(256, 1).to(gpu)
+    iv = synth.synthetic_intervals(T, 90, seed=97)
+    lp = scorer_crf_logprob(scorer, ctx, iv)
+    S, b = scorer(ctx)
+    crf = CRF.NeuralSemiCRFInterval(S.flatten(-2, -1), b.flatten(-2, -1))
+    lp2 = crf.logProb(iv)
+    assert lp.shape == (90,) and bool(torch.isfinite(lp).all()) and float(lp.max()) <= 1e-3
+    assert float((lp - lp2).abs().max()) <= 2e-5 * float(lp2.abs().max())
+    best = crf.decode()
+    lp_best = crf.logProb(best)
+    assert bool((lp_best >= lp2 - 1e-3 * lp2.abs()).all())
+    assert _lib.device_status() == 0

@@ -128,3 +128,23 @@ def synthetic_intervals(T: int, B: int, seed: int = 7, every: int = 16, active_e
                 t = e + 1 + (r >> 16) % every
         out.append(cur)
     return out
+
+
+class StandInBackbone(torch.nn.Module):
+    """A stand-in for the reference's Backbone (LayersTransformer.py:444-660; out of scope here) with its
+    interface: log-mel features [N, 1, T, n_mels, nWin] -> ctx [N, P, T, size].  One Linear over a frame's features plus a
+    learned symbol embedding -- just enough arithmetic for BASELINE configs[3]'s data flow: mel front-end (fp32) -> backbone
+    in bf16 -> fp32 hand-off into the interval scorer.  Benchmarks and tests only; nothing of the hot path depends on it."""
+
+    def __init__(self, n_mels: int = 229, n_win: int = 6, n_sym: int = 90, size: int = 256):
+        super().__init__()
+        self.proj = torch.nn.Linear(n_mels * n_win, size)
+        self.sym = torch.nn.Parameter(torch.zeros(n_sym, size))
+        with torch.no_grad():
+            self.sym.copy_(hash_normal(n_sym * size, 4242).view(n_sym, size) * 0.5)
+            self.proj.weight.copy_(hash_normal(size * n_mels * n_win, 4243).view(size, n_mels * n_win) * (4.0 / (n_mels * n_win) ** 0.5))
+
+    def forward(self, feat: torch.Tensor) -> torch.Tensor:
+        N, _, T = feat.shape[:3]
+        h = self.proj(feat.reshape(N, T, -1) - 0.5)                  # [N, T, size]
+        return h.unsqueeze(1) + self.sym.view(1, -1, 1, h.shape[-1])   # [N, P, T, size]
