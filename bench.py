@@ -165,7 +165,7 @@ def worker(args):
     def step():
         score.grad = None; noise.grad = None
         lp = CRF.NeuralSemiCRFInterval(score, noise).logProb(intervals)  # the public call, Python lists in
-        loss = -lp.sum() / nseg                                          # train.py:187
+        loss = lp.sum() * (-1.0 / nseg)                                  # train.py:187 (-logp.sum(-1).mean()) as one reduction and one scale
         if dist is not None:
             fused_loss_allreduce(loss, float(T), float(nseg))            # train.py:215-217, fused to one [3] over RCCL
         loss.backward()

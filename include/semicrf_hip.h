@@ -162,6 +162,23 @@ int semicrf_eval_path_bwd(const float* gout, int T, int B, const int32_t* pairs,
                           const int32_t* offsets, float* dScore, float* dNoise, semicrf_stream_t stream);
 
 /*
+ * logProb as ONE call each way.  Replaces: NeuralSemiCRFInterval.logProb (:587-588: evalPath(intervals) - computeLogZ())
+ * and its backward (the autograd of :540-548 plus ComputeLogZFasterGrad.backward :469-472).
+ *   semicrf_logprob_fwd: logProb[c] = evalPath[c] - logZ[c]; also leaves logZ [B] and (when non-NULL) v [T][B] for the
+ *     backward.  Workspace: semicrf_workspace_bytes(SEMICRF_OP_LOGZ_FWD, T, B).
+ *   semicrf_logprob_bwd: gradient of sum_c g[c] * logProb[c] with g[c] = gout[c * gout_stride]; gout_stride is 1 or 0 --
+ *     0 reads ONE value for every chain, which is what the loss -logProb.sum() / n hands down (an expanded scalar): no
+ *     [B] copy of it and no negated copy are made.  dScore [T][T][B] is fully written (marginals times -g, +g on the path
+ *     cells, exact zeros for begin > end), dNoise [T-1][B] likewise.  Workspace: SEMICRF_OP_LOGZ_BWD.
+ */
+int semicrf_logprob_fwd(const float* score, const float* noise, int T, int B, const int32_t* pairs, int64_t K,
+                        const int32_t* offsets, float* logProb, float* logZ, float* v, void* ws, size_t ws_bytes,
+                        semicrf_stream_t stream);
+int semicrf_logprob_bwd(const float* score, const float* noise, const float* v, const float* logZ, const float* gout,
+                        int gout_stride, int T, int B, const int32_t* pairs, int64_t K, const int32_t* offsets,
+                        float* dScore, float* dNoise, void* ws, size_t ws_bytes, semicrf_stream_t stream);
+
+/*
  * Interval-score construction.  Replaces: ScaledInnerProductIntervalScorer.forward after the
  * Linear map (LayersTransformer.py:406-441).
  *   q,k: [C][T][D] with row strides ldq/ldk (in floats; >= D); diag: [C][T] with stride ldd between

@@ -370,29 +370,60 @@ class _EvalPath(torch.autograd.Function):
                 dnoise.to(ctx.in_dtypes[1]) if dnoise is not None else None, None, None, None)
 
 
+def _gout_strided(grad_output: torch.Tensor, B: int):
+    """(fp32 tensor, stride): the cotangent as the kernels take it -- B values (stride 1) or, when autograd hands down an
+    expanded scalar (the usual loss, -logProb.sum() / n: train.py:187), that ONE value (stride 0): no [B] copy, no kernel."""
+    assert grad_output.shape[-1] == B      # reference :471
+    g = grad_output.reshape(B) if grad_output.dim() != 1 else grad_output
+    if g.dtype != torch.float32:
+        g = g.float()
+    if B > 1 and g.stride(0) == 0:
+        return g.as_strided((1,), (1,)), 0
+    return g.contiguous(), 1
+
+
 class _LogProb(torch.autograd.Function):
-    """evalPath - logZ as one node; backward = gout * (onehot(path) - marginals) in one dense pass."""
+    """evalPath - logZ as one node (semicrf_logprob_fwd / semicrf_logprob_bwd): the forward subtracts inside the path kernel,
+    the backward writes gout * (onehot(path) - marginals) in one dense pass."""
 
     @staticmethod
     def forward(ctx, score, noiseScore, pairs, offsets):
         score_c, noise_c = _prep(score), _prep(noiseScore)
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        logz, v = _logz_fwd_raw(score_c, noise_c, want_v=need)
-        _ready(pairs)                                   # the intervals' copy ran beside the sweep
-        path = _eval_path_raw(score_c, noise_c, pairs, offsets)
+        T, B = score_c.shape[0], score_c.shape[2]
+        K = getattr(pairs, "_semicrf_K", pairs.shape[0])
+        if _odd_pad(score_c):
+            logz, v = _logz_fwd_raw(score_c, noise_c, want_v=need)
+            _ready(pairs)
+            lp = _eval_path_raw(score_c, noise_c, pairs, offsets) - logz
+        else:
+            dev = score_c.device
+            lp = torch.empty(B, dtype=torch.float32, device=dev)
+            logz = torch.empty(B, dtype=torch.float32, device=dev)
+            v = torch.empty((T, B) if need else (0,), dtype=torch.float32, device=dev)
+            ws = _lib.leased_workspace(_lib.OP_LOGZ_FWD, T, B, dev)
+            _ready(pairs)                               # the intervals' copy ran on a side stream
+            _lib.ops().logprob_fwd(score_c, noise_c, pairs, int(K), offsets, lp, logz, v, need, ws)
         if need:
             ctx.save_for_backward(score_c, noise_c, v, logz, pairs, offsets)
-            ctx.K = getattr(pairs, "_semicrf_K", pairs.shape[0])
+            ctx.K = K
         ctx.in_dtypes = (score.dtype, noiseScore.dtype)
-        return (path - logz).to(score.dtype)
+        return lp.to(score.dtype)
 
     @staticmethod
     def backward(ctx, grad_output):
         score, noise, v, logz, pairs, offsets = ctx.saved_tensors
         T, B = score.shape[0], score.shape[2]
-        g = _gout(grad_output, B)
-        dscore, dnoise, _ = _logz_bwd_raw(score, noise, v, logz, -g)
-        _eval_path_bwd_raw(g, T, B, pairs, offsets, dscore, dnoise, ctx.K)
+        if _odd_pad(score):
+            g = _gout(grad_output, B)
+            dscore, dnoise, _ = _logz_bwd_raw(score, noise, v, logz, -g)
+            _eval_path_bwd_raw(g, T, B, pairs, offsets, dscore, dnoise, ctx.K)
+        else:
+            g, gstride = _gout_strided(grad_output, B)
+            dscore = torch.empty_like(score)
+            dnoise = torch.empty_like(noise)
+            ws = _lib.leased_workspace(_lib.OP_LOGZ_BWD, T, B, score.device)
+            _lib.ops().logprob_bwd(score, noise, v, logz, g, gstride, pairs, int(ctx.K), offsets, dscore, dnoise, ws)
         return dscore.to(ctx.in_dtypes[0]), dnoise.to(ctx.in_dtypes[1]), None, None
 
 

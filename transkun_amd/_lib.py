@@ -47,6 +47,8 @@ _SIGS = {
     "semicrf_viterbi": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i64, _vp, _vp, _sz, _vp]),
     "semicrf_eval_path": (_i, [_vp, _vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "semicrf_eval_path_bwd": (_i, [_vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "semicrf_logprob_fwd": (_i, [_vp, _vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "semicrf_logprob_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "interval_score_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, ctypes.c_float, _i, _i, _vp, _vp, _vp]),
     "interval_score_fwd_p": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, ctypes.c_float, _i, _i, _i, _i, _vp, _vp, _vp]),
     "interval_score_bwd_ws_p": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i64, ctypes.c_float, _i, _i, _i, _vp, _vp, _vp, _i64, _i64, _i64, _vp, ctypes.c_size_t, _vp]),

@@ -26,7 +26,7 @@ void launch_rowseq_sweep(int mode, int dir, const float* score, const float* noi
                          int* code, float* out_last, hipStream_t stream);
 void launch_marginals(const float* score, const float* noise, const float* v, const float* q,
                       const float* logZ, const float* gout, int T, int B, float* dScore, float* dNoise,
-                      hipStream_t stream);
+                      hipStream_t stream, int gstride = 1, float gscale = 1.0f);
 void launch_backtrack(const int* code, int T, int B, const int* start, int forward, int* region, int* counts,
                       int* pairs, long long cap, int* offsets, hipStream_t stream, const unsigned* err, int nerr, int err_stride);
 const unsigned* persist_error_words(void* pws, int* n, int* stride);
@@ -36,9 +36,9 @@ void launch_segment_events(const int* pairs, const int* offsets, int B, int nSym
                            int lastFrameIdx, double frameDur, const double* beginTime, int stepFrames, double* times, unsigned char* flags,
                            int* lastP, int* nextStart, hipStream_t stream);
 void launch_eval_path(const float* score, const float* noise, int T, int B, int K, const int* pairs,
-                      const int* offsets, float* out, hipStream_t stream);
+                      const int* offsets, float* out, hipStream_t stream, const float* sub = nullptr);
 void launch_eval_path_bwd(const float* gout, int T, int B, int K, const int* pairs, const int* offsets,
-                          float* dScore, float* dNoise, hipStream_t stream);
+                          float* dScore, float* dNoise, hipStream_t stream, int gstride = 1, float gscale = 1.0f);
 void launch_interval_score_naive(const float* q, const float* k, const float* diag, int C, int T, int D,
                                  long long ldq, long long ldk, long long ldd, float qscale, int mode, int full,
                                  float* S, hipStream_t stream);
@@ -85,7 +85,7 @@ int read_and_clear_device_status();
 
 int launch_persist_logz_bwd(const float* score, const float* noise, const float* v, const float* logZ,
                             const float* gout, int T, int B, float* dScore, float* dNoise, float* q_out, void* ws,
-                            hipStream_t stream, int lease, unsigned lease_tag);
+                            hipStream_t stream, int lease, unsigned lease_tag, int gstride = 1, float gscale = 1.0f);
 
 static bool use_persist(int T, int B) { return g_impl.load() == 0 && persist_supported(T, B); }
 
@@ -258,13 +258,14 @@ int semicrf_logz_fwd(const float* score, const float* noise, int T, int B, float
     return SEMICRF_OK;
 }
 
-int semicrf_logz_bwd(const float* score, const float* noise, const float* v, const float* logZ,
-                     const float* gout, int T, int B, float* dScore, float* dNoise, float* q_out, void* ws,
-                     size_t ws_bytes, semicrf_stream_t stream)
+static int logz_bwd_impl(const float* score, const float* noise, const float* v, const float* logZ,
+                         const float* gout, int gstride, float gscale, int T, int B, float* dScore, float* dNoise, float* q_out,
+                         void* ws, size_t ws_bytes, semicrf_stream_t stream)
 {
     if (int rc = check_common(score, noise, T, B)) return rc;
     SEMICRF_CHECK_ARG(v && logZ && gout && dScore, "v/logZ/gout/dScore must be non-NULL");
     SEMICRF_CHECK_ARG(dNoise != nullptr || T == 1, "dNoise is NULL");
+    SEMICRF_CHECK_ARG(gstride == 0 || gstride == 1, "gout stride must be 0 (one value for all chains) or 1");
     Carver cv(ws, ws_bytes);
     const bool fast = use_persist(T, B);
     void* pws = fast ? cv.take<char>(persist_workspace_bytes(T, B)) : nullptr;      // first: see semicrf_logz_fwd
@@ -275,16 +276,49 @@ int semicrf_logz_bwd(const float* score, const float* noise, const float* v, con
         // beta sweep fused with the marginals: score is read once, dScore written once
         unsigned ltag = 0;
         const int lease = lease_acquire(ws, SEMICRF_OP_LOGZ_BWD, T, B, &ltag, st);
-        if (launch_persist_logz_bwd(score, noise, v, logZ, gout, T, B, dScore, dNoise, q, pws, st, lease, ltag)) {
+        if (launch_persist_logz_bwd(score, noise, v, logZ, gout, T, B, dScore, dNoise, q, pws, st, lease, ltag, gstride, gscale)) {
             lease_failed(ws);
             set_error("persistent sweep could not be enqueued (too many chain chunks for this device)"); return SEMICRF_ELAUNCH;
         }
     } else {
         lease_failed(ws);
         launch_rowseq_sweep(0, 1, score, noise, T, B, q, nullptr, nullptr, st);
-        launch_marginals(score, noise, v, q, logZ, gout, T, B, dScore, dNoise, st);
+        launch_marginals(score, noise, v, q, logZ, gout, T, B, dScore, dNoise, st, gstride, gscale);
     }
+    return SEMICRF_OK;
+}
+
+int semicrf_logz_bwd(const float* score, const float* noise, const float* v, const float* logZ,
+                     const float* gout, int T, int B, float* dScore, float* dNoise, float* q_out, void* ws,
+                     size_t ws_bytes, semicrf_stream_t stream)
+{
+    if (int rc = logz_bwd_impl(score, noise, v, logZ, gout, 1, 1.0f, T, B, dScore, dNoise, q_out, ws, ws_bytes, stream)) return rc;
     SEMICRF_CHECK_LAUNCH("semicrf_logz_bwd");
+    return SEMICRF_OK;
+}
+
+int semicrf_logprob_fwd(const float* score, const float* noise, int T, int B, const int32_t* pairs, int64_t K,
+                        const int32_t* offsets, float* logProb, float* logZ, float* v, void* ws, size_t ws_bytes,
+                        semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(offsets && logProb && logZ, "offsets/logProb/logZ must be non-NULL");
+    SEMICRF_CHECK_ARG(K >= 0 && K < (1ll << 31) && (K == 0 || pairs), "bad interval count");
+    if (int rc = semicrf_logz_fwd(score, noise, T, B, logZ, v, ws, ws_bytes, stream)) return rc;
+    launch_eval_path(score, noise, T, B, (int)K, pairs, offsets, logProb, (hipStream_t)stream, logZ);
+    SEMICRF_CHECK_LAUNCH("semicrf_logprob_fwd");
+    return SEMICRF_OK;
+}
+
+int semicrf_logprob_bwd(const float* score, const float* noise, const float* v, const float* logZ, const float* gout,
+                        int gout_stride, int T, int B, const int32_t* pairs, int64_t K, const int32_t* offsets, float* dScore,
+                        float* dNoise, void* ws, size_t ws_bytes, semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(offsets, "offsets must be non-NULL");
+    SEMICRF_CHECK_ARG(K >= 0 && K < (1ll << 31) && (K == 0 || pairs), "bad interval count");
+    // d logProb = d evalPath - d logZ: the marginals with -gout, then +gout on the path's cells and uncovered gaps
+    if (int rc = logz_bwd_impl(score, noise, v, logZ, gout, gout_stride, -1.0f, T, B, dScore, dNoise, nullptr, ws, ws_bytes, stream)) return rc;
+    launch_eval_path_bwd(gout, T, B, (int)K, pairs, offsets, dScore, dNoise, (hipStream_t)stream, gout_stride, 1.0f);
+    SEMICRF_CHECK_LAUNCH("semicrf_logprob_bwd");
     return SEMICRF_OK;
 }
 

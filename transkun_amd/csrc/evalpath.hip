@@ -19,7 +19,8 @@ constexpr int EP_THREADS = 256;
 __global__ __launch_bounds__(EP_THREADS) void eval_path_kernel(const float* __restrict__ score,
                                                                const float* __restrict__ noise, int T, int B, int K,
                                                                const int* __restrict__ pairs,
-                                                               const int* __restrict__ offsets, float* __restrict__ out)
+                                                               const int* __restrict__ offsets, float* __restrict__ out,
+                                                               const float* __restrict__ sub)
 {
     __shared__ double red[EP_THREADS];
     const int c = blockIdx.x, tid = threadIdx.x;
@@ -38,16 +39,16 @@ __global__ __launch_bounds__(EP_THREADS) void eval_path_kernel(const float* __re
         if (tid < d) red[tid] += red[tid + d];
         __syncthreads();
     }
-    if (tid == 0) out[c] = (float)red[0];
+    if (tid == 0) out[c] = sub ? (float)red[0] - sub[c] : (float)red[0];       // sub = logZ: logProb (reference :587-588), one fp32 subtraction
 }
 
 // dNoise[t][c] += gout[c]  (d cum[T-1] / d noise): fully parallel
 __global__ __launch_bounds__(256) void eval_path_bwd_noise_kernel(const float* __restrict__ gout, int T, int B,
-                                                                  float* __restrict__ dNoise)
+                                                                  float* __restrict__ dNoise, int gstride, float gscale)
 {
     const size_t n = (size_t)(T - 1) * B;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        dNoise[i] += gout[i % B];
+        dNoise[i] += gscale * gout[(i % B) * gstride];
 }
 
 // One thread per interval: dScore[e][b][c] += g; dNoise[t][c] -= g for the covered gaps t in [b, e).
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void eval_path_bwd_noise_kernel(const float* _
 __global__ __launch_bounds__(256) void eval_path_bwd_pairs_kernel(const float* __restrict__ gout, int T, int B, int K,
                                                                   const int* __restrict__ pairs,
                                                                   const int* __restrict__ offsets,
-                                                                  float* dScore, float* dNoise)
+                                                                  float* dScore, float* dNoise, int gstride, float gscale)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void eval_path_bwd_pairs_kernel(const float* _
         if (offsets[mid] <= k) lo = mid; else hi = mid;
     }
     const int c = lo;
-    const float g = gout[c];
+    const float g = gscale * gout[(size_t)c * gstride];
     const int b = pairs[2 * k], e = pairs[2 * k + 1];
     if (dScore) atomicAdd(dScore + ((size_t)e * T + b) * B + c, g);
     if (dNoise)
@@ -74,23 +75,23 @@ __global__ __launch_bounds__(256) void eval_path_bwd_pairs_kernel(const float* _
 }
 
 void launch_eval_path(const float* score, const float* noise, int T, int B, int K, const int* pairs,
-                      const int* offsets, float* out, hipStream_t stream)
+                      const int* offsets, float* out, hipStream_t stream, const float* sub)
 {
-    hipLaunchKernelGGL(eval_path_kernel, dim3(B), dim3(EP_THREADS), 0, stream, score, noise, T, B, K, pairs, offsets, out);
+    hipLaunchKernelGGL(eval_path_kernel, dim3(B), dim3(EP_THREADS), 0, stream, score, noise, T, B, K, pairs, offsets, out, sub);
 }
 
 void launch_eval_path_bwd(const float* gout, int T, int B, int K, const int* pairs, const int* offsets,
-                          float* dScore, float* dNoise, hipStream_t stream)
+                          float* dScore, float* dNoise, hipStream_t stream, int gstride, float gscale)
 {
     if (dNoise && T > 1) {
         const size_t n = (size_t)(T - 1) * B;
         int g = (int)((n + 255) / 256);
         if (g > 2048) g = 2048;
-        hipLaunchKernelGGL(eval_path_bwd_noise_kernel, dim3(g), dim3(256), 0, stream, gout, T, B, dNoise);
+        hipLaunchKernelGGL(eval_path_bwd_noise_kernel, dim3(g), dim3(256), 0, stream, gout, T, B, dNoise, gstride, gscale);
     }
     if (K > 0)
         hipLaunchKernelGGL(eval_path_bwd_pairs_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, gout, T, B, K,
-                           pairs, offsets, dScore, dNoise);
+                           pairs, offsets, dScore, dNoise, gstride, gscale);
 }
 
 }  // namespace semicrf

@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void marginals_kernel(const float* __restrict_
                                                          const float* __restrict__ q,
                                                          const float* __restrict__ logZ,
                                                          const float* __restrict__ gout, int T, int B,
-                                                         float* __restrict__ dScore)
+                                                         float* __restrict__ dScore, int gstride, float gscale)
 {
     const int e = blockIdx.y;
     const size_t rowlen = (size_t)T * B;
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void marginals_kernel(const float* __restrict_
             const float s = score[base + idx];
             float a = v[(size_t)b * B + c] + ((q[(size_t)e * B + c] - logZ[c]) + s);
             if (b == e) a -= 2.0f * softplus_f(s);
-            g = gout[c] * expf(a);
+            g = gscale * gout[(size_t)c * gstride] * expf(a);
         }
         dScore[base + idx] = g;
     }
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void noise_grad_kernel(const float* __restrict
                                                           const float* __restrict__ q,
                                                           const float* __restrict__ logZ,
                                                           const float* __restrict__ gout, int T, int B,
-                                                          float* __restrict__ dNoise)
+                                                          float* __restrict__ dNoise, int gstride, float gscale)
 {
     const size_t n = (size_t)(T - 1) * B;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
@@ -46,23 +46,23 @@ __global__ __launch_bounds__(256) void noise_grad_kernel(const float* __restrict
         const int t = (int)(idx / B);
         const int c = (int)(idx - (size_t)t * B);
         const float a = ((v[idx] + q[(size_t)(t + 1) * B + c]) + noise[idx]) - logZ[c];
-        dNoise[idx] = gout[c] * expf(a);
+        dNoise[idx] = gscale * gout[(size_t)c * gstride] * expf(a);
     }
 }
 
 void launch_marginals(const float* score, const float* noise, const float* v, const float* q,
                       const float* logZ, const float* gout, int T, int B, float* dScore, float* dNoise,
-                      hipStream_t stream)
+                      hipStream_t stream, int gstride, float gscale)
 {
     const size_t rowlen = (size_t)T * B;
     int gx = (int)((rowlen + 255) / 256);
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(marginals_kernel, dim3(gx, T), dim3(256), 0, stream, score, v, q, logZ, gout, T, B, dScore);
+    hipLaunchKernelGGL(marginals_kernel, dim3(gx, T), dim3(256), 0, stream, score, v, q, logZ, gout, T, B, dScore, gstride, gscale);
     if (T > 1 && dNoise) {
         const size_t n = (size_t)(T - 1) * B;
         int g2 = (int)((n + 255) / 256);
         if (g2 > 2048) g2 = 2048;
-        hipLaunchKernelGGL(noise_grad_kernel, dim3(g2), dim3(256), 0, stream, noise, v, q, logZ, gout, T, B, dNoise);
+        hipLaunchKernelGGL(noise_grad_kernel, dim3(g2), dim3(256), 0, stream, noise, v, q, logZ, gout, T, B, dNoise, gstride, gscale);
     }
 }
 

@@ -130,7 +130,9 @@ struct SweepParams {
     // GRAD (LSE, DIR 1 only): marginals are a by-product of the beta sweep (NeuralSemiCRFInterval.py:424-447, :469-472)
     const float* vfwd;     // [T][B] alpha values by frame (natural log)
     const float* logZ;     // [B]
-    const float* gout;     // [B] upstream gradient
+    const float* gout;     // upstream gradient of chain c: gscale * gout[c * gstride] (gstride 0: one value for every chain)
+    int gstride;
+    float gscale;
     float* dScore;         // [T][T][B]: lower triangle + diagonal written here (the upper triangle by zero_upper_kernel)
     float* dNoise;         // [T-1][B]
 };
@@ -526,7 +528,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
     int* const cons = (int*)(lds + LDS_CTL) + NRBUF;
     const float4* const far = (const float4*)(lds + LDS_FAR);
     float gz = 0.f, lzc = 0.f;
-    if (GRAD && cvalid) { gz = P.gout[c]; lzc = P.logZ[c]; }               // the only global loads of a ring wave
+    if (GRAD && cvalid) { gz = P.gout[(size_t)c * P.gstride] * P.gscale; lzc = P.logZ[c]; }               // the only global loads of a ring wave
     __builtin_amdgcn_s_setprio(1);
 
     for (int k = rw; k < K; k += RING) {
@@ -1005,7 +1007,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
             for (int i = 0; i < 4; ++i) {
                 const bool ok = c + i < c1;
                 lz[i] = ok ? logZp[c + i] : 0.f;
-                gz[i] = ok ? goutp[c + i] : 0.f;
+                gz[i] = ok ? goutp[(size_t)(c + i) * P.gstride] * P.gscale : 0.f;
             }
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
@@ -1580,7 +1582,7 @@ static Knobs read_knobs()
 }
 
 struct GradArgs {
-    const float* vfwd; const float* logZ; const float* gout; float* dScore; float* dNoise;
+    const float* vfwd; const float* logZ; const float* gout; float* dScore; float* dNoise; int gstride; float gscale;
 };
 
 template <int MODE, int DIR, bool GRAD>
@@ -1605,8 +1607,11 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
                                      const GradArgs* grad, int lease, unsigned lease_tag)
 {
     SweepParams P;
-    P.vfwd = nullptr; P.logZ = nullptr; P.gout = nullptr; P.dScore = nullptr; P.dNoise = nullptr;
-    if (grad) { P.vfwd = grad->vfwd; P.logZ = grad->logZ; P.gout = grad->gout; P.dScore = grad->dScore; P.dNoise = grad->dNoise; }
+    P.vfwd = nullptr; P.logZ = nullptr; P.gout = nullptr; P.dScore = nullptr; P.dNoise = nullptr; P.gstride = 1; P.gscale = 1.0f;
+    if (grad) {
+        P.vfwd = grad->vfwd; P.logZ = grad->logZ; P.gout = grad->gout; P.dScore = grad->dScore; P.dNoise = grad->dNoise;
+        P.gstride = grad->gstride; P.gscale = grad->gscale;
+    }
     P.score = score; P.noise = noise; P.T = T; P.B = B; P.K = (T + PB - 1) / PB;
     P.tag = lease_tag ? (lease_tag % 65534u) + 1u : next_tag();
     P.dbg = 0u;
@@ -1725,9 +1730,9 @@ int launch_persist_sweep(int mode, int dir, const float* score, const float* noi
 // Fused backward: beta sweep + marginals (dScore fully written incl. the zero upper triangle, dNoise).
 int launch_persist_logz_bwd(const float* score, const float* noise, const float* v, const float* logZ,
                             const float* gout, int T, int B, float* dScore, float* dNoise, float* q_out, void* ws,
-                            hipStream_t stream, int lease, unsigned lease_tag)
+                            hipStream_t stream, int lease, unsigned lease_tag, int gstride, float gscale)
 {
-    GradArgs ga{v, logZ, gout, dScore, dNoise};
+    GradArgs ga{v, logZ, gout, dScore, dNoise, gstride, gscale};
     return launch_persist_sweep_impl(0, 1, score, noise, T, B, q_out, nullptr, nullptr, ws, stream, &ga, lease, lease_tag);
 }
 

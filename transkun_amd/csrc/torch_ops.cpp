@@ -145,6 +145,31 @@ void eval_path_bwd(Tensor gout, int64_t T, int64_t B, Tensor pairs, int64_t K, T
           "semicrf_eval_path_bwd");
 }
 
+// logProb as one call each way (semicrf_logprob_fwd / _bwd): gout holds B values (gstride 1) or ONE (gstride 0)
+void logprob_fwd(Tensor score, Tensor noise, Tensor pairs, int64_t K, Tensor offsets, Tensor logProb, Tensor logZ, Tensor v, bool want_v,
+                 Tensor ws)
+{
+    Ctx c(score); c.same(score, noise, pairs, offsets, logProb, logZ, v, ws);
+    const Dims d = crf_dims(score, noise);
+    STD_TORCH_CHECK(K >= 0, "semicrf: negative interval count");
+    check(semicrf_logprob_fwd(cfp(score), cfp(noise), d.T, d.B, i32(pairs, 2 * K, "pairs"), K, i32(offsets, d.B + 1, "offsets"),
+                              f32w(logProb, d.B, "logProb"), f32w(logZ, d.B, "logZ"), want_v ? f32w(v, (int64_t)d.T * d.B, "v") : nullptr,
+                              bytes(ws, "ws"), (size_t)ws.numel(), c.stream),
+          "semicrf_logprob_fwd");
+}
+void logprob_bwd(Tensor score, Tensor noise, Tensor v, Tensor logZ, Tensor gout, int64_t gstride, Tensor pairs, int64_t K, Tensor offsets,
+                 Tensor dScore, Tensor dNoise, Tensor ws)
+{
+    Ctx c(score); c.same(score, noise, v, logZ, gout, pairs, offsets, dScore, dNoise, ws);
+    const Dims d = crf_dims(score, noise);
+    const int64_t TB = (int64_t)d.T * d.B;
+    STD_TORCH_CHECK(K >= 0 && (gstride == 0 || gstride == 1), "semicrf: bad interval count / gout stride");
+    check(semicrf_logprob_bwd(cfp(score), cfp(noise), f32(v, TB, "v"), f32(logZ, d.B, "logZ"), f32(gout, gstride ? d.B : 1, "gout"),
+                              (int)gstride, d.T, d.B, i32(pairs, 2 * K, "pairs"), K, i32(offsets, d.B + 1, "offsets"),
+                              f32w(dScore, TB * d.T, "dScore"), f32w(dNoise, TB - d.B, "dNoise"), bytes(ws, "ws"), (size_t)ws.numel(), c.stream),
+          "semicrf_logprob_bwd");
+}
+
 // ---- semi-CRF, CPU (dispatch key CPU): the product's own host kernels (cpu_ops.cpp) -- selected by the tensors' device, never
 // a fallback for GPU tensors.  The workspace argument is ignored (pass an empty tensor).
 void logz_fwd_cpu(Tensor score, Tensor noise, Tensor logZ, Tensor v, bool want_v, Tensor ws)
@@ -216,6 +241,33 @@ void eval_path_bwd_cpu(Tensor gout, int64_t T, int64_t B, Tensor pairs, int64_t 
     check_path(pp, K, oo, (int)T, (int)B);
     semicrf_cpu::eval_path_bwd(f32(gout, B, "gout"), (int)T, (int)B, pp, oo, has_ds ? f32w(dScore, T * T * B, "dScore") : nullptr,
                                has_dn ? f32w(dNoise, (T - 1) * B, "dNoise") : nullptr);
+}
+
+void logprob_fwd_cpu(Tensor score, Tensor noise, Tensor pairs, int64_t K, Tensor offsets, Tensor logProb, Tensor logZ, Tensor v, bool want_v,
+                     Tensor ws)
+{
+    logz_fwd_cpu(score, noise, logZ, v, want_v, ws);
+    eval_path_cpu(score, noise, pairs, K, offsets, logProb, ws);
+    float* lp = (float*)logProb.data_ptr();
+    const float* lz = (const float*)logZ.data_ptr();
+    for (int64_t c = 0; c < score.size(2); ++c) lp[c] -= lz[c];
+}
+void logprob_bwd_cpu(Tensor score, Tensor noise, Tensor v, Tensor logZ, Tensor gout, int64_t gstride, Tensor pairs, int64_t K, Tensor offsets,
+                     Tensor dScore, Tensor dNoise, Tensor ws)
+{
+    all_cpu(score, noise, v, logZ, gout, pairs, offsets, dScore, dNoise);
+    const Dims d = crf_dims(score, noise);
+    const int64_t TB = (int64_t)d.T * d.B;
+    STD_TORCH_CHECK(K >= 0 && (gstride == 0 || gstride == 1), "semicrf: bad interval count / gout stride");
+    const float* g = f32(gout, gstride ? d.B : 1, "gout");
+    std::vector<float> gp((size_t)d.B), gn((size_t)d.B), q((size_t)TB);
+    for (int c = 0; c < d.B; ++c) { gp[(size_t)c] = g[(size_t)c * gstride]; gn[(size_t)c] = -gp[(size_t)c]; }
+    const int32_t* pp = i32(pairs, 2 * K, "pairs");
+    const int32_t* oo = i32(offsets, d.B + 1, "offsets");
+    check_path(pp, K, oo, d.T, d.B);
+    semicrf_cpu::logz_bwd(cfp(score), cfp(noise), f32(v, TB, "v"), f32(logZ, d.B, "logZ"), gn.data(), d.T, d.B, f32w(dScore, TB * d.T, "dScore"),
+                          f32w(dNoise, TB - d.B, "dNoise"), q.data());
+    semicrf_cpu::eval_path_bwd(gp.data(), d.T, d.B, pp, oo, fp(dScore), fp(dNoise));
 }
 
 // ---- interval scorer ---------------------------------------------------------------------------------------------------
@@ -347,6 +399,10 @@ STABLE_TORCH_LIBRARY(semicrf, m)
     m.def("eval_path(Tensor score, Tensor noise, Tensor pairs, int K, Tensor offsets, Tensor(a!) out, Tensor(b!) ws) -> ()");
     m.def("eval_path_bwd(Tensor gout, int T, int B, Tensor pairs, int K, Tensor offsets, Tensor(a!) dScore, bool has_ds, Tensor(b!) dNoise, "
           "bool has_dn) -> ()");
+    m.def("logprob_fwd(Tensor score, Tensor noise, Tensor pairs, int K, Tensor offsets, Tensor(a!) logProb, Tensor(b!) logZ, Tensor(c!) v, "
+          "bool want_v, Tensor(d!) ws) -> ()");
+    m.def("logprob_bwd(Tensor score, Tensor noise, Tensor v, Tensor logZ, Tensor gout, int gstride, Tensor pairs, int K, Tensor offsets, "
+          "Tensor(a!) dScore, Tensor(b!) dNoise, Tensor(c!) ws) -> ()");
     // (group, pitch): the slot layout of the chain axis (include/semicrf_hip.h, *_p entry points); group == pitch: contiguous
     m.def("interval_score_fwd(Tensor q, Tensor k, Tensor diag, int C, int T, int D, int ldq, int ldk, int ldd, float qscale, int mode, "
           "int full, int group, int pitch, Tensor(a!) S, Tensor(b!) noise) -> ()");
@@ -375,6 +431,8 @@ STABLE_TORCH_LIBRARY_IMPL(semicrf, CPU, m)
     m.impl("viterbi", TORCH_BOX(&viterbi_cpu));
     m.impl("eval_path", TORCH_BOX(&eval_path_cpu));
     m.impl("eval_path_bwd", TORCH_BOX(&eval_path_bwd_cpu));
+    m.impl("logprob_fwd", TORCH_BOX(&logprob_fwd_cpu));
+    m.impl("logprob_bwd", TORCH_BOX(&logprob_bwd_cpu));
 }
 
 STABLE_TORCH_LIBRARY_IMPL(semicrf, CUDA, m)
@@ -385,6 +443,8 @@ STABLE_TORCH_LIBRARY_IMPL(semicrf, CUDA, m)
     m.impl("viterbi", TORCH_BOX(&viterbi));
     m.impl("eval_path", TORCH_BOX(&eval_path));
     m.impl("eval_path_bwd", TORCH_BOX(&eval_path_bwd));
+    m.impl("logprob_fwd", TORCH_BOX(&logprob_fwd));
+    m.impl("logprob_bwd", TORCH_BOX(&logprob_bwd));
     m.impl("interval_score_fwd", TORCH_BOX(&interval_score_fwd_op));
     m.impl("interval_score_bwd_ws", TORCH_BOX(&interval_score_bwd_ws_op));
     m.impl("interval_score_bwd_fused_ws", TORCH_BOX(&interval_score_bwd_fused_ws_op));
