@@ -314,7 +314,8 @@ def _cpu_baseline(args, s_d, n_d, T, B, nseg):
             "sample": f"torch-CPU op-loop port of forward_backward + backward multiply, T={T}, all {B} chains, "
                       f"best of {len(times)} reps ({dt:.2f}s); thread probe on {Bs} chains: "
                       + ", ".join(f"{k}t={v:.2f}s" for k, v in probe.items()),
-            "cpu_model": _cpu_model()}
+            "cpu_model": _cpu_model(), "physical_cores": _physical_cores(), "logical_cpus": os.cpu_count(),
+            "cores_note": "cores = the threads the timed run used (the fastest of the probe); physical_cores / logical_cpus = what the box has"}
 
 
 def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time, fwd_ms):
@@ -394,6 +395,16 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
                                                  _lib.ptr(dq), _lib.ptr(dk2), _lib.ptr(ddg), Dq, Dq, 1, _lib.ptr(wsq), nws,
                                                  _lib.stream_of(Sq)), "interval_score_bwd_ws")
         extra["interval_score_bwd_ms"] = round(ev_time(_bwd, 5), 3)
+        # the scorer is the path's matrix-bound kernel: its own roofline object (the line's `roofline` is the HBM-bound sweep)
+        sflop = 2.0 * Cq * (T * (T + 1) / 2) * Dq                           # lower triangle only
+        extra["scorer_roofline"] = {
+            "bound": "mfma", "kernel": "interval_score_tile_kernel<128> (exact fp32, v_mfma_f32_32x32x2_f32)", "unit": "TFLOP/s",
+            "achieved": round(sflop / (extra["interval_score_fwd_ms"] * 1e-3) / 1e12, 2), "peak": 157.3,
+            "frac": round(sflop / (extra["interval_score_fwd_ms"] * 1e-3) / 1e12 / 157.3, 4), "algorithmic_flop": sflop,
+            "note": "time includes the zero fill of the cells above the diagonal (full_square = 0); counters (profiles/r03_derived.json): "
+                    "matrix pipe busy 57 % of the kernel at 2.19 GHz under load",
+            "bf16x3_frac_fp32_equivalent": round(sflop / (extra["interval_score_fwd_bf16x3_ms"] * 1e-3) / 1e12 / 157.3, 4),
+            "backward_frac": round(2 * sflop / (extra["interval_score_bwd_ms"] * 1e-3) / 1e12 / 157.3, 4)}
         extra["interval_score_config"] = f"T={T}, chains={Cq}, D={Dq}, exact-fp32 MFMA, lower triangle"
         del qq, kk, dd, Sq, dq, dk2, ddg, wsq
         log("interval scorer done; segment-shaped path next")
@@ -511,6 +522,24 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
                                   f"on a side stream), {bucket.bytes_per_rank / 1e6:.1f} MB sent per rank; backbone out of scope (ctx is the input)")
     extra["train_step_collectives"] = int(ncoll[0])
     extra["train_step_exchange_bytes_per_rank"] = int(bucket.bytes_per_rank)
+
+
+def _physical_cores():
+    """Distinct (physical id, core id) pairs of /proc/cpuinfo: the box's physical cores (SMT siblings counted once)."""
+    try:
+        seen, phys, core = set(), None, None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":", 1)[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return len(seen) or None
+    except Exception:
+        return None
 
 
 def _cpu_model() -> str:

@@ -1,15 +1,19 @@
-# The exact sequence behind profiles/r02_*: the GPU tests, bench.py, bench.py under rocprofv3 --kernel-trace --stats (headline
-# workload only: --no-extra, so that every persist_sweep row is T=1024, NBatch=352), then separate --pmc passes (FETCH_SIZE and
-# WRITE_SIZE cannot share a pass) for the forward sweep, and cache / stall counters of the gradient sweep.
+# The exact sequence behind profiles/r03_*: GPU tests, bench.py, bench.py under rocprofv3 --kernel-trace --stats twice (headline
+# workload only: --no-extra, every persist_sweep row is T=1024 x 352; and with the extras: every product kernel shows up), then
+# separate --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass): HBM traffic of the forward and gradient sweeps, cache and
+# stall counters of the gradient sweep, and matrix-pipe counters + busy cycles of the scorer kernels.  tools/collect_profiles.py
+# turns the output into profiles/r03_*.
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r02
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r03
 rm -rf $OUT; mkdir -p $OUT
-timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -3 | tee $OUT/pytest.log
-timeout 900 python bench.py 2>$OUT/bench.err | tee $OUT/bench.json | cut -c1-300
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed" | tee $OUT/pytest.log
+timeout 900 python bench.py 2>$OUT/bench.err > $OUT/bench.json
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra > $OUT/kt.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_all -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/kt_all.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_scorer -- python $GRAFT_REPO_ROOT/tools/bench_scorer_all.py 20 > $OUT/kt_scorer.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_fwd_$c -- python $GRAFT_REPO_ROOT/tools/bench_sweep.py --ops fwd --n 5 > $OUT/pmc_fwd_$c.log 2>&1
 done
@@ -17,6 +21,14 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCP_PENDING_STALL_CYC
   n=$(echo $c | tr ' ' '_')
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_bwd_$n -- python $GRAFT_REPO_ROOT/tools/bench_sweep.py --ops bwd --n 5 > $OUT/pmc_bwd_$n.log 2>&1
 done
+for c in "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" FETCH_SIZE WRITE_SIZE; do
+  n=$(echo $c | tr ' ' '_')
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_scorer_$n -- python $GRAFT_REPO_ROOT/tools/bench_scorer_all.py 3 > $OUT/pmc_scorer_$n.log 2>&1
+done
 cd $GRAFT_REPO_ROOT
 timeout 300 python tools/bench_grid.py > $OUT/grid.md 2>/dev/null
-tail -1 $OUT/kt.log | cut -c1-400
+timeout 300 python tools/bench_shapes.py > $OUT/shapes.md 2>/dev/null
+timeout 300 python tools/bench_scorer_all.py 10 > $OUT/scorer.txt 2>/dev/null
+find $OUT -name "*.csv" -size +3M -delete
+find $OUT -name "*agent_info*" -delete
+cat $OUT/pytest.log; cut -c1-300 $OUT/bench.json; cat $OUT/scorer.txt

@@ -47,7 +47,10 @@
 namespace semicrf {
 
 constexpr int PB = 16;             // positions per block
-constexpr int RING = 4;            // waves per ring; band = RING-1 off-diagonal blocks + the diagonal block (5 / 6 measured slower)
+#ifndef SEMICRF_RING
+#define SEMICRF_RING 4
+#endif
+constexpr int RING = SEMICRF_RING; // waves per ring; band = RING-1 off-diagonal blocks + the diagonal block
 constexpr int RS = 4;              // chains per ring (one per lane)
 constexpr int GS = RS;              // chains per spine workgroup
 constexpr int GP = 32;             // chains per panel task (4 per lane)
@@ -258,7 +261,10 @@ __device__ __forceinline__ bool spin_abort(unsigned* ctrl, int& spins, int limit
 //     next broadcast simply reads the lanes of the next row,
 //   * row jj+1 receives its last term through logaddexp2(Vp, u + W) where Vp (everything but that term)
 //     is refreshed one step ahead by the (M,S) push that runs beside it.
-constexpr int NLOADER = 1;                            // loader waves per ring (a row block is RING tiles)
+#ifndef SEMICRF_NLOADER
+#define SEMICRF_NLOADER 1
+#endif
+constexpr int NLOADER = SEMICRF_NLOADER;              // loader waves per ring (a row block is RING tiles)
 constexpr int NRBUF = 4;                              // row-block buffers between the loader and the ring
 constexpr int TILE_BYTES = PB * PB * RS * 4;          // 4096: [column u][row r][chain] floats
 constexpr int NCONST = 3;                             // per-row constants: diagonal cell, noise, alpha (GRAD)
