@@ -492,6 +492,14 @@ __device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds
 // row, so "the value of row j" is a row_newbcast operand (v_add_f32_dpp / v_mov_b32_dpp), no LDS round trip.
 // tools/dpp_probe.hip measures the chains on their own.  The (max,+) sweeps keep their stepwise form (one add and one
 // compare per step, bit-exact candidates).
+// max_push (common.h) as two selects instead of a compare-and-branch: larger value wins, on ties the smaller key
+__device__ __forceinline__ void max_push_sel(float& best, int& key, float t, int k)
+{
+    const bool take = (t > best) | ((t == best) & (k < key));
+    best = take ? t : best;
+    key = take ? k : key;
+}
+
 template <int J>
 __device__ __forceinline__ float row_bcast(float x)       // lane J of this lane's DPP row: row J of the block, same chain
 {
@@ -527,9 +535,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
     const size_t Bs = (size_t)B;
     const bool trace = (dbg & 16u) && sg == 0 && lane == 0;
     float* const ring = (float*)(lds + LDS_RING);
-    float* const dummy = (float*)(lds + LDS_DUMMY);
     const float* rd_base = ring + ch * 2;                                   // + (j % NPOS) * 8 floats
-    const int bp_row0 = ch << 6;                                            // ds_bpermute byte address of this chain's row 0; row jj: + 4 jj
     const int* const ready = (const int*)(lds + LDS_CTL);
     int* const cons = (int*)(lds + LDS_CTL) + NRBUF;
     const float4* const far = (const float4*)(lds + LDS_FAR);
@@ -668,8 +674,8 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
                         acc_push1(aM, aS, p);
                     } else {
                         const int key = frame_of<DIR>(j, T);
-                        if (last && u == PB - 1 && r == 0) max_push(aM, aK, uv + nz, -1);   // the skip candidate goes first
-                        max_push(aM, aK, uv + X.v[u], key);
+                        if (last && u == PB - 1 && r == 0) max_push_sel(aM, aK, uv + nz, -1);   // the skip candidate (key -1 wins every tie)
+                        max_push_sel(aM, aK, uv + X.v[u], key);
                     }
                 }
             }
@@ -697,7 +703,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
             }
             if (rvalid) {
                 if (MODE == 0) acc_push1(aM, aS, f.x);
-                else max_push(aM, aK, f.x, __float_as_int(f.y));
+                else max_push_sel(aM, aK, f.x, __float_as_int(f.y));
             }
         }
 
@@ -737,28 +743,34 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
                 });
             }
         } else {
-            // (max,+): after the push of u[jj] the accumulator of row jj+1 is complete.  Ring entry of position own0 (+8 floats per
-            // step); writers: the four lanes of row 0, the other lanes' stores go to a sink
-            float* const wr = r == 0 ? ring + ch * 2 + (own0 % NPOS) * 8 : dummy + lane * 2;
-            float cv;
-            {
-                const float b0 = prow == 0 ? 0.0f : aM;
-                cv = sp > 0.0f ? b0 + sp : b0;
-                if (r == 0) mykey = prow == 0 ? -1 : aK;
-            }
-#pragma unroll
-            for (int jj = 0; jj < PB; ++jj) {
-                const int j = own0 + jj;
-                const float u = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_row0 + (jj << 2), __float_as_int(cv)));
-                lds_store64(wr + jj * 8, u, j + 1);
-                const int key = frame_of<DIR>(j < T ? j : T - 1, T);
-                if (r == jj + 1) max_push(aM, aK, u + nz, -1);                  // the skip candidate goes first (key -1)
-                max_push(aM, aK, u + X[RING - 1].v[jj], key);
-                cv = sp > 0.0f ? aM + sp : aM;
-                if (r == jj + 1) mykey = aK;
-            }
+            // (max,+): the same walk over the block's triangle on DPP row broadcasts.  Row j's value is final after step j-1 (the
+            // cells of columns >= r are masked to -inf), so all rows advance together: per step ONE broadcast of u[j] = best[j] +
+            // relu-select(diag[j]) and two branch-free candidate selects -- the skip (key -1: it wins every tie) for row j+1 and
+            // the interval (j, r) for the rows below.  Candidates are the same single fp32 adds as before (u + noise, u + cell)
+            // and ties go to the smaller key: the decode stays bit-identical.  (The stepwise form -- an LDS broadcast, a DS
+            // publish and two compare-branch pushes per position -- took 465 cycles per position, 3.1 us per block; the
+            // log-sum-exp sweeps need 1.4 since round 3.)
+            float best = aM;
+            int key = aK;
+            if (prow == 0 || !rvalid) { best = 0.0f; key = -1; }      // the first position has the empty path; rows past the end: stand-ins
+            const float spr = sp > 0.0f ? sp : 0.0f;                   // s * (s > 0), reference :29, :49-51
+            static_for<0, PB - 1>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const float uj = row_bcast<j>(best + spr);
+                const int keyj = frame_of<DIR>(own0 + j < T ? own0 + j : T - 1, T);
+                const float ts = uj + nz;
+                const bool c1 = (r == j + 1) & ((ts > best) | ((ts == best) & (key > -1)));
+                best = c1 ? ts : best;
+                key = c1 ? -1 : key;
+                const float tc = uj + (r > j ? X[RING - 1].v[j] : SEMICRF_NEG_INF);
+                const bool c2 = (tc > best) | ((tc == best) & (keyj < key));
+                best = c2 ? tc : best;
+                key = c2 ? keyj : key;
+            });
+            mine = best + spr;
+            mykey = key;
+            lds_store64(ring + ch * 2 + ((own0 + r) % NPOS) * 8, mine, own0 + r + 1);
             __builtin_amdgcn_s_setprio(1);
-            mine = __uint_as_float((unsigned)lds_load64(rd_base + (prow_c % NPOS) * 8));
         }
         if (trace) ev[7] = __builtin_readcyclecounter();
 
