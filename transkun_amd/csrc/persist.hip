@@ -654,25 +654,47 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
         // `last`: block k-1, whose final column own0-1 is the first sub-diagonal cell of row 0 (skip folded in)
         auto shadow = [&](const SpineBlk& X, int b, bool last) {
             if (trace && b >= k - 3) ev[3 + (b - (k - 3))] = __builtin_readcyclecounter();
+            if (MODE == 0) {
+                // log-sum-exp: the block's 16 terms in one batch -- all terms first, ONE exact maximum, then 16 independent
+                // exponentials relative to it (a push per term costs a dependent compare / select chain each: 16 x ~45 cycles of
+                // a lone wave; the `last` block's batch sits on the ring's critical path, between a mate's publish and the own
+                // diagonal phase)
+                float t[PB];
 #pragma unroll
-            for (int u4 = 0; u4 < PB; u4 += 4) {
-                float uq[4];
-                ring_get4(b * PB + u4, uq);
+                for (int u4 = 0; u4 < PB; u4 += 4) {
+                    float uq[4];
+                    ring_get4(b * PB + u4, uq);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int u = u4 + q;
-                    const int j = b * PB + u;
-                    const float uv = uq[q];
-                    if (MODE == 0) {
-                        float p = fmaf(X.v[u], LOG2E, uv);
+                    for (int q = 0; q < 4; ++q) {
+                        const int u = u4 + q;
+                        const int j = b * PB + u;
+                        float p = fmaf(X.v[u], LOG2E, uq[q]);
                         if (GRAD && rvalid && j < prow) grad_store(j, gz * fexp2(p + arow));
                         if (last && u == PB - 1 && r == 0) {
                             if (GRAD && rvalid)       // noise marginal of the gap between prow-1 and prow
-                                dNoise[(size_t)gap_of<DIR>(prow, T) * Bs + c] = gz * fexp2(uv + nz * LOG2E + arow);
-                            p = uv + wl;
+                                dNoise[(size_t)gap_of<DIR>(prow, T) * Bs + c] = gz * fexp2(uq[q] + nz * LOG2E + arow);
+                            p = uq[q] + wl;
                         }
-                        acc_push1(aM, aS, p);
-                    } else {
+                        t[u] = p;
+                    }
+                }
+                float mx = aM;
+#pragma unroll
+                for (int u = 0; u < PB; u += 2) mx = fmaxf(mx, fmaxf(t[u], t[u + 1]));
+                float sum = aS * fexp2(aM - mx);               // empty accumulator: 0 * exp2(-inf) = 0 (mx is finite: the terms are)
+#pragma unroll
+                for (int u = 0; u < PB; ++u) sum += fexp2(t[u] - mx);
+                aM = mx; aS = sum;
+            } else {
+#pragma unroll
+                for (int u4 = 0; u4 < PB; u4 += 4) {
+                    float uq[4];
+                    ring_get4(b * PB + u4, uq);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int u = u4 + q;
+                        const int j = b * PB + u;
+                        const float uv = uq[q];
                         const int key = frame_of<DIR>(j, T);
                         if (last && u == PB - 1 && r == 0) max_push_sel(aM, aK, uv + nz, -1);   // the skip candidate (key -1 wins every tie)
                         max_push_sel(aM, aK, uv + X.v[u], key);
