@@ -518,8 +518,10 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
     extra["train_step_config"] = (f"per rank: 4 segments x 90 symbols x T=691, D=256: Linear + interval scorer + fused CRF log_prob, "
                                   f"(loss/50).backward(), one [3] all-reduce, gradient exchange of "
                                   f"{sum(p.numel() for p in model.parameters()) / 1e6:.2f} M fp32 parameters from a persistent flat bucket: "
-                                  f"{ncoll[0]} collective(s) per step (reduce-scatter + all-gather over RCCL, started by the backward pass "
-                                  f"on a side stream), {bucket.bytes_per_rank / 1e6:.1f} MB sent per rank; backbone out of scope (ctx is the input)")
+                                  + (f"{ncoll[0]} collective(s) per step (reduce-scatter + all-gather over RCCL, started by the backward pass "
+                                     f"on a side stream), {bucket.bytes_per_rank / 1e6:.1f} MB sent per rank" if ncoll[0] else
+                                     "no exchange at one rank (N > 1: reduce-scatter + all-gather over RCCL, started by the backward pass on a side stream)")
+                                  + "; backbone out of scope (ctx is the input)")
     extra["train_step_collectives"] = int(ncoll[0])
     extra["train_step_exchange_bytes_per_rank"] = int(bucket.bytes_per_rank)
 
