@@ -418,10 +418,10 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
             ctx = (synth.hash_normal(N * P * Ts * D, 11, dev).view(N, P, Ts, D) * 0.5).requires_grad_()
             iv = synth.synthetic_intervals(Ts, N * P, seed=11)
 
-            def seg_step(fused):
+            def seg_step(fused, projection="merged"):
                 m.zero_grad(); ctx.grad = None
                 if fused:
-                    lp = scorer_crf_logprob(m, ctx, iv)
+                    lp = scorer_crf_logprob(m, ctx, iv, projection=projection)
                 else:
                     S, b = m(ctx)
                     lp = CRF.NeuralSemiCRFInterval(S.flatten(-2, -1), b.flatten(-2, -1)).logProb(iv)
@@ -435,6 +435,7 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
 
             tag = f"segment_T691_P90_N{N}"
             extra[tag + "_scorer_crf_logprob_fwd_bwd_ms_fused"] = round(ev_time(lambda: seg_step(True), 5), 3)
+            extra[tag + "_scorer_crf_logprob_fwd_bwd_ms_fused_separate_projection"] = round(ev_time(lambda: seg_step(True, "separate"), 5), 3)
             extra[tag + "_scorer_crf_logprob_fwd_bwd_ms_unfused"] = round(ev_time(lambda: seg_step(False), 5), 3)
             extra[tag + "_scorer_decode_features_ms_device"] = round(ev_time(seg_decode, 5), 3)
             m.contraction = "bf16x3"

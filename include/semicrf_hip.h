@@ -258,6 +258,37 @@ int interval_score_path_bwd_p(const float* gout, const int32_t* pairs, int64_t K
                               int64_t lddd, semicrf_stream_t stream);
 
 /*
+ * MERGED PROJECTION (the *_pc entry points): the scorer with a per-(chain, end) constant inside the contraction,
+ *   S[e,b,c] = qscale * ( <q[c,e,:], k[c,b,:]> + rowc[c,e] ) * len(|e-b|)  (+ diag[c,e] on e == b).
+ * Why: the reference projects ctx twice, q = ctx Wq^T + bq and k = ctx Wk^T + bk (LayersTransformer.py:388-397, :406-410), and
+ * contracts <q_e, k_b>.  Algebraically <q_e, k_b> = <ctx_e A + v, ctx_b> + c_e with A = Wq^T Wk (256 x 256), v = bq Wk,
+ * c_e = <ctx_e, Wq^T bk> + <bq, bk>: ONE 256 -> 256 projection z = ctx A + v, the contraction's second operand is ctx ITSELF
+ * (no k tensor), and c is a matrix-vector product -- half the Linear's flops forward and backward.  The result is fp32-grade
+ * but NOT bit-identical to the reference's operation order (a reassociation; tests/test_gpu_parity.py::test_merged_projection
+ * holds it to the scorer tolerance and the segment goldens to logProb 2e-5), so only this package's own fused route and
+ * transcription step use it (transkun_amd/fused.py); ScaledInnerProductIntervalScorer.forward keeps the two projections.
+ * rowc / drowc: [C][T] with stride ldrc / lddrc between consecutive frames, or NULL (then these are the *_p entry points).
+ * drowc[c,e] = qscale * sum_{b<=e} dS[e,b,c] len(e-b) is WRITTEN by the bwd entry points (summed in a fixed order) and ADDED
+ * to by interval_score_path_bwd_pc.  Needs the LDS-tiled kernels like the slot layout.
+ */
+int interval_score_fwd_pc(const float* q, const float* k, const float* diag, const float* rowc, int C, int T, int D,
+                          int64_t ldq, int64_t ldk, int64_t ldd, int64_t ldrc, float qscale, int length_scaling,
+                          int full_square, int group, int pitch, float* S, float* noise_out, semicrf_stream_t stream);
+int interval_score_bwd_ws_pc(const float* dS, const float* q, const float* k, int C, int T, int D, int64_t ldq,
+                             int64_t ldk, float qscale, int length_scaling, int group, int pitch, float* dq, float* dk,
+                             float* ddiag, float* drowc, int64_t lddq, int64_t lddk, int64_t lddd, int64_t lddrc, void* ws,
+                             size_t ws_bytes, semicrf_stream_t stream);
+int interval_score_bwd_fused_ws_pc(const float* S, const float* alpha, const float* beta, const float* logZ,
+                                   const float* gout, const float* q, const float* k, int C, int T, int D, int64_t ldq,
+                                   int64_t ldk, float qscale, int length_scaling, int group, int pitch, float* dq, float* dk,
+                                   float* ddiag, float* drowc, int64_t lddq, int64_t lddk, int64_t lddd, int64_t lddrc,
+                                   void* ws, size_t ws_bytes, semicrf_stream_t stream);
+int interval_score_path_bwd_pc(const float* gout, const int32_t* pairs, int64_t K, const int32_t* offsets, const float* q,
+                               const float* k, int C, int T, int D, int64_t ldq, int64_t ldk, float qscale,
+                               int length_scaling, int group, int pitch, float* dq, float* dk, float* ddiag, float* drowc,
+                               int64_t lddq, int64_t lddk, int64_t lddd, int64_t lddrc, semicrf_stream_t stream);
+
+/*
  * Backward-direction values only (the beta half of forward_backward, NeuralSemiCRFInterval.py:386-414, without the
  * marginals): beta[t][c] by frame, natural log.  Workspace: semicrf_workspace_bytes(SEMICRF_OP_LOGZ_FWD, T, B).
  * Used by interval_score_bwd_fused, which rebuilds the marginals tile by tile instead of reading a dense gradient.

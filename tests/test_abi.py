@@ -167,7 +167,7 @@ def test_torch_ops_shim_registers_every_op():
     # all-zero scores: logZ = log(number of segmentations weighted by 2 per frame) -- finite, equal for both chains
     assert bool(torch.isfinite(lz).all()) and float(lz[0]) == float(lz[1])
     with pytest.raises(NotImplementedError):
-        ops.interval_score_fwd(torch.zeros(2, 4, 8), torch.zeros(2, 4, 8), torch.zeros(2, 4), 2, 4, 8, 8, 8, 1, 1.0, 0, 0, 2, 2,
+        ops.interval_score_fwd(torch.zeros(2, 4, 8), torch.zeros(2, 4, 8), torch.zeros(2, 4), torch.zeros(2, 4), 2, 4, 8, 8, 8, 1, 0, 1.0, 0, 0, 2, 2,
                                torch.zeros(4, 4, 2), torch.zeros(3, 2))
 
 

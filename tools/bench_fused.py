@@ -12,13 +12,13 @@ for (N, P, T) in ((4, 88, 1024), (4, 90, 691), (4, 96, 691), (1, 90, 691), (1, 9
     iv = synth.synthetic_intervals(T, N * P, seed=7)
     def step(fused):
         m.zero_grad(); ctx = ctx0.clone().requires_grad_()
-        if fused: lp = scorer_crf_logprob(m, ctx, iv)
+        if fused: lp = scorer_crf_logprob(m, ctx, iv, projection=fused)
         else:
             S, b = m(ctx); lp = CRF.NeuralSemiCRFInterval(S.flatten(-2, -1), b.flatten(-2, -1)).logProb(iv)
         (-lp.sum() / 50).backward()
-    for fused in (False, True):
+    for fused in (False, "separate", "merged"):
         for _ in range(2): step(fused)
         torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats(); t0 = time.perf_counter()
         for _ in range(5): step(fused)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
-        print(f"N={N} P={P} T={T} {'fused  ' if fused else 'unfused'}: {dt*1e3:7.2f} ms per fwd+bwd step, peak memory {torch.cuda.max_memory_allocated()/2**30:.2f} GiB", flush=True)
+        print(f"N={N} P={P} T={T} {('fused/' + fused) if fused else 'unfused':14s}: {dt*1e3:7.2f} ms per fwd+bwd step, peak memory {torch.cuda.max_memory_allocated()/2**30:.2f} GiB", flush=True)

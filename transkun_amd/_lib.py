@@ -54,6 +54,10 @@ _SIGS = {
     "interval_score_bwd_ws_p": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i64, ctypes.c_float, _i, _i, _i, _vp, _vp, _vp, _i64, _i64, _i64, _vp, ctypes.c_size_t, _vp]),
     "interval_score_bwd_fused_ws_p": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, ctypes.c_float, _i, _i, _i, _vp, _vp, _vp, _i64, _i64, _i64, _vp, ctypes.c_size_t, _vp]),
     "interval_score_path_bwd_p": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, ctypes.c_float, _i, _i, _i, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "interval_score_fwd_pc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, ctypes.c_float, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "interval_score_bwd_ws_pc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i64, ctypes.c_float, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, ctypes.c_size_t, _vp]),
+    "interval_score_bwd_fused_ws_pc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, ctypes.c_float, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, ctypes.c_size_t, _vp]),
+    "interval_score_path_bwd_pc": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, ctypes.c_float, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "semicrf_beta": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "interval_score_bwd_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, ctypes.c_float, _i, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "interval_score_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i64, ctypes.c_float, _i, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),

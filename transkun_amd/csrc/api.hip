@@ -61,7 +61,9 @@ void launch_interval_features_bwd(const float* gout, const float* ctx, int C, in
 void launch_interval_score_path_bwd(const float* gout, const int* pairs, int K, const int* offsets, const float* q,
                                     const float* k, int C, int T, int D, long long ldq, long long ldk, float qscale, int mode,
                                     float* dq, float* dk, float* ddiag, long long lddq, long long lddk, long long lddd,
-                                    hipStream_t stream, int group, int pitch);
+                                    hipStream_t stream, int group, int pitch, float* drowc = nullptr, long long lddrc = 1);
+void launch_interval_score_bwd_rowsum(const float* dS, const float* const* fused, float* drowc, long long ldrc, int C, int T,
+                                      float qscale, int mode, int group, int pitch, hipStream_t stream);
 void launch_interval_score_bwd_diag(const float* dS, const float* const* fused, float* ddiag, int C, int T, long long lddd,
                                     int group, int pitch, hipStream_t stream);
 bool interval_score_slots_supported(int C, int T, int D, const float* q, const float* k, long long ldq, long long ldk);
@@ -69,10 +71,11 @@ size_t interval_score_bwd_ws_bytes(int C, int T, int D);
 bool launch_interval_score_bwd_packed(const float* dS, const float* q, const float* k, int C, int T, int D, long long ldq,
                                       long long ldk, float qscale, int mode, float* dq, float* dk, long long lddq,
                                       long long lddk, void* ws, size_t ws_bytes, hipStream_t stream,
-                                      const float* const* fused, int group, int pitch);
+                                      const float* const* fused, int group, int pitch, float* drowc = nullptr, long long lddrc = 1);
 int launch_interval_score_mfma(const float* q, const float* k, const float* diag, int C, int T, int D,
                                 long long ldq, long long ldk, long long ldd, float qscale, int mode, int full,
-                                float* S, hipStream_t stream, int prec, int group, int pitch);
+                                float* S, hipStream_t stream, int prec, int group, int pitch, const float* rowc = nullptr,
+                                long long ldrc = 1);
 size_t persist_workspace_bytes(int T, int B);
 bool persist_supported(int T, int B);
 int launch_persist_sweep(int mode, int dir, const float* score, const float* noise, int T, int B, float* u_out,
@@ -412,10 +415,23 @@ static int check_slots(int C, int group, int pitch)
     return SEMICRF_OK;
 }
 
+int interval_score_fwd_pc(const float* q, const float* k, const float* diag, const float* rowc, int C, int T, int D, int64_t ldq,
+                          int64_t ldk, int64_t ldd, int64_t ldrc, float qscale, int length_scaling, int full_square, int group,
+                          int pitch, float* S, float* noise_out, semicrf_stream_t stream);
+
 int interval_score_fwd_p(const float* q, const float* k, const float* diag, int C, int T, int D, int64_t ldq,
                          int64_t ldk, int64_t ldd, float qscale, int length_scaling, int full_square, int group, int pitch,
                          float* S, float* noise_out, semicrf_stream_t stream)
 {
+    return interval_score_fwd_pc(q, k, diag, nullptr, C, T, D, ldq, ldk, ldd, 1, qscale, length_scaling, full_square, group, pitch, S,
+                                 noise_out, stream);
+}
+
+int interval_score_fwd_pc(const float* q, const float* k, const float* diag, const float* rowc, int C, int T, int D, int64_t ldq,
+                          int64_t ldk, int64_t ldd, int64_t ldrc, float qscale, int length_scaling, int full_square, int group,
+                          int pitch, float* S, float* noise_out, semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(!rowc || ldrc >= 1, "bad row-constant stride");
     SEMICRF_CHECK_ARG(C >= 1 && T >= 1 && D >= 1, "C=%d T=%d D=%d must be >= 1", C, T, D);
     SEMICRF_CHECK_ARG(q && k && diag && S, "q/k/diag/S must be non-NULL");
     SEMICRF_CHECK_ARG(ldq >= D && ldk >= D && ldd >= 1, "bad leading dimensions");
@@ -423,18 +439,19 @@ int interval_score_fwd_p(const float* q, const float* k, const float* diag, int 
     SEMICRF_CHECK_ARG(full_square >= 0 && (full_square & 3) <= 2 && (full_square & ~7) == 0, "bad full_square %d", full_square);
     if (int rc = check_slots(C, group, pitch)) return rc;
     if (pitch == group) group = pitch = C;                     // no ghosts: ONE group (quads must not straddle a group's end)
-    const bool slots = pitch != group;
+    const bool slots = pitch != group || rowc != nullptr;
     const int Cs = (C / group) * pitch;
     if (slots)
         SEMICRF_CHECK_ARG(g_impl.load() == 0 && interval_score_slots_supported(C, T, D, q, k, ldq, ldk),
-                          "a padded slot layout needs the shared-operand kernels: 16-byte aligned rows, D %% 64 == 0, T >= 128");
+                          "a padded slot layout / a row constant needs the shared-operand kernels: 16-byte aligned rows, D %% 64 == 0, T >= 128");
     hipStream_t st = (hipStream_t)stream;
     const int prec = (full_square & SEMICRF_SCORE_BF16X3) ? 1 : 0;   // opt-in: three-limb bf16 contraction (scorer_mfma.hip)
     full_square &= 3;
     if (full_square == 0) launch_zero_upper(S, T, Cs, st);     // begin > end: defined (zero), half the bytes of a full fill
     const int full_kernel = full_square == 1 ? 1 : 0;           // 2: lower triangle only, the rest of S is left as it is
     if (g_impl.load() == 0 && interval_score_mfma_supported(C, T, D)) {
-        if (launch_interval_score_mfma(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, length_scaling, full_kernel, S, st, prec, group, pitch) != 0) {
+        if (launch_interval_score_mfma(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, length_scaling, full_kernel, S, st, prec, group, pitch,
+                                       rowc, ldrc) != 0) {
             set_error("interval_score_fwd: work list allocation failed");
             return SEMICRF_ELAUNCH;
         }
@@ -478,10 +495,23 @@ int interval_score_bwd(const float* dS, const float* q, const float* k, int C, i
 
 size_t interval_score_bwd_workspace_bytes(int C, int T, int D) { return interval_score_bwd_ws_bytes(C, T, D); }
 
+int interval_score_bwd_ws_pc(const float* dS, const float* q, const float* k, int C, int T, int D, int64_t ldq, int64_t ldk,
+                             float qscale, int length_scaling, int group, int pitch, float* dq, float* dk, float* ddiag, float* drowc,
+                             int64_t lddq, int64_t lddk, int64_t lddd, int64_t lddrc, void* ws, size_t ws_bytes, semicrf_stream_t stream);
+
 int interval_score_bwd_ws_p(const float* dS, const float* q, const float* k, int C, int T, int D, int64_t ldq, int64_t ldk,
                             float qscale, int length_scaling, int group, int pitch, float* dq, float* dk, float* ddiag, int64_t lddq,
                             int64_t lddk, int64_t lddd, void* ws, size_t ws_bytes, semicrf_stream_t stream)
 {
+    return interval_score_bwd_ws_pc(dS, q, k, C, T, D, ldq, ldk, qscale, length_scaling, group, pitch, dq, dk, ddiag, nullptr, lddq, lddk, lddd,
+                                    1, ws, ws_bytes, stream);
+}
+
+int interval_score_bwd_ws_pc(const float* dS, const float* q, const float* k, int C, int T, int D, int64_t ldq, int64_t ldk,
+                             float qscale, int length_scaling, int group, int pitch, float* dq, float* dk, float* ddiag, float* drowc,
+                             int64_t lddq, int64_t lddk, int64_t lddd, int64_t lddrc, void* ws, size_t ws_bytes, semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(!drowc || lddrc >= 1, "bad row-constant stride");
     SEMICRF_CHECK_ARG(C >= 1 && T >= 1 && D >= 1, "C=%d T=%d D=%d must be >= 1", C, T, D);
     SEMICRF_CHECK_ARG(dS && q && k, "dS/q/k must be non-NULL");
     SEMICRF_CHECK_ARG(ldq >= D && ldk >= D && (!dq || lddq >= D) && (!dk || lddk >= D) && (!ddiag || lddd >= 1),
@@ -494,11 +524,12 @@ int interval_score_bwd_ws_p(const float* dS, const float* q, const float* k, int
     hipStream_t st = (hipStream_t)stream;
     if (g_impl.load() == 0 && (dq || dk) &&
         launch_interval_score_bwd_packed(dS, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, lddq, lddk, ws, ws_bytes, st, nullptr,
-                                         group, pitch)) {
-        if (ddiag) launch_interval_score_bwd_diag(dS, nullptr, ddiag, C, T, lddd, group, pitch, st);
+                                         group, pitch, drowc, lddrc)) {
+        if (ddiag) launch_interval_score_bwd_diag(dS, nullptr, ddiag, C, T, lddd, group, pitch, st);      // (drowc: out of the dq GEMM)
     } else {
         SEMICRF_CHECK_ARG(!slots, "a padded slot layout needs the packed path (workspace, D in {64,128,256}, T >= 64, aligned rows)");
         launch_interval_score_bwd(dS, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, ddiag, lddq, lddk, lddd, st);
+        if (drowc) launch_interval_score_bwd_rowsum(dS, nullptr, drowc, lddrc, C, T, qscale, length_scaling, group, pitch, st);
     }
     SEMICRF_CHECK_LAUNCH("interval_score_bwd_ws");
     return SEMICRF_OK;
@@ -529,11 +560,28 @@ int interval_score_bwd_fused(const float* S, const float* alpha, const float* be
     return SEMICRF_OK;
 }
 
+int interval_score_bwd_fused_ws_pc(const float* S, const float* alpha, const float* beta, const float* logZ,
+                                   const float* gout, const float* q, const float* k, int C, int T, int D, int64_t ldq,
+                                   int64_t ldk, float qscale, int length_scaling, int group, int pitch, float* dq, float* dk, float* ddiag,
+                                   float* drowc, int64_t lddq, int64_t lddk, int64_t lddd, int64_t lddrc, void* ws, size_t ws_bytes,
+                                   semicrf_stream_t stream);
+
 int interval_score_bwd_fused_ws_p(const float* S, const float* alpha, const float* beta, const float* logZ,
                                   const float* gout, const float* q, const float* k, int C, int T, int D, int64_t ldq,
                                   int64_t ldk, float qscale, int length_scaling, int group, int pitch, float* dq, float* dk, float* ddiag,
                                   int64_t lddq, int64_t lddk, int64_t lddd, void* ws, size_t ws_bytes, semicrf_stream_t stream)
 {
+    return interval_score_bwd_fused_ws_pc(S, alpha, beta, logZ, gout, q, k, C, T, D, ldq, ldk, qscale, length_scaling, group, pitch, dq, dk,
+                                          ddiag, nullptr, lddq, lddk, lddd, 1, ws, ws_bytes, stream);
+}
+
+int interval_score_bwd_fused_ws_pc(const float* S, const float* alpha, const float* beta, const float* logZ,
+                                   const float* gout, const float* q, const float* k, int C, int T, int D, int64_t ldq,
+                                   int64_t ldk, float qscale, int length_scaling, int group, int pitch, float* dq, float* dk, float* ddiag,
+                                   float* drowc, int64_t lddq, int64_t lddk, int64_t lddd, int64_t lddrc, void* ws, size_t ws_bytes,
+                                   semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(!drowc || lddrc >= 1, "bad row-constant stride");
     SEMICRF_CHECK_ARG(C >= 1 && T >= 1 && D >= 1, "C=%d T=%d D=%d must be >= 1", C, T, D);
     SEMICRF_CHECK_ARG(S && alpha && beta && logZ && gout && q && k, "S/alpha/beta/logZ/gout/q/k must be non-NULL");
     SEMICRF_CHECK_ARG(ldq >= D && ldk >= D && (!dq || lddq >= D) && (!dk || lddk >= D) && (!ddiag || lddd >= 1),
@@ -547,12 +595,13 @@ int interval_score_bwd_fused_ws_p(const float* S, const float* alpha, const floa
     const float* fused[4] = {alpha, beta, logZ, gout};
     if (g_impl.load() == 0 && (dq || dk) &&
         launch_interval_score_bwd_packed(S, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, lddq, lddk, ws, ws_bytes, st, fused,
-                                         group, pitch)) {
+                                         group, pitch, drowc, lddrc)) {
         if (ddiag) launch_interval_score_bwd_diag(S, fused, ddiag, C, T, lddd, group, pitch, st);
     } else {
         SEMICRF_CHECK_ARG(!slots, "a padded slot layout needs the packed path (workspace, D in {64,128,256}, T >= 64, aligned rows)");
         launch_interval_score_bwd_fused(S, alpha, beta, logZ, gout, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, ddiag, lddq,
                                         lddk, lddd, st);
+        if (drowc) launch_interval_score_bwd_rowsum(S, fused, drowc, lddrc, C, T, qscale, length_scaling, group, pitch, st);
     }
     SEMICRF_CHECK_LAUNCH("interval_score_bwd_fused_ws");
     return SEMICRF_OK;
@@ -567,11 +616,26 @@ int interval_score_bwd_fused_ws(const float* S, const float* alpha, const float*
                                          C > 0 ? C : 1, dq, dk, ddiag, lddq, lddk, lddd, ws, ws_bytes, stream);
 }
 
+int interval_score_path_bwd_pc(const float* gout, const int32_t* pairs, int64_t K, const int32_t* offsets, const float* q,
+                               const float* k, int C, int T, int D, int64_t ldq, int64_t ldk, float qscale, int length_scaling,
+                               int group, int pitch, float* dq, float* dk, float* ddiag, float* drowc, int64_t lddq, int64_t lddk,
+                               int64_t lddd, int64_t lddrc, semicrf_stream_t stream);
+
 int interval_score_path_bwd_p(const float* gout, const int32_t* pairs, int64_t K, const int32_t* offsets, const float* q,
                               const float* k, int C, int T, int D, int64_t ldq, int64_t ldk, float qscale, int length_scaling,
                               int group, int pitch, float* dq, float* dk, float* ddiag, int64_t lddq, int64_t lddk, int64_t lddd,
                               semicrf_stream_t stream)
 {
+    return interval_score_path_bwd_pc(gout, pairs, K, offsets, q, k, C, T, D, ldq, ldk, qscale, length_scaling, group, pitch, dq, dk, ddiag,
+                                      nullptr, lddq, lddk, lddd, 1, stream);
+}
+
+int interval_score_path_bwd_pc(const float* gout, const int32_t* pairs, int64_t K, const int32_t* offsets, const float* q,
+                               const float* k, int C, int T, int D, int64_t ldq, int64_t ldk, float qscale, int length_scaling,
+                               int group, int pitch, float* dq, float* dk, float* ddiag, float* drowc, int64_t lddq, int64_t lddk,
+                               int64_t lddd, int64_t lddrc, semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(!drowc || lddrc >= 1, "bad row-constant stride");
     SEMICRF_CHECK_ARG(C >= 1 && T >= 1 && D >= 1, "C=%d T=%d D=%d must be >= 1", C, T, D);
     SEMICRF_CHECK_ARG(gout && offsets && q && k, "gout/offsets/q/k must be non-NULL");
     SEMICRF_CHECK_ARG(K >= 0 && K < (1ll << 31) && (K == 0 || pairs), "bad interval count");
@@ -581,7 +645,7 @@ int interval_score_path_bwd_p(const float* gout, const int32_t* pairs, int64_t K
     if (int rc = check_slots(C, group, pitch)) return rc;
     if (pitch == group) group = pitch = C;
     launch_interval_score_path_bwd(gout, pairs, (int)K, offsets, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, ddiag,
-                                   lddq, lddk, lddd, (hipStream_t)stream, group, pitch);
+                                   lddq, lddk, lddd, (hipStream_t)stream, group, pitch, drowc, lddrc);
     SEMICRF_CHECK_LAUNCH("interval_score_path_bwd");
     return SEMICRF_OK;
 }

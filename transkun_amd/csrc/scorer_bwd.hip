@@ -229,13 +229,55 @@ __global__ __launch_bounds__(256) void interval_score_bwd_diag_fused_kernel(cons
     ddiag[((size_t)c * T + t) * ldd] = F.gout[sl] * marginal_of(s, F.alpha[(size_t)t * Cs + sl], F.beta[(size_t)t * Cs + sl], F.logZ[sl], true);
 }
 
+// Gradient of the merged projection's per-(chain, end) constant (interval_score_fwd_p, rowc: S[e,b] = qscale (q_e.k_b + rowc_e) len(e-b)):
+//   drowc[c][e] = qscale * sum_{b <= e} dS[e,b,slot(c)] * len(e-b)                  (FUSED: dS = gout * marginal, built on the fly)
+// One thread per (end, chain), chains fastest (coalesced over the slot axis), the begins summed in order: deterministic.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void interval_score_bwd_rowsum_kernel(const float* __restrict__ dS, FusedArgs F,
+                                                                         float* __restrict__ drowc, long long ldrc, int C, int T,
+                                                                         float qscale, int mode, int Cs, ChainSlots SL)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)T * C) return;
+    const int e = (int)(i / C), c = (int)(i % C);
+    const int sl = slot_of_chain(SL, c);
+    float lz = 0.f, gz = 0.f, be = 0.f;
+    if (FUSED) { lz = F.logZ[sl]; gz = F.gout[sl]; be = F.beta[(size_t)e * Cs + sl]; }
+    const float* row = dS + (size_t)e * T * Cs + sl;
+    float acc = 0.0f;
+    for (int b = 0; b <= e; ++b) {
+        float x = row[(size_t)b * Cs];
+        if (FUSED) x = gz * marginal_of(x, F.alpha[(size_t)b * Cs + sl], be, lz, b == e);
+        acc += x * len_scale_bwd(e - b, mode);
+    }
+    drowc[((size_t)c * T + e) * ldrc] = qscale * acc;
+}
+
+void launch_interval_score_bwd_rowsum(const float* dS, const float* const* fused, float* drowc, long long ldrc, int C, int T,
+                                      float qscale, int mode, int group, int pitch, hipStream_t stream)
+{
+    const size_t n = (size_t)T * C;
+    const int Cs = (C / group) * pitch;
+    const ChainSlots SL{group, pitch};
+    if (fused) {
+        const FusedArgs F{fused[0], fused[1], fused[2], fused[3]};
+        hipLaunchKernelGGL(interval_score_bwd_rowsum_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dS, F, drowc, ldrc,
+                           C, T, qscale, mode, Cs, SL);
+    } else {
+        const FusedArgs F{nullptr, nullptr, nullptr, nullptr};
+        hipLaunchKernelGGL(interval_score_bwd_rowsum_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dS, F, drowc, ldrc,
+                           C, T, qscale, mode, Cs, SL);
+    }
+}
+
 // The evalPath part of logProb's gradient pushed through the scorer: every interval (b, e) of chain c contributes
 // w = gout[c] * qscale * len(e-b) to d S[e,b,c], i.e.  dq[c,e,:] += w k[c,b,:],  dk[c,b,:] += w q[c,e,:],
 // ddiag[c,e] += gout[c] when b == e.  One wave per interval; atomics keep duplicate intervals (a caller error) exact.
 __global__ __launch_bounds__(256) void interval_score_path_bwd_kernel(
     const float* __restrict__ gout, const int* __restrict__ pairs, int K, const int* __restrict__ offsets,
     const float* __restrict__ q, const float* __restrict__ k, int C, int T, int D, long long ldq, long long ldk, float qscale,
-    int mode, float* dq, float* dk, float* ddiag, long long lddq, long long lddk, long long lddd, int Cs, ChainSlots SL)
+    int mode, float* dq, float* dk, float* ddiag, long long lddq, long long lddk, long long lddd, int Cs, ChainSlots SL,
+    float* drowc, long long lddrc)
 {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= K) return;
@@ -256,16 +298,18 @@ __global__ __launch_bounds__(256) void interval_score_path_bwd_kernel(
         if (dk) atomicAdd(dk + ((size_t)c * T + b) * lddk + d, w * qe[d]);
     }
     if (ddiag && b == e && lane == 0) atomicAdd(ddiag + ((size_t)c * T + e) * lddd, g);
+    if (drowc && lane == 0) atomicAdd(drowc + ((size_t)c * T + e) * lddrc, w);        // the merged projection's row constant
 }
 
 void launch_interval_score_path_bwd(const float* gout, const int* pairs, int K, const int* offsets, const float* q,
                                     const float* k, int C, int T, int D, long long ldq, long long ldk, float qscale, int mode,
                                     float* dq, float* dk, float* ddiag, long long lddq, long long lddk, long long lddd,
-                                    hipStream_t stream, int group, int pitch)
+                                    hipStream_t stream, int group, int pitch, float* drowc, long long lddrc)
 {
     if (K <= 0) return;
     hipLaunchKernelGGL(interval_score_path_bwd_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, gout, pairs, K, offsets, q, k, C,
-                       T, D, ldq, ldk, qscale, mode, dq, dk, ddiag, lddq, lddk, lddd, (C / group) * pitch, ChainSlots{group, pitch});
+                       T, D, ldq, ldk, qscale, mode, dq, dk, ddiag, lddq, lddk, lddd, (C / group) * pitch, ChainSlots{group, pitch},
+                       drowc, lddrc);
 }
 
 // ddiag alone, for the packed path (which produces dq and dk): plain (F == nullptr) or fused

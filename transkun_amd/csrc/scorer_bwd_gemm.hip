@@ -171,10 +171,15 @@ __global__ __launch_bounds__(256) void score_bwd_pack_kernel(const float* __rest
 // GEMM: out[c][m][:] = sum_k A[m][k] other[c][k][:]   with A = Gt (dq: m = e, k = b) or Gt^T (dk: m = b, k = e)
 // ---------------------------------------------------------------------------------------------
 // AT: A is read transposed (dk).  NW: 32-column blocks per wave (D = 64 NW; NW in {1, 2, 4}).
+// rsum (!AT only, may be NULL): rsum[(c T + m) ldrs] = sum_k A[m][k] -- the gradient of the merged projection's row constant
+// (include/semicrf_hip.h: interval_score_bwd_ws_pc) falls out of the A values this kernel reads anyway: every lane adds up the
+// contraction values of its row that pass through it (a fixed order: chunk, group, component), the two half-waves are combined at
+// the end of the item.
 template <bool AT, int NW>
 __global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __restrict__ Gt, int Tp,
                                                                 const float* __restrict__ other, long long ldo,
-                                                                float* __restrict__ out, long long ldout, int C, int T)
+                                                                float* __restrict__ out, long long ldout, int C, int T,
+                                                                float* __restrict__ rsum, long long ldrs)
 {
     constexpr int D = 64 * NW;
     constexpr int GB_BYTES = GK * D * 4;               // the k/q part of a stage: 32 rows
@@ -295,6 +300,8 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __r
     for (int i = 0; i < GNS - 1; ++i)
         if (nx_valid) { issue_chunk(); ++inflight; }
     int rd_stage = 0;
+    float rs = 0.0f;                                    // !AT && rsum: this lane's part of its row's sum
+    const bool want_rs = !AT && rsum != nullptr;
 
     long long cur_n = blockIdx.x;
     while (true) {
@@ -357,6 +364,7 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __r
 #pragma unroll
                     for (int t = 0; t < NW; ++t)
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(AT ? av[comp] : av4[comp], bv[comp][t], acc[t], 0, 0, 0);
+                if (!AT && want_rs) rs += (av4[0] + av4[1]) + (av4[2] + av4[3]);
             };
             read_group(std::integral_constant<int, 0>{}, a4[0], a1[0], bq[0]);
             wait_group(a4[0], a1[0], bq[0]);
@@ -393,6 +401,12 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __r
                     if (m < T) ob[(size_t)m * ldout + 32 * NW * wn + 32 * t + l31] = acc[t][r];
                     acc[t][r] = 0.0f;
                 }
+            if (!AT && want_rs) {
+                const float tot = rs + __shfl_xor(rs, 32);
+                const int m = mi * GM + 32 * wm + l31;
+                if (wn == 0 && half == 0 && m < T) rsum[((size_t)c * T + m) * ldrs] = tot;
+                rs = 0.0f;
+            }
         }
         cur_n += gridDim.x;
     }
@@ -415,7 +429,7 @@ size_t interval_score_bwd_ws_bytes(int C, int T, int D)
 
 template <bool AT, int NW>
 static void launch_gemm(const float* Gt, int Tp, const float* other, long long ldo, float* out, long long ldout, int C,
-                        int T, hipStream_t stream)
+                        int T, hipStream_t stream, float* rsum = nullptr, long long ldrs = 1)
 {
     const size_t lds = (size_t)GNS * (GA_BYTES + GK * 64 * NW * 4);
     static PerDeviceOnce attr_once;
@@ -427,7 +441,8 @@ static void launch_gemm(const float* Gt, int Tp, const float* other, long long l
         ncu = v;
     const long long nitems = (long long)((T + GM - 1) / GM) * C;
     const int grid = nitems < ncu ? (int)nitems : ncu;
-    hipLaunchKernelGGL((score_bwd_gemm_kernel<AT, NW>), dim3(grid), dim3(512), lds, stream, Gt, Tp, other, ldo, out, ldout, C, T);
+    hipLaunchKernelGGL((score_bwd_gemm_kernel<AT, NW>), dim3(grid), dim3(512), lds, stream, Gt, Tp, other, ldo, out, ldout, C, T,
+                       AT ? nullptr : rsum, ldrs);
 }
 
 // true when the packed path ran (q/k rows must be 16-byte aligned for the LDS loads)
@@ -435,8 +450,10 @@ static void launch_gemm(const float* Gt, int Tp, const float* other, long long l
 bool launch_interval_score_bwd_packed(const float* dS, const float* q, const float* k, int C, int T, int D, long long ldq,
                                       long long ldk, float qscale, int mode, float* dq, float* dk, long long lddq,
                                       long long lddk, void* ws, size_t ws_bytes, hipStream_t stream,
-                                      const float* const* fused, int group, int pitch)
+                                      const float* const* fused, int group, int pitch, float* drowc, long long lddrc)
 {
+    // drowc (may be NULL): row sums of the packed cotangent, out of the dq GEMM (which then must run: dq != NULL)
+    if (drowc && !dq) return false;
     const ChainSlots SL{group, pitch};
     const int Cs = (C / group) * pitch;                       // slots: the chain pitch of dS and of the CRF-side vectors
     const size_t need = interval_score_bwd_ws_bytes(C, T, D);
@@ -455,9 +472,9 @@ bool launch_interval_score_bwd_packed(const float* dS, const float* q, const flo
     }
 #define SEMICRF_GEMM_DISPATCH(AT_, OTHER, LDO, OUT, LDOUT)                                                              \
     switch (D) {                                                                                                        \
-    case 64: launch_gemm<AT_, 1>(Gt, Tp, OTHER, LDO, OUT, LDOUT, C, T, stream); break;                                  \
-    case 128: launch_gemm<AT_, 2>(Gt, Tp, OTHER, LDO, OUT, LDOUT, C, T, stream); break;                                 \
-    default: launch_gemm<AT_, 4>(Gt, Tp, OTHER, LDO, OUT, LDOUT, C, T, stream); break;                                  \
+    case 64: launch_gemm<AT_, 1>(Gt, Tp, OTHER, LDO, OUT, LDOUT, C, T, stream, drowc, lddrc); break;                    \
+    case 128: launch_gemm<AT_, 2>(Gt, Tp, OTHER, LDO, OUT, LDOUT, C, T, stream, drowc, lddrc); break;                   \
+    default: launch_gemm<AT_, 4>(Gt, Tp, OTHER, LDO, OUT, LDOUT, C, T, stream, drowc, lddrc); break;                    \
     }
     if (dq) { SEMICRF_GEMM_DISPATCH(false, k, ldk, dq, lddq) }
     if (dk) { SEMICRF_GEMM_DISPATCH(true, q, ldq, dk, lddk) }

@@ -602,7 +602,7 @@ template <int XTE>
 __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ diag, int C, int T, int D,
     long long ldq, long long ldk, long long ldd, float qscale, int mode, int full, float* __restrict__ S,
-    int ntiles, int nquadp, int Cs, SlotGeom G)
+    int ntiles, int nquadp, int Cs, SlotGeom G, const float* __restrict__ rowc, long long ldrc)
 {
     constexpr int XW = XTE / 16;                   // waves: (row block of 32, column half of 64)
     constexpr int KP = 16 / XW;                    // k pieces (8 rows x 128 bytes) per wave and chunk; q pieces: 2
@@ -667,15 +667,34 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
     unsigned voq[2], vok[4];      // (a [KP] array captured by the lambdas below trips the host compiler)
     const float* nx_q = q;
     const float* nx_k = k;
+    // row constants (rowc != NULL, the merged projection): the XTE constants of chain j of a quad ride along with the chain's first
+    // chunk -- wave j asks for them (one dword per lane, straight into LDS) right after its operand pieces, so every vmcnt wait
+    // below stays at least as strict as without them -- into one of two buffers [chain][row] behind the stages, alternating by
+    // REAL item (padding items request nothing).  The epilogue of item n reads buffer n & 1 while the requests of item n + 1 are
+    // in flight; those of item n + 2 are issued only after a barrier of item n + 1 (>= 2 chunks per chain: D % 64 == 0), which
+    // every wave reaches after its epilogue of item n.
+    static_assert(XNS <= 3, "the two row-constant buffers assume requests run at most two chunks ahead");
+    constexpr int RC_BYTES = 4 * XTE * 4;
+    unsigned vorc[2] = {0u, 0u};
+    const float* nx_rc = rowc;
+    int nx_cnt = 0;
     auto set_chain = [&]() {
         const int c = nx_q4.ck + nx_j;                                       // nx_j < nx_q4.nr: a real chain
         nx_q = q + (size_t)c * T * ldq;
         nx_k = k + (size_t)c * T * ldk;
+        if (rowc) nx_rc = rowc + (size_t)c * T * ldrc;
     };
     auto set_item = [&]() {
         int et = 0, bt = 0;
         // padding items (no real chain) request nothing: the consuming side skips them the same way
         while ((nx_valid = item_of(nx_u, et, bt, nx_q4)) && nx_q4.nr == 0) nx_u += nslots;
+        if (nx_valid && rowc) {
+#pragma unroll
+            for (int h = 0; h < XTE / 64; ++h) {
+                const int er = et * XTE + 64 * h + lane < T ? et * XTE + 64 * h + lane : T - 1;
+                vorc[h] = (unsigned)((size_t)er * ldrc * 4);
+            }
+        }
         if (nx_valid) {
             // loading lanes: a piece is 8 rows x 128 bytes; this wave's q pieces 2*wave.. and k pieces KP*wave..
 #pragma unroll
@@ -711,12 +730,19 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_t*)(dk + 2048), 16, vok[KP - 2], nx_ch * (ZCH * 4), 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_t*)(dk + 3072), 16, vok[KP - 1], nx_ch * (ZCH * 4), 0, 0);
         }
+        if (rowc && nx_ch == 0 && wave == nx_j) {
+            const auto rr = __builtin_amdgcn_make_buffer_rsrc((void*)nx_rc, 0, 0x7fffffff, 0x00020000);
+            char* dr = xlds + XNS * XSTAGE + (nx_cnt & 1) * RC_BYTES + nx_j * (XTE * 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_void_t*)dr, 4, vorc[0], 0, 0, 0);
+            if (XTE == 128) __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_void_t*)(dr + 256), 4, vorc[XTE / 64 - 1], 0, 0, 0);
+        }
         }
         nx_stage = nx_stage + 1 == XNS ? 0 : nx_stage + 1;
         if (++nx_ch == nchunk) {
             nx_ch = 0;
             if (++nx_j == nx_q4.nr) {
                 nx_u += nslots;
+                ++nx_cnt;
                 set_item();
             } else {
                 set_chain();
@@ -742,6 +768,7 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
     for (int i = 0; i < XNS - 1; ++i)
         if (nx_valid) { issue_chunk(); ++inflight; }
     int rd_stage = 0;
+    int cur_cnt = 0;                            // real items consumed: which row-constant buffer
 
     while (true) {
         int et, bt;
@@ -830,31 +857,52 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
         //      row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) ----
         {
             const bool vec = (Cs & 3) == 0 && c4 + 3 < Cs;
+            // merged projection (interval_score_fwd_pc): the row constants of this wave's rows, four consecutive rows (one row group
+            // r >> 2) of the four chains per pass
+            const unsigned rb = lds0 + (unsigned)(XNS * XSTAGE + (cur_cnt & 1) * RC_BYTES + (32 * wer + 4 * half) * 4);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int b = bt * XTB + 64 * wh + 32 * t + row;
+            for (int g = 0; g < 4; ++g) {
+                v4f rcv[4];
+                if (rowc) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int e = et * XTE + 32 * wer + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const int len = e > b ? e - b : b - e;
-                    const float sc = qscale * len_scale_mfma(len, mode);
-                    const float last = t == 0 ? acc0[r] : acc1[r];
-                    float v[4] = {hold[0][t][r] * sc, hold[1][t][r] * sc, hold[2][t][r] * sc, last * sc};
-                    if (e < T && b < T && (full || b <= e) && qi.nr > 0 && !(dbg & 4)) {
-                        if (e == b) {
+                    for (int i = 0; i < 4; ++i)
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(rcv[i]) : "v"(rb + (unsigned)((i * XTE + 8 * g) * 4)));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rcv[0]), "+v"(rcv[1]), "+v"(rcv[2]), "+v"(rcv[3]));
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int b = bt * XTB + 64 * wh + 32 * t + row;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int r = 4 * g + rr;
+                        const int e = et * XTE + 32 * wer + rr + 8 * g + 4 * half;
+                        const int len = e > b ? e - b : b - e;
+                        const float sc = qscale * len_scale_mfma(len, mode);
+                        const float last = t == 0 ? acc0[r] : acc1[r];
+                        float v[4] = {hold[0][t][r], hold[1][t][r], hold[2][t][r], last};
+                        if (rowc) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
-                                if (i < qi.nr) v[i] += diag[((size_t)(qi.ck + i) * T + e) * ldd];
+                                if (i < qi.nr) v[i] += rcv[i][rr];
                         }
-                        float* dst = S + ((size_t)e * T + b) * Cs + c4;
-                        if (vec) {
-                            // (plain stores: L2 merges the eight 16-byte pieces of a line; nontemporal ones do not -- 2.4 ms)
-                            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);      // ghost slots of the quad: exact zeros (hold = 0)
-                            for (int z = 4; z <= qi.tz; z += 4) *(float4*)(dst + z) = make_float4(0.f, 0.f, 0.f, 0.f);   // the group's ghost tail
-                        } else {
 #pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                if (i < qi.nr) dst[i] = v[i];
+                        for (int i = 0; i < 4; ++i) v[i] *= sc;
+                        if (e < T && b < T && (full || b <= e) && qi.nr > 0 && !(dbg & 4)) {
+                            if (e == b) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    if (i < qi.nr) v[i] += diag[((size_t)(qi.ck + i) * T + e) * ldd];
+                            }
+                            float* dst = S + ((size_t)e * T + b) * Cs + c4;
+                            if (vec) {
+                                // (plain stores: L2 merges the eight 16-byte pieces of a line; nontemporal ones do not -- 2.4 ms)
+                                *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);      // ghost slots of the quad: exact zeros (hold = 0)
+                                for (int z = 4; z <= qi.tz; z += 4) *(float4*)(dst + z) = make_float4(0.f, 0.f, 0.f, 0.f);   // the group's ghost tail
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    if (i < qi.nr) dst[i] = v[i];
+                            }
                         }
                     }
                 }
@@ -862,6 +910,7 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
         }
+        if (qi.nr > 0) ++cur_cnt;
         cur_u += nslots;
         int e2, b2;
         QuadInfo q2;
@@ -872,7 +921,7 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
 template <int XTE>
 static int launch_score_tile(const float* q, const float* k, const float* diag, int C, int T, int D, long long ldq,
                              long long ldk, long long ldd, float qscale, int mode, int full, float* S, hipStream_t stream,
-                             int group, int pitch)
+                             int group, int pitch, const float* rowc, long long ldrc)
 {
     const SlotGeom G = slot_geom(C, group, pitch);
     const int Cs = (C / group) * pitch;
@@ -882,7 +931,7 @@ static int launch_score_tile(const float* q, const float* k, const float* diag, 
     else
         for (int et = 0; et < net; ++et) ntiles += (et * XTE + XTE - 1) / XTB + 1 < nbt ? (et * XTE + XTE - 1) / XTB + 1 : nbt;
     const int nquadp = (G.nrq + 7) / 8 * 8;
-    const size_t lds = (size_t)XNS * (XTE + XTB) * 128;
+    const size_t lds = (size_t)XNS * (XTE + XTB) * 128 + 2 * (4 * XTE * 4);     // stages + the two row-constant buffers
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)interval_score_tile_kernel<XTE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -901,7 +950,7 @@ static int launch_score_tile(const float* q, const float* k, const float* diag, 
     if (const char* e = getenv("SEMICRF_SCORE_DEBUG")) dbg = atoi(e) & 0xff;      // timing ablations (wrong results): debug builds only
 #endif
     hipLaunchKernelGGL(interval_score_tile_kernel<XTE>, dim3(grid), dim3(XTE * 4), lds, stream, q, k, diag, C, T, D, ldq, ldk, ldd,
-                       qscale, mode | (dbg << 8), full, S, ntiles, nquadp, Cs, G);
+                       qscale, mode | (dbg << 8), full, S, ntiles, nquadp, Cs, G, rowc, ldrc);
     return 0;
 }
 
@@ -927,7 +976,7 @@ template <int XTE>
 __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ diag, int C, int T, int D,
     long long ldq, long long ldk, long long ldd, float qscale, int mode, int full, float* __restrict__ S,
-    int ntiles, int nquadp, int Cs, SlotGeom G)
+    int ntiles, int nquadp, int Cs, SlotGeom G, const float* __restrict__ rowc, long long ldrc)
 {
     constexpr int NTH = XTE * 4;                 // threads
     constexpr int NR = XTE + XTB;                // rows per stage: q rows | k rows
@@ -1239,7 +1288,15 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
                     const int len = e > b ? e - b : b - e;
                     const float sc = qscale * len_scale_mfma(len, mode);
                     const float last = t == 0 ? acc0[r] : acc1[r];
-                    float v[4] = {hold[0][t][r] * sc, hold[1][t][r] * sc, hold[2][t][r] * sc, last * sc};
+                    float v[4] = {hold[0][t][r], hold[1][t][r], hold[2][t][r], last};
+                    if (rowc && e < T) {
+                        // merged projection (interval_score_fwd_p, rowc): a per-(chain, end) constant joins the contraction
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (i < qi.nr) v[i] += rowc[((size_t)(qi.ck + i) * T + e) * ldrc];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] *= sc;
                     if (e < T && b < T && (full || b <= e) && qi.nr > 0 && !(dbg & 4)) {
                         if (e == b) {
 #pragma unroll
@@ -1277,7 +1334,7 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
 template <int XTE>
 static int launch_score_tile3(const float* q, const float* k, const float* diag, int C, int T, int D, long long ldq,
                               long long ldk, long long ldd, float qscale, int mode, int full, float* S, hipStream_t stream,
-                              int group, int pitch)
+                              int group, int pitch, const float* rowc, long long ldrc)
 {
     const SlotGeom G = slot_geom(C, group, pitch);
     const int Cs = (C / group) * pitch;
@@ -1305,7 +1362,7 @@ static int launch_score_tile3(const float* q, const float* k, const float* diag,
     if (const char* e = getenv("SEMICRF_SCORE_DEBUG")) dbg = atoi(e) & 0xff;      // timing ablations (wrong results): debug builds only
 #endif
     hipLaunchKernelGGL(interval_score_tile3_kernel<XTE>, dim3(grid), dim3(XTE * 4), lds, stream, q, k, diag, C, T, D, ldq, ldk, ldd, qscale,
-                       mode | (dbg << 8), full, S, ntiles, nquadp, Cs, G);
+                       mode | (dbg << 8), full, S, ntiles, nquadp, Cs, G, rowc, ldrc);
     return 0;
 }
 
@@ -1323,9 +1380,10 @@ bool interval_score_slots_supported(int C, int T, int D, const float* q, const f
 
 int launch_interval_score_mfma(const float* q, const float* k, const float* diag, int C, int T, int D,
                                 long long ldq, long long ldk, long long ldd, float qscale, int mode, int full,
-                                float* S, hipStream_t stream, int prec, int group, int pitch)
+                                float* S, hipStream_t stream, int prec, int group, int pitch, const float* rowc, long long ldrc)
 {
-    const bool slots = !(group == C && pitch == C);
+    // rowc (merged projection) lives in the tile kernels like the slot layout
+    const bool slots = !(group == C && pitch == C) || rowc != nullptr;
     if (slots && !interval_score_slots_supported(C, T, D, q, k, ldq, ldk)) return 2;
     const int nt = (T + ST - 1) / ST;
     const size_t lds = (size_t)ST * ST * SPAD * sizeof(float);
@@ -1340,11 +1398,11 @@ int launch_interval_score_mfma(const float* q, const float* k, const float* diag
         if (forced >= 0) variant = forced;
         if (slots && variant != 64) variant = 128;                 // the slot layout lives in the tile kernels
         if (prec == 1 && T >= 128)
-            return launch_score_tile3<128>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream, group, pitch);
+            return launch_score_tile3<128>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream, group, pitch, rowc, ldrc);
         if (variant == 128)
-            return launch_score_tile<128>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream, group, pitch);
+            return launch_score_tile<128>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream, group, pitch, rowc, ldrc);
         if (variant == 64)
-            return launch_score_tile<64>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream, group, pitch);
+            return launch_score_tile<64>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream, group, pitch, rowc, ldrc);
         if (variant == 32)
             return launch_score_stream(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, band, stream);
     }

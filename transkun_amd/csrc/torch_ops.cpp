@@ -288,53 +288,58 @@ inline int64_t slots_of(int64_t C, int64_t group, int64_t pitch)
     STD_TORCH_CHECK(group >= 1 && pitch >= group && C % group == 0 && group < (1ll << 31) && pitch < (1ll << 31), "semicrf: bad slot layout");
     return C / group * pitch;
 }
-void interval_score_fwd_op(Tensor q, Tensor k, Tensor diag, int64_t C, int64_t T, int64_t D, int64_t ldq, int64_t ldk, int64_t ldd,
-                           double qscale, int64_t mode, int64_t full, int64_t group, int64_t pitch, Tensor S, Tensor noise)
+// rowc / drowc (merged projection, *_pc entry points): strided [C][T] views, stride ldrc; ldrc == 0: none
+void interval_score_fwd_op(Tensor q, Tensor k, Tensor diag, Tensor rowc, int64_t C, int64_t T, int64_t D, int64_t ldq, int64_t ldk,
+                           int64_t ldd, int64_t ldrc, double qscale, int64_t mode, int64_t full, int64_t group, int64_t pitch, Tensor S,
+                           Tensor noise)
 {
-    Ctx c(q); c.same(q, k, diag, S, noise);
+    Ctx c(q); c.same(q, k, diag, rowc, S, noise);
     score_dims(C, T, D);
     const int64_t Cs = slots_of(C, group, pitch);
-    check(interval_score_fwd_p(f32s(q, "q"), f32s(k, "k"), f32s(diag, "diag"), (int)C, (int)T, (int)D, ldq, ldk, ldd, (float)qscale, (int)mode,
-                               (int)full, (int)group, (int)pitch, f32w(S, T * T * Cs, "S"),
-                               noise.numel() > 0 ? f32w(noise, (T - 1) * Cs, "noise") : nullptr, c.stream),
+    check(interval_score_fwd_pc(f32s(q, "q"), f32s(k, "k"), f32s(diag, "diag"), ldrc > 0 ? f32s(rowc, "rowc") : nullptr, (int)C, (int)T, (int)D,
+                                ldq, ldk, ldd, ldrc > 0 ? ldrc : 1, (float)qscale, (int)mode, (int)full, (int)group, (int)pitch,
+                                f32w(S, T * T * Cs, "S"), noise.numel() > 0 ? f32w(noise, (T - 1) * Cs, "noise") : nullptr, c.stream),
           "interval_score_fwd");
 }
 void interval_score_bwd_ws_op(Tensor dS, Tensor q, Tensor k, int64_t C, int64_t T, int64_t D, int64_t ldq, int64_t ldk, double qscale,
-                              int64_t mode, int64_t group, int64_t pitch, Tensor dq, Tensor dk, Tensor ddiag, int64_t lddq, int64_t lddk,
-                              int64_t lddd, Tensor ws)
+                              int64_t mode, int64_t group, int64_t pitch, Tensor dq, Tensor dk, Tensor ddiag, Tensor drowc, int64_t lddq,
+                              int64_t lddk, int64_t lddd, int64_t lddrc, Tensor ws)
 {
-    Ctx c(dS); c.same(dS, q, k, dq, dk, ddiag, ws);
+    Ctx c(dS); c.same(dS, q, k, dq, dk, ddiag, drowc, ws);
     score_dims(C, T, D);
     const int64_t Cs = slots_of(C, group, pitch);
-    check(interval_score_bwd_ws_p(f32(dS, T * T * Cs, "dS"), f32s(q, "q"), f32s(k, "k"), (int)C, (int)T, (int)D, ldq, ldk, (float)qscale,
-                                  (int)mode, (int)group, (int)pitch, f32so(dq, "dq"), f32so(dk, "dk"), f32so(ddiag, "ddiag"), lddq, lddk, lddd,
-                                  bytes(ws, "ws"), (size_t)ws.numel(), c.stream),
+    check(interval_score_bwd_ws_pc(f32(dS, T * T * Cs, "dS"), f32s(q, "q"), f32s(k, "k"), (int)C, (int)T, (int)D, ldq, ldk, (float)qscale,
+                                   (int)mode, (int)group, (int)pitch, f32so(dq, "dq"), f32so(dk, "dk"), f32so(ddiag, "ddiag"),
+                                   lddrc > 0 ? f32so(drowc, "drowc") : nullptr, lddq, lddk, lddd, lddrc > 0 ? lddrc : 1, bytes(ws, "ws"),
+                                   (size_t)ws.numel(), c.stream),
           "interval_score_bwd_ws");
 }
 void interval_score_bwd_fused_ws_op(Tensor S, Tensor alpha, Tensor beta_, Tensor logZ, Tensor gout, Tensor q, Tensor k, int64_t C, int64_t T,
                                     int64_t D, int64_t ldq, int64_t ldk, double qscale, int64_t mode, int64_t group, int64_t pitch, Tensor dq,
-                                    Tensor dk, Tensor ddiag, int64_t lddq, int64_t lddk, int64_t lddd, Tensor ws)
+                                    Tensor dk, Tensor ddiag, Tensor drowc, int64_t lddq, int64_t lddk, int64_t lddd, int64_t lddrc, Tensor ws)
 {
-    Ctx c(S); c.same(S, alpha, beta_, logZ, gout, q, k, dq, dk, ddiag, ws);
+    Ctx c(S); c.same(S, alpha, beta_, logZ, gout, q, k, dq, dk, ddiag, drowc, ws);
     score_dims(C, T, D);
     const int64_t Cs = slots_of(C, group, pitch);
-    check(interval_score_bwd_fused_ws_p(f32(S, T * T * Cs, "S"), f32(alpha, T * Cs, "alpha"), f32(beta_, T * Cs, "beta"),
-                                        f32(logZ, Cs, "logZ"), f32(gout, Cs, "gout"), f32s(q, "q"), f32s(k, "k"), (int)C, (int)T, (int)D, ldq,
-                                        ldk, (float)qscale, (int)mode, (int)group, (int)pitch, f32so(dq, "dq"), f32so(dk, "dk"),
-                                        f32so(ddiag, "ddiag"), lddq, lddk, lddd, bytes(ws, "ws"), (size_t)ws.numel(), c.stream),
+    check(interval_score_bwd_fused_ws_pc(f32(S, T * T * Cs, "S"), f32(alpha, T * Cs, "alpha"), f32(beta_, T * Cs, "beta"),
+                                         f32(logZ, Cs, "logZ"), f32(gout, Cs, "gout"), f32s(q, "q"), f32s(k, "k"), (int)C, (int)T, (int)D, ldq,
+                                         ldk, (float)qscale, (int)mode, (int)group, (int)pitch, f32so(dq, "dq"), f32so(dk, "dk"),
+                                         f32so(ddiag, "ddiag"), lddrc > 0 ? f32so(drowc, "drowc") : nullptr, lddq, lddk, lddd,
+                                         lddrc > 0 ? lddrc : 1, bytes(ws, "ws"), (size_t)ws.numel(), c.stream),
           "interval_score_bwd_fused_ws");
 }
 void interval_score_path_bwd_op(Tensor gout, Tensor pairs, int64_t K, Tensor offsets, Tensor q, Tensor k, int64_t C, int64_t T, int64_t D,
                                 int64_t ldq, int64_t ldk, double qscale, int64_t mode, int64_t group, int64_t pitch, Tensor dq, Tensor dk,
-                                Tensor ddiag, int64_t lddq, int64_t lddk, int64_t lddd)
+                                Tensor ddiag, Tensor drowc, int64_t lddq, int64_t lddk, int64_t lddd, int64_t lddrc)
 {
-    Ctx c(gout); c.same(gout, pairs, offsets, q, k, dq, dk, ddiag);
+    Ctx c(gout); c.same(gout, pairs, offsets, q, k, dq, dk, ddiag, drowc);
     score_dims(C, T, D);
     STD_TORCH_CHECK(K >= 0, "semicrf: negative interval count");
     const int64_t Cs = slots_of(C, group, pitch);
-    check(interval_score_path_bwd_p(f32(gout, Cs, "gout"), i32(pairs, 2 * K, "pairs"), K, i32(offsets, Cs + 1, "offsets"), f32s(q, "q"),
-                                    f32s(k, "k"), (int)C, (int)T, (int)D, ldq, ldk, (float)qscale, (int)mode, (int)group, (int)pitch,
-                                    f32so(dq, "dq"), f32so(dk, "dk"), f32so(ddiag, "ddiag"), lddq, lddk, lddd, c.stream),
+    check(interval_score_path_bwd_pc(f32(gout, Cs, "gout"), i32(pairs, 2 * K, "pairs"), K, i32(offsets, Cs + 1, "offsets"), f32s(q, "q"),
+                                     f32s(k, "k"), (int)C, (int)T, (int)D, ldq, ldk, (float)qscale, (int)mode, (int)group, (int)pitch,
+                                     f32so(dq, "dq"), f32so(dk, "dk"), f32so(ddiag, "ddiag"), lddrc > 0 ? f32so(drowc, "drowc") : nullptr, lddq,
+                                     lddk, lddd, lddrc > 0 ? lddrc : 1, c.stream),
           "interval_score_path_bwd");
 }
 
@@ -404,15 +409,18 @@ STABLE_TORCH_LIBRARY(semicrf, m)
     m.def("logprob_bwd(Tensor score, Tensor noise, Tensor v, Tensor logZ, Tensor gout, int gstride, Tensor pairs, int K, Tensor offsets, "
           "Tensor(a!) dScore, Tensor(b!) dNoise, Tensor(c!) ws) -> ()");
     // (group, pitch): the slot layout of the chain axis (include/semicrf_hip.h, *_p entry points); group == pitch: contiguous
-    m.def("interval_score_fwd(Tensor q, Tensor k, Tensor diag, int C, int T, int D, int ldq, int ldk, int ldd, float qscale, int mode, "
-          "int full, int group, int pitch, Tensor(a!) S, Tensor(b!) noise) -> ()");
+    // rowc / drowc, ldrc / lddrc: the merged projection's per-(chain, end) constant (*_pc entry points); stride 0: none (pass any tensor)
+    m.def("interval_score_fwd(Tensor q, Tensor k, Tensor diag, Tensor rowc, int C, int T, int D, int ldq, int ldk, int ldd, int ldrc, "
+          "float qscale, int mode, int full, int group, int pitch, Tensor(a!) S, Tensor(b!) noise) -> ()");
     m.def("interval_score_bwd_ws(Tensor dS, Tensor q, Tensor k, int C, int T, int D, int ldq, int ldk, float qscale, int mode, int group, "
-          "int pitch, Tensor(a!) dq, Tensor(b!) dk, Tensor(c!) ddiag, int lddq, int lddk, int lddd, Tensor(d!) ws) -> ()");
+          "int pitch, Tensor(a!) dq, Tensor(b!) dk, Tensor(c!) ddiag, Tensor(d!) drowc, int lddq, int lddk, int lddd, int lddrc, "
+          "Tensor(e!) ws) -> ()");
     m.def("interval_score_bwd_fused_ws(Tensor S, Tensor alpha, Tensor beta, Tensor logZ, Tensor gout, Tensor q, Tensor k, int C, int T, int D, "
-          "int ldq, int ldk, float qscale, int mode, int group, int pitch, Tensor(a!) dq, Tensor(b!) dk, Tensor(c!) ddiag, int lddq, int lddk, "
-          "int lddd, Tensor(d!) ws) -> ()");
+          "int ldq, int ldk, float qscale, int mode, int group, int pitch, Tensor(a!) dq, Tensor(b!) dk, Tensor(c!) ddiag, Tensor(d!) drowc, "
+          "int lddq, int lddk, int lddd, int lddrc, Tensor(e!) ws) -> ()");
     m.def("interval_score_path_bwd(Tensor gout, Tensor pairs, int K, Tensor offsets, Tensor q, Tensor k, int C, int T, int D, int ldq, int ldk, "
-          "float qscale, int mode, int group, int pitch, Tensor(a!) dq, Tensor(b!) dk, Tensor(c!) ddiag, int lddq, int lddk, int lddd) -> ()");
+          "float qscale, int mode, int group, int pitch, Tensor(a!) dq, Tensor(b!) dk, Tensor(c!) ddiag, Tensor(d!) drowc, int lddq, int lddk, "
+          "int lddd, int lddrc) -> ()");
     m.def("interval_features_gather(Tensor ctx, int C, int T, int D, int ldc, Tensor pairs, int K, Tensor offsets, int nSym, Tensor(a!) out, "
           "Tensor(b!) symIdx, Tensor(c!) scatterIdx) -> ()");
     m.def("interval_features_gather_bwd(Tensor gout, Tensor ctx, int C, int T, int D, int ldc, Tensor pairs, int K, Tensor offsets, "

@@ -27,8 +27,8 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .scorer import (BF16X3, QPAD, ScaledInnerProductIntervalScorer, _ScorerLinear, _interval_score_raw, bwd_workspace, qd_weights,
-                     slot_maps, slot_pitch)
+from .scorer import (BF16X3, QPAD, ScaledInnerProductIntervalScorer, _ScorerLinear, _interval_score_raw, _tn_splitk, bwd_workspace,
+                     qd_weights, slot_maps, slot_pitch)
 
 _nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
 
@@ -39,6 +39,87 @@ def _beta_raw(score, noise):
     ws = _lib.leased_workspace(_lib.OP_LOGZ_FWD, T, B, score.device, "beta")
     _lib.ops().beta(score, noise, beta, ws)
     return beta
+
+
+def merged_weights(W, bias, D):
+    """The reference's two projections q = x Wq^T + bq, k = x Wk^T + bk (LayersTransformer.py:392-397, :406-410) enter the score only
+    through <q_e, k_b> = <x_e A + v, x_b> + c_e with A = Wq^T Wk, v = bq Wk, c_e = <x_e, Wq^T bk> + <bq, bk>: ONE size -> size
+    projection, the second operand of the contraction is x itself.  Returns (Wm [size+QPAD, size], bm [size+QPAD]) of the single
+    GEMM  [z | c | diag | 0 0] = x Wm^T + bm.  Differentiable in W and bias (a 513 x 256 x 256 product: microseconds)."""
+    Wq, Wk, wd = W[:D], W[D:2 * D], W[2 * D:2 * D + 1]
+    bq, bk, bd = bias[:D], bias[D:2 * D], bias[2 * D:2 * D + 1]
+    Wm = torch.cat([Wk.t().mm(Wq), (bk @ Wq).unsqueeze(0), wd, W.new_zeros(QPAD - 2, W.shape[1])])
+    bm = torch.cat([bq @ Wk, (bq @ bk).reshape(1), bd, bias.new_zeros(QPAD - 2)])
+    return Wm, bm
+
+
+def merged_eligible(size: int, T: int) -> bool:
+    """Shapes the row-constant form of the scorer kernels takes (include/semicrf_hip.h: interval_score_fwd_pc)."""
+    return size % 64 == 0 and size <= 256 and T >= 128
+
+
+class _MergedScorerCRFLogProb(torch.autograd.Function):
+    """_ScorerCRFLogProb with the merged projection inside the node: x -> [z | c | diag] (ONE GEMM of half the reference Linear's
+    width), S = qscale (<z_e, x_b> + c_e) len + diag, logProb.  The backward hands back dx (the gradient through z, c, diag AND
+    through x as the contraction's second operand, accumulated inside one GEMM) and the gradients of Wm, bm."""
+
+    @staticmethod
+    def forward(ctx, x, Wm, bm, pairs, offsets, N, P, T, D, mode, fs=2):
+        # x: [N,P,T,size] fp32 contiguous; D: the reference's contraction size (size * expansionFactor) -- only its scale survives
+        C = N * P
+        size = x.shape[-1]
+        pitch = slot_pitch(P, T, size, N)
+        x3 = x.reshape(C, T, size)
+        zc = F.linear(x3, Wm, bm)                                   # [C,T,size+QPAD] = [z | c | diag | 0 0]
+        qs = 1.0 / math.sqrt(D)
+        S, noise = _interval_score_raw(zc[..., :size], x3, zc[..., size + 1], T, C, size, qs, mode, fs, P, pitch, rowc=zc[..., size])
+        if pitch != P:
+            real, offmap = slot_maps(N, P, pitch, S.device)
+            offsets_s = offsets.index_select(0, offmap)
+        else:
+            real, offsets_s = None, offsets
+        logz, v = _nsci._logz_fwd_raw(S, noise, True)
+        K = getattr(pairs, "_semicrf_K", pairs.shape[0])
+        pairs._semicrf_K = K
+        path = _nsci._eval_path_raw(S, noise, pairs, offsets_s)
+        ctx.save_for_backward(x3, zc, Wm, S, noise, v, logz, pairs, offsets_s)
+        ctx.meta = (N, P, T, D, mode, K, pitch)
+        lp = path - logz
+        return lp if real is None else lp.index_select(0, real)
+
+    @staticmethod
+    def backward(ctx, g):
+        x3, zc, Wm, S, noise, v, logz, pairs, offsets_s = ctx.saved_tensors
+        N, P, T, D, mode, K, pitch = ctx.meta
+        C = N * P
+        size = x3.shape[-1]
+        qs = 1.0 / math.sqrt(D)
+        g = g.reshape(C).to(torch.float32).contiguous()
+        if pitch != P:
+            real, _ = slot_maps(N, P, pitch, S.device)
+            g = torch.zeros(N * pitch, dtype=torch.float32, device=S.device).index_copy_(0, real, g)
+        ops = _lib.ops()
+        beta = _beta_raw(S, noise)
+        gneg = (-g).contiguous()
+        z = zc[..., :size]
+        dzc = torch.empty(C, T, size + QPAD, dtype=torch.float32, device=S.device)
+        dzc[..., size + 2:] = 0
+        dz, dc, dd = dzc[..., :size], dzc[..., size], dzc[..., size + 1]
+        dx = torch.empty(C, T, size, dtype=torch.float32, device=S.device)           # the part through the second operand
+        ws = bwd_workspace(C, T, size, S.device)
+        ops.interval_score_bwd_fused_ws(S, v, beta, logz, gneg, z, x3, C, T, size, z.stride(-2), size, qs, mode, P, pitch, dz, dx, dd, dc,
+                                        dz.stride(-2), size, dd.stride(-1), dc.stride(-1), ws)
+        del ws
+        if K > 0:
+            ops.interval_score_path_bwd(g, pairs, int(K), offsets_s, z, x3, C, T, size, z.stride(-2), size, qs, mode, P, pitch, dz, dx, dd,
+                                        dc, dz.stride(-2), size, dd.stride(-1), dc.stride(-1))
+        g2 = dzc.view(-1, size + QPAD)
+        need = ctx.needs_input_grad
+        dx2 = dx.view(-1, size)
+        if need[0]:
+            dx2.addmm_(g2, Wm)                                        # + the part through [z | c | diag]
+        return (dx2.view(N, P, T, size) if need[0] else None, _tn_splitk(g2, x3.view(-1, size)) if need[1] else None,
+                g2.sum(0) if need[2] else None, None, None, None, None, None, None, None, None)
 
 
 class _ScorerCRFLogProb(torch.autograd.Function):
@@ -89,20 +170,23 @@ class _ScorerCRFLogProb(torch.autograd.Function):
         # with a workspace: marginals evaluated by the repack kernel + two tiled GEMMs (scorer_bwd_gemm.hip)
         ws = bwd_workspace(C, T, D, S.device)
         ops.interval_score_bwd_fused_ws(S, v, beta, logz, gneg, q, k, C, T, D, q.stride(-2), k.stride(-2), qs, mode, P, pitch, dq, dk, dd,
-                                        dq.stride(-2), D, dd.stride(-1), ws)
+                                        dd, dq.stride(-2), D, dd.stride(-1), 0, ws)
         del ws
         if K > 0:
             # + g on the path cells: dq[c,e] += g qs len(e-b) k[c,b], dk[c,b] += g qs len(e-b) q[c,e], ddiag[c,t] += g (b == e)
             ops.interval_score_path_bwd(g, pairs, int(K), offsets_s, q, k, C, T, D, q.stride(-2), k.stride(-2), qs, mode, P, pitch, dq, dk,
-                                        dd, dq.stride(-2), D, dd.stride(-1))
+                                        dd, dd, dq.stride(-2), D, dd.stride(-1), 0)
         return (dqd.view(N, P, T, D + QPAD), dk.view(N, P, T, D), None, None, None, None, None, None, None, None)
 
 
-def scorer_crf_logprob(scorer: ScaledInnerProductIntervalScorer, ctx: torch.Tensor, intervals) -> torch.Tensor:
+def scorer_crf_logprob(scorer: ScaledInnerProductIntervalScorer, ctx: torch.Tensor, intervals, projection: str = "merged") -> torch.Tensor:
     """log p(intervals | ctx) per chain, [N*P], differentiable w.r.t. ctx and the scorer's parameters.
 
     ctx: [N, P, T, size] on the GPU; intervals: List (len N*P, chain index n*P + p) of Lists of (begin, end).
-    Equivalent to NeuralSemiCRFInterval(*[x.flatten(-2) for x in scorer(ctx)]).logProb(intervals)."""
+    Equivalent to NeuralSemiCRFInterval(*[x.flatten(-2) for x in scorer(ctx)]).logProb(intervals).
+    projection: "merged" (default; shapes merged_eligible takes, else "separate") -- ONE size -> size GEMM instead of the reference's
+    size -> 2 D + 1 (merged_weights): the same scores up to fp32 reassociation, half the Linear's flops; "separate": q and k
+    projected as the reference does, bit-identical scores to ScaledInnerProductIntervalScorer.forward."""
     assert ctx.dim() == 4
     N, P, T, _ = ctx.shape
     D = scorer.size * scorer.expansionFactor
@@ -113,8 +197,13 @@ def scorer_crf_logprob(scorer: ScaledInnerProductIntervalScorer, ctx: torch.Tens
     lin = scorer.map[0]
     W, bias = lin.weight, lin.bias
     x = ctx.float()
-    Wqd, bqd = qd_weights(W, bias, D)
-    qd, k = _ScorerLinear.apply(x, Wqd, bqd, W[D:2 * D], bias[D:2 * D])
     pairs, offsets = _nsci.pack_intervals(intervals, T, N * P, ctx.device)
     fs = 2 | (BF16X3 if getattr(scorer, "contraction", "fp32") == "bf16x3" else 0)
+    if projection not in ("merged", "separate"):
+        raise ValueError(f"projection must be 'merged' or 'separate', not {projection!r}")
+    if projection == "merged" and merged_eligible(scorer.size, T):
+        Wm, bm = merged_weights(W, bias, D)
+        return _MergedScorerCRFLogProb.apply(x.contiguous(), Wm, bm, pairs, offsets, N, P, T, D, _lib.LEN_MODES[scorer.lengthScaling], fs)
+    Wqd, bqd = qd_weights(W, bias, D)
+    qd, k = _ScorerLinear.apply(x, Wqd, bqd, W[D:2 * D], bias[D:2 * D])
     return _ScorerCRFLogProb.apply(qd, k, pairs, offsets, N, P, T, D, _lib.LEN_MODES[scorer.lengthScaling], fs)

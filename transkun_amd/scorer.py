@@ -50,12 +50,14 @@ def slot_maps(N: int, P: int, pitch: int, device):
     return m
 
 
-def _interval_score_raw(q, k, diag, T: int, C: int, D: int, qscale: float, mode: int, full_square, group: int = 0, pitch: int = 0):
+def _interval_score_raw(q, k, diag, T: int, C: int, D: int, qscale: float, mode: int, full_square, group: int = 0, pitch: int = 0,
+                        rowc=None):
     """q,k: [C,T,D] views with unit stride in d; diag: [C,T] view.  Returns S [T,T,Cs], noise [T-1,Cs]; Cs = C, or with a
     slot layout (group, pitch: include/semicrf_hip.h) C / group * pitch with exact zeros in the ghost slots.
     full_square: False/0 lower triangle + zeros above, True/1 the full square, 2 lower triangle only (the cells with
     begin > end stay uninitialised: for S that only this library's CRF kernels read); | BF16X3 (4): the opt-in three-limb
-    bf16 contraction (include/semicrf_hip.h: SEMICRF_SCORE_BF16X3)."""
+    bf16 contraction (include/semicrf_hip.h: SEMICRF_SCORE_BF16X3).  rowc: [C,T] view, a per-(chain, end) constant inside the
+    contraction (the merged projection, include/semicrf_hip.h: interval_score_fwd_pc)."""
     dev = q.device
     assert q.stride(-1) == 1 and k.stride(-1) == 1
     if not group:
@@ -66,8 +68,9 @@ def _interval_score_raw(q, k, diag, T: int, C: int, D: int, qscale: float, mode:
     if (int(full_square) & 3) == 2 and os.environ.get("SEMICRF_POISON_UNWRITTEN"):
         S.fill_(float("nan"))           # test hook: whatever reads begin > end of a lower-triangle-only S shows up as NaN
     noise = torch.empty(max(T - 1, 0), Cs, dtype=torch.float32, device=dev)
-    _lib.ops().interval_score_fwd(q, k, diag, C, T, D, q.stride(-2), k.stride(-2), diag.stride(-1), float(qscale), int(mode),
-                                  int(full_square), int(group), int(pitch), S, noise)
+    _lib.ops().interval_score_fwd(q, k, diag, rowc if rowc is not None else diag, C, T, D, q.stride(-2), k.stride(-2), diag.stride(-1),
+                                  rowc.stride(-1) if rowc is not None else 0, float(qscale), int(mode), int(full_square), int(group),
+                                  int(pitch), S, noise)
     return S, noise
 
 
@@ -185,8 +188,8 @@ class _IntervalScore(torch.autograd.Function):
             # with a workspace the library repacks dS per chain and runs two LDS-tiled GEMMs (scorer_bwd_gemm.hip);
             # 0 bytes: shapes it does not take -- the direct kernels run
             ws = bwd_workspace(C, T, D, g.device)
-            _lib.ops().interval_score_bwd_ws(g, q, k, C, T, D, q.stride(-2), k.stride(-2), qs, mode, P, pitch, dq, dk, dd,
-                                             dq.stride(-2), D, dd.stride(-1), ws)
+            _lib.ops().interval_score_bwd_ws(g, q, k, C, T, D, q.stride(-2), k.stride(-2), qs, mode, P, pitch, dq, dk, dd, dd,
+                                             dq.stride(-2), D, dd.stride(-1), 0, ws)
             return (dqd.view(N, P, T, D + QPAD), dk.view(N, P, T, D), None, None, None, None, None, None, None)
         if not _IntervalScore._warned_torch_backward:
             _IntervalScore._warned_torch_backward = True

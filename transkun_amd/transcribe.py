@@ -31,7 +31,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib, attributes
-from .scorer import ScaledInnerProductIntervalScorer, slot_maps, slot_pitch
+from . import fused
+from .scorer import ScaledInnerProductIntervalScorer, _interval_score_raw, slot_maps, slot_pitch
 
 _nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
 
@@ -121,8 +122,19 @@ class SegmentTranscriber(nn.Module):
         self.targetMIDIPitch = list(targetMIDIPitch) if targetMIDIPitch is not None else [-64, -67] + list(range(21, 108 + 1))   # :97
         self.scorer = ScaledInnerProductIntervalScorer(size, 1)
         self.scorer.fullSquare = 2      # S goes straight into this package's decode, which never reads begin > end: no zero fill
+        self.projection = "separate"    # "merged": the scorer's two projections as one (see decode_step); scores then differ from
+                                        # the reference's by fp32 reassociation, so the default keeps its operation order
+        self._merged = None
         self.velocityPredictor = _head(size * 3, velocityPredictorHiddenSize, 128, velocityDropoutProb)           # :109-115
         self.refinedOFPredictor = _head(size * 3, refinedOFPredictorHiddenSize, 4, refinedOFDropoutProb)          # :119-125
+
+    def _merged_weights(self):
+        lin = self.scorer.map[0]
+        key = (lin.weight._version, lin.bias._version, lin.weight.data_ptr(), lin.bias.data_ptr())
+        if self._merged is None or self._merged[0] != key:
+            with torch.no_grad():
+                self._merged = (key, fused.merged_weights(lin.weight.float(), lin.bias.float(), self.scorer.size * self.scorer.expansionFactor))
+        return self._merged[1]
 
     # ------------------------------------------------------------------------------------------------------------------
     # one step on the device
@@ -143,12 +155,23 @@ class SegmentTranscriber(nn.Module):
         # the P symbols of a segment in `pitch` slots (96 for 90) -- whole 128-byte lines for the CRF kernels -- with all-zero
         # ghost chains that decode to nothing; the packed result is chain-indexed again before anything else sees it
         pitch = slot_pitch(P, T, D, Fn)
-        self.scorer.slotPitch = pitch if pitch != P else None
-        try:
-            S, b = self.scorer(ctxBatch)
-        finally:
-            self.scorer.slotPitch = None
-        score, noise = S.flatten(-2, -1), b.flatten(-2, -1)
+        if self.projection not in ("separate", "merged"):
+            raise ValueError(f"projection must be 'separate' or 'merged', not {self.projection!r}")
+        if self.projection == "merged" and fused.merged_eligible(D, T) and self.scorer.expansionFactor == 1:
+            # opt-in: ONE size -> size GEMM instead of the reference's size -> 2 size + 1 (fused.merged_weights): the same scores up
+            # to fp32 reassociation -- a decoded path can differ from the reference's only where two paths tie to ~1e-6
+            Wm, bm = self._merged_weights()
+            x3 = ctxBatch.float().contiguous().view(B, T, D)
+            zc = F.linear(x3, Wm, bm)
+            score, noise = _interval_score_raw(zc[..., :D], x3, zc[..., D + 1], T, B, D, 1.0 / math.sqrt(D),
+                                               _lib.LEN_MODES[self.scorer.lengthScaling], 2, P, pitch, rowc=zc[..., D])
+        else:
+            self.scorer.slotPitch = pitch if pitch != P else None
+            try:
+                S, b = self.scorer(ctxBatch)
+            finally:
+                self.scorer.slotPitch = None
+            score, noise = S.flatten(-2, -1), b.flatten(-2, -1)
         if pitch != P:
             real, _ = slot_maps(Fn, P, pitch, dev)
             start_s = None
