@@ -99,7 +99,8 @@ int semicrf_debug_device_status(void);
 int semicrf_debug_wg_ticket(int n_spine, int grid, int block);
 
 /* Test hook, process-wide: force one of interval_score_fwd's kernels where it applies (0 = register loads, 32 = streaming,
- * 64 / 128 = shared-operand tiles); -1 = automatic choice (the default).  The library reads no environment variables. */
+ * 64 / 128 = shared-operand tiles, 2 = the 64 x 128 tiles with the epilogue inside the contraction loop -- all four give
+ * bit-identical scores); -1 = automatic choice (the default).  The library reads no environment variables. */
 void semicrf_debug_score_variant(int variant);
 
 /*

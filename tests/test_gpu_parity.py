@@ -282,12 +282,14 @@ def test_scorer(gpu, impl, oracle, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 32, 64, 128])
+@pytest.mark.parametrize("variant", [0, 32, 64, 128, 2])
 @pytest.mark.parametrize("C,T,D,mode,full", [(5, 70, 64, 0, False), (37, 300, 128, 1, False), (33, 257, 256, 0, True),
-                                              (8, 128, 64, 2, False), (64, 384, 256, 0, False), (3, 31, 64, 0, True)])
+                                              (8, 128, 64, 2, False), (64, 384, 256, 0, False), (3, 31, 64, 0, True),
+                                              (90, 691, 256, 0, False), (7, 200, 192, 1, True)])
 def test_scorer_forward_kernels(gpu, variant, C, T, D, mode, full, monkeypatch):
-    """Every forward kernel of the interval scorer (register-load, streaming, 64- and 128-row shared-operand tiles) against
-    an fp64 einsum of the same definition (LayersTransformer.py:406-441)."""
+    """Every forward kernel of the interval scorer (register-load, streaming, 64- and 128-row shared-operand tiles, 2 = the
+    64 x 128 tiles with the epilogue inside the contraction loop: the default where it applies) against an fp64 einsum of the
+    same definition (LayersTransformer.py:406-441)."""
     from transkun_amd import synth
     from transkun_amd.scorer import _interval_score_raw
     from transkun_amd import _lib
@@ -318,6 +320,34 @@ def _scorer_forward_case(gpu, C, T, D, mode, full):
         assert float((S.double() * (1 - keep)).abs().max()) == 0.0
     err = float((S.double() - ref).abs().max()) / float(ref.abs().max())
     assert err < 2e-6, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,P,pitch,T,D", [(1, 8, 8, 130, 64), (1, 6, 8, 200, 128), (2, 5, 8, 257, 192), (4, 90, 96, 691, 256), (3, 34, 64, 300, 128),
+                                            (1, 88, 88, 1024, 256)])
+@pytest.mark.parametrize("full", [0, 1])
+@pytest.mark.parametrize("use_rc", [False, True])
+def test_scorer_tiled_bits(gpu, N, P, pitch, T, D, full, use_rc):
+    """interval_score_tiled_kernel (scorer_tiled.hip: results of the previous item written during the next one's contraction, row
+    constants and diagonal terms through LDS) gives the bits of interval_score_tile_kernel<128> -- the same fmaf chain per cell --
+    in the contiguous and the slot layout, with and without the merged projection's row constant, lower triangle and full square."""
+    from transkun_amd import _lib, synth
+    from transkun_amd.scorer import _interval_score_raw
+    lib = _lib.load()
+    C = N * P
+    q = synth.hash_normal(C * T * D, 5, gpu).view(C, T, D)
+    k = synth.hash_normal(C * T * D, 6, gpu).view(C, T, D)
+    dg = synth.hash_normal(C * T, 7, gpu).view(C, T)
+    rc = synth.hash_normal(C * T, 8, gpu).view(C, T) if use_rc else None
+    try:
+        lib.semicrf_debug_score_variant(128)
+        ref, _ = _interval_score_raw(q, k, dg, T, C, D, 1.0 / 16, 0, full, P, pitch, rowc=rc)
+        lib.semicrf_debug_score_variant(2)
+        got, _ = _interval_score_raw(q, k, dg, T, C, D, 1.0 / 16, 0, full, P, pitch, rowc=rc)
+    finally:
+        lib.semicrf_debug_score_variant(-1)
+    assert torch.equal(ref, got)
+    assert _lib.device_status() == 0
 
 
 @pytest.mark.gpu

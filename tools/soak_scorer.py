@@ -20,7 +20,7 @@ for it in range(n_cases):
     qs = 1.0 / D ** 0.5
     lib.semicrf_debug_score_variant(0)
     ref, _ = _interval_score_raw(q, k, dg, T, C, D, qs, mode, full)
-    for v in (32, 64, 128):
+    for v in (32, 64, 128, 2):
         lib.semicrf_debug_score_variant(v)
         got, _ = _interval_score_raw(q, k, dg, T, C, D, qs, mode, full)
         err = float((got - ref).abs().max()) / float(ref.abs().max())

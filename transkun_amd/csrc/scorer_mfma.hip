@@ -12,6 +12,7 @@
 // segments), lower triangle only unless the caller asks for the full square.
 #include <atomic>
 #include "common.h"
+#include "scorer_tiles.h"
 
 #include <cstdlib>
 #include <map>
@@ -556,43 +557,6 @@ __device__ __forceinline__ f32x16 mma6(const Limbs3& A, const Limbs3& B, f32x16 
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.m, B.h, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.h, acc, 0, 0, 0);
     return acc;
-}
-
-// Slot layout of the chain axis (interval_score_fwd_p, include/semicrf_hip.h): the C chains come in groups of `group`
-// (the symbols of one segment), each group owns `pitch` >= group SLOTS of S's chain axis; the slots group..pitch-1 of
-// every group are ghosts and read zero.  With pitch a multiple of 32 every 32-slot piece of a cell is one aligned 128-byte
-// line -- what the CRF kernels want (T=691: 90 symbols at pitch 96 run 22 % faster than at pitch 90) -- while the scorer
-// only multiplies the real chains.  Items are quads of REAL chains (ceil(group / 4) per group: no all-ghost items, the
-// static schedule stays balanced); the last quad of a group also writes the zeros of the group's ghost tail.
-// group == pitch == C: the plain contiguous layout.
-struct SlotGeom {
-    int group, pitch, qps, nrq;          // quads per group, real quads in total
-};
-__host__ __device__ inline SlotGeom slot_geom(int C, int group, int pitch)
-{
-    SlotGeom g;
-    g.group = group; g.pitch = pitch;
-    g.qps = (group + 3) / 4;
-    g.nrq = (C / group) * g.qps;
-    return g;
-}
-struct QuadInfo {
-    int c4;      // first slot of the quad (S's chain index)
-    int ck;      // its first chain (q / k / diag index)
-    int nr;      // real chains in it (0: padding item, nothing to do)
-    int tz;      // ghost slots behind it that this item zero-fills (a multiple of 4)
-};
-__device__ __forceinline__ QuadInfo quad_info(const SlotGeom& g, int rq)
-{
-    QuadInfo o;
-    if (rq >= g.nrq) { o.c4 = 0; o.ck = 0; o.nr = 0; o.tz = 0; return o; }
-    const int seg = rq / g.qps, qd = rq - seg * g.qps;
-    o.c4 = seg * g.pitch + qd * 4;
-    o.ck = seg * g.group + qd * 4;
-    o.nr = g.group - qd * 4 < 4 ? g.group - qd * 4 : 4;
-    const int tail = g.pitch - g.qps * 4;
-    o.tz = (qd == g.qps - 1 && tail > 0) ? tail : 0;
-    return o;
 }
 
 // XTE = tile rows (end positions): 128 -> 8 waves, one workgroup per CU; 64 -> 4 waves, two (independent) workgroups
@@ -1366,7 +1330,12 @@ static int launch_score_tile3(const float* q, const float* k, const float* diag,
     return 0;
 }
 
-// test hook: force one of the forward kernels (0 register loads, 32 streaming, 64 / 128 shared-operand tiles; -1 = auto)
+void launch_interval_score_tiled(const float* q, const float* k, const float* diag, const float* rowc, int C, int T, int D,
+                                 long long ldq, long long ldk, long long ldd, long long ldrc, float qscale, int mode, int full,
+                                 float* S, hipStream_t stream, int group, int pitch, int dbg);      // scorer_tiled.hip
+
+// test hook: force one of the forward kernels (0 register loads, 32 streaming, 64 / 128 shared-operand tiles, 2 the tiles with
+// the epilogue inside the contraction loop (scorer_tiled.hip); -1 = auto)
 static std::atomic<int> g_score_variant{-1};
 void set_score_variant(int v) { g_score_variant.store(v, std::memory_order_relaxed); }
 
@@ -1395,7 +1364,17 @@ int launch_interval_score_mfma(const float* q, const float* k, const float* diag
         // 64-row tiles when they waste less of the last tile row (e.g. T=691: 704 vs 768 rows) -- measured 779 vs 814 us
         int variant = T < 256 ? 32 : ((T + 63) / 64 * 64 < (T + 127) / 128 * 128 ? 64 : 128);
         const int forced = g_score_variant.load(std::memory_order_relaxed);     // test hook (semicrf_debug_score_variant), -1 = auto
+        // the tiles with the epilogue inside the contraction loop (scorer_tiled.hip): 4-15 % faster than the kernels below at every
+        // shape measured (T=1024 x 352: 1.09 vs 1.13 ms, 691 x 360: 0.65 vs 0.68, 1024 x 88: 0.31 vs 0.37, 691 x 90: 0.183 vs 0.189)
+        const int Cs = (C / group) * pitch;
+        const bool tiled_ok = prec == 0 && T >= 128 && D <= 256 && (long long)32 * T * Cs * 4 < (1ll << 31);
+        if (tiled_ok && (T >= 256 || slots)) variant = 2;
         if (forced >= 0) variant = forced;
+        if (variant == 2 && tiled_ok) {
+            launch_interval_score_tiled(q, k, diag, rowc, C, T, D, ldq, ldk, ldd, ldrc, qscale, mode, full, S, stream, group, pitch, 0);
+            return 0;
+        }
+        if (variant == 2) variant = 128;
         if (slots && variant != 64) variant = 128;                 // the slot layout lives in the tile kernels
         if (prec == 1 && T >= 128)
             return launch_score_tile3<128>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream, group, pitch, rowc, ldrc);
