@@ -398,11 +398,12 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
         # the scorer is the path's matrix-bound kernel: its own roofline object (the line's `roofline` is the HBM-bound sweep)
         sflop = 2.0 * Cq * (T * (T + 1) / 2) * Dq                           # lower triangle only
         extra["scorer_roofline"] = {
-            "bound": "mfma", "kernel": "interval_score_tile_kernel<128> (exact fp32, v_mfma_f32_32x32x2_f32)", "unit": "TFLOP/s",
+            "bound": "mfma", "kernel": "interval_score_tiled_kernel<4> (exact fp32, v_mfma_f32_32x32x2_f32)", "unit": "TFLOP/s",
             "achieved": round(sflop / (extra["interval_score_fwd_ms"] * 1e-3) / 1e12, 2), "peak": 157.3,
             "frac": round(sflop / (extra["interval_score_fwd_ms"] * 1e-3) / 1e12 / 157.3, 4), "algorithmic_flop": sflop,
-            "note": "time includes the zero fill of the cells above the diagonal (full_square = 0); counters (profiles/r03_derived.json): "
-                    "matrix pipe busy 57 % of the kernel at 2.19 GHz under load",
+            "note": "time includes the zero fill of the cells above the diagonal (full_square = 0); counters: profiles/r03_derived.json "
+                    "(matrix pipe busy fraction, clock under load); cycle stamps: tools/tiled_probe.py -- bound by the CU's "
+                    "vector-memory address path (DESIGN.md section 3)",
             "bf16x3_frac_fp32_equivalent": round(sflop / (extra["interval_score_fwd_bf16x3_ms"] * 1e-3) / 1e12 / 157.3, 4),
             "backward_frac": round(2 * sflop / (extra["interval_score_bwd_ms"] * 1e-3) / 1e12 / 157.3, 4)}
         extra["interval_score_config"] = f"T={T}, chains={Cq}, D={Dq}, exact-fp32 MFMA, lower triangle"

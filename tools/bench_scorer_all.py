@@ -1,5 +1,5 @@
-"""The three scorer kernel families in one process, a few launches each (for rocprofv3 passes): interval_score_tile_kernel (exact
-fp32), interval_score_tile3_kernel (three-limb bf16) and the packed backward (score_bwd_pack_kernel + score_bwd_gemm_kernel), at
+"""The scorer kernel families in one process, a few launches each (for rocprofv3 passes): interval_score_tiled_kernel (exact fp32,
+the default) and interval_score_tile_kernel<128> beside it, interval_score_tile3_kernel (three-limb bf16) and the packed backward (score_bwd_pack_kernel + score_bwd_gemm_kernel), at
 T=1024 x 352 chains x D=256 and at the model's shape in the slot layout (T=691, 4 x 90 symbols at pitch 96).  GPU box only."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,13 +26,16 @@ for (N, P, pitch, T, D) in ((1, 352, 352, 1024, 256), (4, 90, 96, 691, 256)):
     k = synth.hash_normal(C * T * D, 6, dev).view(C, T, D)
     dg = synth.hash_normal(C * T, 7, dev).view(C, T)
     fl = 2.0 * C * (T * (T + 1) / 2) * D
-    f32 = timeit(lambda: _interval_score_raw(q, k, dg, T, C, D, 1.0 / 16, 0, 2, P, pitch))
+    f32 = timeit(lambda: _interval_score_raw(q, k, dg, T, C, D, 1.0 / 16, 0, 2, P, pitch))          # interval_score_tiled_kernel
+    _lib.load().semicrf_debug_score_variant(128)                                                      # the 128-row tiles, for comparison
+    f32_128 = timeit(lambda: _interval_score_raw(q, k, dg, T, C, D, 1.0 / 16, 0, 2, P, pitch))
+    _lib.load().semicrf_debug_score_variant(-1)
     b3 = timeit(lambda: _interval_score_raw(q, k, dg, T, C, D, 1.0 / 16, 0, 2 | 4, P, pitch))
     S, _ = _interval_score_raw(q, k, dg, T, C, D, 1.0 / 16, 0, 0, P, pitch)
     dq = torch.empty_like(q); dk = torch.empty_like(k); dd = torch.empty_like(dg)
     ws = bwd_workspace(C, T, D, dev)
     bw = timeit(lambda: ops.interval_score_bwd_ws(S, q, k, C, T, D, D, D, 1.0 / 16, 0, P, pitch, dq, dk, dd, dd, D, D, 1, 0, ws))
-    print(f"T={T} chains={C} (groups of {P} at pitch {pitch}) D={D}: fwd fp32 {f32:.3f} ms = {fl / f32 / 1e9:.1f} TFLOP/s ({fl / f32 / 1e9 / 157.3:.3f} of 157.3), "
+    print(f"T={T} chains={C} (groups of {P} at pitch {pitch}) D={D}: fwd fp32 {f32:.3f} ms = {fl / f32 / 1e9:.1f} TFLOP/s ({fl / f32 / 1e9 / 157.3:.3f} of 157.3; 128-row tile kernel {f32_128:.3f} ms), "
           f"fwd bf16x3 {b3:.3f} ms = {fl / b3 / 1e9:.1f} TFLOP/s fp32-equivalent, bwd (pack + 2 GEMMs) {bw:.3f} ms = {2 * fl / bw / 1e9:.1f} TFLOP/s", flush=True)
     del q, k, dg, S, dq, dk, dd, ws
     torch.cuda.empty_cache()

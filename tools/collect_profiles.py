@@ -87,7 +87,7 @@ out["grad_traffic_over_algorithmic"] = out["grad_traffic_bytes"] / (740358784 * 
 
 # ---- scorer kernels: matrix-pipe utilisation and the clock under load ------------------------------------------------------------
 sc = {}
-for kn, flop_per_inst in (("interval_score_tile_kernel<128>", 4096), ("interval_score_tile3_kernel<128>", 32768),
+for kn, flop_per_inst in (("interval_score_tiled_kernel<4>", 4096), ("interval_score_tile_kernel<128>", 4096), ("interval_score_tile3_kernel<128>", 32768),
                           ("score_bwd_gemm_kernel<false, 4>", 4096), ("score_bwd_gemm_kernel<true, 4>", 4096)):
     gui, us = g("pmc_scorer_SQ_BUSY_CYCLES_GRBM_GUI_ACTIVE", kn, "GRBM_GUI_ACTIVE")
     insts = g("pmc_scorer_SQ_INSTS_MFMA_SQ_VALU_MFMA_BUSY_CYCLES", kn, "SQ_INSTS_MFMA")[0]
