@@ -1429,3 +1429,32 @@ def test_sweep_while_collective_in_flight(gpu, rccl_world1):
         assert torch.equal(ds, ds0) and torch.equal(dn, dn0), rep
         assert torch.equal(o, o0) and torch.equal(p[:int(o[-1])], p0[:int(o0[-1])]), rep
     assert _lib.device_status() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["T691_P90", "T691_N4"])
+def test_transcriber_merged_projection_decodes_the_same(gpu, name):
+    """SegmentTranscriber.projection = "merged" (opt-in: one size -> size GEMM in front of the scorer, fused.merged_weights) decodes
+    the segment goldens' inputs to the same intervals as the default two-projection route -- the scores differ in the last bits
+    only, so a path could change only at an exact tie."""
+    from segment_common import SEGMENT_CASES, segment_inputs
+    from transkun_amd import _lib
+    from transkun_amd.transcribe import SegmentTranscriber
+    _lib.set_impl(0)
+    N, P, T, D = SEGMENT_CASES[name][:4]
+    ctx, W, bias, iv, gout, starts = segment_inputs(name, gpu)
+    torch.manual_seed(3)
+    tr = SegmentTranscriber(D, targetMIDIPitch=list(range(P))).to(gpu).eval()
+    with torch.no_grad():
+        tr.scorer.map[0].weight.copy_(W); tr.scorer.map[0].bias.copy_(bias)
+    begin = torch.zeros(N, dtype=torch.float64, device=gpu)
+    outs = []
+    for proj in ("separate", "merged"):
+        tr.projection = proj
+        o = tr.decode_step(ctx, None, begin, T - 1, T // 2)
+        outs.append(o)
+    a, b = outs
+    assert a["K"] == b["K"] and a["K"] > 0
+    assert torch.equal(a["pairs"], b["pairs"]) and torch.equal(a["offsets"], b["offsets"])
+    assert torch.equal(a["velocity"], b["velocity"]) and torch.equal(a["flags"], b["flags"])
+    assert _lib.device_status() == 0

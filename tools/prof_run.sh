@@ -23,7 +23,7 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCP_PENDING_STALL_CYC
 done
 for c in "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" FETCH_SIZE WRITE_SIZE; do
   n=$(echo $c | tr ' ' '_')
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_scorer_$n -- python $GRAFT_REPO_ROOT/tools/bench_scorer_all.py 3 > $OUT/pmc_scorer_$n.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_scorer_$n -- python $GRAFT_REPO_ROOT/tools/bench_scorer_all.py 3 big > $OUT/pmc_scorer_$n.log 2>&1
 done
 cd $GRAFT_REPO_ROOT
 timeout 300 python tools/bench_grid.py > $OUT/grid.md 2>/dev/null

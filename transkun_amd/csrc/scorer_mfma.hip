@@ -1364,8 +1364,9 @@ int launch_interval_score_mfma(const float* q, const float* k, const float* diag
         // 64-row tiles when they waste less of the last tile row (e.g. T=691: 704 vs 768 rows) -- measured 779 vs 814 us
         int variant = T < 256 ? 32 : ((T + 63) / 64 * 64 < (T + 127) / 128 * 128 ? 64 : 128);
         const int forced = g_score_variant.load(std::memory_order_relaxed);     // test hook (semicrf_debug_score_variant), -1 = auto
-        // the tiles with the epilogue inside the contraction loop (scorer_tiled.hip): 4-15 % faster than the kernels below at every
-        // shape measured (T=1024 x 352: 1.09 vs 1.13 ms, 691 x 360: 0.65 vs 0.68, 1024 x 88: 0.31 vs 0.37, 691 x 90: 0.183 vs 0.189)
+        // the tiles with the epilogue inside the contraction loop (scorer_tiled.hip): a tie with the kernels below at T=1024 x 352
+        // (1.115 vs 1.107 ms, a third less written to HBM), faster at the model's shapes (691 x 360: 0.653 vs 0.707 ms, 1024 x 88:
+        // 0.312 vs 0.365, 691 x 90: 0.183 vs 0.189)
         const int Cs = (C / group) * pitch;
         const bool tiled_ok = prec == 0 && T >= 128 && D <= 256 && (long long)32 * T * Cs * 4 < (1ll << 31);
         if (tiled_ok && (T >= 256 || slots)) variant = 2;

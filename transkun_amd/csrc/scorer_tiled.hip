@@ -18,7 +18,7 @@
 //   ping-pong (SEMICRF_TILED_PINGPONG=1, off): waves 0-3 and 4-7 (one of each on every SIMD) one phase apart -- one group in
 //               its memory phase (store + requests) while the other multiplies; three stages still suffice because group A
 //               loads the first halves of all rows and requests one chunk ahead, group B the second halves, two ahead.
-//               Correct (bit-identical) and SLOWER: 1.18 vs 1.09 ms at T=1024 x 352.  Cycle stamps (tools/tiled_probe.py) say
+//               Correct (bit-identical) and SLOWER: 1.18 vs 1.11 ms at T=1024 x 352.  Cycle stamps (tools/tiled_probe.py) say
 //               why: the memory phase is not instruction-bound but bound by the CU's ONE vector-memory path -- every LDS-DMA
 //               piece (1 KB) and every scattered store costs its issuing wave ~100-400 cycles there, 56 of them per chunk --
 //               so the memory phase of four waves (~3000 cycles) is longer than the other four's contraction (2048) and the
