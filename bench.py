@@ -66,6 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--impl", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--cpu-sample-nbatch", type=int, default=88)
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for --selftest-launch)")
     ap.add_argument("--selftest-launch", action="store_true",
@@ -208,7 +209,14 @@ def worker(args):
     fwd_ms = ev_time(lambda: nsci._logz_fwd_raw(s_d, n_d, want_v=True), nrep)
     abytes = algorithmic_bytes_logz_fwd(T, B)
     achieved = abytes / (fwd_ms * 1e-3) / 1e9
-    traffic, traffic_note = _traffic_for(T, B)
+    traffic, traffic_note = (None, "")
+    if rank == 0 and args.gpus == 1 and not args.no_live_traffic and args.impl == 0:
+        traffic, traffic_note = _traffic_live(T, B)
+    if traffic is None:
+        live_note = traffic_note
+        traffic, traffic_note = _traffic_for(T, B)
+        if live_note:
+            traffic_note += " (live measurement not available: " + live_note + ")"
     roofline = {"bound": "hbm", "kernel": "semicrf_logz_fwd (log-partition forward sweep)",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
@@ -258,6 +266,46 @@ def _kernel_source_sha() -> str:
         with open(os.path.join(ROOT, "transkun_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def _traffic_live(T: int, B: int):
+    """HBM bytes per launch of the forward sweep, measured IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
+    cannot share one; counters + kernel trace only) around tools/bench_sweep.py --ops fwd in a child process, mean over the
+    dispatches of persist_sweep_kernel<0, 0, false>; FETCH_SIZE is in KB and counts the 128-byte requests of wide reads as
+    64 bytes on gfx950 (x2, MI355X_MICROARCH.md, HBM / rocprofv3 section), WRITE_SIZE is in KB.  (None, reason) when the
+    profiler is not there or a pass fails -- the caller then falls back to the committed, source-stamped constant."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "no rocprofv3 on this box"
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="semicrf_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.join(ROOT, "tools", "bench_sweep.py"), "--ops", "fwd", "--n", "5", "--T", str(T), "--B", str(B)]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=180)
+            except Exception as ex:
+                return None, f"rocprofv3 {ctr} pass: {type(ex).__name__}"
+            if r.returncode != 0:
+                return None, f"rocprofv3 {ctr} pass: exit code {r.returncode}"
+            files = glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True)
+            got = []
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == ctr and "persist_sweep_kernel<0, 0, false>" in row.get("Kernel_Name", ""):
+                        got.append(float(row["Counter_Value"]))
+            if not got:
+                return None, f"rocprofv3 {ctr} pass: no dispatch of the forward sweep in the output"
+            vals[ctr] = sum(got) / len(got)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    nbytes = int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024)
+    return nbytes, ("measured in this run: rocprofv3 --pmc FETCH_SIZE (KB, x2: gfx950 counts the 128-byte requests of wide reads as "
+                    "64) + --pmc WRITE_SIZE (KB), separate passes around tools/bench_sweep.py --ops fwd --n 5, mean per dispatch")
 
 
 def _traffic_for(T: int, B: int):

@@ -11,8 +11,8 @@ rm -rf $OUT; mkdir -p $OUT
 timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed" | tee $OUT/pytest.log
 timeout 900 python bench.py 2>$OUT/bench.err > $OUT/bench.json
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra > $OUT/kt.log 2>&1
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_all -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/kt_all.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra --no-live-traffic > $OUT/kt.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_all -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-live-traffic > $OUT/kt_all.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_scorer -- python $GRAFT_REPO_ROOT/tools/bench_scorer_all.py 20 > $OUT/kt_scorer.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_fwd_$c -- python $GRAFT_REPO_ROOT/tools/bench_sweep.py --ops fwd --n 5 > $OUT/pmc_fwd_$c.log 2>&1
