@@ -1458,3 +1458,40 @@ def test_transcriber_merged_projection_decodes_the_same(gpu, name):
     assert torch.equal(a["pairs"], b["pairs"]) and torch.equal(a["offsets"], b["offsets"])
     assert torch.equal(a["velocity"], b["velocity"]) and torch.equal(a["flags"], b["flags"])
     assert _lib.device_status() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("proj", ["merged", "separate"])
+def test_fused_scorer_crf_expansion_factor(gpu, proj):
+    """expansionFactor = 2 (LayersTransformer.py:392-397: q and k are 2 size wide): the fused route against the unfused one.  The
+    merged projection contracts size values (A = Wq^T Wk is size x size whatever the expansion) with the scale of 2 size."""
+    from transkun_amd import CRF, _lib, synth
+    from transkun_amd.fused import scorer_crf_logprob
+    from transkun_amd.scorer import ScaledInnerProductIntervalScorer
+    _lib.set_impl(0)
+    N, P, T, size = 2, 6, 160, 64
+    torch.manual_seed(77)
+    m = ScaledInnerProductIntervalScorer(size, 2).to(gpu)
+    with torch.no_grad():
+        m.map[0].weight.mul_(0.3)
+    ctx0 = synth.hash_normal(N * P * T * size, 161, gpu).view(N, P, T, size) * 0.5
+    iv = synth.synthetic_intervals(T, N * P, seed=17)
+    gout = synth.hash_normal(N * P, 162, gpu)
+
+    def run(fused):
+        m.zero_grad()
+        ctx = ctx0.clone().requires_grad_()
+        if fused:
+            lp = scorer_crf_logprob(m, ctx, iv, projection=proj)
+        else:
+            S, b = m(ctx)
+            lp = CRF.NeuralSemiCRFInterval(S.flatten(-2, -1), b.flatten(-2, -1)).logProb(iv)
+        (lp * gout).sum().backward()
+        return lp.detach(), ctx.grad.clone(), m.map[0].weight.grad.clone(), m.map[0].bias.grad.clone()
+
+    a, b = run(True), run(False)
+    for x, y, name in zip(a, b, ("logp", "dctx", "dW", "dbias")):
+        assert bool(torch.isfinite(x).all()), name
+        err = float((x - y).abs().max()) / (float(y.abs().max()) + 1e-30)
+        assert err < (1e-3 if name == "dbias" else 2e-4), (name, err)
+    assert _lib.device_status() == 0
