@@ -1495,3 +1495,43 @@ def test_fused_scorer_crf_expansion_factor(gpu, proj):
         err = float((x - y).abs().max()) / (float(y.abs().max()) + 1e-30)
         assert err < (1e-3 if name == "dbias" else 2e-4), (name, err)
     assert _lib.device_status() == 0
+
+
+@pytest.mark.gpu
+def test_fused_merged_projection_with_bf16x3_contraction(gpu):
+    """The merged projection together with the opt-in three-limb bf16 contraction (the row constant then goes through
+    interval_score_tile3_kernel's epilogue): logProb and gradients against the unfused exact-fp32 route."""
+    from transkun_amd import CRF, _lib, synth
+    from transkun_amd.fused import scorer_crf_logprob
+    from transkun_amd.scorer import ScaledInnerProductIntervalScorer
+    _lib.set_impl(0)
+    N, P, T, D = 2, 10, 200, 128
+    torch.manual_seed(99)
+    m = ScaledInnerProductIntervalScorer(D, 1).to(gpu)
+    with torch.no_grad():
+        m.map[0].weight.mul_(0.3)
+    ctx0 = synth.hash_normal(N * P * T * D, 261, gpu).view(N, P, T, D) * 0.5
+    iv = synth.synthetic_intervals(T, N * P, seed=27)
+    gout = synth.hash_normal(N * P, 262, gpu)
+
+    def run(fused):
+        m.zero_grad()
+        ctx = ctx0.clone().requires_grad_()
+        if fused:
+            m.contraction = "bf16x3"
+            try:
+                lp = scorer_crf_logprob(m, ctx, iv, projection="merged")
+            finally:
+                m.contraction = "fp32"
+        else:
+            S, b = m(ctx)
+            lp = CRF.NeuralSemiCRFInterval(S.flatten(-2, -1), b.flatten(-2, -1)).logProb(iv)
+        (lp * gout).sum().backward()
+        return lp.detach(), ctx.grad.clone(), m.map[0].weight.grad.clone(), m.map[0].bias.grad.clone()
+
+    a, b = run(True), run(False)
+    for x, y, name in zip(a, b, ("logp", "dctx", "dW", "dbias")):
+        assert bool(torch.isfinite(x).all()), name
+        err = float((x - y).abs().max()) / (float(y.abs().max()) + 1e-30)
+        assert err < (2e-3 if name == "dbias" else 4e-4), (name, err)
+    assert _lib.device_status() == 0
