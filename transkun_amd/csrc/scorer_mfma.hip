@@ -1332,7 +1332,7 @@ static int launch_score_tile3(const float* q, const float* k, const float* diag,
 
 void launch_interval_score_tiled(const float* q, const float* k, const float* diag, const float* rowc, int C, int T, int D,
                                  long long ldq, long long ldk, long long ldd, long long ldrc, float qscale, int mode, int full,
-                                 float* S, hipStream_t stream, int group, int pitch, int dbg);      // scorer_tiled.hip
+                                 float* S, hipStream_t stream, int group, int pitch);      // scorer_tiled.hip
 
 // test hook: force one of the forward kernels (0 register loads, 32 streaming, 64 / 128 shared-operand tiles, 2 the tiles with
 // the epilogue inside the contraction loop (scorer_tiled.hip); -1 = auto)
@@ -1372,7 +1372,7 @@ int launch_interval_score_mfma(const float* q, const float* k, const float* diag
         if (tiled_ok && (T >= 256 || slots)) variant = 2;
         if (forced >= 0) variant = forced;
         if (variant == 2 && tiled_ok) {
-            launch_interval_score_tiled(q, k, diag, rowc, C, T, D, ldq, ldk, ldd, ldrc, qscale, mode, full, S, stream, group, pitch, 0);
+            launch_interval_score_tiled(q, k, diag, rowc, C, T, D, ldq, ldk, ldd, ldrc, qscale, mode, full, S, stream, group, pitch);
             return 0;
         }
         if (variant == 2) variant = 128;

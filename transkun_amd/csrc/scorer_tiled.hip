@@ -94,7 +94,7 @@ template <int NCH>
 __global__ __launch_bounds__(512, 2) void interval_score_tiled_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ diag, const float* __restrict__ rowc, int C,
     int T, long long ldq, long long ldk, long long ldd, long long ldrc, float qscale, int mode, int full, float* __restrict__ S,
-    int Cs, SlotGeom G, TileGeom TG, int dbg)
+    int Cs, SlotGeom G, TileGeom TG)
 {
     constexpr int NCI = 4 * NCH;                 // chunks of a full item
     extern __shared__ __attribute__((aligned(16))) char ylds[];
@@ -498,19 +498,19 @@ bool interval_score_tiled_supported(int C, int T, int D, const float* q, const f
 template <int NCH>
 static void launch_tiled(const float* q, const float* k, const float* diag, const float* rowc, int C, int T, long long ldq,
                          long long ldk, long long ldd, long long ldrc, float qscale, int mode, int full, float* S, int Cs,
-                         const SlotGeom& G, const TileGeom& TG, int grid, hipStream_t stream, int dbg)
+                         const SlotGeom& G, const TileGeom& TG, int grid, hipStream_t stream)
 {
     static PerDeviceOnce attr_once;
     if (attr_once.first())
         (void)hipFuncSetAttribute((const void*)interval_score_tiled_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, YLDS);
     hipLaunchKernelGGL(interval_score_tiled_kernel<NCH>, dim3(grid), dim3(512), YLDS, stream, q, k, diag, rowc, C, T, ldq, ldk, ldd, ldrc,
-                       qscale, mode, full, S, Cs, G, TG, dbg);
+                       qscale, mode, full, S, Cs, G, TG);
 }
 
 // rowc may be NULL; group / pitch: the slot layout (scorer_tiles.h).  The caller checked interval_score_tiled_supported.
 void launch_interval_score_tiled(const float* q, const float* k, const float* diag, const float* rowc, int C, int T, int D,
                                  long long ldq, long long ldk, long long ldd, long long ldrc, float qscale, int mode, int full,
-                                 float* S, hipStream_t stream, int group, int pitch, int dbg)
+                                 float* S, hipStream_t stream, int group, int pitch)
 {
     const SlotGeom G = slot_geom(C, group, pitch);
     const int Cs = (C / group) * pitch;
@@ -535,10 +535,10 @@ void launch_interval_score_tiled(const float* q, const float* k, const float* di
     const long long need = (supers + YXCD - 1) / YXCD * 32 * YXCD;
     if (grid > need) grid = (int)need;
     switch (D / 64) {
-    case 1: launch_tiled<1>(q, k, diag, rowc, C, T, ldq, ldk, ldd, ldrc, qscale, mode, full, S, Cs, G, TG, grid, stream, dbg); break;
-    case 2: launch_tiled<2>(q, k, diag, rowc, C, T, ldq, ldk, ldd, ldrc, qscale, mode, full, S, Cs, G, TG, grid, stream, dbg); break;
-    case 3: launch_tiled<3>(q, k, diag, rowc, C, T, ldq, ldk, ldd, ldrc, qscale, mode, full, S, Cs, G, TG, grid, stream, dbg); break;
-    default: launch_tiled<4>(q, k, diag, rowc, C, T, ldq, ldk, ldd, ldrc, qscale, mode, full, S, Cs, G, TG, grid, stream, dbg); break;
+    case 1: launch_tiled<1>(q, k, diag, rowc, C, T, ldq, ldk, ldd, ldrc, qscale, mode, full, S, Cs, G, TG, grid, stream); break;
+    case 2: launch_tiled<2>(q, k, diag, rowc, C, T, ldq, ldk, ldd, ldrc, qscale, mode, full, S, Cs, G, TG, grid, stream); break;
+    case 3: launch_tiled<3>(q, k, diag, rowc, C, T, ldq, ldk, ldd, ldrc, qscale, mode, full, S, Cs, G, TG, grid, stream); break;
+    default: launch_tiled<4>(q, k, diag, rowc, C, T, ldq, ldk, ldd, ldrc, qscale, mode, full, S, Cs, G, TG, grid, stream); break;
     }
 }
 
