@@ -324,7 +324,7 @@ def _scorer_forward_case(gpu, C, T, D, mode, full):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,P,pitch,T,D", [(1, 8, 8, 130, 64), (1, 6, 8, 200, 128), (2, 5, 8, 257, 192), (4, 90, 96, 691, 256), (3, 34, 64, 300, 128),
-                                            (1, 88, 88, 1024, 256)])
+                                            (1, 88, 88, 1024, 256), (1, 352, 352, 1024, 256)])
 @pytest.mark.parametrize("full", [0, 1])
 @pytest.mark.parametrize("use_rc", [False, True])
 def test_scorer_tiled_bits(gpu, N, P, pitch, T, D, full, use_rc):
