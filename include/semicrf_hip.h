@@ -35,6 +35,7 @@ extern "C" {
 #define SEMICRF_EINVAL 1      /* bad shape / null pointer / unsupported size */
 #define SEMICRF_EWORKSPACE 2  /* ws_bytes too small */
 #define SEMICRF_ELAUNCH 3     /* HIP reported an error at enqueue time */
+#define SEMICRF_ETIMEOUT 4    /* an EARLIER sweep gave up on a bounded wait on the device (see semicrf_async_error); nothing enqueued */
 
 /* op ids for semicrf_workspace_bytes */
 #define SEMICRF_OP_LOGZ_FWD 0
@@ -92,6 +93,15 @@ int semicrf_get_impl(void);
  * are poisoned, not silently wrong: logZ, the last row of v / q_out / beta and the gradient's last diagonal cells are NaN
  * for the chains of every workgroup that saw a timeout, and semicrf_viterbi writes offsets[B] = -1. */
 int semicrf_debug_device_status(void);
+
+/* The asynchronous error word, WITHOUT synchronising: nonzero (the device's code, 2..13) when a sweep enqueued earlier by this
+ * process has given up on a bounded hand-off wait since the last look; reading clears it.  Every sweep entry point
+ * (semicrf_logz_fwd / _logz_bwd / _beta / _viterbi / _logprob_*) looks first and returns SEMICRF_ETIMEOUT -- enqueueing nothing -- so
+ * that a time-out is an ERROR on the caller's next call at the latest, not only NaN-poisoned outputs; a caller that synchronises
+ * (reads results on the host) can ask here right after its synchronisation.  The word is raised by the device with a
+ * system-scope store when the wait gives up, i.e. before the poisoned outputs are written.  (Error convention of the boundary:
+ * SURVEY.md 8b -- the reference raises on every failure; it has no asynchronous ones.) */
+int semicrf_async_error(void);
 
 /* Host-side view of the sweeps' workgroup -> role map (test hook, no device work): the role ticket of workgroup `block`
  * in a launch of `grid` workgroups of which `n_spine` are ring workgroups.  Tickets < n_spine are rings (ticket = the
@@ -178,6 +188,22 @@ int semicrf_logprob_fwd(const float* score, const float* noise, int T, int B, co
 int semicrf_logprob_bwd(const float* score, const float* noise, const float* v, const float* logZ, const float* gout,
                         int gout_stride, int T, int B, const int32_t* pairs, int64_t K, const int32_t* offsets,
                         float* dScore, float* dNoise, void* ws, size_t ws_bytes, semicrf_stream_t stream);
+
+/*
+ * The two gradient entry points with flags (replacing the same reference lines as semicrf_logz_bwd / semicrf_logprob_bwd).
+ */
+/* flags of semicrf_logz_bwd_f / semicrf_logprob_bwd_f */
+#define SEMICRF_GRAD_UPPER_IS_ZERO 1   /* the caller's promise: every cell begin > end of dScore already holds +0.0f; the call does
+                                        * not write them (a third of the bytes the gradient sweep moves).  transkun_amd keeps a pool
+                                        * of gradient buffers whose upper triangle this library zeroed and nobody has written since
+                                        * (transkun_amd/CRF: _GradPool); the result is the same dense tensor with an exactly-zero
+                                        * upper triangle that NeuralSemiCRFInterval.py:436-440, :469-472 hand to autograd. */
+int semicrf_logz_bwd_f(const float* score, const float* noise, const float* v, const float* logZ,
+                       const float* gout, int T, int B, float* dScore, float* dNoise, float* q_out, int flags,
+                       void* ws, size_t ws_bytes, semicrf_stream_t stream);
+int semicrf_logprob_bwd_f(const float* score, const float* noise, const float* v, const float* logZ, const float* gout,
+                          int gout_stride, int T, int B, const int32_t* pairs, int64_t K, const int32_t* offsets,
+                          float* dScore, float* dNoise, int flags, void* ws, size_t ws_bytes, semicrf_stream_t stream);
 
 /*
  * Interval-score construction.  Replaces: ScaledInnerProductIntervalScorer.forward after the

@@ -86,3 +86,26 @@ def grad_weights(T):
 def rel_err(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0))) if a.size else 0.0
+
+
+def score_backward_torch(dS, q, k, N, P, T, D, mode, full=False):
+    """Plain-torch differentiation of the interval scorer (LayersTransformer.py:410-433) for a cotangent dS [T,T,N,P]: the
+    reference the HIP backward kernels are tested against (test infrastructure; the product has no torch formulation)."""
+    import math
+    import torch
+    C = N * P
+    g = dS.reshape(T, T, C).permute(2, 0, 1)                     # [C, e, b]
+    t = torch.arange(T, device=g.device)
+    ln = (t[:, None] - t[None, :]).abs().to(torch.float32)
+    if mode == 1:
+        ln = ln.sqrt()
+    elif mode == 2:
+        ln = torch.ones_like(ln)
+    gl = g * ln
+    if not full:
+        gl = torch.tril(gl)                                       # only e >= b was produced by the forward
+    qs = 1.0 / math.sqrt(D)
+    dq = torch.bmm(gl, k) * qs                                    # [C,T,D]
+    dk = torch.bmm(gl.transpose(1, 2), q) * qs
+    ddiag = torch.diagonal(g, dim1=1, dim2=2)                     # [C,T]
+    return dq.view(N, P, T, D), dk.view(N, P, T, D), ddiag.reshape(N, P, T).contiguous()

@@ -85,3 +85,62 @@ def test_cpu_ops_check_their_arguments():
     with pytest.raises(RuntimeError):
         ops.viterbi(score, noise, torch.zeros(B, dtype=torch.int64), True, False, torch.empty(2 * T * B, 2, dtype=torch.int32),
                     torch.empty(B + 1, dtype=torch.int32), ws)
+
+
+def _restated_logz(score, noise):
+    """NeuralSemiCRFInterval.py:206-246 restated with torch ops (float64, autograd-traceable) -- test infrastructure."""
+    import torch.nn.functional as F
+    T = score.shape[0]
+    v = [F.softplus(score[0, 0])]
+    for i in range(1, T):
+        cand = torch.stack([v[i - 1] + noise[i - 1]] + [v[j] + score[i, j] for j in range(i)])
+        v.append(torch.logsumexp(cand, 0) + F.softplus(score[i, i]))
+    return v[-1]
+
+
+@pytest.mark.parametrize("mask", ["one_cell", "whole_row"])
+def test_masked_cells_cpu(mask):
+    """-inf scores (masked intervals): torch.logsumexp ignores them and the reference's gradients stay finite; the host
+    kernels must too (ADVICE r3: Lse::push(-inf) on an empty accumulator gave NaN)."""
+    from transkun_amd import CRF, synth
+    T, B = 6, 5
+    score, noise = synth.crf_inputs(T, B, 11, "cpu")
+    if mask == "one_cell":
+        score[T - 1, 0, :] = float("-inf")
+    else:                                   # every way into frame 1: the skip and the interval (0, 1)
+        noise[0, :] = float("-inf")
+        score[1, 0, :] = float("-inf")
+    s64 = score.double().requires_grad_(); n64 = noise.double().requires_grad_()
+    want = _restated_logz(s64, n64)
+    want.sum().backward()
+    s = score.clone().requires_grad_(); n = noise.clone().requires_grad_()
+    got = CRF.NeuralSemiCRFInterval(s, n).computeLogZ()
+    assert torch.isfinite(got).all() and torch.allclose(got.double(), want.detach(), rtol=1e-5)
+    got.sum().backward()
+    assert torch.isfinite(s.grad).all() and torch.isfinite(n.grad).all()
+    if mask == "one_cell":                  # (an unreachable frame: autograd of logsumexp over nothing but -inf is NaN in the restatement)
+        tril = torch.tril(torch.ones(T, T, dtype=torch.bool)).unsqueeze(-1)
+        assert torch.allclose(s.grad.double() * tril, s64.grad * tril, atol=2e-6)
+        assert torch.allclose(n.grad.double(), n64.grad, atol=2e-6)
+
+
+def test_eval_path_gradient_overlapping_intervals_cpu():
+    """evalPath is linear in the noise: a gap counts once, minus once per interval covering it -- also when intervals overlap
+    (outside evalPath's contract, but the backward must stay the derivative of the forward: ADVICE r3)."""
+    from transkun_amd import CRF, synth
+    T, B = 7, 2
+    score, noise = synth.crf_inputs(T, B, 5, "cpu")
+    n = noise.clone().requires_grad_(); s = score.clone().requires_grad_()
+    crf = CRF.NeuralSemiCRFInterval(s, n)
+    intervals = [[(0, 3), (2, 4)], [(1, 1), (5, 6)]]
+    out = crf.evalPath(intervals)
+    out.backward(torch.tensor([2.0, -1.0]))
+    cover = torch.zeros(T - 1, B)
+    for c, lst in enumerate(intervals):
+        for b, e in lst:
+            cover[b:e, c] += 1
+    assert torch.equal(n.grad, (1 - cover) * torch.tensor([2.0, -1.0]))
+    # and it is the derivative of the forward
+    eps = torch.zeros_like(noise); eps[2, 0] = 1.0
+    d = CRF.NeuralSemiCRFInterval(score, noise + eps).evalPath(intervals) - CRF.NeuralSemiCRFInterval(score, noise).evalPath(intervals)
+    assert abs(float(d[0]) - float(n.grad[2, 0]) / 2.0) < 1e-5

@@ -203,3 +203,100 @@ def test_flat_grad_bucket_two_ranks(tmp_path):
             for i, g in enumerate(p[step]["grads"]):
                 want = sum(q[step]["local"][i] for q in parts)
                 assert torch.allclose(g, want, rtol=1e-6, atol=1e-9)
+
+
+def _emulated_reduce_scatter(output, input, op=None, group=None, async_op=False):
+    """reduce_scatter_tensor on a backend that has none (gloo): the SUM of everybody's `input`, my slice of it into `output`
+    -- which the bucket passes as a VIEW of `input` (in place), exactly as it does over RCCL."""
+    full = input.clone()
+    dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    output.copy_(full.view(world, -1)[rank])
+
+
+def _rs_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from transkun_amd import synth
+    from transkun_amd.dist import FlatGradBucket
+    from transkun_amd.trainstep import SegmentModel, train_step
+    torch.manual_seed(0)
+    model = SegmentModel(size=8, total_params=5003)           # an odd total: the flat buffer is padded to world * 64 elements
+    bucket = FlatGradBucket(model.parameters())
+    # drive the branch the RCCL backend takes (slice ownership flat.view(world, -1)[rank], in-place reduce-scatter, in-place
+    # all-gather) over gloo: the backend NAME is faked, reduce_scatter_tensor is emulated, all_gather_into_tensor is gloo's own
+    bucket._backend = lambda: "nccl"
+    real_rs = dist.reduce_scatter_tensor
+    dist.reduce_scatter_tensor = _emulated_reduce_scatter
+    N, P, T = 2, 3, 10
+    out = []
+    try:
+        for step in range(2):
+            ctx = synth.hash_normal(N * P * T * 8, 70 + rank + 10 * step, "cpu").view(N, P, T, 8)
+            if step == 1:
+                for p in model.parameters():                  # what optimizer.zero_grad(set_to_none=True) leaves behind
+                    p.grad = None
+            stats, ncoll = train_step(model, ctx, None, log_prob=_cpu_log_prob, bucket=bucket)
+            local = SegmentModel(size=8, total_params=5003)
+            local.load_state_dict(model.state_dict())
+            logp = _cpu_log_prob(local.scorer, ctx, None).view(N, -1)
+            (-logp.sum(-1).mean() / 50).backward()
+            out.append({"ncoll": ncoll, "bytes": bucket.bytes_per_rank, "rebound": bucket.rebound,
+                        "grads": [p.grad.clone() for p in model.parameters()],
+                        "views": all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket._views)),
+                        "local": [(p.grad.clone() if p.grad is not None else torch.full_like(p, 1e-3)) for p in local.parameters()]})
+    finally:
+        dist.reduce_scatter_tensor = real_rs
+    torch.save(out, os.path.join(out_dir, f"rs{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_grad_bucket_reduce_scatter_branch_two_ranks(tmp_path):
+    """The reduce-scatter + all-gather branch of FlatGradBucket.exchange (the one RCCL takes) at world size 2, through a faked
+    backend name over gloo -- so that the slice arithmetic is not executed for the first time on an 8-GPU node -- and the
+    rebinding of gradients that `p.grad = None` / zero_grad(set_to_none=True) moved out of the flat buffer."""
+    world = 2
+    mp.spawn(_rs_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(tmp_path, f"rs{r}.pt"), weights_only=False) for r in range(world)]
+    for step in range(2):
+        for p in parts:
+            assert p[step]["ncoll"] == 2 and p[step]["bytes"] > 0 and p[step]["views"]
+            for i, g in enumerate(p[step]["grads"]):
+                want = sum(q[step]["local"][i] for q in parts)
+                assert torch.allclose(g, want, rtol=1e-6, atol=1e-9)
+    assert parts[0][0]["rebound"] == 0 and parts[0][1]["rebound"] == 3          # step 1 found every .grad gone and put it back
+
+
+def test_flat_grad_bucket_guards_single_process():
+    """No process group: the aliasing checks and the step bookkeeping of FlatGradBucket."""
+    from transkun_amd.dist import FlatGradBucket
+    torch.manual_seed(0)
+    m = torch.nn.Linear(4, 3)
+    b = FlatGradBucket(m.parameters())
+    x = torch.ones(2, 4)
+    # (1) gradients that autograd wrote into fresh tensors (after p.grad = None) are moved back before the exchange
+    b.zero(); b.arm()
+    for p in m.parameters():
+        p.grad = None
+    m(x).sum().backward()
+    assert b.wait() == 0 and b.rebound == 2
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(b.params, b._views))
+    assert torch.allclose(m.weight.grad, torch.full((3, 4), 2.0)) and torch.allclose(b.flat[:12], torch.full((12,), 2.0))
+    # (2) micro-batches: unarmed backward passes accumulate, arm() before the last one, one exchange
+    b.zero()
+    m(x).sum().backward()
+    b.arm()
+    m(x).sum().backward()
+    assert b.wait() == 0
+    assert torch.allclose(m.weight.grad, torch.full((3, 4), 4.0))
+    # (3) a second backward pass behind ONE arm(): its gradients came after the exchange -> wait() raises
+    b.zero(); b.arm()
+    m(x).sum().backward()
+    m(x).sum().backward()
+    with pytest.raises(RuntimeError, match="after this step's exchange"):
+        b.wait()
+    # (4) wait() without arm(): the exchange happens there; a next step is clean again
+    b.zero()
+    m(x).sum().backward()
+    assert b.wait() == 0 and b._exchanged

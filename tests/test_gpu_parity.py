@@ -370,6 +370,34 @@ def test_scorer_strided_operands(gpu, C, T, D):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,P,T,D,full", [(1, 6, 150, 512, False), (2, 5, 70, 320, False), (1, 4, 66, 48, False), (1, 3, 40, 8, False),
+                                           (1, 6, 150, 256, True), (1, 4, 70, 512, True)])
+def test_scorer_backward_every_size(gpu, N, P, T, D, full):
+    """The interval-score backward reaches the HIP kernels for EVERY contraction size (D = 512 -- expansionFactor
+    2 at size 256 -- used to drop to torch.bmm): column chunks beyond 256, zero padding for sizes that are no multiple of 32, and
+    the reference's full square as a second, transposed pass.  Checked against the plain-torch differentiation (test helper)."""
+    from conftest import score_backward_torch
+    from transkun_amd import _lib, synth
+    from transkun_amd.scorer import QPAD, _IntervalScore
+    _lib.set_impl(0)
+    C = N * P
+    q = synth.hash_normal(C * T * D, 61, gpu).view(N, P, T, D).contiguous()
+    k = synth.hash_normal(C * T * D, 62, gpu).view(N, P, T, D).contiguous()
+    dg = synth.hash_normal(C * T, 63, gpu).view(N, P, T).contiguous()
+    qda = torch.cat([q, dg[..., None], q.new_zeros(N, P, T, QPAD - 1)], dim=-1).requires_grad_()
+    ka = k.clone().requires_grad_()
+    S, b = _IntervalScore.apply(qda, ka, N, P, T, D, 0, full)
+    cot = synth.hash_normal(T * T * C, 64, gpu).view(T, T, N, P)
+    S.backward(cot)
+    ref = score_backward_torch(cot, q.view(C, T, D), k.view(C, T, D), N, P, T, D, 0, full)
+    for got, want, name in ((qda.grad[..., :D], ref[0], "dq"), (ka.grad, ref[1], "dk"), (qda.grad[..., D], ref[2], "ddiag")):
+        scale = float(want.abs().max()) + 1e-30
+        err = float((got - want).abs().max()) / scale
+        assert err < 2e-5, (name, err)
+    assert _lib.device_status() == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,P,T,D,ls", [(1, 5, 70, 64, "linear"), (2, 9, 97, 256, "linear"), (1, 3, 33, 32, "sqrt"),
                                          (1, 8, 64, 128, "none"), (3, 11, 130, 96, "linear")])
 def test_scorer_backward_kernel(gpu, N, P, T, D, ls):
@@ -389,7 +417,8 @@ def test_scorer_backward_kernel(gpu, N, P, T, D, ls):
     S, b = _IntervalScore.apply(qda, ka, N, P, T, D, _lib.LEN_MODES[ls], False)
     cot = synth.hash_normal(T * T * C, 54, gpu).view(T, T, N, P)          # dense: e < b entries must not contribute
     S.backward(cot)
-    ref = _IntervalScore._backward_torch(cot, q.view(C, T, D), k.view(C, T, D), N, P, T, D, _lib.LEN_MODES[ls], False)
+    from conftest import score_backward_torch
+    ref = score_backward_torch(cot, q.view(C, T, D), k.view(C, T, D), N, P, T, D, _lib.LEN_MODES[ls], False)
     assert float(qda.grad[..., D + 1:].abs().max()) == 0.0
     for got, want, name in ((qda.grad[..., :D], ref[0], "dq"), (ka.grad, ref[1], "dk"), (qda.grad[..., D], ref[2], "ddiag")):
         scale = float(want.abs().max()) + 1e-30
@@ -629,9 +658,9 @@ def test_leased_workspace_bitwise(gpu):
             g = synth.hash_normal(B, 5, gpu)
             ds = torch.empty(T, T, B, device=gpu); dn = torch.empty(max(T - 1, 0), B, device=gpu); q = torch.empty(T, B, device=gpu)
             if op == "bwd0":
-                _lib.ops().logz_bwd(s, nz, v, lz, g, ds, dn, none, False, ws)
+                _lib.ops().logz_bwd(s, nz, v, lz, g, ds, dn, none, False, 0, ws)
                 return (ds, dn)
-            _lib.ops().logz_bwd(s, nz, v, lz, g, ds, dn, q, True, ws)
+            _lib.ops().logz_bwd(s, nz, v, lz, g, ds, dn, q, True, 0, ws)
             return (ds, dn, q)
         pairs = torch.empty(B * 2 * T, 2, dtype=torch.int32, device=gpu); offs = torch.empty(B + 1, dtype=torch.int32, device=gpu)
         _lib.ops().viterbi(s, nz, offs, False, False, pairs, offs, ws)
@@ -1535,3 +1564,153 @@ def test_fused_merged_projection_with_bf16x3_contraction(gpu):
         err = float((x - y).abs().max()) / (float(y.abs().max()) + 1e-30)
         assert err < (2e-3 if name == "dbias" else 4e-4), (name, err)
     assert _lib.device_status() == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# round 4: gradient buffers with a standing zero upper triangle, loud time-outs
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("leaf", [True, False], ids=["leaf_score", "intermediate_score"])
+def test_grad_pool_upper_triangle_stays_exact(gpu, oracle, leaf):
+    """The dense gradient's zeros (begin > end; NeuralSemiCRFInterval.py:436-440, :469-472) are written ONCE per pooled buffer
+    (SEMICRF_GRAD_UPPER_IS_ZERO afterwards).  Six consecutive steps -- one after the test scribbled into score.grad in place, one
+    after it kept a view alive -- must all return a gradient whose upper triangle is exactly zero and whose lower triangle equals
+    the first step's (a fully written buffer) bit for bit."""
+    import importlib
+    from transkun_amd import CRF, synth
+    nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
+    T, B = 256, 96                                      # 25 MB: above the pool's threshold
+    score, noise = synth.crf_inputs(T, B, 321, gpu)
+    intervals = synth.synthetic_intervals(T, B, seed=3)
+    nsci.grad_pool_clear()
+    pool = nsci._GRAD_POOL
+    h0, m0 = pool.hits, pool.misses
+    upper = torch.triu(torch.ones(T, T, dtype=torch.bool, device=gpu), diagonal=1)
+    first = None
+    kept_view = None
+    for step in range(6):
+        if leaf:
+            s = score.clone().requires_grad_()
+            src = s
+        else:
+            src = score.clone().requires_grad_()
+            s = src * 1.0                                # the CRF's input is an intermediate tensor, as in the model
+            s.retain_grad()
+        n = noise.clone().requires_grad_()
+        lp = CRF.NeuralSemiCRFInterval(s, n).logProb(intervals)
+        (-lp.sum() / B).backward()
+        g = s.grad
+        assert g.shape == (T, T, B)
+        assert float(g[upper].abs().max()) == 0.0 and not torch.signbit(g[upper]).any(), f"step {step}: upper triangle not +0"
+        if first is None:
+            first = g.clone()
+        else:
+            assert torch.equal(g, first), f"step {step}"
+        if step == 2:
+            g.add_(1.0)                                  # an in-place edit by the caller: the buffer must be written in full next time
+        if step == 3:
+            kept_view = g[5]                             # somebody still looks at the memory: it must not be handed out
+            kept_copy = kept_view.clone()
+        del g, s, src, n, lp
+    assert torch.equal(kept_view, kept_copy), "a gradient buffer was reused while a view of it was alive"
+    assert pool.hits - h0 >= 2, (pool.hits - h0, pool.misses - m0)          # the zeros were skipped at least twice
+    # and against the oracle (the first step's full write is the reference for the others)
+    logz, grad, gn, _, _ = oracle.forward_backward(score.cpu().numpy(), noise.cpu().numpy())
+    want = grad / B                                      # d(-logProb.sum() / B) = (marginals - onehot(path)) / B
+    for c, lst in enumerate(intervals):
+        for b, e in lst:
+            want[e, b, c] -= 1.0 / B
+    assert np.max(np.abs(first.cpu().numpy() - want)) < 2e-5
+    nsci.grad_pool_clear()
+
+
+@pytest.mark.gpu
+def test_untrusted_lease_is_loud(gpu):
+    """A leased workspace that is not in the state its last launch left (here: the test overwrites the generation word) must
+    not be used silently: the launch poisons its outputs (NaN), raises the device status AND the asynchronous error word, the
+    NEXT call raises RuntimeError (SEMICRF_ETIMEOUT, nothing enqueued), and the call after that is correct again."""
+    import importlib
+    from transkun_amd import CRF, _lib, synth
+    nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
+    _lib.set_impl(0)
+    T, B = 333, 44
+    score, noise = synth.crf_inputs(T, B, 77, gpu)
+    crf = CRF.NeuralSemiCRFInterval(score, noise)
+    good = crf.computeLogZ().clone()
+    good2 = crf.computeLogZ().clone()                    # the lease is clean now
+    torch.cuda.synchronize()
+    assert torch.equal(good, good2) and _lib.async_error() == 0
+    ws = _lib.leased_workspace(_lib.OP_LOGZ_FWD, T, B, gpu)
+    ws.view(torch.int32)[96] = 12345                     # CTRL_GEN of chain chunk 0 (persist.hip)
+    bad = crf.computeLogZ()
+    torch.cuda.synchronize()
+    assert torch.isnan(bad).all(), "an untrusted workspace produced numbers"
+    with pytest.raises(RuntimeError, match="earlier sweep"):
+        crf.computeLogZ()
+    assert _lib.device_status() == 13
+    again = crf.computeLogZ()
+    torch.cuda.synchronize()
+    assert torch.equal(again, good) and _lib.async_error() == 0 and _lib.device_status() == 0
+    # decode reports the same way, at its own synchronisation
+    ws = _lib.leased_workspace(_lib.OP_VITERBI, T, B, gpu)
+    want = crf.decode(); crf.decode()
+    words = ws.view(torch.int32)
+    # the sweep's own workspace lies behind u / code / region / counts (csrc/api.hip: semicrf_viterbi), each 256-byte aligned
+    carve = lambda n: (n + 255) // 256 * 256
+    pbase = 2 * carve(T * B * 4) + carve(B * 2 * T * 2 * 4) + carve(B * 4)
+    words[pbase // 4 + 96] = 54321
+    with pytest.raises(RuntimeError, match="timed out"):
+        crf.decode()
+    assert _lib.device_status() == 13
+    assert crf.decode() == want and _lib.async_error() == 0
+
+
+_COTENANT = r"""
+import os, sys, json
+import numpy as np, torch
+sys.path.insert(0, {root!r})
+from transkun_amd import CRF, _lib, synth
+dev = torch.device("cuda:0")
+T, B = 512, 352
+score, noise = synth.crf_inputs(T, B, 5, dev)
+crf = CRF.NeuralSemiCRFInterval(score.clone().requires_grad_(), noise.clone().requires_grad_())
+out = {{"cus": torch.cuda.get_device_properties(0).multi_processor_count}}
+try:
+    lz = crf.computeLogZ()
+    lz.sum().backward()
+    torch.cuda.synchronize()
+    out["nan_logz"] = bool(torch.isnan(lz).any()); out["nan_grad"] = bool(torch.isnan(crf.score.grad).any())
+    out["logz"] = lz.detach().cpu().numpy().tolist()
+    out["async"] = _lib.async_error()
+    out["raised"] = False
+except RuntimeError as ex:
+    out["raised"] = True; out["msg"] = str(ex)[:200]
+out["status"] = _lib.device_status()
+print("RESULT " + json.dumps(out))
+"""
+
+
+@pytest.mark.gpu
+def test_cotenant_cu_mask_is_never_silent(gpu, tmp_path):
+    """The persistent sweeps need every workgroup resident.  Under a CU mask that hides most of the chip (what a co-tenant
+    process holding compute units looks like to the dispatcher) a launch must either still compute the right numbers or be LOUD:
+    NaN-poisoned outputs together with a raised error word / RuntimeError -- never NaN (or garbage) returned as success."""
+    import json, subprocess, sys
+    from transkun_amd import CRF, synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    score, noise = synth.crf_inputs(512, 352, 5, gpu)
+    want = CRF.NeuralSemiCRFInterval(score, noise).computeLogZ().cpu().numpy()
+    script = tmp_path / "cotenant.py"
+    script.write_text(_COTENANT.format(root=root))
+    for mask in ("0:0-63", "0:0-191"):
+        env = dict(os.environ, HSA_CU_MASK=mask)
+        r = subprocess.run(["timeout", "150", sys.executable, str(script)], capture_output=True, text=True, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+        assert lines, (mask, r.returncode, r.stderr[-1500:])
+        out = json.loads(lines[-1][7:])
+        if out["raised"]:
+            continue                                      # loud
+        if out["nan_logz"] or out["nan_grad"]:
+            assert out["async"] != 0 or out["status"] != 0, (mask, out)      # poisoned AND reported
+        else:
+            assert out["status"] == 0 and np.max(np.abs(np.asarray(out["logz"]) - want) / np.abs(want)) < 1e-5, (mask, out)

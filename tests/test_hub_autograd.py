@@ -28,7 +28,7 @@ def nsci(monkeypatch):
         iv = [[tuple(map(int, pairs[i])) for i in range(int(offsets[c]), int(offsets[c + 1]))] for c in range(score.shape[2])]
         return torch.from_numpy(np.asarray(cpu_oracle.eval_path(iv, score.numpy(), noise.numpy()), np.float32))
 
-    def eval_path_bwd(g, T, B, pairs, offsets, dscore, dnoise, K):
+    def eval_path_bwd(g, T, B, pairs, offsets, dscore, dnoise, K, pooled=False):
         for c in range(B):
             covered = np.zeros(max(T - 1, 0), bool)
             for i in range(int(offsets[c]), int(offsets[c + 1])):

@@ -158,16 +158,118 @@ def _logz_fwd_raw(score, noise, want_v: bool):
     return logz, (v if want_v else None)
 
 
+# --------------------------------------------------------------------------------------
+# the dense gradient's buffers
+# --------------------------------------------------------------------------------------
+# The reference's contract is a DENSE [T,T,B] gradient whose upper triangle (begin > end) is exactly zero
+# (NeuralSemiCRFInterval.py:436-440, :469-472).  Those zeros are a third of the bytes the gradient sweep moves (0.74 of
+# 2.22 GB at T=1024, NBatch=352) and they never change.  The pool below keeps the MEMORY of gradient tensors this library
+# has fully written once (zeros included) and hands it out again -- with SEMICRF_GRAD_UPPER_IS_ZERO, so that the sweep skips
+# the zeros -- only while both hold:
+#   * nothing else references the storage (every tensor that aliased it -- score.grad, views, what autograd kept -- is gone);
+#   * the version counter the handed-out tensor shares with all of its aliases is where the library's last write left it:
+#     any in-place operation on the gradient by anybody (grad.add_(..), zero_(), an optimizer, AccumulateGrad adding a second
+#     gradient into it) moves the counter, and the buffer is then written in full (zeros included) on its next use.
+# The pool keeps `P.detach()` (same storage, same version counter, its own TensorImpl) and not P itself: autograd takes a
+# gradient as .grad without a copy only when nobody else holds the tensor object.
+GRAD_UPPER_IS_ZERO = 1          # include/semicrf_hip.h: SEMICRF_GRAD_UPPER_IS_ZERO
+
+
+def _storage_users(t: torch.Tensor) -> int:
+    st = t.untyped_storage()
+    return torch._C._storage_Use_Count(st._cdata) - 1           # minus the temporary `st`
+
+
+class _GradPool:
+    def __init__(self):
+        import threading
+        self.lock = threading.Lock()
+        self.entries = []            # [key, keeper, version] -- most recently used last
+        self.enabled = not os.environ.get("SEMICRF_NO_GRAD_POOL")
+        self.max_bytes = int(os.environ.get("SEMICRF_GRAD_POOL_BYTES", str(8 << 30)))
+        self.min_bytes = 16 << 20    # smaller gradients: the zeros cost microseconds
+        self.hits = self.misses = 0  # statistics (tests, bench)
+
+    def take(self, T: int, B: int, device):
+        """(dscore [T,T,B] fp32, flags): a pooled buffer with flags = GRAD_UPPER_IS_ZERO, or a fresh one with flags 0."""
+        nbytes = 4 * T * T * B
+        if not self.enabled or device.type != "cuda" or nbytes < self.min_bytes or torch.cuda.is_current_stream_capturing():
+            return torch.empty(T, T, B, dtype=torch.float32, device=device), 0, None
+        key = (device.index if device.index is not None else torch.cuda.current_device(),
+               torch.cuda.current_stream(device).cuda_stream, T, B)
+        with self.lock:
+            for i in range(len(self.entries) - 1, -1, -1):
+                k, keeper, ver = self.entries[i]
+                if k == key and _storage_users(keeper) == 1:
+                    del self.entries[i]
+                    if keeper._version == ver:
+                        self.hits += 1
+                        return keeper, GRAD_UPPER_IS_ZERO, key           # keeper becomes the handed-out tensor, see give()
+                    self.misses += 1
+                    return keeper, 0, key                                # written in place since: everything is written again
+            self.misses += 1
+        return torch.empty(T, T, B, dtype=torch.float32, device=device), 0, key
+
+    def give(self, key, dscore: torch.Tensor) -> None:
+        """After the library's last write into `dscore` (its upper triangle holds exact zeros now): remember the memory."""
+        if key is None:
+            return
+        keeper = dscore.detach()
+        nbytes = keeper.numel() * 4
+        with self.lock:
+            self.entries.append([key, keeper, keeper._version])
+            total = 0
+            for i in range(len(self.entries) - 1, -1, -1):               # newest first; drop what exceeds the budget
+                total += self.entries[i][1].numel() * 4
+                if total > max(self.max_bytes, nbytes):
+                    del self.entries[:i + 1]
+                    break
+
+    def rerecord(self, dscore: torch.Tensor) -> None:
+        """The library itself has written cells with begin <= end into a pooled buffer again (the path cells of evalPath's
+        gradient): that write is not an edit of the upper triangle."""
+        if dscore is None:
+            return
+        ptr = dscore.data_ptr()
+        with self.lock:
+            for e in self.entries:
+                if e[1].data_ptr() == ptr:
+                    e[2] = e[1]._version
+
+    def clear(self) -> None:
+        with self.lock:
+            self.entries.clear()
+
+
+_GRAD_POOL = _GradPool()
+
+
+def grad_pool_clear() -> None:
+    """Release the gradient buffers the pool holds (they are otherwise kept until the budget SEMICRF_GRAD_POOL_BYTES, 8 GiB by
+    default, is exceeded; SEMICRF_NO_GRAD_POOL=1 disables the pool)."""
+    _GRAD_POOL.clear()
+
+
+def _raise_async_error(what: str) -> None:
+    """A hand-off wait that timed out on the device poisons its outputs with NaN and raises a pinned host word; wherever the
+    mirror has synchronised anyway it looks at the word (no synchronisation of its own) and turns it into an exception."""
+    code = _lib.async_error()
+    if code:
+        raise RuntimeError(f"{what}: a bounded hand-off wait timed out on the device (code {code}: GPU shared with work that kept "
+                           "part of the persistent kernel from running, or a CU mask?); the results are invalid")
+
+
 def _logz_bwd_raw(score, noise, v, logz, gout, want_q: bool = False):
     if _odd_pad(score):
         ds, dn, q = _logz_bwd_raw(_pad1(score), _pad1(noise), _pad1(v), _pad1(logz), _pad1(gout), want_q)
         return ds[:, :, :-1].contiguous(), dn[:, :-1].contiguous(), (q[:, :-1].contiguous() if q is not None else None)
     T, B = score.shape[0], score.shape[2]
-    dscore = torch.empty_like(score)
+    dscore, flags, pkey = _GRAD_POOL.take(T, B, score.device)
     dnoise = torch.empty_like(noise)
     q = torch.empty((T, B) if want_q else (0,), dtype=torch.float32, device=score.device)
     ws = _lib.leased_workspace(_lib.OP_LOGZ_BWD, T, B, score.device)
-    _lib.ops().logz_bwd(score, noise, v, logz, gout, dscore, dnoise, q, want_q, ws)
+    _lib.ops().logz_bwd(score, noise, v, logz, gout, dscore, dnoise, q, want_q, flags, ws)
+    _GRAD_POOL.give(pkey, dscore)
     return dscore, dnoise, (q if want_q else None)
 
 
@@ -190,10 +292,14 @@ def _empty(device):
     return e
 
 
-def _eval_path_bwd_raw(gout, T, B, pairs, offsets, dscore, dnoise, K: int):
+def _eval_path_bwd_raw(gout, T, B, pairs, offsets, dscore, dnoise, K: int, pooled: bool = False):
+    """pooled: dscore is a gradient buffer this pass got from _logz_bwd_raw and nobody but this library has written to since
+    (the scatter touches cells begin <= end only: the pool's record of the buffer stays valid)."""
     e = _empty(gout.device)
     _lib.ops().eval_path_bwd(gout, T, B, pairs, int(K), offsets, dscore if dscore is not None else e, dscore is not None,
                              dnoise if dnoise is not None else e, dnoise is not None)
+    if pooled:
+        _GRAD_POOL.rerecord(dscore)
 
 
 def _gout(grad_output: torch.Tensor, B: int) -> torch.Tensor:
@@ -239,22 +345,29 @@ class _HubState:
             a = self.acc[tid] = {"ds": None, "dn": None, "paths": [], "shape": None, "dev": None}
             if len(self.acc) > 8:                       # passes that never reached the hub (an error mid-backward)
                 for k in list(self.acc)[:-8]:
+                    if self.acc[k]["ds"] is not None or self.acc[k]["paths"]:
+                        import warnings
+                        warnings.warn("transkun_amd.CRF: more than 8 backward passes through one NeuralSemiCRFInterval object are in "
+                                      "flight; the oldest one's deposited gradient is dropped (re-entrant / multi-threaded backward "
+                                      "sharing one CRF object?) -- its score gradient will be incomplete")
                     del self.acc[k]
         return a
 
     @staticmethod
     def _scatter(a, path):
         g, pairs, offsets, K, T, B = path
-        _eval_path_bwd_raw(g, T, B, pairs, offsets, a["ds"], a["dn"], K)
+        _eval_path_bwd_raw(g, T, B, pairs, offsets, a["ds"], a["dn"], K, pooled=a.get("pristine", False))
 
     def deposit_dense(self, tid, dscore, dnoise):
         a = self._slot(tid)
         if a["ds"] is None:
             a["ds"], a["dn"] = dscore, dnoise
+            a["pristine"] = True                    # straight from _logz_bwd_raw: only this library has written to it
             for p in a["paths"]:
                 self._scatter(a, p)
             a["paths"] = []
         else:
+            a["pristine"] = False
             a["ds"].add_(dscore)
             if dnoise is not None and a["dn"] is not None:
                 a["dn"].add_(dnoise)
@@ -417,13 +530,14 @@ class _LogProb(torch.autograd.Function):
         if _odd_pad(score):
             g = _gout(grad_output, B)
             dscore, dnoise, _ = _logz_bwd_raw(score, noise, v, logz, -g)
-            _eval_path_bwd_raw(g, T, B, pairs, offsets, dscore, dnoise, ctx.K)
+            _eval_path_bwd_raw(g, T, B, pairs, offsets, dscore, dnoise, ctx.K)          # (a padded copy: sliced below, never pooled)
         else:
             g, gstride = _gout_strided(grad_output, B)
-            dscore = torch.empty_like(score)
+            dscore, flags, pkey = _GRAD_POOL.take(T, B, score.device)
             dnoise = torch.empty_like(noise)
             ws = _lib.leased_workspace(_lib.OP_LOGZ_BWD, T, B, score.device)
-            _lib.ops().logprob_bwd(score, noise, v, logz, g, gstride, pairs, int(ctx.K), offsets, dscore, dnoise, ws)
+            _lib.ops().logprob_bwd(score, noise, v, logz, g, gstride, pairs, int(ctx.K), offsets, dscore, dnoise, flags, ws)
+            _GRAD_POOL.give(pkey, dscore)
         return dscore.to(ctx.in_dtypes[0]), dnoise.to(ctx.in_dtypes[1]), None, None
 
 
@@ -466,6 +580,7 @@ def _decode(score, noiseScore, forcedStartPos: Optional[Sequence[int]], forward:
         off_h = offsets.cpu()                      # the one host sync of decode
         total = int(off_h[-1])
         if total < 0:
+            _lib.async_error()                     # consumed here: the next call must not report this time-out again
             raise RuntimeError("semicrf_viterbi: a bounded hand-off wait timed out on the device (GPU shared with work that "
                                "kept part of the persistent kernel from running?); the decode result is invalid")
         pairs_h = pairs[:total].cpu()
@@ -516,7 +631,7 @@ class NeuralSemiCRFInterval:
         """
         self.score = score
         self.noiseScore = noiseScore
-        self._hub = None            # (id(score), id(noiseScore), score alias, noise alias, _HubState)
+        self._hub = None            # (score, noiseScore, score alias, noise alias, _HubState): strong references, compared by identity
 
     def _hubbed(self):
         """(score, noiseScore, hub state) for the differentiable methods: aliases behind this object's private hub node when a

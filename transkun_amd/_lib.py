@@ -40,6 +40,9 @@ _SIGS = {
     "semicrf_set_impl": (None, [_i]),
     "semicrf_get_impl": (ctypes.c_int, []),
     "semicrf_debug_device_status": (ctypes.c_int, []),
+    "semicrf_async_error": (ctypes.c_int, []),
+    "semicrf_logz_bwd_f": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "semicrf_logprob_bwd_f": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "semicrf_debug_wg_ticket": (_i, [_i, _i, _i]),
     "semicrf_debug_score_variant": (None, [_i]),
     "semicrf_logz_fwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
@@ -206,6 +209,12 @@ def set_impl(impl: int) -> None:
 def device_status() -> int:
     """Synchronising debug hook: sticky device status word (0 = OK), cleared on read."""
     return int(load().semicrf_debug_device_status())
+
+
+def async_error() -> int:
+    """The asynchronous error word (semicrf_async_error): nonzero when a sweep enqueued earlier gave up on a bounded wait; reading
+    clears it; never synchronises."""
+    return int(load().semicrf_async_error())
 
 
 def get_impl() -> int:

@@ -88,7 +88,7 @@ int read_and_clear_device_status();
 
 int launch_persist_logz_bwd(const float* score, const float* noise, const float* v, const float* logZ,
                             const float* gout, int T, int B, float* dScore, float* dNoise, float* q_out, void* ws,
-                            hipStream_t stream, int lease, unsigned lease_tag, int gstride = 1, float gscale = 1.0f);
+                            hipStream_t stream, int lease, unsigned lease_tag, int gstride = 1, float gscale = 1.0f, int keep_upper = 0);
 
 static bool use_persist(int T, int B) { return g_impl.load() == 0 && persist_supported(T, B); }
 
@@ -122,6 +122,58 @@ struct Lease { size_t bytes; int op, T, B; bool clean; unsigned count; };
 static std::mutex g_lease_mu;
 static std::unordered_map<void*, Lease> g_leases;
 static unsigned* g_abort_word = nullptr;                 // pinned + mapped: the device address equals the host address
+static std::atomic<bool> g_abort_on_device[64];          // the kernels of device d know the word's address
+
+// The pinned abort word exists for EVERY caller of the sweeps (round 4; until then only for leased workspaces): a bounded wait
+// that timed out on the device raises it with a system-scope store, and the NEXT sweep entry point of this library reports it as
+// SEMICRF_ETIMEOUT instead of launching -- a time-out is loud on every path (the poisoned outputs of the launch that aborted have
+// been handed out by then: nothing synchronises the host; semicrf_async_error lets a caller that does synchronise ask earlier).
+static int ensure_abort_word(hipStream_t stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (g_abort_on_device[dev].load()) return 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return 0;   // not now: the set-up synchronises
+    {
+        std::lock_guard<std::mutex> lk(g_lease_mu);
+        if (!g_abort_word) {
+            void* p = nullptr;
+            if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return 1;
+            memset(p, 0, 64);
+            g_abort_word = (unsigned*)p;
+        }
+    }
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, g_abort_word, 0) != hipSuccess || persist_set_host_abort_word((unsigned*)dp)) return 1;
+    g_abort_on_device[dev].store(true);
+    return 0;
+}
+
+// the code a device-side time-out left behind (0: none); clears it and distrusts every lease
+static unsigned take_async_error()
+{
+    if (!g_abort_word) return 0u;
+    const unsigned code = __atomic_exchange_n(g_abort_word, 0u, __ATOMIC_RELAXED);
+    if (code != 0u) {
+        std::lock_guard<std::mutex> lk(g_lease_mu);
+        for (auto& kv : g_leases) kv.second.clean = false;          // some launch gave up: its workspace is in an unknown state
+    }
+    return code;
+}
+
+// first thing in every sweep entry point
+static int sweep_prologue(const char* what, hipStream_t stream)
+{
+    if (ensure_abort_word(stream)) { set_error("%s: could not set up the device's abort word", what); return SEMICRF_ELAUNCH; }
+    if (const unsigned code = take_async_error()) {
+        set_error("%s: an earlier sweep on this GPU gave up on a bounded hand-off wait (device code %u: the GPU is shared with work that "
+                  "kept part of the persistent kernel from running, or a CU mask hides compute units); the results of that launch "
+                  "and of launches enqueued behind it are invalid (NaN-poisoned).  Nothing was enqueued by this call.", what, code);
+        return SEMICRF_ETIMEOUT;
+    }
+    return SEMICRF_OK;
+}
 
 // what the next sweep into `ws` has to do: 0 ordinary, 1 fill + self-clean, 2 clean already; tag = the lease's launch count
 static int lease_acquire(void* ws, int op, int T, int B, unsigned* tag, hipStream_t stream)
@@ -142,15 +194,12 @@ static int lease_acquire(void* ws, int op, int T, int B, unsigned* tag, hipStrea
             return 0;
         }
     }
-    if (g_abort_word && __atomic_load_n(g_abort_word, __ATOMIC_RELAXED) != 0u) {
-        __atomic_store_n(g_abort_word, 0u, __ATOMIC_RELAXED);
-        for (auto& kv : g_leases) kv.second.clean = false;          // some launch gave up: its workspace is in an unknown state
-    }
+    // (an abort word raised since the entry point's prologue is left for the next prologue: it reports AND distrusts the leases)
     Lease& L = it->second;
     const bool clean = L.clean && L.op == op && L.T == T && L.B == B;
     L.op = op; L.T = T; L.B = B; L.clean = true;                    // the launch enqueued next leaves it clean
     *tag = ++L.count;
-    if (L.count == 0u) *tag = ++L.count;
+    if (L.count == 0u) { *tag = ++L.count; return 1; }              // the count wrapped: the kernel's generation check expects count - 1
     return clean ? 2 : 1;
 }
 // a sweep that could not be enqueued leaves nothing behind, and a launch of the row-sequential kernels (impl 1) carves its
@@ -173,27 +222,14 @@ const char* semicrf_last_error(void) { return g_err; }
 void semicrf_set_impl(int impl) { g_impl.store(impl); }
 int semicrf_get_impl(void) { return g_impl.load(); }
 int semicrf_debug_device_status(void) { return read_and_clear_device_status(); }
+int semicrf_async_error(void) { return (int)take_async_error(); }
 int semicrf_debug_wg_ticket(int n_spine, int grid, int block) { return persist_wg_ticket(n_spine, grid, block); }
 void semicrf_debug_score_variant(int variant) { set_score_variant(variant); }
 
 int semicrf_workspace_register(void* ws, size_t ws_bytes)
 {
     SEMICRF_CHECK_ARG(ws != nullptr && ws_bytes > 0, "workspace is NULL or empty");
-    {
-        std::lock_guard<std::mutex> lk(g_lease_mu);
-        if (!g_abort_word) {
-            void* p = nullptr;
-            if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
-                set_error("hipHostMalloc of the abort word failed"); return SEMICRF_ELAUNCH;
-            }
-            memset(p, 0, 64);
-            g_abort_word = (unsigned*)p;
-        }
-    }
-    void* dp = nullptr;
-    if (hipHostGetDevicePointer(&dp, g_abort_word, 0) != hipSuccess || persist_set_host_abort_word((unsigned*)dp)) {
-        set_error("could not hand the abort word to the device"); return SEMICRF_ELAUNCH;
-    }
+    if (ensure_abort_word(nullptr)) { set_error("could not hand the abort word to the device"); return SEMICRF_ELAUNCH; }
     std::lock_guard<std::mutex> lk(g_lease_mu);
     g_leases[ws] = Lease{ws_bytes, -1, 0, 0, false, 0u};
     return SEMICRF_OK;
@@ -237,6 +273,7 @@ int semicrf_logz_fwd(const float* score, const float* noise, int T, int B, float
 {
     if (int rc = check_common(score, noise, T, B)) return rc;
     SEMICRF_CHECK_ARG(logZ != nullptr, "logZ is NULL");
+    if (int rc = sweep_prologue("semicrf_logz_fwd", (hipStream_t)stream)) return rc;
     Carver cv(ws, ws_bytes);
     // the sweep's own workspace comes FIRST: a leased ws is only clean where the previous launch left it clean, so its place
     // must not depend on which optional outputs the caller passes (v == NULL used to move it behind the scratch alpha: a
@@ -263,9 +300,12 @@ int semicrf_logz_fwd(const float* score, const float* noise, int T, int B, float
 
 static int logz_bwd_impl(const float* score, const float* noise, const float* v, const float* logZ,
                          const float* gout, int gstride, float gscale, int T, int B, float* dScore, float* dNoise, float* q_out,
-                         void* ws, size_t ws_bytes, semicrf_stream_t stream)
+                         int flags, void* ws, size_t ws_bytes, semicrf_stream_t stream)
 {
     if (int rc = check_common(score, noise, T, B)) return rc;
+    SEMICRF_CHECK_ARG((flags & ~SEMICRF_GRAD_UPPER_IS_ZERO) == 0, "unknown flags %d", flags);
+    if (int rc = sweep_prologue("semicrf_logz_bwd", (hipStream_t)stream)) return rc;
+    const int keep_upper = (flags & SEMICRF_GRAD_UPPER_IS_ZERO) ? 1 : 0;
     SEMICRF_CHECK_ARG(v && logZ && gout && dScore, "v/logZ/gout/dScore must be non-NULL");
     SEMICRF_CHECK_ARG(dNoise != nullptr || T == 1, "dNoise is NULL");
     SEMICRF_CHECK_ARG(gstride == 0 || gstride == 1, "gout stride must be 0 (one value for all chains) or 1");
@@ -279,7 +319,7 @@ static int logz_bwd_impl(const float* score, const float* noise, const float* v,
         // beta sweep fused with the marginals: score is read once, dScore written once
         unsigned ltag = 0;
         const int lease = lease_acquire(ws, SEMICRF_OP_LOGZ_BWD, T, B, &ltag, st);
-        if (launch_persist_logz_bwd(score, noise, v, logZ, gout, T, B, dScore, dNoise, q, pws, st, lease, ltag, gstride, gscale)) {
+        if (launch_persist_logz_bwd(score, noise, v, logZ, gout, T, B, dScore, dNoise, q, pws, st, lease, ltag, gstride, gscale, keep_upper)) {
             lease_failed(ws);
             set_error("persistent sweep could not be enqueued (too many chain chunks for this device)"); return SEMICRF_ELAUNCH;
         }
@@ -291,13 +331,20 @@ static int logz_bwd_impl(const float* score, const float* noise, const float* v,
     return SEMICRF_OK;
 }
 
+int semicrf_logz_bwd_f(const float* score, const float* noise, const float* v, const float* logZ,
+                       const float* gout, int T, int B, float* dScore, float* dNoise, float* q_out, int flags, void* ws,
+                       size_t ws_bytes, semicrf_stream_t stream)
+{
+    if (int rc = logz_bwd_impl(score, noise, v, logZ, gout, 1, 1.0f, T, B, dScore, dNoise, q_out, flags, ws, ws_bytes, stream)) return rc;
+    SEMICRF_CHECK_LAUNCH("semicrf_logz_bwd");
+    return SEMICRF_OK;
+}
+
 int semicrf_logz_bwd(const float* score, const float* noise, const float* v, const float* logZ,
                      const float* gout, int T, int B, float* dScore, float* dNoise, float* q_out, void* ws,
                      size_t ws_bytes, semicrf_stream_t stream)
 {
-    if (int rc = logz_bwd_impl(score, noise, v, logZ, gout, 1, 1.0f, T, B, dScore, dNoise, q_out, ws, ws_bytes, stream)) return rc;
-    SEMICRF_CHECK_LAUNCH("semicrf_logz_bwd");
-    return SEMICRF_OK;
+    return semicrf_logz_bwd_f(score, noise, v, logZ, gout, T, B, dScore, dNoise, q_out, 0, ws, ws_bytes, stream);
 }
 
 int semicrf_logprob_fwd(const float* score, const float* noise, int T, int B, const int32_t* pairs, int64_t K,
@@ -316,10 +363,17 @@ int semicrf_logprob_bwd(const float* score, const float* noise, const float* v, 
                         int gout_stride, int T, int B, const int32_t* pairs, int64_t K, const int32_t* offsets, float* dScore,
                         float* dNoise, void* ws, size_t ws_bytes, semicrf_stream_t stream)
 {
+    return semicrf_logprob_bwd_f(score, noise, v, logZ, gout, gout_stride, T, B, pairs, K, offsets, dScore, dNoise, 0, ws, ws_bytes, stream);
+}
+
+int semicrf_logprob_bwd_f(const float* score, const float* noise, const float* v, const float* logZ, const float* gout,
+                          int gout_stride, int T, int B, const int32_t* pairs, int64_t K, const int32_t* offsets, float* dScore,
+                          float* dNoise, int flags, void* ws, size_t ws_bytes, semicrf_stream_t stream)
+{
     SEMICRF_CHECK_ARG(offsets, "offsets must be non-NULL");
     SEMICRF_CHECK_ARG(K >= 0 && K < (1ll << 31) && (K == 0 || pairs), "bad interval count");
     // d logProb = d evalPath - d logZ: the marginals with -gout, then +gout on the path's cells and uncovered gaps
-    if (int rc = logz_bwd_impl(score, noise, v, logZ, gout, gout_stride, -1.0f, T, B, dScore, dNoise, nullptr, ws, ws_bytes, stream)) return rc;
+    if (int rc = logz_bwd_impl(score, noise, v, logZ, gout, gout_stride, -1.0f, T, B, dScore, dNoise, nullptr, flags, ws, ws_bytes, stream)) return rc;
     launch_eval_path_bwd(gout, T, B, (int)K, pairs, offsets, dScore, dNoise, (hipStream_t)stream, gout_stride, 1.0f);
     SEMICRF_CHECK_LAUNCH("semicrf_logprob_bwd");
     return SEMICRF_OK;
@@ -330,6 +384,7 @@ int semicrf_beta(const float* score, const float* noise, int T, int B, float* be
 {
     if (int rc = check_common(score, noise, T, B)) return rc;
     SEMICRF_CHECK_ARG(beta, "beta must be non-NULL");
+    if (int rc = sweep_prologue("semicrf_beta", (hipStream_t)stream)) return rc;
     Carver cv(ws, ws_bytes);
     const bool fast = use_persist(T, B);
     void* pws = fast ? cv.take<char>(persist_workspace_bytes(T, B)) : nullptr;
@@ -357,6 +412,7 @@ int semicrf_viterbi(const float* score, const float* noise, int T, int B, const 
     if (int rc = check_common(score, noise, T, B)) return rc;
     SEMICRF_CHECK_ARG(pairs && offsets && cap >= 0, "pairs/offsets must be non-NULL");
     SEMICRF_CHECK_ARG((long long)B * 2 * T < (1ll << 31), "B*2T exceeds int32 offsets");
+    if (int rc = sweep_prologue("semicrf_viterbi", (hipStream_t)stream)) return rc;
     Carver cv(ws, ws_bytes);
     float* u = cv.take<float>((size_t)T * B);
     int* code = cv.take<int>((size_t)T * B);

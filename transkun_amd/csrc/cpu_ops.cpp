@@ -28,10 +28,11 @@ struct Lse {                                    // running log-sum-exp with exac
     double s;
     inline void push(float x)
     {
+        if (x == -INFINITY) return;             // a masked cell adds nothing (and -inf - -inf would poison the sum with NaN)
         if (x <= m) s += (double)expf(x - m);
         else { s = s * (double)expf(m - x) + 1.0; m = x; }
     }
-    inline float value() const { return m + (float)log(s); }
+    inline float value() const { return s == 0.0 ? -INFINITY : m + (float)log(s); }   // nothing pushed: logsumexp of the empty set
 };
 }  // namespace
 
@@ -59,14 +60,17 @@ void logz_fwd(const float* score, const float* noise, int T, int B, float* logZ,
                 const float* cell = row + (size_t)j * Bs + c0;
                 for (int c = 0; c < nc; ++c) { const float x = vj[c] + cell[c]; m[c] = x > m[c] ? x : m[c]; }
             }
-            for (int c = 0; c < nc; ++c) s[c] = (double)expf(vp[c] + nz[c] - m[c]);
+            // every candidate -inf (masked cells, torch.logsumexp gives -inf): the reference point is 0, every term exp(-inf) = 0
+            float mm[CB];
+            for (int c = 0; c < nc; ++c) mm[c] = m[c] == -INFINITY ? 0.0f : m[c];
+            for (int c = 0; c < nc; ++c) s[c] = (double)expf(vp[c] + nz[c] - mm[c]);
             for (int j = 0; j < i; ++j) {
                 const float* vj = v + (size_t)j * Bs + c0;
                 const float* cell = row + (size_t)j * Bs + c0;
-                for (int c = 0; c < nc; ++c) s[c] += (double)expf(vj[c] + cell[c] - m[c]);
+                for (int c = 0; c < nc; ++c) s[c] += (double)expf(vj[c] + cell[c] - mm[c]);
             }
             const float* dg = row + (size_t)i * Bs + c0;
-            for (int c = 0; c < nc; ++c) vi[c] = m[c] + (float)log(s[c]) + softplus(dg[c]);
+            for (int c = 0; c < nc; ++c) vi[c] = (s[c] == 0.0 ? -INFINITY : mm[c] + (float)log(s[c])) + softplus(dg[c]);
         }
         for (int c = 0; c < nc; ++c) logZ[c0 + c] = v[(size_t)(T - 1) * Bs + c0 + c];
     }
@@ -247,15 +251,17 @@ void eval_path_bwd(const float* gout, int T, int B, const int32_t* pairs, const 
     const size_t Bs = (size_t)B;
 #pragma omp parallel for schedule(dynamic, 8)
     for (int c = 0; c < B; ++c) {
-        std::vector<char> covered((size_t)(T > 1 ? T - 1 : 0), 0);
+        // the derivative of eval_path above, which is LINEAR in the noise: every gap counts once (cum[T-1]) and once less per
+        // interval that covers it -- also for overlapping intervals, where a 0/1 "covered" flag is not the derivative of the
+        // forward (the reference's gathers :540-548 and evalpath.hip's eval_path_bwd_pairs_kernel agree)
+        if (dNoise)
+            for (int t = 0; t + 1 < T; ++t) dNoise[(size_t)t * Bs + c] += gout[c];
         for (int i = offsets[c]; i < offsets[c + 1]; ++i) {
             const int b = pairs[2 * i], e = pairs[2 * i + 1];
             if (dScore) dScore[((size_t)e * T + b) * Bs + c] += gout[c];
-            for (int t = b; t < e; ++t) covered[(size_t)t] = 1;
+            if (dNoise)
+                for (int t = b; t < e; ++t) dNoise[(size_t)t * Bs + c] -= gout[c];
         }
-        if (dNoise)
-            for (int t = 0; t + 1 < T; ++t)
-                if (!covered[(size_t)t]) dNoise[(size_t)t * Bs + c] += gout[c];
     }
 }
 

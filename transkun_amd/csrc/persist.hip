@@ -98,6 +98,8 @@ constexpr unsigned U_EMPTY = 0xffffffffu;  // not-yet-published u (a NaN pattern
 // slow every dequeue down to tens of microseconds).
 constexpr size_t CTRL_WORDS = 256;   // control words per chain chunk
 constexpr int CTRL_EXIT = 64;         // [64]: workgroups that have left (leased workspaces: the last one resets the control words)
+constexpr int CTRL_GEN = 96;          // [96]: leased workspaces: the tag of the launch that last cleaned up here (CTRL_INIT after a fill);
+                                      // every workgroup of the next launch compares it with what the host expects (error 13)
 
 typedef unsigned long long u64;
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -119,6 +121,8 @@ struct SweepParams {
     int zeroWaves;         // GRAD: waves per panel workgroup that write the zero upper triangle of dScore (0: separate kernel)
     unsigned tag;          // nonzero launch epoch
     int selfclean;         // leased workspace (semicrf_workspace_register): the launch leaves u and its control words as the fill would
+    unsigned expect_gen;   // ... and finds ctrl[CTRL_GEN] == expect_gen: the previous launch into this workspace was the one the host
+                           // counted, and it finished its clean-up (otherwise: error 13, outputs poisoned)
     unsigned dbg;          // SEMICRF_DEBUG_FLAGS (timing experiments only; results are wrong when set):
                            // 1 spine ignores far partials, 2 panels exit at once, 4 panels do not wait for u,
                            // 8 spine exits at once, 16 spine 0 records per-block timestamps,
@@ -1426,7 +1430,12 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
     // pinned abort word, but launches it had already enqueued arrive first): this launch gives up at once -- its waits see the
     // word within a few polls, its outputs are poisoned like the aborted launch's own.
     if (threadIdx.x == 0) {
-        s_abort = __hip_atomic_load(P.ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != CTRL_INIT ? 1 : 0;
+        const unsigned e1 = __hip_atomic_load(P.ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned gen = P.selfclean ? __hip_atomic_load(P.ctrl + CTRL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : P.expect_gen;
+        s_abort = e1 != CTRL_INIT ? 1 : 0;
+        // a "clean" lease that is not in the state its last launch must have left (somebody else wrote to the workspace, or a launch
+        // the host never saw): nothing in it can be trusted
+        if (gen != P.expect_gen) { set_error(P.ctrl, 13u); s_abort = 1; }
         s_exit = 0;
     }
     // flags and sequence numbers start at 0
@@ -1513,7 +1522,7 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
             if (before + 1u == gridDim.x &&
                 __hip_atomic_load(P.ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == CTRL_INIT) {
                 for (int i = threadIdx.x & 63; i < (int)CTRL_WORDS; i += 64)
-                    __hip_atomic_store(P.ctrl + i, CTRL_INIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(P.ctrl + i, i == CTRL_GEN ? P.tag : CTRL_INIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -1623,6 +1632,7 @@ static Knobs read_knobs()
 
 struct GradArgs {
     const float* vfwd; const float* logZ; const float* gout; float* dScore; float* dNoise; int gstride; float gscale;
+    int keep_upper;       // the cells begin > end of dScore hold zeros already (SEMICRF_GRAD_UPPER_IS_ZERO): not written
 };
 
 template <int MODE, int DIR, bool GRAD>
@@ -1676,6 +1686,8 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
     // instantiated HIP graph -- wrong results or a memory fault -- while this kernel replays correctly)
     if (lease != 2) hipLaunchKernelGGL(fill_ff_kernel, dim3(1024), dim3(256), 0, stream, (v4u*)ws, (fill_bytes + 15) / 16);
     P.selfclean = lease != 0 && P.dbg == 0u;
+    // what ctrl[CTRL_GEN] must read when the kernel starts: the previous launch's tag (a clean lease) or the fill
+    P.expect_gen = (lease == 2 && P.selfclean) ? ((lease_tag - 1u) % 65534u) + 1u : CTRL_INIT;
     static const Knobs knobs = read_knobs();
 
     // Chain chunks: at most a quarter of the CUs host spines in one launch (every workgroup must be resident
@@ -1737,7 +1749,7 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         // the zero upper triangle of the gradient: by spare waves of the first chunk's panel workgroups, or (no
         // panel workgroups: short sequences) by its own kernel
         int zw = 0;
-        if (grad && ci == 0) {
+        if (grad && ci == 0 && !grad->keep_upper) {
             zw = 2;
             if (knobs.zero_waves >= 0) zw = knobs.zero_waves;
             if (zw > NT / 64 - pw) zw = NT / 64 - pw;
@@ -1770,9 +1782,9 @@ int launch_persist_sweep(int mode, int dir, const float* score, const float* noi
 // Fused backward: beta sweep + marginals (dScore fully written incl. the zero upper triangle, dNoise).
 int launch_persist_logz_bwd(const float* score, const float* noise, const float* v, const float* logZ,
                             const float* gout, int T, int B, float* dScore, float* dNoise, float* q_out, void* ws,
-                            hipStream_t stream, int lease, unsigned lease_tag, int gstride, float gscale)
+                            hipStream_t stream, int lease, unsigned lease_tag, int gstride, float gscale, int keep_upper)
 {
-    GradArgs ga{v, logZ, gout, dScore, dNoise, gstride, gscale};
+    GradArgs ga{v, logZ, gout, dScore, dNoise, gstride, gscale, keep_upper};
     return launch_persist_sweep_impl(0, 1, score, noise, T, B, q_out, nullptr, nullptr, ws, stream, &ga, lease, lease_tag);
 }
 

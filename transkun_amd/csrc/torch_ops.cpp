@@ -95,14 +95,14 @@ void logz_fwd(Tensor score, Tensor noise, Tensor logZ, Tensor v, bool want_v, Te
           "semicrf_logz_fwd");
 }
 void logz_bwd(Tensor score, Tensor noise, Tensor v, Tensor logZ, Tensor gout, Tensor dScore, Tensor dNoise, Tensor q, bool want_q,
-              Tensor ws)
+              int64_t flags, Tensor ws)
 {
     Ctx c(score); c.same(score, noise, v, logZ, gout, dScore, dNoise, q, ws);
     const Dims d = crf_dims(score, noise);
     const int64_t TB = (int64_t)d.T * d.B;
-    check(semicrf_logz_bwd(cfp(score), cfp(noise), f32(v, TB, "v"), f32(logZ, d.B, "logZ"), f32(gout, d.B, "gout"), d.T, d.B,
-                           f32w(dScore, TB * d.T, "dScore"), f32w(dNoise, TB - d.B, "dNoise"), want_q ? f32w(q, TB, "q") : nullptr,
-                           bytes(ws, "ws"), (size_t)ws.numel(), c.stream),
+    check(semicrf_logz_bwd_f(cfp(score), cfp(noise), f32(v, TB, "v"), f32(logZ, d.B, "logZ"), f32(gout, d.B, "gout"), d.T, d.B,
+                             f32w(dScore, TB * d.T, "dScore"), f32w(dNoise, TB - d.B, "dNoise"), want_q ? f32w(q, TB, "q") : nullptr,
+                             (int)flags, bytes(ws, "ws"), (size_t)ws.numel(), c.stream),
           "semicrf_logz_bwd");
 }
 void beta(Tensor score, Tensor noise, Tensor out, Tensor ws)
@@ -158,15 +158,16 @@ void logprob_fwd(Tensor score, Tensor noise, Tensor pairs, int64_t K, Tensor off
           "semicrf_logprob_fwd");
 }
 void logprob_bwd(Tensor score, Tensor noise, Tensor v, Tensor logZ, Tensor gout, int64_t gstride, Tensor pairs, int64_t K, Tensor offsets,
-                 Tensor dScore, Tensor dNoise, Tensor ws)
+                 Tensor dScore, Tensor dNoise, int64_t flags, Tensor ws)
 {
     Ctx c(score); c.same(score, noise, v, logZ, gout, pairs, offsets, dScore, dNoise, ws);
     const Dims d = crf_dims(score, noise);
     const int64_t TB = (int64_t)d.T * d.B;
     STD_TORCH_CHECK(K >= 0 && (gstride == 0 || gstride == 1), "semicrf: bad interval count / gout stride");
-    check(semicrf_logprob_bwd(cfp(score), cfp(noise), f32(v, TB, "v"), f32(logZ, d.B, "logZ"), f32(gout, gstride ? d.B : 1, "gout"),
-                              (int)gstride, d.T, d.B, i32(pairs, 2 * K, "pairs"), K, i32(offsets, d.B + 1, "offsets"),
-                              f32w(dScore, TB * d.T, "dScore"), f32w(dNoise, TB - d.B, "dNoise"), bytes(ws, "ws"), (size_t)ws.numel(), c.stream),
+    check(semicrf_logprob_bwd_f(cfp(score), cfp(noise), f32(v, TB, "v"), f32(logZ, d.B, "logZ"), f32(gout, gstride ? d.B : 1, "gout"),
+                                (int)gstride, d.T, d.B, i32(pairs, 2 * K, "pairs"), K, i32(offsets, d.B + 1, "offsets"),
+                                f32w(dScore, TB * d.T, "dScore"), f32w(dNoise, TB - d.B, "dNoise"), (int)flags, bytes(ws, "ws"),
+                                (size_t)ws.numel(), c.stream),
           "semicrf_logprob_bwd");
 }
 
@@ -184,7 +185,7 @@ void logz_fwd_cpu(Tensor score, Tensor noise, Tensor logZ, Tensor v, bool want_v
     semicrf_cpu::logz_fwd(cfp(score), cfp(noise), d.T, d.B, f32w(logZ, d.B, "logZ"), vv);
 }
 void logz_bwd_cpu(Tensor score, Tensor noise, Tensor v, Tensor logZ, Tensor gout, Tensor dScore, Tensor dNoise, Tensor q, bool want_q,
-                  Tensor ws)
+                  int64_t flags, Tensor ws)       // flags: a permission (SEMICRF_GRAD_UPPER_IS_ZERO); the host kernels write everything
 {
     all_cpu(score, noise, v, logZ, gout, dScore, dNoise, q);
     const Dims d = crf_dims(score, noise);
@@ -253,7 +254,7 @@ void logprob_fwd_cpu(Tensor score, Tensor noise, Tensor pairs, int64_t K, Tensor
     for (int64_t c = 0; c < score.size(2); ++c) lp[c] -= lz[c];
 }
 void logprob_bwd_cpu(Tensor score, Tensor noise, Tensor v, Tensor logZ, Tensor gout, int64_t gstride, Tensor pairs, int64_t K, Tensor offsets,
-                     Tensor dScore, Tensor dNoise, Tensor ws)
+                     Tensor dScore, Tensor dNoise, int64_t flags, Tensor ws)
 {
     all_cpu(score, noise, v, logZ, gout, pairs, offsets, dScore, dNoise);
     const Dims d = crf_dims(score, noise);
@@ -397,7 +398,7 @@ STABLE_TORCH_LIBRARY(semicrf, m)
 {
     m.def("logz_fwd(Tensor score, Tensor noise, Tensor(a!) logZ, Tensor(b!) v, bool want_v, Tensor(c!) ws) -> ()");
     m.def("logz_bwd(Tensor score, Tensor noise, Tensor v, Tensor logZ, Tensor gout, Tensor(a!) dScore, Tensor(b!) dNoise, Tensor(c!) q, "
-          "bool want_q, Tensor(d!) ws) -> ()");
+          "bool want_q, int flags, Tensor(d!) ws) -> ()");
     m.def("beta(Tensor score, Tensor noise, Tensor(a!) out, Tensor(b!) ws) -> ()");
     m.def("viterbi(Tensor score, Tensor noise, Tensor start, bool has_start, bool forward, Tensor(a!) pairs, Tensor(b!) offsets, "
           "Tensor(c!) ws) -> ()");
@@ -407,7 +408,7 @@ STABLE_TORCH_LIBRARY(semicrf, m)
     m.def("logprob_fwd(Tensor score, Tensor noise, Tensor pairs, int K, Tensor offsets, Tensor(a!) logProb, Tensor(b!) logZ, Tensor(c!) v, "
           "bool want_v, Tensor(d!) ws) -> ()");
     m.def("logprob_bwd(Tensor score, Tensor noise, Tensor v, Tensor logZ, Tensor gout, int gstride, Tensor pairs, int K, Tensor offsets, "
-          "Tensor(a!) dScore, Tensor(b!) dNoise, Tensor(c!) ws) -> ()");
+          "Tensor(a!) dScore, Tensor(b!) dNoise, int flags, Tensor(c!) ws) -> ()");
     // (group, pitch): the slot layout of the chain axis (include/semicrf_hip.h, *_p entry points); group == pitch: contiguous
     // rowc / drowc, ldrc / lddrc: the merged projection's per-(chain, end) constant (*_pc entry points); stride 0: none (pass any tensor)
     m.def("interval_score_fwd(Tensor q, Tensor k, Tensor diag, Tensor rowc, int C, int T, int D, int ldq, int ldk, int ldd, int ldrc, "

@@ -117,21 +117,58 @@ class FlatGradBucket:
         unit = self.world * 64                                   # every rank's slice starts on a 256-byte boundary
         self.numel = n
         self.flat = torch.zeros((n + unit - 1) // unit * unit, dtype=torch.float32, device=dev)
+        self._views = []
         off = 0
         for p in self.params:
             if p.device != dev or p.dtype != torch.float32:
                 raise ValueError("FlatGradBucket: parameters must be fp32 on one device")
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            v = self.flat[off:off + p.numel()].view_as(p)
+            self._views.append(v)
+            p.grad = v
             off += p.numel()
         self._hooks = []
         self._pending = 0
+        self._armed = False                  # arm() has been called and no exchange has happened since
+        self._exchanged = False              # an exchange has run since the last arm() / zero()
+        self._closed = True                  # wait() has closed the step (gradients arriving now belong to the next one)
+        self._late = 0                       # gradients that arrived between this step's exchange and its wait()
         self._event = None
         self._side = None
+        self.rebound = 0                     # gradients found outside the flat buffer and moved back in (statistics / tests)
         self.collectives = 0                 # issued by the last exchange
         self.bytes_per_rank = 0
 
+    # ---- the .grad <-> flat aliasing is checked, not assumed ------------------------------------------------------------------
+    # optimizer.zero_grad(set_to_none=True) (the default) and the `p.grad = None` idiom rebind .grad: autograd then writes the
+    # next gradient into a FRESH tensor and the flat buffer would be exchanged stale.  Every entry point below therefore
+    # verifies that each p.grad is the view made in __init__ (same storage address) and repairs what is not.
+    def _rebind(self, after_backward: bool) -> int:
+        """after_backward=False (arm / zero): a gradient that is None becomes the (zeroed) view again, a foreign tensor is
+        copied into its slice.  after_backward=True (before an exchange): a foreign tensor holds THIS step's gradient -- what
+        the slice holds is stale -- and replaces the slice's content; None means 'no gradient this step': the slice is zeroed."""
+        n = 0
+        for p, v in zip(self.params, self._views):
+            g = p.grad
+            if g is not None and g.data_ptr() == v.data_ptr() and g.numel() == v.numel():
+                continue
+            with torch.no_grad():
+                if g is None:
+                    v.zero_()
+                else:
+                    if g.shape != v.shape:
+                        raise RuntimeError("FlatGradBucket: a parameter's .grad changed its shape")
+                    v.copy_(g)
+            p.grad = v
+            n += 1
+        self.rebound += n
+        return n
+
     def zero(self) -> None:
+        self._rebind(after_backward=False)
         self.flat.zero_()
+        self._exchanged = False
+        self._closed = False
+        self._late = 0
 
     def _backend(self) -> str:
         import torch.distributed as dist
@@ -144,8 +181,11 @@ class FlatGradBucket:
     def exchange(self) -> int:
         """SUM over the ranks, in place, on the current stream.  Returns the number of collectives issued."""
         import torch.distributed as dist
+        self._rebind(after_backward=True)
         self.collectives = 0
         self.bytes_per_rank = 0
+        self._exchanged = True
+        self._armed = False
         if not self._active():
             return 0
         if self._backend() == "nccl":
@@ -162,25 +202,38 @@ class FlatGradBucket:
 
     # ---- hook-started exchange on a side stream ---------------------------------------------------------------------------
     def arm(self) -> None:
-        """The next backward pass starts the exchange itself, as soon as every parameter of the bucket has its gradient."""
+        """The next backward pass starts the exchange itself, as soon as every parameter of the bucket has its gradient.
+        ONE backward pass per arm(): with gradient accumulation over micro-batches, arm() before the LAST one only (the hooks of
+        an unarmed bucket count nothing) -- a second backward after the armed one is reported by wait()."""
+        self._rebind(after_backward=False)
         if not self._hooks:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._pending = len(self.params)
+        self._armed = True
+        self._exchanged = False
+        self._closed = False
+        self._late = 0
         self._event = None
 
     def disarm(self) -> None:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        self._armed = False
 
     def _on_grad(self, p) -> None:
-        self._pending -= 1
-        if self._pending == 0:
-            self._start()
+        if self._armed:
+            self._pending -= 1
+            if self._pending == 0:
+                self._start()
+        elif self._exchanged and not self._closed:
+            self._late += 1                                        # behind the exchange of a step that is still open
+        # (not armed, step closed or not begun: plain accumulation into the flat buffer, nothing is counted)
 
     def _start(self) -> None:
         if not self._active():
+            self.exchange()                                        # (rebinds and marks the step as exchanged; no collective)
             return
         if not self.flat.is_cuda:
             self.exchange()
@@ -188,18 +241,27 @@ class FlatGradBucket:
         cur = torch.cuda.current_stream(self.flat.device)
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.flat.device)
+        self._rebind(after_backward=True)                          # copies, if any, belong on the producing stream
         self._side.wait_stream(cur)                                # the gradients are complete on the producing stream
         with torch.cuda.stream(self._side):
             self.exchange()
             self._event = self._side.record_event()
 
     def wait(self) -> int:
-        """Make the current stream wait for the hook-started exchange (or run it now if no hook fired).  Returns the number
-        of collectives of this step."""
+        """Make the current stream wait for the hook-started exchange, or run the exchange now if none has happened since the
+        last arm() / zero() (not every parameter received a gradient, the bucket was not armed, ...).  Returns the number of
+        collectives of this step.  Raises when gradients arrived AFTER the exchange of this step had started (more backward
+        passes than arm() calls): those gradients were not summed over the ranks."""
+        late, self._late = self._late, 0
         if self._event is not None:
             torch.cuda.current_stream(self.flat.device).wait_event(self._event)
             self._event = None
-            return self.collectives
-        if self._pending > 0 or not self._hooks:
-            return self.exchange()
+        elif not self._exchanged:
+            self.exchange()
+        self._armed = False
+        self._closed = True
+        if late:
+            raise RuntimeError(f"FlatGradBucket: {late} gradient(s) arrived after this step's exchange had started (a second "
+                               "backward pass behind one arm()?): arm() before the LAST backward pass only, or call exchange() "
+                               "yourself after all of them -- those gradients were not summed over the ranks")
         return self.collectives

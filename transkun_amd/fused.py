@@ -69,8 +69,10 @@ def _mm_blocks(a, b, nb: int = 16):
 
 
 def merged_eligible(size: int, T: int) -> bool:
-    """Shapes the row-constant form of the scorer kernels takes (include/semicrf_hip.h: interval_score_fwd_pc)."""
-    return size % 64 == 0 and size <= 256 and T >= 128
+    """Shapes the row-constant form of the scorer kernels takes (include/semicrf_hip.h: interval_score_fwd_pc): the LDS-tiled
+    kernels (size % 64 == 0, size <= 256, T >= 128, 16-byte aligned rows -- x and [z | c | diag | 0 0] are contiguous fp32 rows of
+    size and size + 4 floats) of the default implementation; anything else takes projection="separate"."""
+    return size % 64 == 0 and size <= 256 and T >= 128 and _lib.get_impl() == 0
 
 
 class _MergedScorerCRFLogProb(torch.autograd.Function):

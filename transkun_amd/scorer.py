@@ -12,7 +12,6 @@ from __future__ import annotations
 
 import math
 import os
-import warnings
 
 import torch
 import torch.nn as nn
@@ -117,6 +116,44 @@ def _tn_splitk(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _column_chunks(D: int, widths):
+    out, d0 = [], 0
+    while d0 < D:
+        w = next((w for w in widths if D - d0 >= w), None)
+        if w is None:
+            raise ValueError(f"contraction size {D} cannot be cut into column chunks of {widths}")
+        out.append((d0, w))
+        d0 += w
+    return out
+
+
+def score_backward_hip(g, q, k, C: int, T: int, D: int, qs: float, mode: int, P: int, pitch: int, dq, dk, dd) -> None:
+    """dq [C,T,D], dk [C,T,D], dd [C,T] (views with unit stride in d; dd may be None) from the cotangent g [T,T,Cs] -- the autograd
+    of LayersTransformer.py:410-433 -- on the HIP kernels for EVERY contraction size.  D is an OUTPUT dimension of both
+    products (dq[e,:] = sum_b G[e,b] k[b,:]), so a size beyond what one launch takes (D <= 256; the packed GEMMs: 64 / 128 / 256)
+    runs as column chunks of the same operands (D = 512, expansionFactor 2 at size 256: two launches of 256 columns), and a size
+    that is no multiple of 32 on zero-padded copies of q and k.  qs stays 1 / sqrt(D) of the whole contraction."""
+    ops = _lib.ops()
+    dev = g.device
+    if D % 32 != 0:
+        Dp = (D + 31) // 32 * 32
+        qp, kp = F.pad(q, (0, Dp - D)), F.pad(k, (0, Dp - D))
+        dqp = torch.empty(C, T, Dp, dtype=torch.float32, device=dev)
+        dkp = torch.empty(C, T, Dp, dtype=torch.float32, device=dev)
+        score_backward_hip(g, qp, kp, C, T, Dp, qs, mode, P, pitch, dqp, dkp, dd)
+        dq.copy_(dqp[..., :D])
+        dk.copy_(dkp[..., :D])
+        return
+    none = torch.empty(0, dtype=torch.float32, device=dev)
+    widths = (256, 128, 64) if pitch != P else (256, 128, 64, 32)          # a padded slot pitch needs the packed GEMMs
+    for i, (d0, w) in enumerate(_column_chunks(D, widths)):
+        ws = bwd_workspace(C, T, w, dev)                                    # 0 bytes: shapes the packed path does not take -> direct kernels
+        ddi = dd if (i == 0 and dd is not None) else none
+        ops.interval_score_bwd_ws(g, q[..., d0:d0 + w], k[..., d0:d0 + w], C, T, w, q.stride(-2), k.stride(-2), qs, mode, P, pitch,
+                                  dq[..., d0:d0 + w], dk[..., d0:d0 + w], ddi, none, dq.stride(-2), dk.stride(-2),
+                                  ddi.stride(-1) if ddi.numel() else 1, 0, ws)
+
+
 class _ScorerLinear(torch.autograd.Function):
     """The scorer's Linear map (LayersTransformer.py:392-397, :408) as its two GEMMs [q | diag | pad] and k with a backward
     of its own.  Stock autograd computes a weight gradient as ONE GEMM dY^T x: 260 x 256 outputs over a contraction of
@@ -151,7 +188,7 @@ class _ScorerLinear(torch.autograd.Function):
 
 class _IntervalScore(torch.autograd.Function):
     """S = lenscale * (q*qscale) k^T + diag, chain-minor layout; forward and backward are HIP kernels
-    (the backward falls back to torch for contraction sizes the kernel does not take).
+    (every contraction size: wider than 256 runs as column chunks, a size that is no multiple of 32 is zero-padded).
     qd: [N,P,T,D+QPAD] = [q | diag | zeros]; k: [N,P,T,D]."""
 
     @staticmethod
@@ -166,8 +203,6 @@ class _IntervalScore(torch.autograd.Function):
         ctx.meta = (N, P, T, D, mode, (int(full_square) & 3) == 1, pitch)
         return S.view(T, T, N, pitch), noise.view(max(T - 1, 0), N, pitch)
 
-    _warned_torch_backward = False
-
     @staticmethod
     def backward(ctx, dS, dnoise):
         qd3, k = ctx.saved_tensors
@@ -175,52 +210,31 @@ class _IntervalScore(torch.autograd.Function):
         C = N * P
         qs = 1.0 / math.sqrt(D)
         q = qd3[..., :D]
-        if D % 32 == 0 and D <= 256 and dS.is_cuda and not full:
-            # HIP kernels: dq/dk from dS in its native [T,T,C] layout on the matrix cores (exact fp32), written straight
-            # into the gradient of [q | diag | pad]
-            g = dS.reshape(T, T, N * pitch)
-            if not g.is_contiguous():
-                g = g.contiguous()
-            dqd = torch.empty(C, T, D + QPAD, dtype=torch.float32, device=g.device)
-            dqd[..., D + 1:] = 0
-            dq, dd = dqd[..., :D], dqd[..., D]
-            dk = torch.empty(C, T, D, dtype=torch.float32, device=g.device)
-            # with a workspace the library repacks dS per chain and runs two LDS-tiled GEMMs (scorer_bwd_gemm.hip);
-            # 0 bytes: shapes it does not take -- the direct kernels run
-            ws = bwd_workspace(C, T, D, g.device)
-            _lib.ops().interval_score_bwd_ws(g, q, k, C, T, D, q.stride(-2), k.stride(-2), qs, mode, P, pitch, dq, dk, dd, dd,
-                                             dq.stride(-2), D, dd.stride(-1), 0, ws)
-            return (dqd.view(N, P, T, D + QPAD), dk.view(N, P, T, D), None, None, None, None, None, None, None)
-        if not _IntervalScore._warned_torch_backward:
-            _IntervalScore._warned_torch_backward = True
-            warnings.warn("transkun_amd.scorer: the interval-score backward runs as plain torch ops (contraction size D=%d not a "
-                          "multiple of 32 or > 256, or the full square was requested): about 10x slower than the HIP kernels" % D)
-        if pitch != P:
-            dS = dS[..., :P]
-        dq, dk, dd = _IntervalScore._backward_torch(dS, q, k, N, P, T, D, mode, full)[:3]
-        dqd = torch.cat([dq.reshape(C, T, D), dd.reshape(C, T, 1), dq.new_zeros(C, T, QPAD - 1)], dim=-1)
-        return (dqd.view(N, P, T, D + QPAD), dk, None, None, None, None, None, None, None)
-
-    @staticmethod
-    def _backward_torch(dS, q, k, N, P, T, D, mode, full=False):
-        """Plain-torch differentiation (any D; also the reference the HIP backward is tested against)."""
-        C = N * P
-        g = dS.reshape(T, T, C).permute(2, 0, 1)                     # [C, e, b]
-        t = torch.arange(T, device=g.device)
-        ln = (t[:, None] - t[None, :]).abs().to(torch.float32)
-        if mode == 1:
-            ln = ln.sqrt()
-        elif mode == 2:
-            ln = torch.ones_like(ln)
-        gl = g * ln
-        if not full:
-            gl = torch.tril(gl)                                       # only e >= b was produced by the forward
-        qs = 1.0 / math.sqrt(D)
-        dq = torch.bmm(gl, k) * qs                                    # [C,T,D]
-        dk = torch.bmm(gl.transpose(1, 2), q) * qs
-        ddiag = torch.diagonal(g, dim1=1, dim2=2)                     # [C,T]
-        return (dq.view(N, P, T, D), dk.view(N, P, T, D), ddiag.reshape(N, P, T).contiguous(),
-                None, None, None, None, None, None)
+        # HIP kernels for every shape: dq/dk from dS in its native [T,T,C] layout on the matrix cores (exact fp32), written
+        # straight into the gradient of [q | diag | pad]
+        g = dS.reshape(T, T, N * pitch)
+        if g.dtype != torch.float32:
+            g = g.float()
+        if not g.is_contiguous():
+            g = g.contiguous()
+        dqd = torch.empty(C, T, D + QPAD, dtype=torch.float32, device=g.device)
+        dqd[..., D + 1:] = 0
+        dq, dd = dqd[..., :D], dqd[..., D]
+        dk = torch.empty(C, T, D, dtype=torch.float32, device=g.device)
+        score_backward_hip(g, q, k, C, T, D, qs, mode, P, pitch, dq, dk, dd)
+        if full:
+            # the reference's full square (fullSquare=True): the cells begin > end were computed as well, S[e,b] = qs <q_e, k_b>
+            # len(b-e), so a consumer's gradient there flows too.  Transposed, that strict upper triangle is a strict lower
+            # triangle with the roles of q and k exchanged: the same kernels once more (a rarely used compatibility path: it
+            # pays a transposed copy of dS).
+            gT = g.transpose(0, 1).contiguous()
+            gT.diagonal(dim1=0, dim2=1).zero_()
+            dq2 = torch.empty(C, T, D, dtype=torch.float32, device=g.device)
+            dk2 = torch.empty(C, T, D, dtype=torch.float32, device=g.device)
+            score_backward_hip(gT, k, q, C, T, D, qs, mode, P, pitch, dk2, dq2, None)
+            dq.add_(dq2)
+            dk.add_(dk2)
+        return (dqd.view(N, P, T, D + QPAD), dk.view(N, P, T, D), None, None, None, None, None, None, None)
 
 
 class ScaledInnerProductIntervalScorer(nn.Module):
