@@ -35,6 +35,17 @@ if stored_q[1:].any():
     print("  stored per quarter: mean %s; slowest quarter mean %.2f p90 %.2f; far - slowest: mean %.2f p90 %.2f" % (
         np.round(d.mean(1), 2).tolist(), d.max(0).mean(), np.percentile(d.max(0), 90), (far[ks] - p - d.max(0)).mean(),
         np.percentile(far[ks] - p - d.max(0), 90)))
+if ts.shape[0] >= 960 and ts[640:960].any():
+    st, ce, ri, ne, po = ts[640:704], ts[704:768], ts[768:832], ts[832:896], ts[896:960]
+    print("  far wave phases, us after publish(k-4): k: start  cells  ring-entries  near-done  partials-in | entry written")
+    for k in list(range(5, 40, 3)) + [48, 56, 63]:
+        if k >= K: break
+        p0 = pub[k - 4]
+        print(f"  {k:3d}: {st[k]-p0:7.2f} {ce[k]-p0:7.2f} {ri[k]-p0:7.2f} {ne[k]-p0:7.2f} {po[k]-p0:7.2f} | {far[k]-p0:7.2f}")
+    ks2 = np.arange(6, min(K, 64))
+    for name, arr in (("start", st), ("cells", ce), ("ring", ri), ("near", ne), ("partials", po)):
+        d = arr[ks2] - pub[ks2 - 4]
+        print(f"    {name:9s}: mean {d.mean():6.2f} median {np.median(d):6.2f}")
 print("  publish time of block k (us):", [round(float(pub[k] - t0), 1) for k in range(0, min(K, 64), 4)])
 per = np.diff(pub[:min(K, 64)])
 ctl = ws[:1024].view(torch.int32).cpu().numpy().astype(np.int64)

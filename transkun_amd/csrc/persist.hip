@@ -17,8 +17,8 @@
 //     band cells in LDS with asynchronous global->LDS loads several blocks ahead, and a FAR wave collects the
 //     panels' partial results into LDS (see the SPINE section).
 //   * PANEL waves (four per panel workgroup; every wave pulls its own tasks, no workgroup-level
-//     synchronisation): a task is (position block k >= 4, column part of <= 16 tiles, 32 chains, 4 of the 16
-//     rows).  The wave streams the far field -- cells (p in its rows, j < 16(k-3)) -- tile by tile through
+//     synchronisation): a task is (position block k >= FAR0, column part of <= 16 tiles, 32 chains, 4 of the 16
+//     rows).  The wave streams the far field -- cells (p in its rows, j < 16(k-FAR0+1)) -- tile by tile through
 //     three LDS stages filled by asynchronous global->LDS loads (it counts its own outstanding loads), keeps
 //     the partial accumulators in registers and hands ONE number per (position, chain, part) to the spine.
 //   * Hand-offs carry their own flag -- u: a float that reads U_EMPTY until published; far-field partials: 8-byte
@@ -44,6 +44,10 @@
 #define SEMICRF_PROBE_HIST 0       // 1 (with SEMICRF_PANEL_PROBES): the per-tile activity histogram of tools/activity_hist.py (spills: its own build)
 #endif
 
+#ifndef SEMICRF_CT_DBG
+#define SEMICRF_CT_DBG -1          // >= 0 (with SEMICRF_PANEL_PROBES=1): the debug flags as a compile-time constant -- a timing ablation
+#endif                              // without the probe build's register pressure (the flags' dead branches fold away)
+
 namespace semicrf {
 
 constexpr int PB = 16;             // positions per block
@@ -51,6 +55,17 @@ constexpr int PB = 16;             // positions per block
 #define SEMICRF_RING 4
 #endif
 constexpr int RING = SEMICRF_RING; // waves per ring; band = RING-1 off-diagonal blocks + the diagonal block
+#ifndef SEMICRF_NNEAR
+#define SEMICRF_NNEAR 0
+#endif
+// NEAR tiles (round 4): the NNEAR column blocks just beyond the band -- tile (k, k-RING-n), n < NNEAR -- are applied INSIDE the spine
+// workgroup, by its far wave, from cells the loader stages in LDS and from the u values in the LDS ring: no trip through memory.
+// The panels' far field of block k ends NNEAR blocks earlier (newest tile k - FAR0), so the hand-off chain (publish u -> a panel
+// notices, finishes its newest tile, stores its partial -> the far wave notices -> the owner) has RING + NNEAR blocks of slack
+// instead of RING.  Measured chain: 7.5 us (88 chains) to 10 us (352) against 4 x 1.4 us of ring time per band; every extra tile
+// costs the loader 4 more 64-line loads per row block (ring alone: 1.34 -> 1.64 us per block at 88 chains, 1.41 -> 1.88 at 352).
+constexpr int NNEAR = SEMICRF_NNEAR;
+constexpr int FAR0 = RING + NNEAR; // first block with a far field of its own; the newest far tile of block k is k - FAR0
 constexpr int RS = 4;              // chains per ring (one per lane)
 constexpr int GS = RS;              // chains per spine workgroup
 constexpr int GP = 32;             // chains per panel task (4 per lane)
@@ -107,6 +122,7 @@ typedef unsigned v4u_a4 __attribute__((ext_vector_type(4), aligned(4)));      //
 template <int V>
 struct IC { static constexpr int value = V; };
 
+#define DBGF(P) (SEMICRF_CT_DBG >= 0 ? (unsigned)SEMICRF_CT_DBG : (P).dbg)
 struct SweepParams {
     const float* score;
     const float* noise;
@@ -269,7 +285,10 @@ __device__ __forceinline__ bool spin_abort(unsigned* ctrl, int& spins, int limit
 #define SEMICRF_NLOADER 1
 #endif
 constexpr int NLOADER = SEMICRF_NLOADER;              // loader waves per ring (a row block is RING tiles)
-constexpr int NRBUF = 4;                              // row-block buffers between the loader and the ring
+#ifndef SEMICRF_NRBUF
+#define SEMICRF_NRBUF 4
+#endif
+constexpr int NRBUF = SEMICRF_NRBUF;                  // row-block buffers between the loader and the ring
 constexpr int TILE_BYTES = PB * PB * RS * 4;          // 4096: [column u][row r][chain] floats
 constexpr int NCONST = 3;                             // per-row constants: diagonal cell, noise, alpha (GRAD)
 constexpr int LDS_TILES = 0;
@@ -277,9 +296,37 @@ constexpr int LDS_CONST = LDS_TILES + NRBUF * RING * TILE_BYTES;       // [NRBUF
 constexpr int LDS_FAR = LDS_CONST + NRBUF * NCONST * 256;              // [8][64] x {value, key, seq, pad}
 constexpr int NFAR = 8;                               // far-partial entries (blocks) between the far wave and the ring (>= RING)
 constexpr int NPOS = 128;                             // positions kept in the LDS ring (>= the band, RING blocks)
-static_assert(NFAR >= RING && NPOS >= RING * PB && RING + NLOADER + 1 <= NT / 64, "ring geometry");
+static_assert(NFAR >= RING && NPOS >= RING * PB, "ring geometry");
 constexpr int LDS_RING = LDS_FAR + NFAR * 64 * 16;                     // [NPOS][RS] x {u, seq}
-constexpr int LDS_CTL = LDS_RING + NPOS * RS * 8;                       // ready[NRBUF], cons[RING] (ints)
+#ifndef SEMICRF_STAGGER
+#define SEMICRF_STAGGER 32          // s_sleep units (64 cycles) per block of distance before a panel wave starts on its known first task
+#endif
+#ifndef SEMICRF_LOADER_AUX
+#define SEMICRF_LOADER_AUX 0        // cache policy bits of the loader's band loads: 1 sc0, 2 nt, 16 sc1
+#endif
+#ifndef SEMICRF_SPH
+#define SEMICRF_SPH 1               // spines (4-chain rings with their loader and far wave) per spine workgroup: 1 or 2
+#endif
+#ifndef SEMICRF_FAR_EARLY
+#define SEMICRF_FAR_EARLY 0         // 1: the far wave requests a block's first four partials before its near-tile work (measured: neutral)
+#endif
+#ifndef SEMICRF_FAR_PRIO
+#define SEMICRF_FAR_PRIO 0          // s_setprio of the far wave(s) (2: above the ring's shadow phase; measured: neutral)
+#endif
+#ifndef SEMICRF_NFARW
+#define SEMICRF_NFARW 1
+#endif
+// Far waves per spine workgroup: far wave f takes the blocks k = RING + f, RING + f + NFARW, ...  One far wave needs a device-scope
+// round trip per block even when the partial has long been stored (issue the poll, wait for it: ~2 us behind the loader's
+// traffic in the same compute unit) -- the block period of every hand-off-bound shape sat exactly there (2.1 - 2.2 us at 88
+// chains); two of them take turns.
+constexpr int NFARW = SEMICRF_NFARW;
+constexpr int NNSLOT = 8;                             // near-tile slots (row blocks) between the loader and the far waves
+constexpr int NEAR_SLOT_BYTES = NNEAR * TILE_BYTES + 256;              // NNEAR tiles + alpha of the row block (GRAD)
+constexpr int LDS_NEAR = LDS_RING + NPOS * RS * 8;                      // [NNSLOT] near slots
+constexpr int LDS_CTL = LDS_NEAR + (NNEAR > 0 ? NNSLOT * NEAR_SLOT_BYTES : 0);   // ready[NRBUF], cons[RING], nready[NNSLOT], fcons[NFARW] (ints)
+// (the far wave reads the ring entries of block k - RING - n while the ring has written up to block k - 1)
+static_assert(NPOS >= (FAR0 + 1) * PB && NNSLOT >= FAR0 + 1 && NRBUF + RING + NNSLOT + NFARW <= 64 && NNSLOT % NFARW == 0, "near geometry");
 constexpr int LDS_DUMMY = LDS_CTL + 256;                               // sink of the non-writer lanes' ring stores
 constexpr int LDS_SPINE_BYTES = LDS_DUMMY + (64 * 2 + PB * 8) * 4;
 
@@ -357,7 +404,9 @@ __device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* 
     const int cc = cbase + cch < P.c1 ? cbase + cch : cbase;
     int* const ready = (int*)(lds + LDS_CTL);
     int* const cons = ready + NRBUF;
-    constexpr int NL = RING * 4 + 2 + (GRAD ? 1 : 0);            // loads per row block (exactly, the waits count them)
+    int* const nready = cons + RING;
+    const int* const fcons = nready + NNSLOT;
+    constexpr int NL = RING * 4 + 2 + (GRAD ? 1 : 0) + NNEAR * 4 + ((GRAD && NNEAR > 0) ? 1 : 0);   // loads per row block (exactly, the waits count them)
     constexpr int LDEPTH = 3 * NL <= 63 ? 3 : 2;
     static_assert(2 * NL <= 63, "loader pipeline");
 
@@ -374,7 +423,7 @@ __device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* 
                 size_t off = cell_index<DIR>(prow_t, pj, T) * Bs + cbase;
                 off = off < last4 ? off : last4;
                 __builtin_amdgcn_global_load_lds((gbl_void_t*)(score + off),
-                                                 (lds_void_t*)(lds + LDS_TILES + (slot * RING + i) * TILE_BYTES + q * 1024), 16, 0, 0);
+                                                 (lds_void_t*)(lds + LDS_TILES + (slot * RING + i) * TILE_BYTES + q * 1024), 16, 0, SEMICRF_LOADER_AUX);
             }
         }
         const int prow_c = kr * PB + cr < T ? kr * PB + cr : T - 1;
@@ -385,9 +434,30 @@ __device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* 
                                          (lds_void_t*)(cb + 256), 4, 0, 0);
         if (GRAD)
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(vfwd + (size_t)frow * Bs + cc), (lds_void_t*)(cb + 512), 4, 0, 0);
+        if (NNEAR > 0) {
+            // the near tiles of row block kr: column blocks kr - RING - n (clamped: the first blocks have none, nobody reads them)
+            char* const nb = lds + LDS_NEAR + (kr % NNSLOT) * NEAR_SLOT_BYTES;
+#pragma unroll
+            for (int n = 0; n < NNEAR; ++n) {
+                const int kc = kr - RING - n > 0 ? kr - RING - n : 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int pj = kc * PB + 4 * q + tu;
+                    pj = pj < prow_t ? pj : (prow_t > 0 ? prow_t - 1 : 0);
+                    size_t off = cell_index<DIR>(prow_t, pj, T) * Bs + cbase;
+                    off = off < last4 ? off : last4;
+                    __builtin_amdgcn_global_load_lds((gbl_void_t*)(score + off), (lds_void_t*)(nb + n * TILE_BYTES + q * 1024), 16, 0, SEMICRF_LOADER_AUX);
+                }
+            }
+            if (GRAD)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(vfwd + (size_t)frow * Bs + cc), (lds_void_t*)(nb + NNEAR * TILE_BYTES), 4, 0, 0);
+        }
     };
     auto publish = [&](int kr) {
-        if (lane == 0) lds_flag_store_asm(ready + kr % NRBUF, kr + 1);
+        if (lane == 0) {
+            lds_flag_store_asm(ready + kr % NRBUF, kr + 1);
+            if (NNEAR > 0) lds_flag_store_asm(nready + kr % NNSLOT, kr + 1);
+        }
     };
 
     // NLOADER loader waves take the row blocks round-robin (lid = this wave's index); each keeps LDEPTH of its own
@@ -399,6 +469,14 @@ __device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* 
             const int w = (kr - NRBUF) % RING;
             int spins = 0;
             while (lds_flag_load_asm(cons + w) < kr - NRBUF + 1) {
+                __builtin_amdgcn_s_sleep(2);
+                if (spin_abort(ctrl, spins, SPIN_LIMIT_LDS, 6)) return;
+            }
+        }
+        if (NNEAR > 0 && kr >= NNSLOT && !(SEMICRF_PANEL_PROBES && (DBGF(P) & 9u))) {
+            // ... and the near slot's previous row block (kr - NNSLOT) by the far wave
+            int spins = 0;
+            while (lds_flag_load_asm(fcons + (kr - NNSLOT - RING + NFARW * NNSLOT) % NFARW) < kr - NNSLOT + 1 && kr - NNSLOT >= RING) {
                 __builtin_amdgcn_s_sleep(2);
                 if (spin_abort(ctrl, spins, SPIN_LIMIT_LDS, 6)) return;
             }
@@ -417,9 +495,19 @@ __device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* 
     if (prev1 >= 0) publish(prev1);
 }
 
+// max_push (common.h) as two selects instead of a compare-and-branch: larger value wins, on ties the smaller key
+__device__ __forceinline__ void max_push_sel(float& best, int& key, float t, int k)
+{
+    const bool take = (t > best) | ((t == best) & (k < key));
+    best = take ? t : best;
+    key = take ? k : key;
+}
+
 // ---- far wave -------------------------------------------------------------------------------------------
-template <int MODE, int DIR>
-__device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds)
+// Per block k >= RING, one combined value per (row, chain) for the owner's diagonal phase: the NEAR tiles (k, k-RING-n) from LDS --
+// cells staged by the loader, u from the ring's own LDS entries -- and the panels' partials of the far field (tiles 0 .. k-FAR0).
+template <int MODE, int DIR, bool GRAD>
+__device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds, int fw)
 {
     const int T = P.T, B = P.B, K = P.K;
     unsigned* const ctrl = P.ctrl;
@@ -430,27 +518,121 @@ __device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds
     const int r = spine_row(lane), ch = spine_chain(lane);
     const int c = P.c0 + sg * GS + ch;
     const bool cvalid = c < P.c1;
+    const int cc = cvalid ? c : P.c0;
     float4* const far = (float4*)(lds + LDS_FAR);
     const bool cbase_is_first = sg == 0;
-    for (int k = RING; k < K; ++k) {
+    const float* const ring = (const float*)(lds + LDS_RING);
+    const float* const rd_base = ring + ch * 2;
+    const int* const nready = (const int*)(lds + LDS_CTL) + NRBUF + RING;
+    int* const fcons = (int*)(lds + LDS_CTL) + NRBUF + RING + NNSLOT + fw;          // this far wave's own counter
+    float* const dScore = P.dScore;
+    float gz = 0.f, lzc = 0.f;
+    if (GRAD && NNEAR > 0 && cvalid) { gz = P.gout[(size_t)c * P.gstride] * P.gscale; lzc = P.logZ[c]; }
+    __builtin_amdgcn_s_setprio(SEMICRF_FAR_PRIO);     // above the ring's shadow phase (1), below its diagonal phase (3)
+    const bool fprobe = SEMICRF_PANEL_PROBES && (DBGF(P) & 16u) && cbase_is_first && lane == 0;
+    for (int k = RING + fw; k < K; k += NFARW) {
+        if (fprobe && k < 64) P.ts[640 + k] = __builtin_amdgcn_s_memrealtime();
         const int prow = k * PB + r;
         const bool rvalid = cvalid && prow < T;
-        // parts of block k: the panels' column parts of its far tiles 0 .. k-RING
-        const int nparts = nparts_of(k - RING);
+        const int prow_c = prow < T ? prow : T - 1;
         float aM = SEMICRF_NEG_INF, aS = 0.f;
         int aK = 0x7fffffff;
-        if (rvalid) {
-            // all parts are requested together (they complete in any order); the poll repeats for the missing ones
+        // parts of block k: the panels' column parts of its far tiles 0 .. k-FAR0
+        const int nparts = k >= FAR0 ? nparts_of(k - FAR0) : 0;
+        u64 eq[4] = {0, 0, 0, 0};                       // the early request of parts 0..3 (see below)
+        if (SEMICRF_FAR_EARLY && rvalid && nparts > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nparts) eq[i] = load_granule(farg + ((size_t)i * T + prow) * Bs + c);
+        }
+        // ---- near tiles: cells (and alpha) of row block k into registers, then the slot goes back to the loader -------------
+        float ncell[NNEAR > 0 ? NNEAR : 1][PB];
+        float arow = 0.f;
+        if (NNEAR > 0) {
+            int spins = 0;
+            while (lds_flag_load(nready + k % NNSLOT) != k + 1) {
+                __builtin_amdgcn_s_sleep(1);
+                if (spin_abort(ctrl, spins, SPIN_LIMIT_LDS, 11)) break;
+            }
+            const char* nb = lds + LDS_NEAR + (k % NNSLOT) * NEAR_SLOT_BYTES;
+#pragma unroll
+            for (int n = 0; n < NNEAR; ++n)
+#pragma unroll
+                for (int u = 0; u < PB; ++u) ncell[n][u] = *(const float*)(nb + n * TILE_BYTES + u * (PB * RS * 4) + (r * RS + ch) * 4);
+            if (GRAD) arow = rvalid ? (((const float*)(nb + NNEAR * TILE_BYTES))[lane] - lzc) * LOG2E : 0.f;
+            if (lane == 0) lds_flag_store(fcons, k + 1);          // in-order DS queue: after the reads above
+        }
+        if (fprobe && k < 64) P.ts[704 + k] = __builtin_amdgcn_s_memrealtime();
+        // ---- near tiles (oldest column block first: a fixed merge order) ---------------------------------------------------------
+        if (NNEAR > 0) {
+            // GRAD stores as in the ring: wave-uniform base + one per-lane byte offset
+            const int own0 = k * PB;
+            const unsigned bvoff = DIR == 0 ? (unsigned)(((size_t)(prow_c - own0) * T * Bs + cc) * 4)
+                                            : (unsigned)(((size_t)(T - 1 - prow_c) * Bs + cc) * 4);
+#pragma unroll
+            for (int n = NNEAR - 1; n >= 0; --n) {
+                const int b = k - RING - n;
+                if (b < 0) continue;
+                float uq[PB];
+#pragma unroll
+                for (int u4 = 0; u4 < PB; u4 += 4) {
+                    const int j = b * PB + u4;
+                    const float* e = rd_base + (j % NPOS) * 8;
+                    u64 w0, w1, w2, w3;
+                    int spins = 0;
+                    while (true) {
+                        w0 = lds_load64(e); w1 = lds_load64(e + 2 * RS); w2 = lds_load64(e + 4 * RS); w3 = lds_load64(e + 6 * RS);
+                        if (__all((int)(w0 >> 32) == j + 1 && (int)(w1 >> 32) == j + 2 && (int)(w2 >> 32) == j + 3 && (int)(w3 >> 32) == j + 4)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (spin_abort(ctrl, spins, SPIN_LIMIT_LDS, 12)) break;
+                    }
+                    uq[u4] = __uint_as_float((unsigned)w0); uq[u4 + 1] = __uint_as_float((unsigned)w1);
+                    uq[u4 + 2] = __uint_as_float((unsigned)w2); uq[u4 + 3] = __uint_as_float((unsigned)w3);
+                }
+                if (fprobe && k < 64 && n == 0) P.ts[768 + k] = __builtin_amdgcn_s_memrealtime();
+                if (MODE == 0) {
+                    float t[PB];
+#pragma unroll
+                    for (int u = 0; u < PB; ++u) {
+                        t[u] = fmaf(ncell[n][u], LOG2E, uq[u]);
+                        if (GRAD && rvalid) {
+                            const int j = b * PB + u;
+                            const size_t co = DIR == 0 ? ((size_t)own0 * T + (size_t)j) * Bs : (size_t)(T - 1 - j) * T * Bs;
+                            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(dScore + co), 0, 0x7fffffff, 0x00020000);
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gz * fexp2(t[u] + arow)), rs, bvoff, 0, 0);
+                        }
+                    }
+                    float mx = aM;
+#pragma unroll
+                    for (int u = 0; u < PB; u += 2) mx = fmaxf(mx, fmaxf(t[u], t[u + 1]));
+                    float sum = aS * fexp2(aM - mx);
+#pragma unroll
+                    for (int u = 0; u < PB; ++u) sum += fexp2(t[u] - mx);
+                    aM = mx; aS = sum;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < PB; ++u) max_push_sel(aM, aK, uq[u] + ncell[n][u], frame_of<DIR>(b * PB + u, T));
+                }
+            }
+        }
+        if (fprobe && k < 64) P.ts[832 + k] = __builtin_amdgcn_s_memrealtime();
+        if (rvalid && nparts > 0) {
+            // all parts are requested together (they complete in any order); the poll repeats for the missing ones.  The FIRST
+            // request of the first four parts went out at the top of the iteration (eq[]): a request is a device-scope round
+            // trip of ~2 us from this compute unit -- behind the loader's traffic -- whether or not the partial has long been
+            // stored, and the near tiles' work hides it.
             for (int p0 = 0; p0 < nparts; p0 += 4) {
                 const int np = nparts - p0 < 4 ? nparts - p0 : 4;
                 u64 gq[4];
                 bool have[4] = {false, false, false, false};
                 int spins = 0;
+                bool first = SEMICRF_FAR_EARLY && p0 == 0;
                 while (true) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         if (i < np && !have[i])
-                            gq[i] = load_granule(farg + ((size_t)(p0 + i) * T + prow) * Bs + c);
+                            gq[i] = first ? eq[i] : load_granule(farg + ((size_t)(p0 + i) * T + prow) * Bs + c);
+                    first = false;
                     bool all = true;
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
@@ -473,9 +655,11 @@ __device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds
                     }
             }
         }
+        if (fprobe && k < 64) P.ts[896 + k] = __builtin_amdgcn_s_memrealtime();
+        // (LSE: an empty accumulator -- rows past the end, ghost chains -- gives -inf + log2(0) = NaN, which nobody reads)
         const float val = MODE == 0 ? aM + flog2(aS) : aM;
         lds_store128(far + (k % NFAR) * 64 + lane, make_float4(val, __int_as_float(aK), __int_as_float(k + 1), 0.0f));   // one DS write: data + seq
-        if (SEMICRF_PANEL_PROBES && (P.dbg & 16u) && cbase_is_first && lane == 0) P.ts[128 + k] = __builtin_amdgcn_s_memrealtime();   // chain probe
+        if (SEMICRF_PANEL_PROBES && (DBGF(P) & 16u) && cbase_is_first && lane == 0) P.ts[128 + k] = __builtin_amdgcn_s_memrealtime();   // chain probe
     }
 }
 
@@ -496,13 +680,6 @@ __device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds
 // row, so "the value of row j" is a row_newbcast operand (v_add_f32_dpp / v_mov_b32_dpp), no LDS round trip.
 // tools/dpp_probe.hip measures the chains on their own.  The (max,+) sweeps keep their stepwise form (one add and one
 // compare per step, bit-exact candidates).
-// max_push (common.h) as two selects instead of a compare-and-branch: larger value wins, on ties the smaller key
-__device__ __forceinline__ void max_push_sel(float& best, int& key, float t, int k)
-{
-    const bool take = (t > best) | ((t == best) & (k < key));
-    best = take ? t : best;
-    key = take ? k : key;
-}
 
 template <int J>
 __device__ __forceinline__ float row_bcast(float x)       // lane J of this lane's DPP row: row J of the block, same chain
@@ -521,7 +698,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
     // kernel arguments are copied into locals: lambdas that capture the struct by reference make the
     // compiler spill it to scratch and reload fields inside the step loops
     const int T = P.T, B = P.B, K = P.K;
-    const unsigned dbg = P.dbg;
+    const unsigned dbg = DBGF(P);
     unsigned* const ctrl = P.ctrl;
     u64* const ts = P.ts;
     unsigned* const ug = P.ug;
@@ -733,7 +910,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
             }
         }
 
-        if (SEMICRF_PANEL_PROBES && trace) ts[64 + k] = __builtin_amdgcn_s_memrealtime();            // chain probe: far partial in hand
+        if (SEMICRF_PANEL_PROBES && trace) { ts[64 + k] = __builtin_amdgcn_s_memrealtime(); ev[2] = __builtin_readcyclecounter(); }   // chain probe: far partial in hand
         int mykey = -1;
         float mine = 0.f;                    // this lane's finished u (log2 units for LSE)
         if (MODE == 0) {
@@ -803,7 +980,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
         // ---- once per block: publish the 16 finished positions to HBM -----------------------------
         if (rvalid) {
             if (k == K - 1 && lds_flag_load(&s_abort) != 0) mine = __uint_as_float(0x7fc00000u);     // a wait timed out: poison the results
-            if (k < K - RING) {                                 // the far field of block k' ends at block k' - RING: nobody reads the last RING blocks' u
+            if (k < K - FAR0) {                                 // the far field of block k' ends at block k' - FAR0: nobody reads the last FAR0 blocks' u
                 unsigned ub = __float_as_uint(mine);
                 if (ub == U_EMPTY) ub = 0x7fc00000u;            // keep the one reserved pattern free (NaN input scores)
                 __hip_atomic_store(ug + (size_t)prow * Bs + c, ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -834,11 +1011,19 @@ constexpr int PSTAGE_BYTES = 10240;          // 8 KB of cells + 2 KB of u values
 #endif
 constexpr int PW_MAX = SEMICRF_PW_MAX;       // panel waves per workgroup (LDS: PW_MAX * PNS * PSTAGE_BYTES = 150 KB; four of them run unless the sweep is throughput-bound)
 constexpr int LDS_PANEL_BYTES = PW_MAX * PNS * PSTAGE_BYTES;
-constexpr int LDS_HYBRID_PANEL = (LDS_SPINE_BYTES + 1023) / 1024 * 1024;     // stages of a spine workgroup's panel waves
-constexpr int HPW_MAX = (160 * 1024 - 512 - LDS_HYBRID_PANEL) / (PNS * PSTAGE_BYTES) < NT / 64 - RING - NLOADER - 1
-                            ? (160 * 1024 - 512 - LDS_HYBRID_PANEL) / (PNS * PSTAGE_BYTES) : NT / 64 - RING - NLOADER - 1;
+// Spines per spine workgroup (round 4).  A spine -- ring of RING waves, its loader(s) and far wave(s), LDS_SPINE_BYTES of LDS -- is
+// self-contained; SPH of them share a workgroup, i.e. a compute unit: the tail of the headline sweep is bound by the far field's
+// streaming rate, ~26 GB/s per compute unit that is NOT a spine, and with one spine per unit 88 of the 256 were spines at
+// NBatch = 352 (the panels alone, fed without any dependency, need 147 us there; the whole sweep took 175).
+constexpr int SPH = SEMICRF_SPH;
+constexpr int HWAVES = RING + NLOADER + NFARW;                                  // waves of one spine
+constexpr int LDS_HALF = (LDS_SPINE_BYTES + 1023) / 1024 * 1024;              // LDS of one spine
+constexpr int LDS_HYBRID_PANEL = SPH * LDS_HALF;                              // stages of a spine workgroup's panel waves
+constexpr int HPW_MAX = (160 * 1024 - 512 - LDS_HYBRID_PANEL) / (PNS * PSTAGE_BYTES) < NT / 64 - SPH * HWAVES
+                            ? (160 * 1024 - 512 - LDS_HYBRID_PANEL) / (PNS * PSTAGE_BYTES) : NT / 64 - SPH * HWAVES;
+static_assert(SPH * HWAVES <= NT / 64 && SPH * LDS_HALF <= 160 * 1024 - 512 && (GP / GS) % SPH == 0, "wave roles");
 constexpr int LDS_HYBRID_BYTES = LDS_HYBRID_PANEL + (HPW_MAX > 0 ? HPW_MAX : 0) * PNS * PSTAGE_BYTES;
-constexpr int LDS_DYN_MAX2 = LDS_SPINE_BYTES > LDS_PANEL_BYTES ? LDS_SPINE_BYTES : LDS_PANEL_BYTES;
+constexpr int LDS_DYN_MAX2 = SPH * LDS_HALF > LDS_PANEL_BYTES ? SPH * LDS_HALF : LDS_PANEL_BYTES;
 constexpr int LDS_DYN_BYTES = LDS_HYBRID_BYTES > LDS_DYN_MAX2 ? LDS_HYBRID_BYTES : LDS_DYN_MAX2;   // > half of the CU's 160 KB: one workgroup per CU
 // A wave owns rows pi = 16k + 4*q4 + rr (rr < 4) of position block k for 32 chains.  lane = slot*8 + q8:
 // q8 selects 4 of the 32 chains (8 consecutive lanes read one 128-byte line), slot selects the columns
@@ -944,7 +1129,7 @@ __device__ __forceinline__ void panel_wait_younger(int y)
 }
 
 // ---- task selection -----------------------------------------------------------------------------------------------
-// Block k = RING + q has q + 1 far tiles, cut at fixed columns into FULL parts of TPT tiles and one LAST part (see
+// Block k = FAR0 + q has q + 1 far tiles, cut at fixed columns into FULL parts of TPT tiles and one LAST part (see
 // part_tiles), each split in four row quarters and 32-chain groups.  ONE queue in (block, part, chain group, row
 // quarter) order: an atomic counter.  (Per-part earliest-deadline queues, full parts handed out early, next-task
 // prefetch and "recent-tile" waves on the spine CUs were all measured slower, DESIGN.md section 3 "Round 2".)
@@ -957,14 +1142,14 @@ __device__ __forceinline__ void panel_task_decode(const SweepParams& P, int task
     const int t2 = task >> 2;
     t.g = t2 % P.nPanelGroups;
     int tt = t2 / P.nPanelGroups;
-    if (tt < LEADT - 1) { t.part = 0; t.k = RING + tt; return; }      // the first LEADT - 1 blocks: one part
+    if (tt < LEADT - 1) { t.part = 0; t.k = FAR0 + tt; return; }      // the first LEADT - 1 blocks: one part
     tt -= LEADT - 1;
     int a = 0;
     while (tt >= TPT * (a + 1) * (a + 2) / 2) ++a;          // group a: blocks with a+1 parts
     tt -= TPT * a * (a + 1) / 2;
     const int q = a * TPT + tt / (a + 1) + LEADT - 1;
     t.part = tt % (a + 1);
-    t.k = RING + q;
+    t.k = FAR0 + q;
 }
 
 __device__ __forceinline__ bool panel_next_task(const SweepParams& P, PanelTask& t)
@@ -982,7 +1167,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
 {
     const int T = P.T, B = P.B;
     const int c0 = P.c0, c1 = P.c1;
-    const unsigned dbg = P.dbg;
+    const unsigned dbg = DBGF(P);
     unsigned* const ctrl = P.ctrl;
     u64* const farg = P.farg;
     const float* const vfwd = P.vfwd;
@@ -1019,14 +1204,22 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
     while (true) {
         // ---- next task: (k, part, g, q4); a task only waits on spine progress below k-3 ----
         PanelTask tk;
-        if (first_task >= 0 && first_task < P.nTasks) panel_task_decode(P, first_task, tk);
-        else if (!panel_next_task(P, tk)) break;
+        if (first_task >= 0 && first_task < P.nTasks) {
+            panel_task_decode(P, first_task, tk);
+#if SEMICRF_STAGGER > 0
+            // Staggered start (round 4): the ~700 panel waves of a launch all know their first task and used to request its first
+            // tiles in the same microsecond -- 20 MB that the spines' loaders (and the first hand-offs) queued behind: the first 8
+            // blocks took 20 - 27 us where the ring alone needs 11.  A wave whose first task belongs to block k waits roughly
+            // until the ring can be there.
+            for (int i = 0, n = tk.k - FAR0 < 48 ? tk.k - FAR0 : 48; i < n; ++i) __builtin_amdgcn_s_sleep(SEMICRF_STAGGER);
+#endif
+        } else if (!panel_next_task(P, tk)) break;
         first_task = -1;
         if (SEMICRF_PROBE_TASKS && (dbg & 256u) && tk.k == RING && tk.part == 0 && tk.g == 0 && tk.q4 == 0) tracer = true;
         u64* const tsp = P.ts + (3 * T) / 2 + 5 * tn;
         const bool tr = SEMICRF_PROBE_TASKS && tracer && lane == 0 && 5 * tn + 5 <= T / 2;
         if (tr) tsp[0] = __builtin_amdgcn_s_memrealtime();
-        const int q = tk.k - RING;                                  // the newest far tile of this block
+        const int q = tk.k - FAR0;                                  // the newest far tile of this block
         int m0, m1;
         part_tiles(q, tk.part, m0, m1);                             // tiles m0 .. m1-1 of the q+1 panel tiles of block k
         const int k = tk.k, part = tk.part, g = tk.g, q4 = tk.q4;
@@ -1385,7 +1578,7 @@ __device__ __forceinline__ void zero_role(const SweepParams& P)
 // earlier first-come ticket (an atomic per workgroup) clustered them by luck of arrival.
 __host__ __device__ __forceinline__ int wg_ticket(int nSpine, int grid, int b)
 {
-    constexpr int X = 8, SPG = GP / GS;                      // XCDs, spines per panel group
+    constexpr int X = 8, SPG = GP / GS / SPH;                // XCDs, spine WORKGROUPS per panel group (nSpine counts workgroups here)
     const int ngroups = (nSpine + SPG - 1) / SPG;
     int S[X], W[X];
     bool fits = true;
@@ -1439,31 +1632,54 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
         s_exit = 0;
     }
     // flags and sequence numbers start at 0
-    for (int i = threadIdx.x; i < (LDS_DUMMY - LDS_FAR) / 4; i += NT) ((int*)(s_dyn + LDS_FAR))[i] = 0;
+    for (int h = 0; h < SPH; ++h)
+        for (int i = threadIdx.x; i < (LDS_DUMMY - LDS_FAR) / 4; i += NT) ((int*)(s_dyn + h * LDS_HALF + LDS_FAR))[i] = 0;
     __syncthreads();
     // Roles by workgroup index: every workgroup of the launch is resident (one per CU, the grid never exceeds the CUs) and
     // the dispatcher starts them in index order, so a workgroup still only waits on earlier ones.  (An atomic ticket cost
     // every workgroup a device-scope round trip before it could do anything, on a line that hundreds of waves hit with
     // their first task draws at the same moment.)
-    const int ticket = wg_ticket(P.nSpine, (int)gridDim.x, (int)blockIdx.x);
+    const int nSpineWG = (P.nSpine + SPH - 1) / SPH;
+    const int ticket = wg_ticket(nSpineWG, (int)gridDim.x, (int)blockIdx.x);
     const int wave = (int)(threadIdx.x >> 6);
     // clock probe (probe build, debug flag 128): shader cycles and 100 MHz ticks of one panel workgroup over the launch
-    const bool clk = SEMICRF_PANEL_PROBES && (P.dbg & 128u) && ticket == P.nSpine + 3 && threadIdx.x == 0;
+    const bool clk = SEMICRF_PANEL_PROBES && (DBGF(P) & 128u) && ticket == nSpineWG + 3 && threadIdx.x == 0;
     if (clk) { P.ts[600] = __builtin_readcyclecounter(); P.ts[601] = __builtin_amdgcn_s_memrealtime(); }
-    if (SEMICRF_PROBE_HIST && (P.dbg & 1024u) && threadIdx.x == 0)          // activity histogram: t0 = the first workgroup's start
+    if (SEMICRF_PROBE_HIST && (DBGF(P) & 1024u) && threadIdx.x == 0)          // activity histogram: t0 = the first workgroup's start
         atomicMin((unsigned long long*)(P.ts + (3 * P.T) / 2), (unsigned long long)__builtin_amdgcn_s_memrealtime());
-    if (ticket < P.nSpine) {
+    if (ticket < nSpineWG) {
         // chain group = ticket: neighbouring groups read neighbouring 16-byte pieces of the same sectors, and
         // measured fetch traffic is 3x lower this way than with groups spread 8 tickets apart (0.13 vs 0.36 GB for
         // the band at T=1024, NBatch=352)
-        const int sg = ticket;
-        if (wave < RING) {
-            if (!(P.dbg & 8u)) spine_role<MODE, DIR, GRAD>(P, sg, wave, s_dyn);
-            if (P.selfclean && wave == (P.K - 1) % RING) {
+        const int half = wave / HWAVES, hw = wave % HWAVES;       // which spine of the workgroup, which wave of that spine
+        const int sg = ticket * SPH + half;
+        char* const lds_h = s_dyn + half * LDS_HALF;
+        if (half >= SPH) {
+            const int xw = wave - SPH * HWAVES;
+            if (!(DBGF(P) & 2u) && xw < P.hybridPanelWaves) {
+                // Spare waves stream tiles like the panel workgroups do (their stages lie behind the spines' LDS) -- but only
+                // once the sweep is bound by the far field: during the first blocks the ring sets the pace and a streaming
+                // wave on its CU only slows it down.  They wait until the (first) ring has taken row block hybridStart.
+                {
+                    const int* cons = (const int*)(s_dyn + LDS_CTL) + NRBUF;
+                    int spins = 0;
+                    while (lds_flag_load(cons + (P.hybridStart % RING)) < P.hybridStart + 1 && P.hybridStart < P.K &&
+                           !(SEMICRF_PANEL_PROBES && (DBGF(P) & 8u))) {
+                        __builtin_amdgcn_s_sleep(127);
+                        if (spin_abort(P.ctrl, spins, SPIN_LIMIT_LDS, 10)) break;
+                    }
+                }
+                panel_role<MODE, DIR, GRAD>(P, s_dyn + LDS_HYBRID_PANEL, xw, 1);
+            }
+        } else if (sg >= P.nSpine) {
+            // (an odd number of spines: the last workgroup's second one has no chains)
+        } else if (hw < RING) {
+            if (!(DBGF(P) & 8u)) spine_role<MODE, DIR, GRAD>(P, sg, hw, lds_h);
+            if (P.selfclean && hw == (P.K - 1) % RING) {
                 // Leased workspace: u goes back to U_EMPTY.  When ANY ring of a 32-chain group is through, so is every panel
                 // task of the group (a task stores its partials for all of the group's chains at once, after its last look
                 // at u, and this ring took its last partials before its last block), and every u a task reads has been
-                // published (the last RING blocks' u is never stored).  So the group's u is dead, and each of its rings --
+                // published (the last FAR0 blocks' u is never stored).  So the group's u is dead, and each of its rings --
                 // through its last block's owner, the ring mates return earlier -- clears one share of the rows in whole
                 // 128-byte pieces (its own 16 bytes of every row would be 8x the line writes: measured +25 us).
                 const int lane = threadIdx.x & 63;
@@ -1483,27 +1699,14 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
                     }
                 }
             }
-        } else if (wave < RING + NLOADER) {
-            if (!(P.dbg & 8u)) loader_role<DIR, GRAD>(P, sg, s_dyn, wave - RING);
-        } else if (wave == RING + NLOADER) {
-            if (!(P.dbg & 9u)) far_role<MODE, DIR>(P, sg, s_dyn);
-        } else if (!(P.dbg & 2u) && wave - (RING + NLOADER + 1) < P.hybridPanelWaves) {
-            // Spare waves stream tiles like the panel workgroups do (their stages lie behind the spine's LDS) -- but only
-            // once the sweep is bound by the far field: during the first blocks the ring sets the pace and a streaming
-            // wave on its CU only slows it down.  They wait until the ring has taken row block hybridStart.
-            {
-                const int* cons = (const int*)(s_dyn + LDS_CTL) + NRBUF;
-                int spins = 0;
-                while (lds_flag_load(cons + (P.hybridStart % RING)) < P.hybridStart + 1 && P.hybridStart < P.K) {
-                    __builtin_amdgcn_s_sleep(127);
-                    if (spin_abort(P.ctrl, spins, SPIN_LIMIT_LDS, 10)) break;
-                }
-            }
-            panel_role<MODE, DIR, GRAD>(P, s_dyn + LDS_HYBRID_PANEL, wave - (RING + NLOADER + 1), 1);
+        } else if (hw < RING + NLOADER) {
+            if (!(DBGF(P) & 8u)) loader_role<DIR, GRAD>(P, sg, lds_h, hw - RING);
+        } else {
+            if (!(DBGF(P) & 9u)) far_role<MODE, DIR, GRAD>(P, sg, lds_h, hw - (RING + NLOADER));
         }
     } else {
-        if (!(P.dbg & 2u) && wave < P.panelWaves)
-            panel_role<MODE, DIR, GRAD>(P, s_dyn, wave, 0, P.taskBase > 0 ? (ticket - P.nSpine) * P.panelWaves + wave : -1);
+        if (!(DBGF(P) & 2u) && wave < P.panelWaves)
+            panel_role<MODE, DIR, GRAD>(P, s_dyn, wave, 0, P.taskBase > 0 ? (ticket - nSpineWG) * P.panelWaves + wave : -1);
         else if (GRAD && wave - P.panelWaves >= 0 && wave - P.panelWaves < P.zeroWaves) zero_role(P);
     }
     if (clk) { P.ts[602] = __builtin_readcyclecounter(); P.ts[603] = __builtin_amdgcn_s_memrealtime(); }
@@ -1533,7 +1736,7 @@ constexpr size_t CTRL_BYTES = MAX_CHUNKS * CTRL_WORDS * sizeof(unsigned);
 static int max_parts(int T)
 {
     const int K = (T + PB - 1) / PB;
-    return K > RING ? nparts_of(K - 1 - RING) : 1;
+    return K > FAR0 ? nparts_of(K - 1 - FAR0) : 1;
 }
 
 // writes the exact zeros of the upper triangle (begin > end) of the dense gradient: row e, columns e+1..T-1
@@ -1669,6 +1872,7 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
 #if SEMICRF_PANEL_PROBES
     // timing ablations (results are wrong when set): only the probe build reads them
     if (const char* dbg = getenv("SEMICRF_DEBUG_FLAGS")) P.dbg = (unsigned)atoi(dbg);
+    if (SEMICRF_CT_DBG >= 0) P.dbg = (unsigned)SEMICRF_CT_DBG;
 #endif
     char* w = (char*)ws;
     P.ts = (u64*)(w + CTRL_BYTES);
@@ -1709,9 +1913,9 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         const int nb = P.c1 - P.c0;
         P.nSpine = (nb + GS - 1) / GS;
         P.nPanelGroups = (nb + GP - 1) / GP;
-        // panel tasks per chain group: block k = RING + q has nparts_of(q) column parts, each split in 4 row quarters
+        // panel tasks per chain group: block k = FAR0 + q has nparts_of(q) column parts, each split in 4 row quarters
         long long ntask = 0;
-        for (int q = 0; q < P.K - RING; ++q) ntask += nparts_of(q);
+        for (int q = 0; q < P.K - FAR0; ++q) ntask += nparts_of(q);
         ntask *= 4;
         P.nTasks = (int)(ntask * P.nPanelGroups);
         P.ctrl = (unsigned*)w + (size_t)ci * CTRL_WORDS;
@@ -1720,7 +1924,8 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         // mean longer memory queues, and the spine's band loads and hand-offs wait in the same queues; the far
         // field grows with T^2 and the spine's chain with T, so longer sequences get more panel waves, and
         // the gradient sweep (which also stores a tile per tile loaded) a few more.
-        int nPanelWG = ncu - P.nSpine;
+        const int nSpineWG = (P.nSpine + SPH - 1) / SPH;
+        int nPanelWG = ncu - nSpineWG;
         if (nPanelWG < 0) nPanelWG = 0;
         // The spine workgroups' two spare waves stream tiles too, from row block hybridStart on: while the ring sets
         // the pace (the first third of the blocks) a streaming wave on its CU only slows it down; afterwards the sweep is
@@ -1760,7 +1965,7 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         }
         P.zeroWaves = zw;
         if (P.nTasks == 0) nPanelWG = 0;
-        const int grid = P.nSpine + nPanelWG;
+        const int grid = nSpineWG + nPanelWG;
         // the panel workgroups' waves know their first task (the first draws of ~700 waves all hit one counter at the start)
         P.taskBase = nPanelWG * P.panelWaves;
         if (P.taskBase > P.nTasks) P.taskBase = P.nTasks;
@@ -1790,6 +1995,7 @@ int launch_persist_logz_bwd(const float* score, const float* noise, const float*
 
 // host-side view of the workgroup -> role map (tests/test_abi.py checks that it is a permutation for every launch shape)
 int persist_wg_ticket(int nSpine, int grid, int b) { return wg_ticket(nSpine, grid, b); }
+int persist_spine_wgs_per_group() { return GP / GS / SPH; }
 
 // the error word of every chain chunk of a sweep launched into `pws` (0xffffffff = no wait timed out)
 const unsigned* persist_error_words(void* pws, int* n, int* stride)
