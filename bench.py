@@ -186,10 +186,31 @@ def worker(args):
     for _ in range(args.steps):
         step()
     sync_all()
-    elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, dev)
+    elapsed_local = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed_local, dev)
     value = seen_world * args.steps / elapsed
     log(f"timed region done: {elapsed / args.steps * 1e3:.3f} ms/step")
+    # N > 1: what the scaling number is made of (the first multi-GPU run should explain itself): every rank's own time per step,
+    # and the [3] loss all-reduce on its own
+    diag = None
+    if dist is not None:
+        diag = {}
+        try:
+            mine = torch.tensor([elapsed_local / args.steps * 1e3], dtype=torch.float64, device=dev)
+            allr = [torch.zeros_like(mine) for _ in range(seen_world)]
+            dist.all_gather(allr, mine)
+            diag["per_rank_ms_per_step"] = [round(float(x.item()), 4) for x in allr]
+            probe = torch.zeros((), device=dev)
+            for _ in range(3):
+                fused_loss_allreduce(probe, 1.0, 1.0)
+            torch.cuda.synchronize(dev); dist.barrier(); torch.cuda.synchronize(dev)
+            tA = time.perf_counter()
+            for _ in range(20):
+                fused_loss_allreduce(probe, 1.0, 1.0)
+            torch.cuda.synchronize(dev)
+            diag["loss_allreduce3_us"] = round(max_over_ranks((time.perf_counter() - tA) / 20, dev) * 1e6, 2)
+        except Exception as ex:
+            diag["diag_error"] = repr(ex)[:200]
 
     def ev_time(fn, n, warm=2):
         for _ in range(warm):
@@ -250,6 +271,8 @@ def worker(args):
                                       + ("; [3] fp32 loss all-reduce per step over RCCL" if seen_world > 1 else "")},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "extra": extra,
         }
+        if diag is not None:
+            line["multi_gpu_diagnostics"] = diag
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
@@ -414,7 +437,12 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
             torch.cuda.synchronize(dev)
             dt = (time.perf_counter() - t1) / 3
             dk = ev_time(lambda: nsci._viterbi_raw(sd, nd, st_t, False), 5) * 1e-3
+            t1 = time.perf_counter()
+            for _ in range(3):
+                crf_d.decode_packed(forcedStartPos=start)
+            dpk = (time.perf_counter() - t1) / 3
             tag = f"decode_T2048_B352_{kind}"
+            extra[tag + "_ms_end_to_end_packed_arrays"] = round(dpk * 1e3, 3)      # decode_packed: the same path as int32 arrays
             extra[tag + "_intervals"] = nint
             extra[tag + "_ms_end_to_end_python_lists"] = round(dt * 1e3, 3)
             extra[tag + "_segments_per_s_end_to_end"] = round((Bd / 88) / dt, 2)
@@ -505,7 +533,7 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
                 feat = mel(normalize_gain(makeFrame(audio, 1024, 4096)))
                 c = backbone(feat.to(torch.bfloat16)).float()
                 return scorer_crf_logprob(m, c, iv1)
-        extra["segment_full_forward_ms"] = round(ev_time(full_forward, 5), 3)
+        extra["segment_full_forward_standin_backbone_ms"] = round(ev_time(full_forward, 5), 3)
         extra["segment_full_forward_config"] = ("16 s @ 44.1 kHz stereo -> makeFrame (T=691) -> 6-window log-mel (229 bands, fp32) -> stand-in "
                                                 "backbone in bf16 -> fp32 ctx [1,90,691,256] -> Linear + interval scorer + CRF logProb (forward only)")
         del audio, mel, backbone
@@ -574,6 +602,19 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
                                   + "; backbone out of scope (ctx is the input)")
     extra["train_step_collectives"] = int(ncoll[0])
     extra["train_step_exchange_bytes_per_rank"] = int(bucket.bytes_per_rank)
+    if dist is not None:
+        # the gradient exchange on its own (reduce-scatter + all-gather of the flat bucket, in place, current stream)
+        try:
+            for _ in range(2):
+                bucket.exchange()
+            sync_all()
+            t2 = time.perf_counter()
+            for _ in range(5):
+                bucket.exchange()
+            torch.cuda.synchronize(dev)
+            extra["train_step_exchange_ms"] = round(max_over_ranks((time.perf_counter() - t2) / 5, dev) * 1e3, 3)
+        except Exception as ex:
+            extra["train_step_exchange_error"] = repr(ex)[:200]
 
 
 def _physical_cores():

@@ -109,8 +109,10 @@ int semicrf_async_error(void);
 int semicrf_debug_wg_ticket(int n_spine, int grid, int block);
 
 /* Test hook, process-wide: force one of interval_score_fwd's kernels where it applies (0 = register loads, 32 = streaming,
- * 64 / 128 = shared-operand tiles, 2 = the 64 x 128 tiles with the epilogue inside the contraction loop -- all four give
- * bit-identical scores); -1 = automatic choice (the default).  The library reads no environment variables. */
+ * 2 = the 64 x 128 tiles with the epilogue inside the contraction loop; 64 / 128 = the earlier shared-operand tiles, compiled into
+ * the DEBUG library only -- libsemicrf_hip_debug.so, the same ABI built with -DSEMICRF_DEBUG_BUILD=1, which the parity tests load
+ * through ctypes as the bit-level reference; the release library ignores 64 / 128 -- all give bit-identical scores); -1 =
+ * automatic choice (the default).  The release library reads no environment variables. */
 void semicrf_debug_score_variant(int variant);
 
 /*

@@ -109,3 +109,36 @@ def score_backward_torch(dS, q, k, N, P, T, D, mode, full=False):
     dk = torch.bmm(gl.transpose(1, 2), q) * qs
     ddiag = torch.diagonal(g, dim1=1, dim2=2)                     # [C,T]
     return dq.view(N, P, T, D), dk.view(N, P, T, D), ddiag.reshape(N, P, T).contiguous()
+
+
+def interval_score_variant(variant, q, k, dg, T, C, D, qs, mode, full, group=0, pitch=0, rowc=None):
+    """interval_score_fwd with ONE of its kernels forced (semicrf_debug_score_variant).  The release library carries the register-load
+    (0), streaming (32), tiled (2) and three-limb kernels; the 64- / 128-row tile kernels (64, 128) -- the bit-level reference of the
+    tiled kernel -- live in the DEBUG library (transkun_amd/libsemicrf_hip_debug.so), called here through ctypes on the same C ABI."""
+    import ctypes
+    import torch
+    from transkun_amd import _lib
+    from transkun_amd.scorer import _interval_score_raw
+    if variant not in (64, 128):
+        lib = _lib.load()
+        lib.semicrf_debug_score_variant(int(variant))
+        try:
+            return _interval_score_raw(q, k, dg, T, C, D, qs, mode, full, group, pitch, rowc=rowc)
+        finally:
+            lib.semicrf_debug_score_variant(-1)
+    lib = _lib.load_debug()
+    if not group:
+        group = pitch = C
+    Cs = C // group * pitch
+    S = torch.empty(T, T, Cs, dtype=torch.float32, device=q.device)
+    noise = torch.empty(max(T - 1, 0), Cs, dtype=torch.float32, device=q.device)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    lib.semicrf_debug_score_variant(int(variant))
+    try:
+        rc = lib.interval_score_fwd_pc(vp(q), vp(k), vp(dg), vp(rowc) if rowc is not None else None, C, T, D, q.stride(-2), k.stride(-2),
+                                       dg.stride(-1), rowc.stride(-1) if rowc is not None else 1, float(qs), int(mode), int(full), int(group),
+                                       int(pitch), vp(S), vp(noise), ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream))
+    finally:
+        lib.semicrf_debug_score_variant(-1)
+    assert rc == 0, lib.semicrf_last_error().decode()
+    return S, noise

@@ -227,6 +227,9 @@ def test_full_size_decode(gpu):
         h = hashlib.sha256(); h.update(off.astype("<i8").tobytes()); h.update(pairs.astype("<i4").tobytes())
         assert h.hexdigest() == str(g[f"decode_{name}_sha256"])
         assert np.array_equal(pairs[:64], g[f"decode_{name}_head"])
+        # the packed form (an extension: decode_packed) is the same path without the Python lists
+        pk, ok = crf.decode_packed(forcedStartPos=st)
+        assert pk.dtype == np.int32 and np.array_equal(ok, off.astype(np.int32)) and np.array_equal(pk, pairs)
     # forward and backward Viterbi are both optimal up to fp32 round-off of their own sums, so the paths may
     # differ at near-ties (the reference's do too); their scores must agree, and evalPath(decode) <= logZ.
     full_b = crf.decode()
@@ -290,25 +293,17 @@ def test_scorer_forward_kernels(gpu, variant, C, T, D, mode, full, monkeypatch):
     """Every forward kernel of the interval scorer (register-load, streaming, 64- and 128-row shared-operand tiles, 2 = the
     64 x 128 tiles with the epilogue inside the contraction loop: the default where it applies) against an fp64 einsum of the
     same definition (LayersTransformer.py:406-441)."""
-    from transkun_amd import synth
-    from transkun_amd.scorer import _interval_score_raw
-    from transkun_amd import _lib
-    lib = _lib.load()
-    lib.semicrf_debug_score_variant(variant)            # process-wide test hook (the library reads no environment)
-    try:
-        _scorer_forward_case(gpu, C, T, D, mode, full)
-    finally:
-        lib.semicrf_debug_score_variant(-1)
+    _scorer_forward_case(gpu, C, T, D, mode, full, variant)       # (64 / 128: the debug library's reference tile kernels)
 
 
-def _scorer_forward_case(gpu, C, T, D, mode, full):
+def _scorer_forward_case(gpu, C, T, D, mode, full, variant=-1):
+    from conftest import interval_score_variant
     from transkun_amd import synth
-    from transkun_amd.scorer import _interval_score_raw
     q = synth.hash_normal(C * T * D, 71, "cpu").view(C, T, D).to(gpu)
     k = synth.hash_normal(C * T * D, 72, "cpu").view(C, T, D).to(gpu)
     dg = synth.hash_normal(C * T, 73, "cpu").view(C, T).to(gpu)
     qs = 1.0 / D ** 0.5
-    S, _ = _interval_score_raw(q, k, dg, T, C, D, qs, mode, full)
+    S, _ = interval_score_variant(variant, q, k, dg, T, C, D, qs, mode, full)
     t = torch.arange(T, device=gpu)
     ln = (t[:, None] - t[None, :]).abs().double()
     ln = ln if mode == 0 else (ln.sqrt() if mode == 1 else torch.ones_like(ln))
@@ -339,13 +334,9 @@ def test_scorer_tiled_bits(gpu, N, P, pitch, T, D, full, use_rc):
     k = synth.hash_normal(C * T * D, 6, gpu).view(C, T, D)
     dg = synth.hash_normal(C * T, 7, gpu).view(C, T)
     rc = synth.hash_normal(C * T, 8, gpu).view(C, T) if use_rc else None
-    try:
-        lib.semicrf_debug_score_variant(128)
-        ref, _ = _interval_score_raw(q, k, dg, T, C, D, 1.0 / 16, 0, full, P, pitch, rowc=rc)
-        lib.semicrf_debug_score_variant(2)
-        got, _ = _interval_score_raw(q, k, dg, T, C, D, 1.0 / 16, 0, full, P, pitch, rowc=rc)
-    finally:
-        lib.semicrf_debug_score_variant(-1)
+    from conftest import interval_score_variant
+    ref, _ = interval_score_variant(128, q, k, dg, T, C, D, 1.0 / 16, 0, full, P, pitch, rowc=rc)       # debug library
+    got, _ = interval_score_variant(2, q, k, dg, T, C, D, 1.0 / 16, 0, full, P, pitch, rowc=rc)         # release library
     assert torch.equal(ref, got)
     assert _lib.device_status() == 0
 
@@ -1323,11 +1314,10 @@ def test_scorer_slot_layout(gpu, N, P, pitch, T, D, bf16x3):
     qs = 1.0 / D ** 0.5
     fs = 0 | (BF16X3 if bf16x3 else 0)
     from transkun_amd import _lib
-    _lib.load().semicrf_debug_score_variant(128)       # the slot layout lives in the tile kernels: the same kernel for the reference
-    try:
-        ref, _ = _interval_score_raw(q, k, dg, T, C, D, qs, 0, fs)
-    finally:
-        _lib.load().semicrf_debug_score_variant(-1)
+    from conftest import interval_score_variant
+    # the contiguous layout on the SAME family of kernels (the slot layout lives in the tile kernels; below T = 256 the automatic
+    # choice for a contiguous layout is the streaming kernel, whose summation order differs): the debug library's 128-row tiles
+    ref, _ = interval_score_variant(128, q, k, dg, T, C, D, qs, 0, fs)
     got, nz = _interval_score_raw(q, k, dg, T, C, D, qs, 0, fs, P, pitch)
     assert got.shape == (T, T, N * pitch) and nz.shape == (T - 1, N * pitch) and float(nz.abs().max()) == 0.0
     g4 = got.view(T, T, N, pitch)

@@ -562,7 +562,7 @@ def _viterbi_raw(score_c, noise_c, start, forward: bool):
     return pairs, offsets
 
 
-def _decode(score, noiseScore, forcedStartPos: Optional[Sequence[int]], forward: bool) -> Intervals:
+def _decode(score, noiseScore, forcedStartPos: Optional[Sequence[int]], forward: bool, packed: bool = False):
     assert len(score.shape) == 3
     assert score.shape[0] == score.shape[1]
     T, B = _check_inputs(score, noiseScore)
@@ -584,6 +584,8 @@ def _decode(score, noiseScore, forcedStartPos: Optional[Sequence[int]], forward:
             raise RuntimeError("semicrf_viterbi: a bounded hand-off wait timed out on the device (GPU shared with work that "
                                "kept part of the persistent kernel from running?); the decode result is invalid")
         pairs_h = pairs[:total].cpu()
+    if packed:
+        return pairs_h.numpy(), off_h.numpy()
     return unpack_intervals(pairs_h, off_h, T)
 
 
@@ -651,6 +653,14 @@ class NeuralSemiCRFInterval:
             return viterbi(self.score, self.noiseScore, forcedStartPos)
         else:
             return viterbiBackward(self.score, self.noiseScore, forcedStartPos)
+
+    def decode_packed(self, forcedStartPos=None, forward=False):
+        """An EXTENSION of the reference's surface: the decoded path of `decode` as two int32 arrays -- pairs [K, 2] of
+        (begin, end), chain after chain and ascending within a chain, and offsets [nBatch + 1] (chain c owns
+        pairs[offsets[c]:offsets[c + 1]]) -- i.e. what the device produced, before the Python lists are built.  `decode` spends
+        ~25 ns of CPython object creation per interval on top of it (657 k intervals at T=2048, nBatch=352: 17 ms against 1 ms
+        here); callers that go on with arrays anyway should take this one."""
+        return _decode(self.score, self.noiseScore, forcedStartPos, bool(forward), packed=True)
 
     def evalPath(self, intervals):
         """compute the unnormalized score"""

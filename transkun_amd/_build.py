@@ -109,10 +109,45 @@ def build_torch_shim(force: bool = False, verbose: bool = False) -> str:
     return TORCH_LIB
 
 
+DEBUG_LIB = os.path.join(HERE, "libsemicrf_hip_debug.so")
+
+
+def build_debug(force: bool = False, verbose: bool = False) -> str:
+    """libsemicrf_hip_debug.so: every source compiled with -DSEMICRF_DEBUG_BUILD=1 -- the reference tile kernels of the interval
+    scorer (scorer_mfma.hip: interval_score_tile_kernel<64|128>), all of semicrf_debug_score_variant's choices and the launch
+    geometry knobs of tools/ (read from the environment).  The parity tests load it explicitly (through ctypes, the same C ABI)
+    as the bit-level reference of the default kernels; nothing under transkun_amd/ uses it."""
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    if not force and os.path.exists(DEBUG_LIB) and os.path.getmtime(DEBUG_LIB) > max(os.path.getmtime(d) for d in deps):
+        return DEBUG_LIB
+    objdir = os.path.join(CSRC, "_obj_debug")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off", "-Wno-unused-function",
+             "-DSEMICRF_DEBUG_BUILD=1"]
+    objs, procs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        cmd = [_hipcc()] + flags + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode())
+            raise RuntimeError("hipcc failed (debug library)")
+    tmp = DEBUG_LIB + ".tmp"
+    subprocess.check_call([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs)
+    os.replace(tmp, DEBUG_LIB)
+    return DEBUG_LIB
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     build_marshal(force)
     path = _build_hip(force, verbose)
     build_torch_shim(force, verbose)
+    build_debug(force, verbose)
     return path
 
 

@@ -99,6 +99,26 @@ def load():
     return _lib
 
 
+_dbg = None
+DEBUG_LIB_PATH = os.path.join(_HERE, "libsemicrf_hip_debug.so")
+
+
+def load_debug():
+    """The DEBUG build of the HIP library (same C ABI; transkun_amd/_build.py: build_debug): reference kernels that the release
+    library no longer carries, for the parity tests and tools/ -- through ctypes only, never behind the torch ops."""
+    global _dbg
+    if _dbg is None:
+        if not os.path.exists(DEBUG_LIB_PATH):
+            raise SemiCRFLibraryError(f"{DEBUG_LIB_PATH} not found: build it with `python -m transkun_amd._build`")
+        lib = ctypes.CDLL(DEBUG_LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _dbg = lib
+    return _dbg
+
+
 _ops = None
 TORCH_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libsemicrf_torch.so")     # next to the HIP library it links
 

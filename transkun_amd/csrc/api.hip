@@ -506,8 +506,14 @@ int interval_score_fwd_pc(const float* q, const float* k, const float* diag, con
     if (full_square == 0) launch_zero_upper(S, T, Cs, st);     // begin > end: defined (zero), half the bytes of a full fill
     const int full_kernel = full_square == 1 ? 1 : 0;           // 2: lower triangle only, the rest of S is left as it is
     if (g_impl.load() == 0 && interval_score_mfma_supported(C, T, D)) {
-        if (launch_interval_score_mfma(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, length_scaling, full_kernel, S, st, prec, group, pitch,
-                                       rowc, ldrc) != 0) {
+        const int lrc = launch_interval_score_mfma(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, length_scaling, full_kernel, S, st, prec, group,
+                                                   pitch, rowc, ldrc);
+        if (lrc == 2) {
+            set_error("interval_score_fwd: a padded slot layout / a row constant needs the tiled kernels (D <= 256, D %% 64 == 0, T >= 128, "
+                      "16-byte aligned rows, 32 T Cs floats within 32-bit offsets)");
+            return SEMICRF_EINVAL;
+        }
+        if (lrc != 0) {
             set_error("interval_score_fwd: work list allocation failed");
             return SEMICRF_ELAUNCH;
         }

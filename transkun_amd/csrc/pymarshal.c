@@ -134,10 +134,218 @@ static PyObject* m_pack_into(PyObject* self, PyObject* args)
     return PyLong_FromLongLong(k);
 }
 
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * The cross-segment event merge of TransKun.transcribe (ModelTransformer.py:803-843) and Data.resolveOverlapping (Data.py:170-214)
+ * for the packed per-step results of transkun_amd.transcribe (rows of 7 doubles: start, end, hasOnset, hasOffset, velocity,
+ * symbol index, chain index).  The reference walks Python Note objects event by event; at the event density of a batched
+ * transcription (thousands of events per step) that walk, not the device, set the pace.  Here the merge state is a C array per
+ * (recording, symbol) and Note objects are only made for the events that survive, once, at the end.
+ *
+ *   tm_new(n_files, P, merge) -> capsule
+ *   tm_add(capsule, step, rows_addr, K, active_files)        rows in chain order (ascending time within a chain)
+ *   tm_finish(capsule, file, pitches, NoteClass, vel_is_float, resolve) -> list of Note
+ * ---------------------------------------------------------------------------------------------------------------------- */
+#include <descrobject.h>
+#include <structmember.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { double start, end, vel; char on, off; } TmEv;
+typedef struct { TmEv* v; long n, cap; int seen; long first_step; double first_start, first_end; } TmTrack;
+typedef struct { long n_files, P; int merge; TmTrack* tracks; } TmMerger;
+
+static void tm_free(PyObject* cap)
+{
+    TmMerger* m = (TmMerger*)PyCapsule_GetPointer(cap, "semicrf.tm");
+    if (!m) return;
+    if (m->tracks) { for (long i = 0; i < m->n_files * m->P; ++i) free(m->tracks[i].v); free(m->tracks); }
+    free(m);
+}
+
+static PyObject* m_tm_new(PyObject* self, PyObject* args)
+{
+    long n_files, P; int merge;
+    if (!PyArg_ParseTuple(args, "llp", &n_files, &P, &merge)) return NULL;
+    if (n_files < 1 || P < 1) { PyErr_SetString(PyExc_ValueError, "bad sizes"); return NULL; }
+    TmMerger* m = (TmMerger*)calloc(1, sizeof(TmMerger));
+    if (!m) return PyErr_NoMemory();
+    m->n_files = n_files; m->P = P; m->merge = merge;
+    m->tracks = (TmTrack*)calloc((size_t)(n_files * P), sizeof(TmTrack));
+    if (!m->tracks) { free(m); return PyErr_NoMemory(); }
+    return PyCapsule_New(m, "semicrf.tm", tm_free);
+}
+
+static int tm_push(TmTrack* t, const TmEv* e)
+{
+    if (t->n == t->cap) {
+        const long nc = t->cap ? 2 * t->cap : 16;
+        TmEv* nv = (TmEv*)realloc(t->v, (size_t)nc * sizeof(TmEv));
+        if (!nv) return -1;
+        t->v = nv; t->cap = nc;
+    }
+    t->v[t->n++] = *e;
+    return 0;
+}
+
+static PyObject* m_tm_add(PyObject* self, PyObject* args)
+{
+    PyObject *cap, *active;
+    long step; unsigned long long addr; long long K;
+    if (!PyArg_ParseTuple(args, "OlKLO", &cap, &step, &addr, &K, &active)) return NULL;
+    TmMerger* m = (TmMerger*)PyCapsule_GetPointer(cap, "semicrf.tm");
+    if (!m) return NULL;
+    PyObject* seq = PySequence_Fast(active, "active must be a sequence of recording indices");
+    if (!seq) return NULL;
+    const Py_ssize_t na = PySequence_Fast_GET_SIZE(seq);
+    long files[256];
+    if (na > 256) { Py_DECREF(seq); PyErr_SetString(PyExc_ValueError, "too many recordings in one step"); return NULL; }
+    for (Py_ssize_t i = 0; i < na; ++i) {
+        files[i] = PyLong_AsLong(PySequence_Fast_GET_ITEM(seq, i));
+        if (files[i] < 0 || files[i] >= m->n_files) { Py_DECREF(seq); PyErr_SetString(PyExc_IndexError, "recording index out of range"); return NULL; }
+    }
+    Py_DECREF(seq);
+    const double* rows = (const double*)(uintptr_t)addr;
+    for (long long i = 0; i < K; ++i) {
+        const double* r = rows + 7 * i;
+        const long sym = (long)r[5], chain = (long)r[6];
+        const long sg = chain / m->P;
+        if (sym < 0 || sym >= m->P || sg < 0 || sg >= na) { PyErr_SetString(PyExc_IndexError, "event row out of range"); return NULL; }
+        TmTrack* t = &m->tracks[files[sg] * m->P + sym];
+        TmEv e; e.start = r[0]; e.end = r[1]; e.on = r[2] != 0.0; e.off = r[3] != 0.0; e.vel = r[4];
+        if (!t->seen) { t->seen = 1; t->first_step = step; t->first_start = e.start; t->first_end = e.end; }
+        if (m->merge && t->n > 0) {                                   /* ModelTransformer.py:806-822 */
+            TmEv* last = &t->v[t->n - 1];
+            if (e.start < last->end) {
+                if (e.on) *last = e;
+                else { last->off = e.off; if (e.end > last->end) last->end = e.end; }
+                continue;
+            }
+        }
+        if (e.on && tm_push(t, &e)) return PyErr_NoMemory();            /* :824-825 */
+    }
+    Py_RETURN_NONE;
+}
+
+typedef struct { double start, end, vel; long sym, pitch, idx; char on, off; } TmOut;
+static int tm_cmp_time(const void* a, const void* b)
+{
+    const TmOut* x = (const TmOut*)a; const TmOut* y = (const TmOut*)b;
+    if (x->start != y->start) return x->start < y->start ? -1 : 1;
+    if (x->end != y->end) return x->end < y->end ? -1 : 1;
+    if (x->pitch != y->pitch) return x->pitch < y->pitch ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+typedef struct { long step; double start, end; long pitch, sym; } TmKey;
+static int tm_cmp_key(const void* a, const void* b)
+{
+    const TmKey* x = (const TmKey*)a; const TmKey* y = (const TmKey*)b;
+    if (x->step != y->step) return x->step < y->step ? -1 : 1;
+    if (x->start != y->start) return x->start < y->start ? -1 : 1;
+    if (x->end != y->end) return x->end < y->end ? -1 : 1;
+    return x->pitch < y->pitch ? -1 : (x->pitch > y->pitch);
+}
+
+static Py_ssize_t slot_offset(PyObject* cls, const char* name)
+{
+    PyObject* d = PyObject_GetAttrString(cls, name);
+    if (!d) return -1;
+    Py_ssize_t off = -1;
+    if (Py_TYPE(d) == &PyMemberDescr_Type) off = ((PyMemberDescrObject*)d)->d_member->offset;
+    Py_DECREF(d);
+    if (off < 0) PyErr_Format(PyExc_TypeError, "the Note class must define __slots__ with `%s`", name);
+    return off;
+}
+
+static PyObject* m_tm_finish(PyObject* self, PyObject* args)
+{
+    PyObject *cap, *pitches, *cls;
+    long file; int vel_float, resolve;
+    if (!PyArg_ParseTuple(args, "OlOOpp", &cap, &file, &pitches, &cls, &vel_float, &resolve)) return NULL;
+    TmMerger* m = (TmMerger*)PyCapsule_GetPointer(cap, "semicrf.tm");
+    if (!m) return NULL;
+    if (file < 0 || file >= m->n_files) { PyErr_SetString(PyExc_IndexError, "recording index out of range"); return NULL; }
+    PyObject* pseq = PySequence_Fast(pitches, "pitches must be a sequence");
+    if (!pseq) return NULL;
+    if (PySequence_Fast_GET_SIZE(pseq) != m->P || !PyType_Check(cls)) { Py_DECREF(pseq); PyErr_SetString(PyExc_ValueError, "bad pitches / class"); return NULL; }
+    const char* names[6] = {"start", "end", "pitch", "velocity", "hasOnset", "hasOffset"};
+    Py_ssize_t so[6];
+    for (int i = 0; i < 6; ++i) if ((so[i] = slot_offset(cls, names[i])) < 0) { Py_DECREF(pseq); return NULL; }
+    TmTrack* tr = m->tracks + file * m->P;
+    long total = 0;
+    for (long s = 0; s < m->P; ++s) {
+        if (tr[s].n > 0) tr[s].v[tr[s].n - 1].off = 1;               /* :831-834 */
+        total += tr[s].n;
+    }
+    TmOut* ev = (TmOut*)malloc((size_t)(total > 0 ? total : 1) * sizeof(TmOut));
+    TmKey* keys = (TmKey*)malloc((size_t)m->P * sizeof(TmKey));
+    long* lastp = (long*)malloc((size_t)m->P * sizeof(long));
+    if (!ev || !keys || !lastp) { free(ev); free(keys); free(lastp); Py_DECREF(pseq); return PyErr_NoMemory(); }
+    /* the reference flattens byType.values(): symbols in the order their first event was SEEN (:837-841) */
+    long nk = 0;
+    for (long s = 0; s < m->P; ++s)
+        if (tr[s].seen) {
+            keys[nk].step = tr[s].first_step; keys[nk].start = tr[s].first_start; keys[nk].end = tr[s].first_end;
+            keys[nk].pitch = PyLong_AsLong(PySequence_Fast_GET_ITEM(pseq, s)); keys[nk].sym = s; ++nk;
+        }
+    qsort(keys, (size_t)nk, sizeof(TmKey), tm_cmp_key);
+    long n = 0;
+    for (long k = 0; k < nk; ++k) {
+        const long s = keys[k].sym;
+        for (long i = 0; i < tr[s].n; ++i)
+            if (tr[s].v[i].off) {
+                TmOut* o = &ev[n];
+                o->start = tr[s].v[i].start; o->end = tr[s].v[i].end; o->vel = tr[s].v[i].vel; o->sym = s; o->pitch = keys[k].pitch;
+                o->on = tr[s].v[i].on; o->off = 1; o->idx = n; ++n;
+            }
+    }
+    if (resolve) {                                                      /* Data.py:170-214 */
+        qsort(ev, (size_t)n, sizeof(TmOut), tm_cmp_time);
+        for (long s = 0; s < m->P; ++s) lastp[s] = -1;
+        for (long i = 0; i < n; ++i) {
+            const long j = lastp[ev[i].sym];
+            if (j >= 0 && ev[j].end > ev[i].start) ev[j].end = ev[i].start;
+            lastp[ev[i].sym] = i;
+        }
+        long w = 0;
+        for (long i = 0; i < n; ++i) if (ev[i].start < ev[i].end) { ev[w] = ev[i]; ev[w].idx = w; ++w; }
+        n = w;
+        qsort(ev, (size_t)n, sizeof(TmOut), tm_cmp_time);
+    }
+    PyObject* out = PyList_New(n);
+    PyTypeObject* tp = (PyTypeObject*)cls;
+    int ok = out != NULL;
+    for (long i = 0; ok && i < n; ++i) {
+        PyObject* o = tp->tp_alloc(tp, 0);                             /* slots start as NULL; filled below, no __init__ call */
+        if (!o) { ok = 0; break; }
+        PyObject* vals[6];
+        vals[0] = PyFloat_FromDouble(ev[i].start);
+        vals[1] = PyFloat_FromDouble(ev[i].end);
+        vals[2] = PySequence_Fast_GET_ITEM(pseq, ev[i].sym); Py_INCREF(vals[2]);
+        vals[3] = vel_float ? PyFloat_FromDouble(ev[i].vel) : PyLong_FromLong((long)ev[i].vel);
+        vals[4] = ev[i].on ? Py_True : Py_False; Py_INCREF(vals[4]);
+        vals[5] = ev[i].off ? Py_True : Py_False; Py_INCREF(vals[5]);
+        for (int k = 0; k < 6; ++k) {
+            if (!vals[k]) { ok = 0; continue; }
+            *(PyObject**)((char*)o + so[k]) = vals[k];
+        }
+        PyList_SET_ITEM(out, i, o);
+    }
+    free(ev); free(keys); free(lastp); Py_DECREF(pseq);
+    if (!ok) {
+        if (out) { for (long i = 0; i < n; ++i) if (!PyList_GET_ITEM(out, i)) { Py_INCREF(Py_None); PyList_SET_ITEM(out, i, Py_None); } Py_DECREF(out); }
+        return PyErr_Occurred() ? NULL : PyErr_NoMemory();
+    }
+    return out;
+}
+
 static PyMethodDef methods[] = {
     {"unpack", m_unpack, METH_VARARGS, "packed int32 pairs/offsets (host addresses) -> list of lists of (begin, end)"},
     {"pack_into", m_pack_into, METH_VARARGS, "list of lists of (begin, end) -> packed int32 buffers; returns K"},
     {"count", m_count, METH_O, "total number of intervals"},
+    {"tm_new", m_tm_new, METH_VARARGS, "event merger for n_files recordings of P symbols"},
+    {"tm_add", m_tm_add, METH_VARARGS, "merge the packed events of one step (rows of 7 doubles at a host address)"},
+    {"tm_finish", m_tm_finish, METH_VARARGS, "the final Note list of one recording"},
     {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_semicrf_marshal", "interval-list marshalling", -1, methods};

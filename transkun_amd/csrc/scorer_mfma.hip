@@ -25,6 +25,12 @@ namespace semicrf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#if defined(SEMICRF_DEBUG_BUILD) && SEMICRF_DEBUG_BUILD
+#define SEMICRF_HAVE_TILE_REF 1
+#else
+#define SEMICRF_HAVE_TILE_REF 0
+#endif
+
 constexpr int ST = 32;        // tile edge (positions)
 constexpr int SC = 16;        // chains per workgroup
 constexpr int SPAD = SC + 1;  // LDS row padding: conflict-free column writes
@@ -562,6 +568,11 @@ __device__ __forceinline__ f32x16 mma6(const Limbs3& A, const Limbs3& B, f32x16 
 // XTE = tile rows (end positions): 128 -> 8 waves, one workgroup per CU; 64 -> 4 waves, two (independent) workgroups
 // per CU whose barriers and operand reads fall into each other's matrix phases (24 instead of 32 flop per byte).
 // C = real chains; Cs = slots (the chain pitch of S); see SlotGeom.
+// The 64- / 128-row shared-operand tile kernels: superseded as the default by scorer_tiled.hip (bit-identical results); since
+// round 4 they are compiled into the DEBUG library only (libsemicrf_hip_debug.so, -DSEMICRF_DEBUG_BUILD=1), where the parity tests
+// load them explicitly as the reference of test_scorer_tiled_bits.  The release library keeps the tiled kernel (default), the
+// streaming kernel (T < 256), the register-load kernel (any alignment / contraction size) and the opt-in three-limb kernel.
+#if SEMICRF_HAVE_TILE_REF
 template <int XTE>
 __global__ __launch_bounds__(512, 2) void interval_score_tile_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ diag, int C, int T, int D,
@@ -917,6 +928,7 @@ static int launch_score_tile(const float* q, const float* k, const float* diag, 
                        qscale, mode | (dbg << 8), full, S, ntiles, nquadp, Cs, G, rowc, ldrc);
     return 0;
 }
+#endif  // SEMICRF_HAVE_TILE_REF
 
 // ---------------------------------------------------------------------------------------------
 // 128x128 tile kernel with the three-limb bf16 contraction (opt-in: interval_score_fwd, full_square | SEMICRF_SCORE_BF16X3)
@@ -1379,10 +1391,16 @@ int launch_interval_score_mfma(const float* q, const float* k, const float* diag
         if (slots && variant != 64) variant = 128;                 // the slot layout lives in the tile kernels
         if (prec == 1 && T >= 128)
             return launch_score_tile3<128>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream, group, pitch, rowc, ldrc);
+#if SEMICRF_HAVE_TILE_REF
         if (variant == 128)
             return launch_score_tile<128>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream, group, pitch, rowc, ldrc);
         if (variant == 64)
             return launch_score_tile<64>(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, stream, group, pitch, rowc, ldrc);
+#else
+        // release library: what the tiled kernel does not take (D > 256, 32 T Cs floats beyond 32-bit offsets) runs on the
+        // register-load kernel below; a slot layout / row constant there is refused by the caller's check
+        if (slots) return 2;
+#endif
         if (variant == 32)
             return launch_score_stream(q, k, diag, C, T, D, ldq, ldk, ldd, qscale, mode, full, S, band, stream);
     }

@@ -103,6 +103,38 @@ class EventMerger:
         return resolveOverlapping(events) if resolve else events
 
 
+class PackedEventMerger:
+    """EventMerger + resolveOverlapping for ALL recordings of a transcribe_many call, on the packed rows of a step (start, end,
+    hasOnset, hasOffset, velocity, symbol index, chain index as float64) instead of Note objects: the merge state lives in C
+    (csrc/pymarshal.c: tm_*), one pass over the rows per step, and Note objects are made once, for the events that survive.  Same
+    results as the Python classes above (tests/test_transcribe_merge.py); at the event density of a batched transcription the
+    per-event Python walk, not the device, used to set the pace (8 ms of host work per 0.7 ms step)."""
+
+    def __init__(self, n_files: int, pitches: Sequence[int], mergeIncompleteEvent: bool = True):
+        self.pitches = [int(p) for p in pitches]
+        self.n_files = n_files
+        self._m = _lib.marshal()
+        self._h = self._m.tm_new(n_files, len(self.pitches), bool(mergeIncompleteEvent))
+        self.vel_float = False
+
+    def add_step(self, step_index: int, rows, K: int, active: Sequence[int]) -> None:
+        """rows: a contiguous float64 [>= K, 7] host array (numpy or a CPU torch tensor), in chain order as the device wrote them."""
+        if K <= 0:
+            return
+        addr = rows.data_ptr() if hasattr(rows, "data_ptr") else rows.ctypes.data
+        self._m.tm_add(self._h, int(step_index), int(addr), int(K), list(active))
+
+    def finish(self, file: int, resolve: bool = True) -> List[Note]:
+        import gc
+        was = gc.isenabled()
+        gc.disable()          # tens of thousands of fresh (cycle-free) objects would otherwise trigger several full collections
+        try:
+            return self._m.tm_finish(self._h, int(file), self.pitches, Note, bool(self.vel_float), bool(resolve))
+        finally:
+            if was:
+                gc.enable()
+
+
 def _head(n_in: int, hidden: int, n_out: int, dropout: float) -> nn.Sequential:
     return nn.Sequential(nn.Linear(n_in, hidden), nn.GELU(), nn.Dropout(dropout), nn.Linear(hidden, n_out))
 
@@ -230,6 +262,14 @@ class SegmentTranscriber(nn.Module):
             return torch.argmax(tmp * torch.arange(128, 0., -1, device=dev), dim=-1)
         raise Exception("Unrecognized criterion: {}".format(criterion))
 
+    @staticmethod
+    def _packed_rows(step: dict) -> torch.Tensor:
+        """The step's events as ONE float64 [K, 7] device tensor (every field is exactly representable): start, end, hasOnset,
+        hasOffset, velocity, symbol index, chain index."""
+        return torch.stack([step["times"][:, 0], step["times"][:, 1], step["flags"][:, 0].to(torch.float64),
+                            step["flags"][:, 1].to(torch.float64), step["velocity"].to(torch.float64),
+                            step["symIdx"].to(torch.float64), step["scatterIdx"].to(torch.float64)], dim=1)
+
     def _notes_of_step(self, step: dict, n_files: int) -> List[List[Note]]:
         """Host objects of a step: per recording the Notes in the reference's order (sorted by (start, end, pitch), :722)."""
         K = step["K"]
@@ -237,10 +277,8 @@ class SegmentTranscriber(nn.Module):
         if K == 0:
             return out
         P = len(self.targetMIDIPitch)
-        # ONE copy to the host: every field is exactly representable in float64
-        packed = torch.stack([step["times"][:, 0], step["times"][:, 1], step["flags"][:, 0].to(torch.float64),
-                              step["flags"][:, 1].to(torch.float64), step["velocity"].to(torch.float64),
-                              step["symIdx"].to(torch.float64), step["scatterIdx"].to(torch.float64)], dim=1).cpu().numpy()
+        # ONE copy to the host
+        packed = self._packed_rows(step).cpu().numpy()
         seg = packed[:, 6].astype(np.int64) // P
         pitch = np.asarray(self.targetMIDIPitch, dtype=np.int64)[packed[:, 5].astype(np.int64)]
         order = np.lexsort((pitch, packed[:, 1], packed[:, 0], seg))             # by recording, then (start, end, pitch)
@@ -303,32 +341,53 @@ class SegmentTranscriber(nn.Module):
         plans = [self.segment_plan(n, stepInSecond, segmentSizeInSecond) for n in nSamples]
         P = len(self.targetMIDIPitch)
         dev = next(self.parameters()).device
-        mergers = [EventMerger(mergeIncompleteEvent) for _ in plans]
+        merger = PackedEventMerger(len(plans), self.targetMIDIPitch, mergeIncompleteEvent)
         nsteps = max(len(p["begins"]) for p in plans)
         T = plans[0]["nFrame"]
         stepFrames = int(plans[0]["stepSize"] / self.hopSize)                           # :791
         onsetBound = plans[0]["stepSize"] if discardSecondHalf else None                # :779-782 (the reference passes samples)
         start = torch.full((len(plans) * P,), plans[0]["startFrameIdx"], dtype=torch.int32, device=dev)      # :751-752
         active_prev = list(range(len(plans)))
-        pending = None                                                                  # (step dict, active files): host part runs one step late
+        pending = None                  # (step index, K, pinned rows, copy event, active files): the host part runs one step late
+        bufs = [None, None]             # two pinned row buffers, alternating: step s fills one while step s-1's is merged
+
+        def to_host(s, step):
+            K = step["K"]
+            if K == 0:
+                return None
+            merger.vel_float = step["velocity"].is_floating_point()
+            rows = self._packed_rows(step)
+            if dev.type != "cuda":
+                return (s, K, rows.contiguous(), None)
+            b = bufs[s & 1]
+            if b is None or b.shape[0] < K:
+                b = bufs[s & 1] = torch.empty(max(2 * K, 4096), 7, dtype=torch.float64, pin_memory=True)
+            b[:K].copy_(rows, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            return (s, K, b, ev)
+
+        def merge(p):
+            if p is None or p[0] is None:
+                return
+            (s, K, rows, ev), active = p
+            if ev is not None:
+                ev.synchronize()
+            merger.add_step(s, rows, K, active)
+
         for s in range(nsteps):
             active = [f for f, p in enumerate(plans) if s < len(p["begins"])]
             if active != active_prev:                                                   # recordings that ended drop out of the batch
                 keep = torch.tensor([active_prev.index(f) for f in active], device=dev)
                 start = start.view(len(active_prev), P)[keep].reshape(-1).contiguous()
                 active_prev = active
-            ctxBatch = torch.cat([ctx_fns[f](s, T) for f in active], dim=0)
+            ctxBatch = torch.cat([ctx_fns[f](s, T) for f in active], dim=0) if len(active) > 1 else ctx_fns[active[0]](s, T)
             beginTime = torch.tensor([plans[f]["begins"][s] / self.fs - plans[f]["padTimeBegin"] for f in active], dtype=torch.float64,
                                      device=dev)                                         # :766
             step = self.decode_step(ctxBatch, start, beginTime, plans[0]["lastFrameIdx"], stepFrames, onsetBound)
             start = step["nextStart"]                                                   # :789-791, stays on the device
-            if pending is not None:
-                self._merge_step(*pending, mergers)
-            pending = (step, active)
-        if pending is not None:
-            self._merge_step(*pending, mergers)
-        return [m.finish(resolve) for m in mergers]
-
-    def _merge_step(self, step, active, mergers):
-        for f, notes in zip(active, self._notes_of_step(step, len(active))):
-            mergers[f].add_segment(notes)
+            host = to_host(s, step)                                                     # the rows' copy runs behind the step's kernels
+            merge(pending)                                                              # ... while the host merges the previous step
+            pending = (host, active)
+        merge(pending)
+        return [merger.finish(f, resolve) for f in range(len(plans))]
