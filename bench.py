@@ -572,8 +572,11 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
     from transkun_amd.dist import FlatGradBucket
     bucket = FlatGradBucket(model.parameters())      # gradients live in one persistent flat buffer; reduce-scatter + all-gather
 
+    ctx.requires_grad_()          # the backbone's output: its gradient (dctx) is part of the step ...
+
     def tstep():
-        _, ncoll[0] = train_step(model, ctx.requires_grad_(), iv, bucket=bucket)
+        ctx.grad = None           # ... but it is an intermediate tensor in the model: no accumulation into a leaf's .grad (255 MB add)
+        _, ncoll[0] = train_step(model, ctx, iv, bucket=bucket)
 
     def sync_all():
         torch.cuda.synchronize(dev)

@@ -1698,6 +1698,7 @@ def test_cotenant_cu_mask_is_never_silent(gpu, tmp_path):
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
         assert lines, (mask, r.returncode, r.stderr[-1500:])
         out = json.loads(lines[-1][7:])
+        print("co-tenant mask", mask, {k: v for k, v in out.items() if k != "logz"})
         if out["raised"]:
             continue                                      # loud
         if out["nan_logz"] or out["nan_grad"]:

@@ -27,21 +27,14 @@ for (N, P, pitch, T, D) in ((1, 352, 352, 1024, 256), (4, 90, 96, 691, 256))[:1 
     k = synth.hash_normal(C * T * D, 6, dev).view(C, T, D)
     dg = synth.hash_normal(C * T, 7, dev).view(C, T)
     fl = 2.0 * C * (T * (T + 1) / 2) * D
-    # interval_score_tiled_kernel (the default) and the 128-row tiles beside it, in alternating rounds (whichever runs second in a
-    # pair of back-to-back measurements looks ~3 % faster)
-    f32 = f32_128 = 0.0
-    rounds = 4
-    for _ in range(rounds):
-        f32 += timeit(lambda: _interval_score_raw(q, k, dg, T, C, D, 1.0 / 16, 0, 2, P, pitch), max(n // 2, 2), 1) / rounds
-        _lib.load().semicrf_debug_score_variant(128)
-        f32_128 += timeit(lambda: _interval_score_raw(q, k, dg, T, C, D, 1.0 / 16, 0, 2, P, pitch), max(n // 2, 2), 1) / rounds
-        _lib.load().semicrf_debug_score_variant(-1)
+    # interval_score_tiled_kernel (the default; the 64- / 128-row reference tiles live in the debug library since round 4)
+    f32 = timeit(lambda: _interval_score_raw(q, k, dg, T, C, D, 1.0 / 16, 0, 2, P, pitch), n, 1)
     b3 = timeit(lambda: _interval_score_raw(q, k, dg, T, C, D, 1.0 / 16, 0, 2 | 4, P, pitch))
     S, _ = _interval_score_raw(q, k, dg, T, C, D, 1.0 / 16, 0, 0, P, pitch)
     dq = torch.empty_like(q); dk = torch.empty_like(k); dd = torch.empty_like(dg)
     ws = bwd_workspace(C, T, D, dev)
     bw = timeit(lambda: ops.interval_score_bwd_ws(S, q, k, C, T, D, D, D, 1.0 / 16, 0, P, pitch, dq, dk, dd, dd, D, D, 1, 0, ws))
-    print(f"T={T} chains={C} (groups of {P} at pitch {pitch}) D={D}: fwd fp32 {f32:.3f} ms = {fl / f32 / 1e9:.1f} TFLOP/s ({fl / f32 / 1e9 / 157.3:.3f} of 157.3; 128-row tile kernel {f32_128:.3f} ms), "
+    print(f"T={T} chains={C} (groups of {P} at pitch {pitch}) D={D}: fwd fp32 {f32:.3f} ms = {fl / f32 / 1e9:.1f} TFLOP/s ({fl / f32 / 1e9 / 157.3:.3f} of 157.3), "
           f"fwd bf16x3 {b3:.3f} ms = {fl / b3 / 1e9:.1f} TFLOP/s fp32-equivalent, bwd (pack + 2 GEMMs) {bw:.3f} ms = {2 * fl / bw / 1e9:.1f} TFLOP/s", flush=True)
     del q, k, dg, S, dq, dk, dd, ws
     torch.cuda.empty_cache()

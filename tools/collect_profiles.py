@@ -4,7 +4,7 @@ profiles/traffic_latest.json stamped with the hash of the sweep sources.  Run he
 import collections, csv, glob, hashlib, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + TAG)
 DST = os.path.join(ROOT, "profiles")
 
@@ -19,7 +19,8 @@ def short(kn):
     return kn[:kn.index("(")] if "(" in kn else kn[:70]
 
 
-for sub, name in (("kt", "bench_kernel_stats"), ("kt_all", "bench_all_kernels_stats"), ("kt_scorer", "scorer_kernel_stats")):
+for sub, name in (("kt", "bench_kernel_stats"), ("kt_all", "bench_all_kernels_stats"), ("kt_scorer", "scorer_kernel_stats"),
+                  ("kt_train", "train_step_kernel_stats")):
     f = newest(f"{SRC}/{sub}/runc/*_kernel_stats.csv")
     if f:
         shutil.copy(f, f"{DST}/{TAG}_{name}.csv")

@@ -1,18 +1,20 @@
-# The exact sequence behind profiles/r03_*: GPU tests, bench.py, bench.py under rocprofv3 --kernel-trace --stats twice (headline
+# The exact sequence behind profiles/<tag>_*: GPU tests, bench.py, bench.py under rocprofv3 --kernel-trace --stats twice (headline
 # workload only: --no-extra, every persist_sweep row is T=1024 x 352; and with the extras: every product kernel shows up), then
 # separate --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass): HBM traffic of the forward and gradient sweeps, cache and
 # stall counters of the gradient sweep, and matrix-pipe counters + busy cycles of the scorer kernels.  tools/collect_profiles.py
-# turns the output into profiles/r03_*.
+# turns the output into profiles/<tag>_*.
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r03
+TAG=${1:-r04}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed" | tee $OUT/pytest.log
 timeout 900 python bench.py 2>$OUT/bench.err > $OUT/bench.json
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra --no-live-traffic > $OUT/kt.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_all -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-live-traffic > $OUT/kt_all.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_train -- python $GRAFT_REPO_ROOT/tools/train_step_probe.py > $OUT/kt_train.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_scorer -- python $GRAFT_REPO_ROOT/tools/bench_scorer_all.py 20 > $OUT/kt_scorer.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_fwd_$c -- python $GRAFT_REPO_ROOT/tools/bench_sweep.py --ops fwd --n 5 > $OUT/pmc_fwd_$c.log 2>&1

@@ -301,6 +301,9 @@ constexpr int LDS_RING = LDS_FAR + NFAR * 64 * 16;                     // [NPOS]
 #ifndef SEMICRF_STAGGER
 #define SEMICRF_STAGGER 32          // s_sleep units (64 cycles) per block of distance before a panel wave starts on its known first task
 #endif
+#ifndef SEMICRF_LOADER_PACE
+#define SEMICRF_LOADER_PACE 0       // s_sleep units between the loader's 1 KB band loads (0: a burst per row block)
+#endif
 #ifndef SEMICRF_LOADER_AUX
 #define SEMICRF_LOADER_AUX 0        // cache policy bits of the loader's band loads: 1 sc0, 2 nt, 16 sc1
 #endif
@@ -424,6 +427,7 @@ __device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* 
                 off = off < last4 ? off : last4;
                 __builtin_amdgcn_global_load_lds((gbl_void_t*)(score + off),
                                                  (lds_void_t*)(lds + LDS_TILES + (slot * RING + i) * TILE_BYTES + q * 1024), 16, 0, SEMICRF_LOADER_AUX);
+                if (SEMICRF_LOADER_PACE > 0) __builtin_amdgcn_s_sleep(SEMICRF_LOADER_PACE);
             }
         }
         const int prow_c = kr * PB + cr < T ? kr * PB + cr : T - 1;
