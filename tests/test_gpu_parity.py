@@ -1705,3 +1705,36 @@ def test_cotenant_cu_mask_is_never_silent(gpu, tmp_path):
             assert out["async"] != 0 or out["status"] != 0, (mask, out)      # poisoned AND reported
         else:
             assert out["status"] == 0 and np.max(np.abs(np.asarray(out["logz"]) - want) / np.abs(want)) < 1e-5, (mask, out)
+
+
+@pytest.mark.gpu
+def test_score_pool_upper_triangle_stays_exact(gpu):
+    """interval_score_fwd with full_square == 0 promises zeros above the diagonal; they are written once per pooled buffer.  Five calls
+    (one after an in-place edit of the previous result, one while a view of it is alive): the cells begin > end are +0.0 every time and
+    the rest equals the first call's bits."""
+    import importlib
+    from transkun_amd import synth
+    from transkun_amd.scorer import _interval_score_raw, _score_pool
+    nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
+    nsci.grad_pool_clear()
+    C, T, D = 96, 256, 64
+    q = synth.hash_normal(C * T * D, 91, gpu).view(C, T, D)
+    k = synth.hash_normal(C * T * D, 92, gpu).view(C, T, D)
+    dg = synth.hash_normal(C * T, 93, gpu).view(C, T)
+    upper = torch.triu(torch.ones(T, T, dtype=torch.bool, device=gpu), diagonal=1)
+    first, view, h0 = None, None, _score_pool().hits
+    for step in range(5):
+        S, nz = _interval_score_raw(q, k, dg, T, C, D, 0.125, 0, False)
+        assert float(S[upper].abs().max()) == 0.0 and not torch.signbit(S[upper]).any(), step
+        if first is None:
+            first = S.clone()
+        else:
+            assert torch.equal(S, first), step
+        if step == 1:
+            S.mul_(2.0)
+        if step == 2:
+            view, view_copy = S[3], S[3].clone()
+        del S, nz
+    assert torch.equal(view, view_copy)
+    assert _score_pool().hits - h0 >= 1
+    nsci.grad_pool_clear()

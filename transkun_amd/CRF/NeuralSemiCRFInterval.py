@@ -246,8 +246,12 @@ _GRAD_POOL = _GradPool()
 
 def grad_pool_clear() -> None:
     """Release the gradient buffers the pool holds (they are otherwise kept until the budget SEMICRF_GRAD_POOL_BYTES, 8 GiB by
-    default, is exceeded; SEMICRF_NO_GRAD_POOL=1 disables the pool)."""
+    default, is exceeded; SEMICRF_NO_GRAD_POOL=1 disables the pool) -- and the interval scorer's pool of score tensors, which
+    works the same way (transkun_amd/scorer.py)."""
     _GRAD_POOL.clear()
+    from .. import scorer as _sc
+    if _sc._SCORE_POOL is not None:
+        _sc._SCORE_POOL.clear()
 
 
 def _raise_async_error(what: str) -> None:
