@@ -318,6 +318,31 @@ int interval_score_path_bwd_pc(const float* gout, const int32_t* pairs, int64_t 
                                int64_t lddq, int64_t lddk, int64_t lddd, int64_t lddrc, semicrf_stream_t stream);
 
 /*
+ * The scorer's projection.  Replaces: the nn.Linear of ScaledInnerProductIntervalScorer (LayersTransformer.py:388-397: `self.map`,
+ * applied at :406-410) and its autograd, as exact-fp32 matrix-core GEMMs of this library (csrc/proj_gemm.hip: an fp32 fmaf chain per
+ * output, v_mfma_f32_32x32x2_f32) -- in the packed forms this package uses: y = [q | diag | 0 0 0] or [z | c | diag | 0 0], i.e. N
+ * "main" columns (N in {64, 128, 256}) followed by two extra columns and zero padding.
+ *
+ *   scorer_proj_nn:  out[M][ldout] (+)= A[M][lda] (K columns used) * B[Kpad][ldb] (N columns)  (+ bias[N])
+ *                    B is row-major with the contraction index as ROW and holds whole chunks of 32 rows, zero beyond K (Kpad =
+ *                    K rounded up to 32: the caller pads; K % 4 == 0).  Forward: A = x, B = W[:N]^T.  Input gradient: A = dy (K =
+ *                    the packed width), B = W (its N = the Linear's input size), accumulate = 1 adds to what out holds.
+ *                    w2 != NULL (forward): two more output columns out[m][N + j] = <A[m], w2[j]> + b2[j] (w2 [2][K]), and
+ *                    zero_cols columns of zeros behind them.
+ *   scorer_proj_tn:  dW[total_rows][lddw] (N columns) = dy[M][lddy]^T x[M][ldx], db[total_rows] = column sums of dy: the R main
+ *                    columns of dy through the matrix cores, the two columns extra_col0, extra_col0 + 1 (or -1: none) as dot
+ *                    products on the side, rows / entries beyond them zero.  The contraction over M is cut into slices whose
+ *                    partial results go through `ws` (scorer_proj_tn_workspace_bytes) and are summed in a fixed order.
+ * Rows must be 16-byte aligned (pointers and leading dimensions), M * ld * 4 < 2^31.  SEMICRF_EINVAL for anything else (the
+ * Python mirror then uses torch's GEMM).
+ */
+int scorer_proj_nn(const float* A, int64_t lda, int64_t M, int K, const float* B, int64_t ldb, int N, float* out, int64_t ldout,
+                   const float* bias, const float* w2, const float* b2, int zero_cols, int accumulate, semicrf_stream_t stream);
+size_t scorer_proj_tn_workspace_bytes(int64_t M, int R, int N);
+int scorer_proj_tn(const float* dy, int64_t lddy, int64_t M, int R, int extra_col0, int total_rows, const float* x, int64_t ldx, int N,
+                   float* dW, int64_t lddw, float* db, void* ws, size_t ws_bytes, semicrf_stream_t stream);
+
+/*
  * Backward-direction values only (the beta half of forward_backward, NeuralSemiCRFInterval.py:386-414, without the
  * marginals): beta[t][c] by frame, natural log.  Workspace: semicrf_workspace_bytes(SEMICRF_OP_LOGZ_FWD, T, B).
  * Used by interval_score_bwd_fused, which rebuilds the marginals tile by tile instead of reading a dense gradient.

@@ -1738,3 +1738,45 @@ def test_score_pool_upper_triangle_stays_exact(gpu):
     assert torch.equal(view, view_copy)
     assert _score_pool().hits - h0 >= 1
     nsci.grad_pool_clear()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,n_main,packed", [(1000, 256, 256, True), (4321, 256, 256, False), (130, 64, 64, True), (2999, 128, 128, True),
+                                                (62190, 256, 256, True), (33, 256, 256, True)])
+def test_projection_kernels(gpu, M, K, n_main, packed):
+    """The scorer's projection and its autograd on the library's own exact-fp32 GEMMs (csrc/proj_gemm.hip; LayersTransformer.py:388-397,
+    :406-410): forward with the two extra packed columns, input gradient (plain and accumulating), weight and bias gradients through
+    the sliced contraction -- against float64, at row counts that are no multiple of the tile or the chunk."""
+    from transkun_amd import _lib, synth
+    from transkun_amd.scorer import QPAD, proj_forward, proj_input_grad, proj_weight_grad
+    _lib.set_impl(0)
+    Nout = n_main + QPAD if packed else n_main
+    x = synth.hash_normal(M * K, 301, gpu).view(M, K)
+    W = synth.hash_normal(Nout * K, 302, gpu).view(Nout, K) / K ** 0.5
+    b = synth.hash_normal(Nout, 303, gpu)
+    if packed:
+        W[n_main + 2:] = 0; b[n_main + 2:] = 0
+    y = proj_forward(x, W, b, n_main)
+    ref = x.double() @ W.double().t() + b.double()
+    assert y.shape == (M, Nout)
+    assert float((y.double() - ref).abs().max()) < 2e-6 * float(ref.abs().max()) * 4
+    if packed:
+        assert float(y[:, n_main + 2:].abs().max()) == 0.0
+    dy = synth.hash_normal(M * Nout, 304, gpu).view(M, Nout)
+    if packed:
+        dy[:, n_main + 2:] = 0
+    dx = proj_input_grad(dy, W)
+    rdx = dy.double() @ W.double()
+    assert float((dx.double() - rdx).abs().max()) < 1e-5 * float(rdx.abs().max())
+    base = synth.hash_normal(M * K, 305, gpu).view(M, K).contiguous()
+    acc = base.clone()
+    out = proj_input_grad(dy, W, out=acc)
+    assert out.data_ptr() == acc.data_ptr()
+    assert float((acc.double() - (base.double() + rdx)).abs().max()) < 1e-5 * float(rdx.abs().max())
+    dW, db = proj_weight_grad(dy, x, n_main)
+    rdW = dy.double().t() @ x.double()
+    rdb = dy.double().sum(0)
+    assert dW.shape == (Nout, K) and db.shape == (Nout,)
+    assert float((dW.double() - rdW).abs().max()) < 2e-5 * float(rdW.abs().max())
+    assert float((db.double() - rdb).abs().max()) < 2e-5 * float(rdb.abs().max())
+    assert _lib.device_status() == 0

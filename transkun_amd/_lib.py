@@ -62,6 +62,9 @@ _SIGS = {
     "interval_score_bwd_fused_ws_pc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, ctypes.c_float, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, ctypes.c_size_t, _vp]),
     "interval_score_path_bwd_pc": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, ctypes.c_float, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "semicrf_beta": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "scorer_proj_nn": (_i, [_vp, _i64, _i64, _i, _vp, _i64, _i, _vp, _i64, _vp, _vp, _vp, _i, _i, _vp]),
+    "scorer_proj_tn_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "scorer_proj_tn": (_i, [_vp, _i64, _i64, _i, _i, _i, _vp, _i64, _i, _vp, _i64, _vp, _vp, _sz, _vp]),
     "interval_score_bwd_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, ctypes.c_float, _i, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "interval_score_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i64, ctypes.c_float, _i, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "interval_score_bwd_fused_ws": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, ctypes.c_float, _i, _vp, _vp, _vp, _i64, _i64, _i64, _vp, ctypes.c_size_t, _vp]),

@@ -76,6 +76,11 @@ int launch_interval_score_mfma(const float* q, const float* k, const float* diag
                                 long long ldq, long long ldk, long long ldd, float qscale, int mode, int full,
                                 float* S, hipStream_t stream, int prec, int group, int pitch, const float* rowc = nullptr,
                                 long long ldrc = 1);
+int launch_proj_nn(const float* A, long long lda, long long M, int K, const float* B, long long ldb, int N, float* out, long long ldout,
+                   const float* bias, const float* w2, const float* b2, int zero_cols, int accumulate, hipStream_t stream);
+size_t proj_tn_workspace_bytes(long long M, int R, int N);
+int launch_proj_tn(const float* A, long long lda, long long M, int R, int extra_col0, int total_rows, const float* X, long long ldx, int N,
+                   float* dW, long long lddw, float* db, void* ws, size_t ws_bytes, hipStream_t stream);
 size_t persist_workspace_bytes(int T, int B);
 bool persist_supported(int T, int B);
 int launch_persist_sweep(int mode, int dir, const float* score, const float* noise, int T, int B, float* u_out,
@@ -719,6 +724,33 @@ int interval_score_path_bwd(const float* gout, const int32_t* pairs, int64_t K, 
 {
     return interval_score_path_bwd_p(gout, pairs, K, offsets, q, k, C, T, D, ldq, ldk, qscale, length_scaling, C > 0 ? C : 1, C > 0 ? C : 1,
                                      dq, dk, ddiag, lddq, lddk, lddd, stream);
+}
+
+int scorer_proj_nn(const float* A, int64_t lda, int64_t M, int K, const float* B, int64_t ldb, int N, float* out, int64_t ldout,
+                   const float* bias, const float* w2, const float* b2, int zero_cols, int accumulate, semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(A && B && out, "A/B/out must be non-NULL");
+    SEMICRF_CHECK_ARG(M >= 1 && K >= 4 && lda >= K && ldb >= N && zero_cols >= 0 && (!w2 || b2), "bad sizes");
+    SEMICRF_CHECK_ARG(ldout >= N + (w2 ? 2 + zero_cols : 0), "ldout too small for the packed output");
+    SEMICRF_CHECK_ARG(launch_proj_nn(A, lda, M, K, B, ldb, N, out, ldout, bias, w2, b2, zero_cols, accumulate, (hipStream_t)stream) == 0,
+                      "scorer_proj_nn: N must be 64, 128 or 256, K %% 4 == 0, rows 16-byte aligned, M * ld * 4 < 2^31 (N=%d K=%d)", N, K);
+    SEMICRF_CHECK_LAUNCH("scorer_proj_nn");
+    return SEMICRF_OK;
+}
+
+size_t scorer_proj_tn_workspace_bytes(int64_t M, int R, int N) { return M >= 1 && R >= 1 ? proj_tn_workspace_bytes(M, R, N) : 0; }
+
+int scorer_proj_tn(const float* dy, int64_t lddy, int64_t M, int R, int extra_col0, int total_rows, const float* x, int64_t ldx, int N,
+                   float* dW, int64_t lddw, float* db, void* ws, size_t ws_bytes, semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(dy && x && dW, "dy/x/dW must be non-NULL");
+    SEMICRF_CHECK_ARG(M >= 1 && R >= 1 && total_rows >= R && lddy >= R && ldx >= N && lddw >= N, "bad sizes");
+    SEMICRF_CHECK_ARG(extra_col0 < 0 || (extra_col0 >= R && extra_col0 + 2 <= total_rows && extra_col0 + 2 <= lddy), "bad extra columns");
+    const int rc = launch_proj_tn(dy, lddy, M, R, extra_col0, total_rows, x, ldx, N, dW, lddw, db, ws, ws_bytes, (hipStream_t)stream);
+    if (rc == 2) { set_error("scorer_proj_tn: workspace missing or too small"); return SEMICRF_EWORKSPACE; }
+    SEMICRF_CHECK_ARG(rc == 0, "scorer_proj_tn: N must be 64, 128 or 256, rows 16-byte aligned, M * ld * 4 < 2^31 (N=%d)", N);
+    SEMICRF_CHECK_LAUNCH("scorer_proj_tn");
+    return SEMICRF_OK;
 }
 
 int interval_features_gather(const float* ctx, int C, int T, int D, int64_t ldc, const int32_t* pairs, int64_t K,

@@ -345,6 +345,32 @@ void interval_score_path_bwd_op(Tensor gout, Tensor pairs, int64_t K, Tensor off
 }
 
 // ---- attribute-head features ------------------------------------------------------------------------------------------
+// the scorer's projection (csrc/proj_gemm.hip): strided row-major matrices, the strides are the caller's statement
+void proj_nn_op(Tensor A, int64_t lda, int64_t M, int64_t K, Tensor B, int64_t ldb, int64_t N, Tensor out, int64_t ldout, Tensor bias,
+                bool has_bias, Tensor w2, Tensor b2, bool has_w2, int64_t zero_cols, bool accumulate)
+{
+    Ctx c(A); c.same(A, B, out);
+    if (has_bias) c.same(A, bias);
+    if (has_w2) c.same(A, w2, b2);
+    STD_TORCH_CHECK(M >= 1 && K >= 4 && N >= 1 && M < (1ll << 31) && K < (1 << 20) && N <= 256, "semicrf: bad M / K / N");
+    STD_TORCH_CHECK(A.numel() >= (M - 1) * lda + K && out.numel() >= (M - 1) * ldout + N + (has_w2 ? 2 + zero_cols : 0), "semicrf: A / out too small");
+    STD_TORCH_CHECK(B.numel() >= ((K + 31) / 32 * 32 - 1) * ldb + N, "semicrf: B must hold whole chunks of 32 rows (zero beyond K)");
+    check(scorer_proj_nn(f32s(A, "A"), lda, M, (int)K, f32s(B, "B"), ldb, (int)N, f32so(out, "out"), ldout, has_bias ? f32(bias, N, "bias") : nullptr,
+                         has_w2 ? f32(w2, 2 * K, "w2") : nullptr, has_w2 ? f32(b2, 2, "b2") : nullptr, (int)zero_cols, accumulate ? 1 : 0, c.stream),
+          "scorer_proj_nn");
+}
+void proj_tn_op(Tensor dy, int64_t lddy, int64_t M, int64_t R, int64_t extra_col0, int64_t total_rows, Tensor x, int64_t ldx, int64_t N, Tensor dW,
+                int64_t lddw, Tensor db, Tensor ws)
+{
+    Ctx c(dy); c.same(dy, x, dW, db, ws);
+    STD_TORCH_CHECK(M >= 1 && R >= 1 && N >= 1 && N <= 256 && M < (1ll << 31) && total_rows >= R && total_rows < (1 << 20), "semicrf: bad sizes");
+    STD_TORCH_CHECK(dy.numel() >= (M - 1) * lddy + R && x.numel() >= (M - 1) * ldx + N && dW.numel() >= (total_rows - 1) * lddw + N,
+                    "semicrf: dy / x / dW too small");
+    check(scorer_proj_tn(f32s(dy, "dy"), lddy, M, (int)R, (int)extra_col0, (int)total_rows, f32s(x, "x"), ldx, (int)N, f32so(dW, "dW"), lddw,
+                         f32w(db, total_rows, "db"), bytes(ws, "ws"), (size_t)ws.numel(), c.stream),
+          "scorer_proj_tn");
+}
+
 void interval_features_gather_op(Tensor ctx, int64_t C, int64_t T, int64_t D, int64_t ldc, Tensor pairs, int64_t K, Tensor offsets,
                                  int64_t nSym, Tensor out, Tensor symIdx, Tensor scatterIdx)
 {
@@ -422,6 +448,10 @@ STABLE_TORCH_LIBRARY(semicrf, m)
     m.def("interval_score_path_bwd(Tensor gout, Tensor pairs, int K, Tensor offsets, Tensor q, Tensor k, int C, int T, int D, int ldq, int ldk, "
           "float qscale, int mode, int group, int pitch, Tensor(a!) dq, Tensor(b!) dk, Tensor(c!) ddiag, Tensor(d!) drowc, int lddq, int lddk, "
           "int lddd, int lddrc) -> ()");
+    m.def("proj_nn(Tensor A, int lda, int M, int K, Tensor B, int ldb, int N, Tensor(a!) out, int ldout, Tensor bias, bool has_bias, Tensor w2, "
+          "Tensor b2, bool has_w2, int zero_cols, bool accumulate) -> ()");
+    m.def("proj_tn(Tensor dy, int lddy, int M, int R, int extra_col0, int total_rows, Tensor x, int ldx, int N, Tensor(a!) dW, int lddw, "
+          "Tensor(b!) db, Tensor(c!) ws) -> ()");
     m.def("interval_features_gather(Tensor ctx, int C, int T, int D, int ldc, Tensor pairs, int K, Tensor offsets, int nSym, Tensor(a!) out, "
           "Tensor(b!) symIdx, Tensor(c!) scatterIdx) -> ()");
     m.def("interval_features_gather_bwd(Tensor gout, Tensor ctx, int C, int T, int D, int ldc, Tensor pairs, int K, Tensor offsets, "
@@ -458,6 +488,8 @@ STABLE_TORCH_LIBRARY_IMPL(semicrf, CUDA, m)
     m.impl("interval_score_bwd_ws", TORCH_BOX(&interval_score_bwd_ws_op));
     m.impl("interval_score_bwd_fused_ws", TORCH_BOX(&interval_score_bwd_fused_ws_op));
     m.impl("interval_score_path_bwd", TORCH_BOX(&interval_score_path_bwd_op));
+    m.impl("proj_nn", TORCH_BOX(&proj_nn_op));
+    m.impl("proj_tn", TORCH_BOX(&proj_tn_op));
     m.impl("interval_features_gather", TORCH_BOX(&interval_features_gather_op));
     m.impl("interval_features_gather_bwd", TORCH_BOX(&interval_features_gather_bwd_op));
     m.impl("segment_onset_filter", TORCH_BOX(&segment_onset_filter_op));

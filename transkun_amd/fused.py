@@ -27,8 +27,8 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .scorer import (BF16X3, QPAD, ScaledInnerProductIntervalScorer, _ScorerLinear, _interval_score_raw, _tn_splitk, bwd_workspace,
-                     qd_weights, slot_maps, slot_pitch)
+from .scorer import (BF16X3, QPAD, ScaledInnerProductIntervalScorer, _ScorerLinear, _interval_score_raw, bwd_workspace, proj_forward,
+                     proj_input_grad, proj_weight_grad, qd_weights, slot_maps, slot_pitch)
 
 _nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
 
@@ -87,7 +87,7 @@ class _MergedScorerCRFLogProb(torch.autograd.Function):
         size = x.shape[-1]
         pitch = slot_pitch(P, T, size, N)
         x3 = x.reshape(C, T, size)
-        zc = F.linear(x3, Wm, bm)                                   # [C,T,size+QPAD] = [z | c | diag | 0 0]
+        zc = proj_forward(x3.view(-1, size), Wm, bm, size).view(C, T, size + QPAD)   # [z | c | diag | 0 0]: the library's own GEMM
         qs = 1.0 / math.sqrt(D)
         S, noise = _interval_score_raw(zc[..., :size], x3, zc[..., size + 1], T, C, size, qs, mode, fs, P, pitch, rowc=zc[..., size])
         if pitch != P:
@@ -134,9 +134,12 @@ class _MergedScorerCRFLogProb(torch.autograd.Function):
         need = ctx.needs_input_grad
         dx2 = dx.view(-1, size)
         if need[0]:
-            dx2.addmm_(g2, Wm)                                        # + the part through [z | c | diag]
-        return (dx2.view(N, P, T, size) if need[0] else None, _tn_splitk(g2, x3.view(-1, size)) if need[1] else None,
-                g2.sum(0) if need[2] else None, None, None, None, None, None, None, None, None)
+            proj_input_grad(g2, Wm, out=dx2)                          # + the part through [z | c | diag]
+        dWm = dbm = None
+        if need[1] or need[2]:
+            dWm, dbm = proj_weight_grad(g2, x3.view(-1, size), size)
+        return (dx2.view(N, P, T, size) if need[0] else None, dWm if need[1] else None, dbm if need[2] else None, None, None, None, None, None,
+                None, None, None)
 
 
 class _ScorerCRFLogProb(torch.autograd.Function):

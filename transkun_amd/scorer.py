@@ -176,6 +176,78 @@ def score_backward_hip(g, q, k, C: int, T: int, D: int, qs: float, mode: int, P:
                                   ddi.stride(-1) if ddi.numel() else 1, 0, ws)
 
 
+# ---- the projection on this library's own GEMM kernels (csrc/proj_gemm.hip) ---------------------------------------------------------
+_PROJ_SIZES = (64, 128, 256)
+
+
+def _proj_ok(a2: torch.Tensor, n_cols: int) -> bool:
+    """a2 [M, w]: a row-major fp32 matrix on the GPU whose rows are 16-byte aligned and short enough for 32-bit buffer offsets."""
+    return (a2.is_cuda and a2.dtype == torch.float32 and a2.dim() == 2 and a2.is_contiguous() and a2.shape[1] % 4 == 0
+            and a2.data_ptr() % 16 == 0 and a2.shape[0] >= 1 and a2.shape[0] * (max(a2.shape[1], n_cols) + 8) * 4 < 2 ** 31
+            and _lib.get_impl() == 0 and not os.environ.get("SEMICRF_TORCH_PROJECTION"))
+
+
+def proj_forward(x2: torch.Tensor, W: torch.Tensor, b: torch.Tensor, n_main: int) -> torch.Tensor:
+    """y [M, Nout] = x2 W^T + b for the PACKED projection outputs of this package (LayersTransformer.py:388-397, :406-410 regrouped):
+    W [Nout, K] holds n_main main rows, then -- if Nout > n_main -- two extra rows ([diag | 0] or [c | diag]) and zero rows.  On the
+    library's exact-fp32 GEMM (scorer_proj_nn) where it applies, torch's GEMM otherwise."""
+    M, K = x2.shape
+    Nout = W.shape[0]
+    if not (_proj_ok(x2, Nout) and K in _PROJ_SIZES and n_main in _PROJ_SIZES and (Nout == n_main or Nout >= n_main + 2) and Nout % 4 == 0):
+        return F.linear(x2, W, b)
+    Wt = W.new_zeros((K + 31) // 32 * 32, n_main)            # the contraction index as row, whole chunks of 32 rows
+    Wt[:K] = W[:n_main].t()
+    y = torch.empty(M, Nout, dtype=torch.float32, device=x2.device)
+    has2 = Nout > n_main
+    w2 = W[n_main:n_main + 2].contiguous() if has2 else b
+    b2 = b[n_main:n_main + 2].contiguous() if has2 else b
+    _lib.ops().proj_nn(x2, K, M, K, Wt, n_main, n_main, y, Nout, b[:n_main].contiguous(), True, w2, b2, has2, Nout - n_main - 2 if has2 else 0,
+                       False)
+    return y
+
+
+def proj_input_grad(dy2: torch.Tensor, W: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """dy2 [M, Nout] W [Nout, K] -> [M, K]; with `out` the product is ADDED to it (the gradient through a second use of the input)."""
+    M, Nout = dy2.shape
+    K = W.shape[1]
+    if not (_proj_ok(dy2, K) and K in _PROJ_SIZES and (out is None or (out.is_contiguous() and out.shape == (M, K)))):
+        return dy2.mm(W) if out is None else out.addmm_(dy2, W)
+    Wp = W.new_zeros((Nout + 31) // 32 * 32, K)
+    Wp[:Nout] = W
+    dx = out if out is not None else torch.empty(M, K, dtype=torch.float32, device=dy2.device)
+    none = _lib_none(dy2.device)
+    _lib.ops().proj_nn(dy2, Nout, M, Nout, Wp, K, K, dx, K, none, False, none, none, False, 0, out is not None)
+    return dx
+
+
+def proj_weight_grad(dy2: torch.Tensor, x2: torch.Tensor, n_main: int):
+    """(dW [Nout, K], db [Nout]) = (dy2^T x2, column sums of dy2) with the contraction over the M rows split into slices (partial sums
+    in a workspace, fixed summation order)."""
+    M, Nout = dy2.shape
+    K = x2.shape[1]
+    if not (_proj_ok(dy2, K) and _proj_ok(x2, Nout) and K in _PROJ_SIZES and 1 <= n_main <= Nout and (Nout == n_main or Nout >= n_main + 2)):
+        return _tn_splitk(dy2, x2), dy2.sum(0)
+    dW = torch.empty(Nout, K, dtype=torch.float32, device=dy2.device)
+    db = torch.empty(Nout, dtype=torch.float32, device=dy2.device)
+    key = ("tn", M, n_main, K)
+    n = _BWD_WS.get(key)
+    if n is None:
+        n = _BWD_WS[key] = int(_lib.load().scorer_proj_tn_workspace_bytes(M, n_main, K))
+    ws = torch.empty(n, dtype=torch.uint8, device=dy2.device)
+    _lib.ops().proj_tn(dy2, Nout, M, n_main, n_main if Nout > n_main else -1, Nout, x2, K, K, dW, K, db, ws)
+    return dW, db
+
+
+_NONE = {}
+
+
+def _lib_none(device):
+    e = _NONE.get(device)
+    if e is None:
+        e = _NONE[device] = torch.empty(0, dtype=torch.float32, device=device)
+    return e
+
+
 class _ScorerLinear(torch.autograd.Function):
     """The scorer's Linear map (LayersTransformer.py:392-397, :408) as its two GEMMs [q | diag | pad] and k with a backward
     of its own.  Stock autograd computes a weight gradient as ONE GEMM dY^T x: 260 x 256 outputs over a contraction of
@@ -186,6 +258,15 @@ class _ScorerLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, Wqd, bqd, Wk, bk):
         ctx.save_for_backward(x, Wqd, Wk)
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        D = Wk.shape[0]
+        if _proj_ok(x2, D + QPAD) and K in _PROJ_SIZES and D in _PROJ_SIZES:
+            # this library's exact-fp32 GEMMs (csrc/proj_gemm.hip): [q | diag | 0 0 0] with the diagonal term as a dot product of the
+            # rows the kernel reads anyway, then k
+            qd = proj_forward(x2, Wqd, bqd, D).view(*x.shape[:-1], D + QPAD)
+            k = proj_forward(x2, Wk, bk, D).view(*x.shape[:-1], D)
+            return qd, k
         return F.linear(x, Wqd, bqd), F.linear(x, Wk, bk)
 
     @staticmethod
@@ -198,14 +279,22 @@ class _ScorerLinear(torch.autograd.Function):
         g2 = dk.reshape(-1, Wk.shape[0]) if dk is not None else None
         need = ctx.needs_input_grad
         dx = None
+        if g1 is not None and not g1.is_contiguous():
+            g1 = g1.contiguous()
+        if g2 is not None and not g2.is_contiguous():
+            g2 = g2.contiguous()
         if need[0]:
-            dx = g1.mm(Wqd) if g1 is not None else None
+            dx = proj_input_grad(g1, Wqd) if g1 is not None else None
             if g2 is not None:
-                dx = g2.mm(Wk) if dx is None else dx.addmm_(g2, Wk)
+                dx = proj_input_grad(g2, Wk) if dx is None else proj_input_grad(g2, Wk, out=dx)
             dx = dx.view(x.shape) if dx is not None else None
-        return (dx,
-                _tn_splitk(g1, x2) if need[1] and g1 is not None else None, g1.sum(0) if need[2] and g1 is not None else None,
-                _tn_splitk(g2, x2) if need[3] and g2 is not None else None, g2.sum(0) if need[4] and g2 is not None else None)
+        D = Wk.shape[0]
+        dW1 = db1 = dW2 = db2 = None
+        if (need[1] or need[2]) and g1 is not None:
+            dW1, db1 = proj_weight_grad(g1, x2, D)
+        if (need[3] or need[4]) and g2 is not None:
+            dW2, db2 = proj_weight_grad(g2, x2, D)
+        return (dx, dW1 if need[1] else None, db1 if need[2] else None, dW2 if need[3] else None, db2 if need[4] else None)
 
 
 class _IntervalScore(torch.autograd.Function):
