@@ -191,6 +191,16 @@ def worker(args):
     elapsed = max_over_ranks(elapsed_local, dev)
     value = seen_world * args.steps / elapsed
     log(f"timed region done: {elapsed / args.steps * 1e3:.3f} ms/step")
+    # the same K steps four more times (each bracketed like the timed region): the spread of the headline on THIS box.  `value`
+    # stays the first region's.
+    repeats = [elapsed / args.steps * 1e3]
+    for _ in range(4 if not args.no_extra else 0):
+        sync_all()
+        tr = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync_all()
+        repeats.append(max_over_ranks(time.perf_counter() - tr, dev) / args.steps * 1e3)
     # N > 1: what the scaling number is made of (the first multi-GPU run should explain itself): every rank's own time per step,
     # and the [3] loss all-reduce on its own
     diag = None
@@ -246,6 +256,11 @@ def worker(args):
     log(f"logz_fwd: {fwd_ms * 1e3:.1f} us/launch = {achieved:.1f} GB/s algorithmic")
 
     extra = {}
+    if len(repeats) > 1:
+        srt = sorted(repeats)
+        extra["headline_ms_per_step_repeats"] = [round(v, 4) for v in repeats]
+        extra["headline_steps_per_s_min_median_max"] = [round(seen_world * 1e3 / srt[-1], 1), round(seen_world * 1e3 / srt[len(srt) // 2], 1),
+                                                        round(seen_world * 1e3 / srt[0], 1)]
     if not args.no_extra:
         try:
             _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time, fwd_ms)
@@ -382,7 +397,29 @@ def _cpu_baseline(args, s_d, n_d, T, B, nseg):
     while len(times) < 3 and time.perf_counter() - t_all < 20.0:
         times.append(one(sc, nc, gout))
     dt = min(times)
-    return {"value": round(1.0 / dt, 5), "unit": "steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
+    # beside it: the PRODUCT's own host kernels (csrc/cpu_ops.cpp behind the same Python API on CPU tensors, OpenMP over the chains)
+    # -- not the baseline (it is this repo's code, not the reference's algorithm as written), but what a CPU-only user of the
+    # drop-in gets
+    product = None
+    try:
+        from transkun_amd import CRF as _CRF, synth as _synth
+        iv = _synth.synthetic_intervals(T, B, seed=1234)
+        sc_p = sc.clone().requires_grad_(); nc_p = nc.clone().requires_grad_()
+        pt = []
+        t_all = time.perf_counter()
+        while len(pt) < 3 and time.perf_counter() - t_all < 15.0:
+            sc_p.grad = None; nc_p.grad = None
+            t1 = time.perf_counter()
+            lp = _CRF.NeuralSemiCRFInterval(sc_p, nc_p).logProb(iv)
+            (lp.sum() * (-1.0 / nseg)).backward()
+            pt.append(time.perf_counter() - t1)
+        product = {"value": round(1.0 / min(pt), 4), "unit": "steps/s", "best_of": len(pt),
+                   "what": "NeuralSemiCRFInterval(score, noise).logProb(intervals) forward + backward on CPU tensors: this library's host "
+                           "kernels (cpu_ops.cpp, OpenMP over chains, all logical CPUs), same workload"}
+        del sc_p, nc_p
+    except Exception as ex:
+        product = {"error": repr(ex)[:200]}
+    return {"value": round(1.0 / dt, 5), "unit": "steps/s", "cores": int(torch.get_num_threads()), "kind": "port", "product_host_kernels": product,
             "sample": f"torch-CPU op-loop port of forward_backward + backward multiply, T={T}, all {B} chains, "
                       f"best of {len(times)} reps ({dt:.2f}s); thread probe on {Bs} chains: "
                       + ", ".join(f"{k}t={v:.2f}s" for k, v in probe.items()),

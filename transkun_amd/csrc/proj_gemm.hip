@@ -56,6 +56,8 @@ struct Args {
     const float* bias;                                    // !AT: [64 NW] added to the result, or NULL
     const float* w2; const float* b2;                     // !AT: two extra output columns N, N+1 = <A row, w2[j]> + b2[j] ([2][K], [2]); NULL: none
     int zero_cols;                                        // !AT with w2: columns N+2 .. N+1+zero_cols are set to zero
+    int ktail;                                            // !AT: 1 = the last chunk holds at most 8 contraction values (a packed width of 256 + 8): it runs as ONE
+                                                          // group of matrix instructions (k = 4 half + component) instead of four
     int nslices, kslice;                                  // AT: row slices of the contraction (chunks per slice)
     int extra_col0;                                       // AT: A columns extra_col0, +1 give two extra output rows (or -1)
     float* part_bias;                                     // AT: [S][bias_pitch] column sums of A over the slice
@@ -109,6 +111,8 @@ __global__ __launch_bounds__(512, 2) void proj_gemm_kernel(Args P)
         rdA[mm] = (unsigned)(row * 128 + (((4 * half + mm) ^ ((row >> 1) & 7)) * 16));
     }
     const unsigned rdAT = (unsigned)(half * 16 * (GM * 4) + (32 * wm + l31) * 4);
+    const unsigned rdAtail = (unsigned)((32 * wm + l31) * 128 + ((half ^ (((32 * wm + l31) >> 1) & 7)) * 16));
+    const unsigned rdBtail = (unsigned)(GA_BYTES + half * 4 * (D * 4) + (32 * NW * wn + l31) * 4);
     const unsigned rdB = (unsigned)(GA_BYTES + half * 16 * (D * 4) + (32 * NW * wn + l31) * 4);
 
     // ---- request side (identical in all waves) -------------------------------------------------------------------------------------
@@ -300,6 +304,27 @@ __global__ __launch_bounds__(512, 2) void proj_gemm_kernel(Args P)
                     asm volatile("" : "+v"(cs));
                 }
             };
+            if (!AT && !EX && P.ktail && kbeg + j == nkt - 1) {
+                // the short last chunk: its (at most) 8 values as one group, k = 4 half + component
+                {
+                    const unsigned addr = sb + rdAtail;
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(a4[0]) : "v"(addr));
+                }
+                static_for<0, 4>([&](auto cc) {
+                    constexpr int comp = decltype(cc)::value;
+                    static_for<0, NW>([&](auto tc) {
+                        constexpr int t = decltype(tc)::value;
+                        float& dst = bq[0][comp][t];
+                        const unsigned addr = sb + rdBtail;
+                        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(comp * (D * 4) + t * 128));
+                    });
+                });
+                wait_group(a4[0], a1[0], bq[0], xw[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                mul_group(a4[0], a1[0], bq[0], xw[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
             read_group(std::integral_constant<int, 0>{}, a4[0], a1[0], bq[0], xw[0]);
             wait_group(a4[0], a1[0], bq[0], xw[0]);
             __builtin_amdgcn_sched_barrier(0);
@@ -539,6 +564,7 @@ int launch_proj_nn(const float* A, long long lda, long long M, int K, const floa
     P.B = B; P.ldb = ldb; P.Brows = (K + pj::GK - 1) / pj::GK * pj::GK;     // B holds whole chunks of rows, zero beyond K (the caller's promise)
     P.out = out; P.ldout = ldout; P.Mout = (int)M; P.K = K; P.accumulate = accumulate; P.bias = bias;
     P.w2 = w2; P.b2 = b2; P.zero_cols = zero_cols; P.nslices = 1; P.kslice = 0; P.extra_col0 = -1;
+    P.ktail = (!w2 && K > pj::GK && K % pj::GK != 0 && K % pj::GK <= 8) ? 1 : 0;
     const int Kpad = (K + pj::GK - 1) / pj::GK * pj::GK;
     const long long nitems = (M + pj::GM - 1) / pj::GM;
     switch (N) {
