@@ -1294,6 +1294,16 @@ def test_transcribe_many_equals_one_by_one(gpu):
     together = m.transcribe_many([fn_a, fn_b, fn_b], [n_full, n_short, n_full])
     for x, y in zip(alone, together):
         assert [e.astuple() for e in x] == [e.astuple() for e in y]
+    # the same with every step waiting for its interval count (round 3's loop), and with a cap so small that the one-step-late check
+    # finds a truncated step and the call starts over synchronously: the same Notes
+    waited = m.transcribe_many([fn_a, fn_b, fn_b], [n_full, n_short, n_full], synchronous=True)
+    m.capFactor, m.capFloor = 0.05, 8
+    try:
+        restarted = m.transcribe_many([fn_a, fn_b, fn_b], [n_full, n_short, n_full])
+    finally:
+        m.capFactor, m.capFloor = 2.0, 4096
+    for x, y, z in zip(together, waited, restarted):
+        assert [e.astuple() for e in x] == [e.astuple() for e in y] == [e.astuple() for e in z]
 
 
 # ---- slot layout of the chain axis (include/semicrf_hip.h "SLOT LAYOUT") ------------------------------

@@ -154,6 +154,7 @@ class SegmentTranscriber(nn.Module):
         self.targetMIDIPitch = list(targetMIDIPitch) if targetMIDIPitch is not None else [-64, -67] + list(range(21, 108 + 1))   # :97
         self.scorer = ScaledInnerProductIntervalScorer(size, 1)
         self.scorer.fullSquare = 2      # S goes straight into this package's decode, which never reads begin > end: no zero fill
+        self.capFactor, self.capFloor = 2.0, 4096     # transcribe_many: rows for the heads = capFactor x the largest count seen, at least capFloor
         self.projection = "separate"    # "merged": the scorer's two projections as one (see decode_step); scores then differ from
                                         # the reference's by fp32 reassociation, so the default keeps its operation order
         self._merged = None
@@ -173,10 +174,14 @@ class SegmentTranscriber(nn.Module):
     # ------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def decode_step(self, ctxBatch: torch.Tensor, start: Optional[torch.Tensor], beginTime: torch.Tensor, lastFrameIdx: int,
-                    stepFrames: int, onsetBound: Optional[int] = None, velocityCriteron: str = "hamming"):
+                    stepFrames: int, onsetBound: Optional[int] = None, velocityCriteron: str = "hamming", k_cap: Optional[int] = None):
         """ctxBatch [F, P, T, D] (one segment of each of F recordings); start: int32 [F*P] forced start positions on the device
         or None; beginTime: float64 [F] on the device.  Returns a dict of DEVICE tensors: pairs [K,2], offsets [F*P+1],
-        symIdx [K], scatterIdx [K], velocity [K], times [K,2] f64, flags [K,2] u8, lastP [F*P], nextStart [F*P], and K."""
+        symIdx [K], scatterIdx [K], velocity [K], times [K,2] f64, flags [K,2] u8, lastP [F*P], nextStart [F*P], and K.
+
+        k_cap: run WITHOUT the host synchronisation for K: everything behind the decode is sized for k_cap intervals (the rows
+        behind the real count hold harmless values), `K` in the result is None and `Kdev` is the count on the device; the caller
+        checks it later (it must not exceed k_cap: beyond it the chains' events -- and `nextStart` -- are cut off)."""
         assert ctxBatch.dim() == 4
         Fn, P, T, D = ctxBatch.shape
         assert P == len(self.targetMIDIPitch)
@@ -220,9 +225,16 @@ class SegmentTranscriber(nn.Module):
             counts = torch.empty(B, dtype=torch.int32, device=dev)
             ops.segment_onset_filter(pairs, offsets, B, int(onsetBound), pairs2, offsets2, counts)
             pairs, offsets = pairs2, offsets2
-        K = int(offsets[-1])                                                             # the step's one host sync
-        if K < 0:
-            raise RuntimeError("semicrf_viterbi: a bounded hand-off wait timed out on the device; the decode result is invalid")
+        Kdev = offsets[-1:]
+        if k_cap is not None:
+            # no host trip: k_cap rows, the chains' ranges cut at k_cap, the (begin, end) of the unused rows made valid frame indices
+            K = int(k_cap)
+            offsets = torch.clamp(offsets, max=K)
+            pairs = pairs[:K].clamp(0, T - 1)
+        else:
+            K = int(offsets[-1])                                                         # the step's one host sync
+            if K < 0:
+                raise RuntimeError("semicrf_viterbi: a bounded hand-off wait timed out on the device; the decode result is invalid")
         lastP = torch.empty(B, dtype=torch.int32, device=dev)
         nextStart = torch.empty(B, dtype=torch.int32, device=dev)
         if K == 0:                                                                       # :570-572: nothing detected
@@ -235,15 +247,15 @@ class SegmentTranscriber(nn.Module):
         logitsVelocity = self.velocityPredictor(attributeInput)
         velocity = self._velocity(logitsVelocity, velocityCriteron)
         ofValue, ofPresence = self.refinedOFPredictor(attributeInput).chunk(2, dim=-1)               # :646-655
-        ofDist = torch.distributions.ContinuousBernoulli(logits=ofValue)
+        ofDist = torch.distributions.ContinuousBernoulli(logits=ofValue, validate_args=False)   # (the argument check is a host sync)
         ofValue = torch.clamp((ofDist.mean - 0.5) / 0.99, -0.5, 0.5).float().contiguous()
         ofPresence = (ofPresence > 0).contiguous()
         times = torch.empty(K, 2, dtype=torch.float64, device=dev)
         flags = torch.empty(K, 2, dtype=torch.uint8, device=dev)
         ops.segment_events(pairs, K, offsets, B, P, ofValue, ofPresence.view(torch.uint8), int(lastFrameIdx), self.hopSize / self.fs,
                            beginTime, int(stepFrames), times, flags, lastP, nextStart)
-        return dict(K=K, pairs=pairs[:K], offsets=offsets, symIdx=sym, scatterIdx=sc, velocity=velocity, times=times, flags=flags,
-                    lastP=lastP, nextStart=nextStart, ofValue=ofValue, ofPresence=ofPresence)
+        return dict(K=K if k_cap is None else None, Kdev=Kdev, k_cap=k_cap, pairs=pairs[:K], offsets=offsets, symIdx=sym, scatterIdx=sc,
+                    velocity=velocity, times=times, flags=flags, lastP=lastP, nextStart=nextStart, ofValue=ofValue, ofPresence=ofPresence)
 
     @staticmethod
     def _velocity(logitsVelocity: torch.Tensor, criterion: str) -> torch.Tensor:
@@ -335,9 +347,15 @@ class SegmentTranscriber(nn.Module):
 
     @torch.no_grad()
     def transcribe_many(self, ctx_fns: Sequence[Callable[[int, int], torch.Tensor]], nSamples: Sequence[int], stepInSecond=None,
-                        segmentSizeInSecond=None, discardSecondHalf=False, mergeIncompleteEvent=True, resolve=True) -> List[List[Note]]:
+                        segmentSizeInSecond=None, discardSecondHalf=False, mergeIncompleteEvent=True, resolve=True,
+                        synchronous: bool = False) -> List[List[Note]]:
         """Several recordings in lock step: step s decodes segment s of every recording that still has one as ONE batch
-        (NBatch = 90 x #recordings).  The forced start positions of step s+1 never leave the device."""
+        (NBatch = 90 x #recordings).  The forced start positions of step s+1 never leave the device.
+
+        After the first step nothing waits for the device inside a step: the attribute heads run on a CAPPED number of rows (twice
+        the largest interval count seen so far per recording in the batch), the real count travels to the host with the step's rows
+        and is checked one step late, when the rows are merged.  A count above the cap (the heads saw a truncated list) restarts
+        the whole call with `synchronous=True`: every step then waits for its count, as in round 3.  Same Notes either way."""
         plans = [self.segment_plan(n, stepInSecond, segmentSizeInSecond) for n in nSamples]
         P = len(self.targetMIDIPitch)
         dev = next(self.parameters()).device
@@ -351,29 +369,48 @@ class SegmentTranscriber(nn.Module):
         pending = None                  # (step index, K, pinned rows, copy event, active files): the host part runs one step late
         bufs = [None, None]             # two pinned row buffers, alternating: step s fills one while step s-1's is merged
 
+        use_cap = dev.type == "cuda" and not synchronous
+        kpin = torch.empty(2, dtype=torch.int32, pin_memory=True) if use_cap else None
+        kmax_per_file = [0.0]           # largest verified interval count per recording of a batch
+
+        class _Overflow(Exception):
+            pass
+
         def to_host(s, step):
             K = step["K"]
-            if K == 0:
+            cap = step.get("k_cap")
+            n = K if cap is None else cap
+            if n == 0:
                 return None
             merger.vel_float = step["velocity"].is_floating_point()
             rows = self._packed_rows(step)
             if dev.type != "cuda":
-                return (s, K, rows.contiguous(), None)
+                return (s, K, rows.contiguous(), None, None)
             b = bufs[s & 1]
-            if b is None or b.shape[0] < K:
-                b = bufs[s & 1] = torch.empty(max(2 * K, 4096), 7, dtype=torch.float64, pin_memory=True)
-            b[:K].copy_(rows, non_blocking=True)
+            if b is None or b.shape[0] < n:
+                b = bufs[s & 1] = torch.empty(max(2 * n, 4096), 7, dtype=torch.float64, pin_memory=True)
+            b[:n].copy_(rows, non_blocking=True)
+            if cap is not None:
+                kpin[(s & 1):(s & 1) + 1].copy_(step["Kdev"], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            return (s, K, b, ev)
+            return (s, K, b, ev, cap)
 
         def merge(p):
             if p is None or p[0] is None:
                 return
-            (s, K, rows, ev), active = p
+            (s, K, rows, ev, cap), active = p
             if ev is not None:
                 ev.synchronize()
-            merger.add_step(s, rows, K, active)
+            if cap is not None:
+                K = int(kpin[s & 1])
+                if K < 0:
+                    raise RuntimeError("semicrf_viterbi: a bounded hand-off wait timed out on the device; the decode result is invalid")
+                if K > cap:
+                    raise _Overflow()
+            kmax_per_file[0] = max(kmax_per_file[0], K / max(len(active), 1))
+            if K > 0:
+                merger.add_step(s, rows, K, active)
 
         for s in range(nsteps):
             active = [f for f, p in enumerate(plans) if s < len(p["begins"])]
@@ -384,10 +421,23 @@ class SegmentTranscriber(nn.Module):
             ctxBatch = torch.cat([ctx_fns[f](s, T) for f in active], dim=0) if len(active) > 1 else ctx_fns[active[0]](s, T)
             beginTime = torch.tensor([plans[f]["begins"][s] / self.fs - plans[f]["padTimeBegin"] for f in active], dtype=torch.float64,
                                      device=dev)                                         # :766
-            step = self.decode_step(ctxBatch, start, beginTime, plans[0]["lastFrameIdx"], stepFrames, onsetBound)
+            cap = None
+            if use_cap and s > 0:
+                cap = max(int(self.capFloor), (int(self.capFactor * kmax_per_file[0] * len(active)) + 1023) // 1024 * 1024)
+            step = self.decode_step(ctxBatch, start, beginTime, plans[0]["lastFrameIdx"], stepFrames, onsetBound, k_cap=cap)
             start = step["nextStart"]                                                   # :789-791, stays on the device
+            if step["K"] is not None:                                                   # (a synchronous step knows its count at once)
+                kmax_per_file[0] = max(kmax_per_file[0], step["K"] / max(len(active), 1))
             host = to_host(s, step)                                                     # the rows' copy runs behind the step's kernels
-            merge(pending)                                                              # ... while the host merges the previous step
+            try:
+                merge(pending)                                                          # ... while the host merges the previous step
+            except _Overflow:
+                return self.transcribe_many(ctx_fns, nSamples, stepInSecond, segmentSizeInSecond, discardSecondHalf, mergeIncompleteEvent,
+                                            resolve, synchronous=True)
             pending = (host, active)
-        merge(pending)
+        try:
+            merge(pending)
+        except _Overflow:
+            return self.transcribe_many(ctx_fns, nSamples, stepInSecond, segmentSizeInSecond, discardSecondHalf, mergeIncompleteEvent,
+                                        resolve, synchronous=True)
         return [merger.finish(f, resolve) for f in range(len(plans))]
