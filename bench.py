@@ -404,6 +404,8 @@ def _cpu_baseline(args, s_d, n_d, T, B, nseg):
     try:
         from transkun_amd import CRF as _CRF, synth as _synth
         iv = _synth.synthetic_intervals(T, B, seed=1234)
+        nthreads = max(1, min(avail, _physical_cores() or avail, 64))        # (its OpenMP loop has B / 8 tasks)
+        torch.set_num_threads(nthreads)
         sc_p = sc.clone().requires_grad_(); nc_p = nc.clone().requires_grad_()
         pt = []
         t_all = time.perf_counter()
@@ -413,13 +415,13 @@ def _cpu_baseline(args, s_d, n_d, T, B, nseg):
             lp = _CRF.NeuralSemiCRFInterval(sc_p, nc_p).logProb(iv)
             (lp.sum() * (-1.0 / nseg)).backward()
             pt.append(time.perf_counter() - t1)
-        product = {"value": round(1.0 / min(pt), 4), "unit": "steps/s", "best_of": len(pt),
+        product = {"value": round(1.0 / min(pt), 4), "unit": "steps/s", "best_of": len(pt), "cores": nthreads,
                    "what": "NeuralSemiCRFInterval(score, noise).logProb(intervals) forward + backward on CPU tensors: this library's host "
                            "kernels (cpu_ops.cpp, OpenMP over chains, all logical CPUs), same workload"}
         del sc_p, nc_p
     except Exception as ex:
         product = {"error": repr(ex)[:200]}
-    return {"value": round(1.0 / dt, 5), "unit": "steps/s", "cores": int(torch.get_num_threads()), "kind": "port", "product_host_kernels": product,
+    return {"value": round(1.0 / dt, 5), "unit": "steps/s", "cores": int(best), "kind": "port", "product_host_kernels": product,
             "sample": f"torch-CPU op-loop port of forward_backward + backward multiply, T={T}, all {B} chains, "
                       f"best of {len(times)} reps ({dt:.2f}s); thread probe on {Bs} chains: "
                       + ", ".join(f"{k}t={v:.2f}s" for k, v in probe.items()),

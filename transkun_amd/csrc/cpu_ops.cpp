@@ -18,7 +18,7 @@
 namespace semicrf_cpu {
 
 namespace {
-constexpr int CB = 16;                          // chains per block: one 64-byte line of every cell
+constexpr int CB = 8;             // chains per task: half a 64-byte line of the chain-minor tensors (352 chains = 44 tasks for the OpenMP loop)
 
 inline float softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }      // F.softplus, threshold 20 (reference :218,:395)
 inline float relu_sel(float x) { return x > 0.0f ? x : 0.0f; }                   // s * (s > 0), reference :29, :49-51
