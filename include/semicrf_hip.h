@@ -343,6 +343,20 @@ int scorer_proj_tn(const float* dy, int64_t lddy, int64_t M, int R, int extra_co
                    float* dW, int64_t lddw, float* db, void* ws, size_t ws_bytes, semicrf_stream_t stream);
 
 /*
+ * The weights of the MERGED projection and their gradient.  Replaces: nothing the reference computes as such -- its two projections
+ * q = x Wq^T + bq, k = x Wk^T + bk (LayersTransformer.py:392-397, applied at :406-410) enter the score only through
+ * <q_e, k_b> = <x_e A + v, x_b> + c_e with A = Wq^T Wk, v = bq Wk, c_e = <x_e, Wq^T bk> + <bq, bk>, so ONE size -> size GEMM
+ * [z | c | diag | 0 ..] = x Wm^T + bm does (transkun_amd.fused.merged_weights).  W [2 D + 1][size] and bias [2 D + 1] are the
+ * Linear's parameters (rows Wq, Wk, the diagonal row); Wm [rows][size], bm [rows] with rows >= size + 2:
+ *   Wm[i] = sum_r Wk1[r][i] Wq[r] (i <= size, Wk1 = [Wk | bk]),  Wm[size + 1] = the diagonal row,  zero rows behind;  bm alike.
+ * _bwd: dW [2 D + 1][size], dbias [2 D + 1] from dWm, dbm (the autograd of the forward).  size <= 256, contiguous rows.
+ */
+int scorer_merge_weights_fwd(const float* W, const float* bias, int D, int size, int rows, float* Wm, float* bm, semicrf_stream_t stream);
+size_t scorer_merge_weights_bwd_workspace_bytes(int size);           /* the transpose of dWm's first size + 1 rows */
+int scorer_merge_weights_bwd(const float* W, const float* bias, const float* dWm, const float* dbm, int D, int size, int rows, float* dW,
+                             float* dbias, void* ws, size_t ws_bytes, semicrf_stream_t stream);
+
+/*
  * Backward-direction values only (the beta half of forward_backward, NeuralSemiCRFInterval.py:386-414, without the
  * marginals): beta[t][c] by frame, natural log.  Workspace: semicrf_workspace_bytes(SEMICRF_OP_LOGZ_FWD, T, B).
  * Used by interval_score_bwd_fused, which rebuilds the marginals tile by tile instead of reading a dense gradient.

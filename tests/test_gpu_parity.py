@@ -1282,6 +1282,28 @@ def test_transcribe_end_to_end_vs_reference(gpu, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("size,exp", [(256, 1), (64, 1), (128, 2), (100, 1)])
+def test_merged_weights_kernels(gpu, size, exp):
+    """csrc/merge_weights.hip (one launch each way) against the torch formulation of fused.merged_weights in float64: the merged
+    weights, and the gradients of the Linear's parameters for a random cotangent."""
+    from transkun_amd.fused import QPAD, merged_weights, merged_weights_torch
+    torch.manual_seed(size + exp)
+    D = size * exp
+    W = (torch.randn(2 * D + 1, size, device=gpu) * 0.2).requires_grad_()
+    b = (torch.randn(2 * D + 1, device=gpu) * 0.2).requires_grad_()
+    Wm, bm = merged_weights(W, b, D)
+    assert Wm.shape == (size + QPAD, size) and bm.shape == (size + QPAD,)
+    gW, gb = torch.randn_like(Wm), torch.randn_like(bm)
+    dW, db = torch.autograd.grad([Wm, bm], [W, b], [gW, gb])
+    W64, b64 = W.detach().double().requires_grad_(), b.detach().double().requires_grad_()
+    Wm64, bm64 = merged_weights_torch(W64, b64, D)
+    dW64, db64 = torch.autograd.grad([Wm64, bm64], [W64, b64], [gW.double(), gb.double()])
+    for got, want in ((Wm, Wm64), (bm, bm64), (dW, dW64), (db, db64)):
+        assert float((got.double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())) * 4
+    assert float(Wm[size + 2:].abs().max()) == 0.0 and float(bm[size + 2:].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
 def test_transcribe_many_equals_one_by_one(gpu):
     """Recordings of different lengths decoded in lock step (one batch of 90 x #files chains per step, forced starts handed over
     on the device) give exactly the events of transcribing each recording alone."""

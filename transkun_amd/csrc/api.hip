@@ -79,6 +79,10 @@ int launch_interval_score_mfma(const float* q, const float* k, const float* diag
 int launch_proj_nn(const float* A, long long lda, long long M, int K, const float* B, long long ldb, int N, float* out, long long ldout,
                    const float* bias, const float* w2, const float* b2, int zero_cols, int accumulate, hipStream_t stream);
 size_t proj_tn_workspace_bytes(long long M, int R, int N);
+void launch_merge_weights_fwd(const float* W, const float* bias, int D, int size, int rows, float* Wm, float* bm, hipStream_t stream);
+void launch_merge_weights_bwd(const float* W, const float* bias, const float* dWm, const float* dbm, int D, int size, float* dW, float* dbias,
+                              float* ws, hipStream_t stream);
+size_t merge_weights_bwd_workspace_bytes(int size);
 int launch_proj_tn(const float* A, long long lda, long long M, int R, int extra_col0, int total_rows, const float* X, long long ldx, int N,
                    float* dW, long long lddw, float* db, void* ws, size_t ws_bytes, hipStream_t stream);
 size_t persist_workspace_bytes(int T, int B);
@@ -750,6 +754,28 @@ int scorer_proj_tn(const float* dy, int64_t lddy, int64_t M, int R, int extra_co
     if (rc == 2) { set_error("scorer_proj_tn: workspace missing or too small"); return SEMICRF_EWORKSPACE; }
     SEMICRF_CHECK_ARG(rc == 0, "scorer_proj_tn: N must be 64, 128 or 256, rows 16-byte aligned, M * ld * 4 < 2^31 (N=%d)", N);
     SEMICRF_CHECK_LAUNCH("scorer_proj_tn");
+    return SEMICRF_OK;
+}
+
+int scorer_merge_weights_fwd(const float* W, const float* bias, int D, int size, int rows, float* Wm, float* bm, semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(W && bias && Wm && bm, "W/bias/Wm/bm must be non-NULL");
+    SEMICRF_CHECK_ARG(D >= 1 && size >= 1 && size <= 256 && rows >= size + 2, "scorer_merge_weights: D=%d size=%d (<= 256) rows=%d (>= size + 2)", D, size, rows);
+    launch_merge_weights_fwd(W, bias, D, size, rows, Wm, bm, (hipStream_t)stream);
+    SEMICRF_CHECK_LAUNCH("scorer_merge_weights_fwd");
+    return SEMICRF_OK;
+}
+
+size_t scorer_merge_weights_bwd_workspace_bytes(int size) { return size >= 1 ? merge_weights_bwd_workspace_bytes(size) : 0; }
+
+int scorer_merge_weights_bwd(const float* W, const float* bias, const float* dWm, const float* dbm, int D, int size, int rows, float* dW,
+                             float* dbias, void* ws, size_t ws_bytes, semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(W && bias && dWm && dbm && dW && dbias, "W/bias/dWm/dbm/dW/dbias must be non-NULL");
+    SEMICRF_CHECK_ARG(D >= 1 && size >= 1 && size <= 256 && rows >= size + 2, "scorer_merge_weights: D=%d size=%d (<= 256) rows=%d (>= size + 2)", D, size, rows);
+    if (!ws || ws_bytes < merge_weights_bwd_workspace_bytes(size) || ((uintptr_t)ws & 3)) { set_error("scorer_merge_weights_bwd: workspace missing or too small"); return SEMICRF_EWORKSPACE; }
+    launch_merge_weights_bwd(W, bias, dWm, dbm, D, size, dW, dbias, (float*)ws, (hipStream_t)stream);
+    SEMICRF_CHECK_LAUNCH("scorer_merge_weights_bwd");
     return SEMICRF_OK;
 }
 

@@ -371,6 +371,24 @@ void proj_tn_op(Tensor dy, int64_t lddy, int64_t M, int64_t R, int64_t extra_col
           "scorer_proj_tn");
 }
 
+void merge_weights_fwd_op(Tensor W, Tensor bias, int64_t D, int64_t size, int64_t rows, Tensor Wm, Tensor bm)
+{
+    Ctx c(W); c.same(W, bias, Wm, bm);
+    STD_TORCH_CHECK(D >= 1 && size >= 1 && size <= 256 && rows >= size + 2 && rows < (1 << 20), "semicrf: bad D / size / rows");
+    check(scorer_merge_weights_fwd(f32(W, (2 * D + 1) * size, "W"), f32(bias, 2 * D + 1, "bias"), (int)D, (int)size, (int)rows,
+                                   f32w(Wm, rows * size, "Wm"), f32w(bm, rows, "bm"), c.stream),
+          "scorer_merge_weights_fwd");
+}
+void merge_weights_bwd_op(Tensor W, Tensor bias, Tensor dWm, Tensor dbm, int64_t D, int64_t size, int64_t rows, Tensor dW, Tensor dbias, Tensor ws)
+{
+    Ctx c(W); c.same(W, bias, dWm, dbm); c.same(W, dW, dbias, ws);
+    STD_TORCH_CHECK(D >= 1 && size >= 1 && size <= 256 && rows >= size + 2 && rows < (1 << 20), "semicrf: bad D / size / rows");
+    check(scorer_merge_weights_bwd(f32(W, (2 * D + 1) * size, "W"), f32(bias, 2 * D + 1, "bias"), f32(dWm, rows * size, "dWm"),
+                                   f32(dbm, rows, "dbm"), (int)D, (int)size, (int)rows, f32w(dW, (2 * D + 1) * size, "dW"),
+                                   f32w(dbias, 2 * D + 1, "dbias"), bytes(ws, "ws"), (size_t)ws.numel(), c.stream),
+          "scorer_merge_weights_bwd");
+}
+
 void interval_features_gather_op(Tensor ctx, int64_t C, int64_t T, int64_t D, int64_t ldc, Tensor pairs, int64_t K, Tensor offsets,
                                  int64_t nSym, Tensor out, Tensor symIdx, Tensor scatterIdx)
 {
@@ -450,6 +468,8 @@ STABLE_TORCH_LIBRARY(semicrf, m)
           "int lddd, int lddrc) -> ()");
     m.def("proj_nn(Tensor A, int lda, int M, int K, Tensor B, int ldb, int N, Tensor(a!) out, int ldout, Tensor bias, bool has_bias, Tensor w2, "
           "Tensor b2, bool has_w2, int zero_cols, bool accumulate) -> ()");
+    m.def("merge_weights_fwd(Tensor W, Tensor bias, int D, int size, int rows, Tensor(a!) Wm, Tensor(b!) bm) -> ()");
+    m.def("merge_weights_bwd(Tensor W, Tensor bias, Tensor dWm, Tensor dbm, int D, int size, int rows, Tensor(a!) dW, Tensor(b!) dbias, Tensor(c!) ws) -> ()");
     m.def("proj_tn(Tensor dy, int lddy, int M, int R, int extra_col0, int total_rows, Tensor x, int ldx, int N, Tensor(a!) dW, int lddw, "
           "Tensor(b!) db, Tensor(c!) ws) -> ()");
     m.def("interval_features_gather(Tensor ctx, int C, int T, int D, int ldc, Tensor pairs, int K, Tensor offsets, int nSym, Tensor(a!) out, "
@@ -490,6 +510,8 @@ STABLE_TORCH_LIBRARY_IMPL(semicrf, CUDA, m)
     m.impl("interval_score_path_bwd", TORCH_BOX(&interval_score_path_bwd_op));
     m.impl("proj_nn", TORCH_BOX(&proj_nn_op));
     m.impl("proj_tn", TORCH_BOX(&proj_tn_op));
+    m.impl("merge_weights_fwd", TORCH_BOX(&merge_weights_fwd_op));
+    m.impl("merge_weights_bwd", TORCH_BOX(&merge_weights_bwd_op));
     m.impl("interval_features_gather", TORCH_BOX(&interval_features_gather_op));
     m.impl("interval_features_gather_bwd", TORCH_BOX(&interval_features_gather_bwd_op));
     m.impl("segment_onset_filter", TORCH_BOX(&segment_onset_filter_op));

@@ -41,7 +41,47 @@ def _beta_raw(score, noise):
     return beta
 
 
+class _MergedWeights(torch.autograd.Function):
+    """merged_weights on the library's two kernels (csrc/merge_weights.hip): one launch forward, one backward, where the torch
+    formulation below costs ~10 small kernels forward and ~25 backward (slices, cats, two single-tile hipBLASLt products, fill +
+    copy + add per slice gradient)."""
+
+    @staticmethod
+    def forward(ctx, W, bias, D):
+        size = W.shape[1]
+        Wc, bc = W.contiguous(), bias.contiguous()
+        Wm = torch.empty(size + QPAD, size, dtype=torch.float32, device=W.device)
+        bm = torch.empty(size + QPAD, dtype=torch.float32, device=W.device)
+        _lib.ops().merge_weights_fwd(Wc, bc, D, size, size + QPAD, Wm, bm)
+        ctx.save_for_backward(Wc, bc)
+        ctx.D = D
+        return Wm, bm
+
+    @staticmethod
+    def backward(ctx, dWm, dbm):
+        Wc, bc = ctx.saved_tensors
+        D, size = ctx.D, Wc.shape[1]
+        if dWm is None:
+            dWm = torch.zeros(size + QPAD, size, dtype=torch.float32, device=Wc.device)
+        if dbm is None:
+            dbm = torch.zeros(size + QPAD, dtype=torch.float32, device=Wc.device)
+        dW = torch.empty_like(Wc)
+        dbias = torch.empty_like(bc)
+        ws = torch.empty(size * (size + 1) * 4, dtype=torch.uint8, device=Wc.device)          # dWm's first size + 1 rows, transposed
+        _lib.ops().merge_weights_bwd(Wc, bc, dWm.contiguous(), dbm.contiguous(), D, size, size + QPAD, dW, dbias, ws)
+        return dW, dbias, None
+
+
 def merged_weights(W, bias, D):
+    """(Wm, bm) of the merged projection -- see merged_weights_torch for the algebra.  On the GPU (fp32 parameters of the Linear's
+    own shape, size <= 256, the default implementation) one kernel each way; anything else as torch operations."""
+    if (W.is_cuda and W.dtype == torch.float32 and bias.dtype == torch.float32 and W.dim() == 2 and W.shape[0] == 2 * D + 1
+            and bias.shape == (2 * D + 1,) and W.shape[1] <= 256 and _lib.get_impl() == 0):
+        return _MergedWeights.apply(W, bias, D)
+    return merged_weights_torch(W, bias, D)
+
+
+def merged_weights_torch(W, bias, D):
     """The reference's two projections q = x Wq^T + bq, k = x Wk^T + bk (LayersTransformer.py:392-397, :406-410) enter the score only
     through <q_e, k_b> = <x_e A + v, x_b> + c_e with A = Wq^T Wk, v = bq Wk, c_e = <x_e, Wq^T bk> + <bq, bk>: ONE size -> size
     projection, the second operand of the contraction is x itself.  Returns (Wm [size+QPAD, size], bm [size+QPAD]) of the single
