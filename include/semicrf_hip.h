@@ -351,7 +351,8 @@ int scorer_proj_tn(const float* dy, int64_t lddy, int64_t M, int R, int extra_co
  *   Wm[i] = sum_r Wk1[r][i] Wq[r] (i <= size, Wk1 = [Wk | bk]),  Wm[size + 1] = the diagonal row,  zero rows behind;  bm alike.
  * _bwd: dW [2 D + 1][size], dbias [2 D + 1] from dWm, dbm (the autograd of the forward).  size <= 256, contiguous rows.
  */
-int scorer_merge_weights_fwd(const float* W, const float* bias, int D, int size, int rows, float* Wm, float* bm, semicrf_stream_t stream);
+int scorer_merge_weights_fwd(const float* W, const float* bias, int D, int size, int rows, float* Wm, float* bm, float* WmT,
+                             semicrf_stream_t stream);    /* WmT (or NULL): [size][size], WmT[k][n] = Wm[n][k] for n < size -- scorer_proj_nn's B */
 size_t scorer_merge_weights_bwd_workspace_bytes(int size);           /* the transpose of dWm's first size + 1 rows */
 int scorer_merge_weights_bwd(const float* W, const float* bias, const float* dWm, const float* dbm, int D, int size, int rows, float* dW,
                              float* dbias, void* ws, size_t ws_bytes, semicrf_stream_t stream);

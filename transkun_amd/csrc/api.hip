@@ -79,7 +79,7 @@ int launch_interval_score_mfma(const float* q, const float* k, const float* diag
 int launch_proj_nn(const float* A, long long lda, long long M, int K, const float* B, long long ldb, int N, float* out, long long ldout,
                    const float* bias, const float* w2, const float* b2, int zero_cols, int accumulate, hipStream_t stream);
 size_t proj_tn_workspace_bytes(long long M, int R, int N);
-void launch_merge_weights_fwd(const float* W, const float* bias, int D, int size, int rows, float* Wm, float* bm, hipStream_t stream);
+void launch_merge_weights_fwd(const float* W, const float* bias, int D, int size, int rows, float* Wm, float* bm, float* WmT, hipStream_t stream);
 void launch_merge_weights_bwd(const float* W, const float* bias, const float* dWm, const float* dbm, int D, int size, float* dW, float* dbias,
                               float* ws, hipStream_t stream);
 size_t merge_weights_bwd_workspace_bytes(int size);
@@ -757,11 +757,12 @@ int scorer_proj_tn(const float* dy, int64_t lddy, int64_t M, int R, int extra_co
     return SEMICRF_OK;
 }
 
-int scorer_merge_weights_fwd(const float* W, const float* bias, int D, int size, int rows, float* Wm, float* bm, semicrf_stream_t stream)
+int scorer_merge_weights_fwd(const float* W, const float* bias, int D, int size, int rows, float* Wm, float* bm, float* WmT,
+                             semicrf_stream_t stream)
 {
     SEMICRF_CHECK_ARG(W && bias && Wm && bm, "W/bias/Wm/bm must be non-NULL");
     SEMICRF_CHECK_ARG(D >= 1 && size >= 1 && size <= 256 && rows >= size + 2, "scorer_merge_weights: D=%d size=%d (<= 256) rows=%d (>= size + 2)", D, size, rows);
-    launch_merge_weights_fwd(W, bias, D, size, rows, Wm, bm, (hipStream_t)stream);
+    launch_merge_weights_fwd(W, bias, D, size, rows, Wm, bm, WmT, (hipStream_t)stream);
     SEMICRF_CHECK_LAUNCH("scorer_merge_weights_fwd");
     return SEMICRF_OK;
 }

@@ -18,7 +18,7 @@
 namespace semicrf_cpu {
 
 namespace {
-constexpr int CB = 8;             // chains per task: half a 64-byte line of the chain-minor tensors (352 chains = 44 tasks for the OpenMP loop)
+constexpr int CB = 16;                          // chains per block: one 64-byte line of every cell (a thread owns whole lines of what it writes)
 
 inline float softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }      // F.softplus, threshold 20 (reference :218,:395)
 inline float relu_sel(float x) { return x > 0.0f ? x : 0.0f; }                   // s * (s > 0), reference :29, :49-51
@@ -39,40 +39,47 @@ struct Lse {                                    // running log-sum-exp with exac
 // alpha sweep (computeLogZ :207-246; forward_backward :394-410, :417): v [T][B], logZ [B]
 void logz_fwd(const float* score, const float* noise, int T, int B, float* logZ, float* v)
 {
+    // Row by row with the chain blocks spread over the threads INSIDE a row: all threads stream the same 4 B T bytes of row i at
+    // the same time.  (A thread per chain block walking the whole tensor on its own -- 64 bytes out of every 4 B -- touched a new
+    // page every third cell: 4.9 s per step at T=1024 x 352 on 16 threads where the torch op loop takes 2.3.)
     const size_t Bs = (size_t)B;
-#pragma omp parallel for schedule(dynamic, 1)
-    for (int c0 = 0; c0 < B; c0 += CB) {
-        const int nc = B - c0 < CB ? B - c0 : CB;
-        for (int i = 0; i < T; ++i) {
-            const float* row = score + (size_t)i * T * Bs;
+    const int nblk = (B + CB - 1) / CB;
+#pragma omp parallel
+    for (int i = 0; i < T; ++i) {
+        const float* row = score + (size_t)i * T * Bs;
+#pragma omp for schedule(static)
+        for (int blk = 0; blk < nblk; ++blk) {
+            const int c0 = blk * CB;
+            const int nc = B - c0 < CB ? B - c0 : CB;
             float* vi = v + (size_t)i * Bs + c0;
             if (i == 0) {
                 for (int c = 0; c < nc; ++c) vi[c] = softplus(row[c0 + c]);
-                continue;
+            } else {
+                const float* vp = v + (size_t)(i - 1) * Bs + c0;
+                const float* nz = noise + (size_t)(i - 1) * Bs + c0;
+                float m[CB];
+                double s[CB];
+                for (int c = 0; c < nc; ++c) m[c] = vp[c] + nz[c];
+                for (int j = 0; j < i; ++j) {
+                    const float* vj = v + (size_t)j * Bs + c0;
+                    const float* cell = row + (size_t)j * Bs + c0;
+                    for (int c = 0; c < nc; ++c) { const float x = vj[c] + cell[c]; m[c] = x > m[c] ? x : m[c]; }
+                }
+                // every candidate -inf (masked cells, torch.logsumexp gives -inf): the reference point is 0, every term exp(-inf) = 0
+                float mm[CB];
+                for (int c = 0; c < nc; ++c) mm[c] = m[c] == -INFINITY ? 0.0f : m[c];
+                for (int c = 0; c < nc; ++c) s[c] = (double)expf(vp[c] + nz[c] - mm[c]);
+                for (int j = 0; j < i; ++j) {
+                    const float* vj = v + (size_t)j * Bs + c0;
+                    const float* cell = row + (size_t)j * Bs + c0;
+                    for (int c = 0; c < nc; ++c) s[c] += (double)expf(vj[c] + cell[c] - mm[c]);
+                }
+                const float* dg = row + (size_t)i * Bs + c0;
+                for (int c = 0; c < nc; ++c) vi[c] = (s[c] == 0.0 ? -INFINITY : mm[c] + (float)log(s[c])) + softplus(dg[c]);
             }
-            const float* vp = v + (size_t)(i - 1) * Bs + c0;
-            const float* nz = noise + (size_t)(i - 1) * Bs + c0;
-            float m[CB];
-            double s[CB];
-            for (int c = 0; c < nc; ++c) m[c] = vp[c] + nz[c];
-            for (int j = 0; j < i; ++j) {
-                const float* vj = v + (size_t)j * Bs + c0;
-                const float* cell = row + (size_t)j * Bs + c0;
-                for (int c = 0; c < nc; ++c) { const float x = vj[c] + cell[c]; m[c] = x > m[c] ? x : m[c]; }
-            }
-            // every candidate -inf (masked cells, torch.logsumexp gives -inf): the reference point is 0, every term exp(-inf) = 0
-            float mm[CB];
-            for (int c = 0; c < nc; ++c) mm[c] = m[c] == -INFINITY ? 0.0f : m[c];
-            for (int c = 0; c < nc; ++c) s[c] = (double)expf(vp[c] + nz[c] - mm[c]);
-            for (int j = 0; j < i; ++j) {
-                const float* vj = v + (size_t)j * Bs + c0;
-                const float* cell = row + (size_t)j * Bs + c0;
-                for (int c = 0; c < nc; ++c) s[c] += (double)expf(vj[c] + cell[c] - mm[c]);
-            }
-            const float* dg = row + (size_t)i * Bs + c0;
-            for (int c = 0; c < nc; ++c) vi[c] = (s[c] == 0.0 ? -INFINITY : mm[c] + (float)log(s[c])) + softplus(dg[c]);
-        }
-        for (int c = 0; c < nc; ++c) logZ[c0 + c] = v[(size_t)(T - 1) * Bs + c0 + c];
+            if (i == T - 1)
+                for (int c = 0; c < nc; ++c) logZ[c0 + c] = vi[c];
+        }                                               // (implicit barrier: the threads stay in the same row)
     }
 }
 
@@ -83,12 +90,16 @@ void logz_bwd(const float* score, const float* noise, const float* v, const floa
               float* dScore, float* dNoise, float* q)
 {
     const size_t Bs = (size_t)B;
-#pragma omp parallel for schedule(dynamic, 1)
-    for (int c0 = 0; c0 < B; c0 += CB) {
-        const int nc = B - c0 < CB ? B - c0 : CB;
-        std::vector<Lse> acc((size_t)T * CB, Lse{-INFINITY, 0.0});
-        for (int e = T - 1; e >= 0; --e) {
-            const float* row = score + (size_t)e * T * Bs;
+    const int nblk = (B + CB - 1) / CB;
+    std::vector<Lse> acc_all((size_t)nblk * T * CB, Lse{-INFINITY, 0.0});      // per chain block: the accumulators of the frames t < e
+#pragma omp parallel
+    for (int e = T - 1; e >= 0; --e) {                    // row by row, the chain blocks spread over the threads inside a row (see logz_fwd)
+        const float* row = score + (size_t)e * T * Bs;
+#pragma omp for schedule(static)
+        for (int blk = 0; blk < nblk; ++blk) {
+            const int c0 = blk * CB;
+            const int nc = B - c0 < CB ? B - c0 : CB;
+            Lse* const acc = acc_all.data() + (size_t)blk * T * CB;
             const float* dg = row + (size_t)e * Bs + c0;
             float* qe = q + (size_t)e * Bs + c0;
             if (e == T - 1) {

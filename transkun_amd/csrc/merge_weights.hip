@@ -50,7 +50,7 @@ __device__ __forceinline__ float col_times_rows(const float* __restrict__ col, c
 }
 
 __global__ __launch_bounds__(256) void merge_weights_fwd_kernel(const float* __restrict__ W, const float* __restrict__ bias, int D, int size,
-                                                                int rows, float* __restrict__ Wm, float* __restrict__ bm)
+                                                                int rows, float* __restrict__ Wm, float* __restrict__ bm, float* __restrict__ WmT)
 {
     extern __shared__ float col[];                        // [D]: column i of Wk1 = [Wk | bk]
     __shared__ float sh[256];
@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void merge_weights_fwd_kernel(const float* __r
         __syncthreads();
         const float acc = col_times_rows(col, Wq, D, size, j);
         if (j < size) Wm[(size_t)i * size + j] = acc;
+        if (WmT && i < size && j < size) WmT[(size_t)j * size + i] = acc;      // the main rows transposed: the forward GEMM's B operand
         float bacc = 0.0f;
         for (int r = j; r < D; r += 256) bacc = fmaf(col[r], bq[r], bacc);
         const float b = block_sum_256(bacc, sh);
@@ -132,9 +133,9 @@ __global__ __launch_bounds__(256) void merge_weights_bwd_kernel(const float* __r
 
 }  // namespace
 
-void launch_merge_weights_fwd(const float* W, const float* bias, int D, int size, int rows, float* Wm, float* bm, hipStream_t stream)
+void launch_merge_weights_fwd(const float* W, const float* bias, int D, int size, int rows, float* Wm, float* bm, float* WmT, hipStream_t stream)
 {
-    hipLaunchKernelGGL(merge_weights_fwd_kernel, dim3(rows), dim3(256), (size_t)D * sizeof(float), stream, W, bias, D, size, rows, Wm, bm);
+    hipLaunchKernelGGL(merge_weights_fwd_kernel, dim3(rows), dim3(256), (size_t)D * sizeof(float), stream, W, bias, D, size, rows, Wm, bm, WmT);
 }
 size_t merge_weights_bwd_workspace_bytes(int size) { return (size_t)size * (size + 1) * sizeof(float); }
 

@@ -371,12 +371,13 @@ void proj_tn_op(Tensor dy, int64_t lddy, int64_t M, int64_t R, int64_t extra_col
           "scorer_proj_tn");
 }
 
-void merge_weights_fwd_op(Tensor W, Tensor bias, int64_t D, int64_t size, int64_t rows, Tensor Wm, Tensor bm)
+void merge_weights_fwd_op(Tensor W, Tensor bias, int64_t D, int64_t size, int64_t rows, Tensor Wm, Tensor bm, Tensor WmT, bool has_t)
 {
     Ctx c(W); c.same(W, bias, Wm, bm);
+    if (has_t) c.same(W, WmT);
     STD_TORCH_CHECK(D >= 1 && size >= 1 && size <= 256 && rows >= size + 2 && rows < (1 << 20), "semicrf: bad D / size / rows");
     check(scorer_merge_weights_fwd(f32(W, (2 * D + 1) * size, "W"), f32(bias, 2 * D + 1, "bias"), (int)D, (int)size, (int)rows,
-                                   f32w(Wm, rows * size, "Wm"), f32w(bm, rows, "bm"), c.stream),
+                                   f32w(Wm, rows * size, "Wm"), f32w(bm, rows, "bm"), has_t ? f32w(WmT, size * size, "WmT") : nullptr, c.stream),
           "scorer_merge_weights_fwd");
 }
 void merge_weights_bwd_op(Tensor W, Tensor bias, Tensor dWm, Tensor dbm, int64_t D, int64_t size, int64_t rows, Tensor dW, Tensor dbias, Tensor ws)
@@ -468,7 +469,7 @@ STABLE_TORCH_LIBRARY(semicrf, m)
           "int lddd, int lddrc) -> ()");
     m.def("proj_nn(Tensor A, int lda, int M, int K, Tensor B, int ldb, int N, Tensor(a!) out, int ldout, Tensor bias, bool has_bias, Tensor w2, "
           "Tensor b2, bool has_w2, int zero_cols, bool accumulate) -> ()");
-    m.def("merge_weights_fwd(Tensor W, Tensor bias, int D, int size, int rows, Tensor(a!) Wm, Tensor(b!) bm) -> ()");
+    m.def("merge_weights_fwd(Tensor W, Tensor bias, int D, int size, int rows, Tensor(a!) Wm, Tensor(b!) bm, Tensor(c!) WmT, bool has_t) -> ()");
     m.def("merge_weights_bwd(Tensor W, Tensor bias, Tensor dWm, Tensor dbm, int D, int size, int rows, Tensor(a!) dW, Tensor(b!) dbias, Tensor(c!) ws) -> ()");
     m.def("proj_tn(Tensor dy, int lddy, int M, int R, int extra_col0, int total_rows, Tensor x, int ldx, int N, Tensor(a!) dW, int lddw, "
           "Tensor(b!) db, Tensor(c!) ws) -> ()");

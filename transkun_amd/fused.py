@@ -50,11 +50,19 @@ class _MergedWeights(torch.autograd.Function):
     def forward(ctx, W, bias, D):
         size = W.shape[1]
         Wc, bc = W.contiguous(), bias.contiguous()
-        Wm = torch.empty(size + QPAD, size, dtype=torch.float32, device=W.device)
-        bm = torch.empty(size + QPAD, dtype=torch.float32, device=W.device)
-        _lib.ops().merge_weights_fwd(Wc, bc, D, size, size + QPAD, Wm, bm)
+        # the GEMM kernels' operand layouts come out of the same launch: Wm with its rows padded to whole chunks of 32 (zero rows:
+        # scorer_proj_nn's B for the input gradient) and, for sizes that are whole chunks, the main rows transposed (the forward's B)
+        rows = (size + QPAD + 31) // 32 * 32
+        full = torch.empty(rows, size, dtype=torch.float32, device=W.device)
+        bfull = torch.empty(rows, dtype=torch.float32, device=W.device)
+        has_t = size % 32 == 0
+        WmT = torch.empty(size, size, dtype=torch.float32, device=W.device) if has_t else full
+        _lib.ops().merge_weights_fwd(Wc, bc, D, size, rows, full, bfull, WmT, has_t)
         ctx.save_for_backward(Wc, bc)
         ctx.D = D
+        Wm, bm = full[:size + QPAD], bfull[:size + QPAD]
+        Wm._semicrf_padded = full
+        Wm._semicrf_T = WmT if has_t else None
         return Wm, bm
 
     @staticmethod
@@ -127,7 +135,8 @@ class _MergedScorerCRFLogProb(torch.autograd.Function):
         size = x.shape[-1]
         pitch = slot_pitch(P, T, size, N)
         x3 = x.reshape(C, T, size)
-        zc = proj_forward(x3.view(-1, size), Wm, bm, size).view(C, T, size + QPAD)   # [z | c | diag | 0 0]: the library's own GEMM
+        zc = proj_forward(x3.view(-1, size), Wm, bm, size, Wt=getattr(Wm, "_semicrf_T", None)).view(C, T, size + QPAD)   # [z | c | diag | 0 0]
+        ctx.Wp = getattr(Wm, "_semicrf_padded", None)      # Wm with its rows padded to whole chunks (the input gradient's B), if it came so
         qs = 1.0 / math.sqrt(D)
         S, noise = _interval_score_raw(zc[..., :size], x3, zc[..., size + 1], T, C, size, qs, mode, fs, P, pitch, rowc=zc[..., size])
         if pitch != P:
@@ -174,7 +183,7 @@ class _MergedScorerCRFLogProb(torch.autograd.Function):
         need = ctx.needs_input_grad
         dx2 = dx.view(-1, size)
         if need[0]:
-            proj_input_grad(g2, Wm, out=dx2)                          # + the part through [z | c | diag]
+            proj_input_grad(g2, Wm, out=dx2, Wp=ctx.Wp)               # + the part through [z | c | diag]
         dWm = dbm = None
         if need[1] or need[2]:
             dWm, dbm = proj_weight_grad(g2, x3.view(-1, size), size)

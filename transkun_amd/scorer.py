@@ -187,7 +187,7 @@ def _proj_ok(a2: torch.Tensor, n_cols: int) -> bool:
             and _lib.get_impl() == 0 and not os.environ.get("SEMICRF_TORCH_PROJECTION"))
 
 
-def proj_forward(x2: torch.Tensor, W: torch.Tensor, b: torch.Tensor, n_main: int) -> torch.Tensor:
+def proj_forward(x2: torch.Tensor, W: torch.Tensor, b: torch.Tensor, n_main: int, Wt: torch.Tensor = None) -> torch.Tensor:
     """y [M, Nout] = x2 W^T + b for the PACKED projection outputs of this package (LayersTransformer.py:388-397, :406-410 regrouped):
     W [Nout, K] holds n_main main rows, then -- if Nout > n_main -- two extra rows ([diag | 0] or [c | diag]) and zero rows.  On the
     library's exact-fp32 GEMM (scorer_proj_nn) where it applies, torch's GEMM otherwise."""
@@ -195,8 +195,9 @@ def proj_forward(x2: torch.Tensor, W: torch.Tensor, b: torch.Tensor, n_main: int
     Nout = W.shape[0]
     if not (_proj_ok(x2, Nout) and K in _PROJ_SIZES and n_main in _PROJ_SIZES and (Nout == n_main or Nout >= n_main + 2) and Nout % 4 == 0):
         return F.linear(x2, W, b)
-    Wt = W.new_zeros((K + 31) // 32 * 32, n_main)            # the contraction index as row, whole chunks of 32 rows
-    Wt[:K] = W[:n_main].t()
+    if Wt is None or Wt.shape != ((K + 31) // 32 * 32, n_main) or not Wt.is_contiguous():
+        Wt = W.new_zeros((K + 31) // 32 * 32, n_main)        # the contraction index as row, whole chunks of 32 rows
+        Wt[:K] = W[:n_main].t()
     y = torch.empty(M, Nout, dtype=torch.float32, device=x2.device)
     has2 = Nout > n_main
     w2 = W[n_main:n_main + 2].contiguous() if has2 else b
@@ -206,14 +207,15 @@ def proj_forward(x2: torch.Tensor, W: torch.Tensor, b: torch.Tensor, n_main: int
     return y
 
 
-def proj_input_grad(dy2: torch.Tensor, W: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+def proj_input_grad(dy2: torch.Tensor, W: torch.Tensor, out: torch.Tensor = None, Wp: torch.Tensor = None) -> torch.Tensor:
     """dy2 [M, Nout] W [Nout, K] -> [M, K]; with `out` the product is ADDED to it (the gradient through a second use of the input)."""
     M, Nout = dy2.shape
     K = W.shape[1]
     if not (_proj_ok(dy2, K) and K in _PROJ_SIZES and (out is None or (out.is_contiguous() and out.shape == (M, K)))):
         return dy2.mm(W) if out is None else out.addmm_(dy2, W)
-    Wp = W.new_zeros((Nout + 31) // 32 * 32, K)
-    Wp[:Nout] = W
+    if Wp is None or Wp.shape != ((Nout + 31) // 32 * 32, K) or not Wp.is_contiguous():       # (W with zero rows up to whole chunks)
+        Wp = W.new_zeros((Nout + 31) // 32 * 32, K)
+        Wp[:Nout] = W
     dx = out if out is not None else torch.empty(M, K, dtype=torch.float32, device=dy2.device)
     none = _lib_none(dy2.device)
     _lib.ops().proj_nn(dy2, Nout, M, Nout, Wp, K, K, dx, K, none, False, none, none, False, 0, out is not None)

@@ -199,7 +199,7 @@ class SegmentTranscriber(nn.Module):
             # to fp32 reassociation -- a decoded path can differ from the reference's only where two paths tie to ~1e-6
             Wm, bm = self._merged_weights()
             x3 = ctxBatch.float().contiguous().view(B, T, D)
-            zc = proj_forward(x3.view(-1, D), Wm, bm, D).view(B, T, -1)
+            zc = proj_forward(x3.view(-1, D), Wm, bm, D, Wt=getattr(Wm, "_semicrf_T", None)).view(B, T, -1)
             score, noise = _interval_score_raw(zc[..., :D], x3, zc[..., D + 1], T, B, D, 1.0 / math.sqrt(D),
                                                _lib.LEN_MODES[self.scorer.lengthScaling], 2, P, pitch, rowc=zc[..., D])
         else:
