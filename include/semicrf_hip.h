@@ -353,6 +353,11 @@ int scorer_proj_tn(const float* dy, int64_t lddy, int64_t M, int R, int extra_co
  */
 int scorer_merge_weights_fwd(const float* W, const float* bias, int D, int size, int rows, float* Wm, float* bm, float* WmT,
                              semicrf_stream_t stream);    /* WmT (or NULL): [size][size], WmT[k][n] = Wm[n][k] for n < size -- scorer_proj_nn's B */
+/* The Linear's parameters (W [2 D + 1][size], bias) in the layouts scorer_proj_nn reads, one launch: BT [size][2 D] (BT[k][n] = W[n][k] for
+ * the q and k rows: B of the two forward products, ldb = 2 D), Wqd [rows_pad][size] = [Wq; diagonal row; zero rows] (B of the input
+ * gradient through [q | diag | 0 ..]), w2 [2][size] = [diagonal row; 0], b2 [2] = [its bias, 0] (the forward's two extra columns). */
+int scorer_stage_linear(const float* W, const float* bias, int D, int size, int rows_pad, float* BT, float* Wqd, float* w2, float* b2,
+                        semicrf_stream_t stream);
 size_t scorer_merge_weights_bwd_workspace_bytes(int size);           /* the transpose of dWm's first size + 1 rows */
 int scorer_merge_weights_bwd(const float* W, const float* bias, const float* dWm, const float* dbm, int D, int size, int rows, float* dW,
                              float* dbias, void* ws, size_t ws_bytes, semicrf_stream_t stream);

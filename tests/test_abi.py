@@ -16,7 +16,7 @@ def _declared_functions():
     src = open(os.path.join(ROOT, "include", "semicrf_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = re.findall(r"\b([a-z_0-9]+)\s*\([^;{]*\)\s*;", src)
-    return sorted(set(n for n in names if n.startswith(("semicrf_", "interval_score", "interval_features", "segment_", "scorer_proj", "scorer_merge"))))
+    return sorted(set(n for n in names if n.startswith(("semicrf_", "interval_score", "interval_features", "segment_", "scorer_proj", "scorer_merge", "scorer_stage"))))
 
 
 def test_library_builds_and_exports_header_symbols():

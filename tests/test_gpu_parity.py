@@ -1282,6 +1282,35 @@ def test_transcribe_end_to_end_vs_reference(gpu, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("size,which", [(256, "both"), (128, "both"), (64, "q"), (256, "k")])
+def test_scorer_linear_packed(gpu, size, which):
+    """_ScorerLinearPacked (the Linear's own parameters through scorer_stage_linear + the projection kernels, gradients written into
+    one dW / dbias) against the regrouped torch route (qd_weights + _ScorerLinear on torch's GEMMs) in float64: outputs, dx, dW, db --
+    with a cotangent for both outputs, for [q | diag] alone and for k alone."""
+    import transkun_amd.scorer as sc
+    torch.manual_seed(size)
+    D, M = size, 3000
+    W = (torch.randn(2 * D + 1, size, device=gpu) * 0.1).requires_grad_()
+    b = (torch.randn(2 * D + 1, device=gpu) * 0.1).requires_grad_()
+    x = torch.randn(2, 5, M // 10, size, device=gpu).requires_grad_()
+    assert sc._ScorerLinearPacked.eligible(x, W, b, D)
+    qd, k = sc._ScorerLinearPacked.apply(x, W, b, D)
+    gq, gk = torch.randn_like(qd), torch.randn_like(k)
+    outs, gs = {"both": ([qd, k], [gq, gk]), "q": ([qd], [gq]), "k": ([k], [gk])}[which]
+    dx, dW, db = torch.autograd.grad(outs, [x, W, b], gs)
+    x64, W64, b64 = (t.detach().double().requires_grad_() for t in (x, W, b))
+    Wqd, bqd = sc.qd_weights(W64, b64, D)
+    qd64 = torch.nn.functional.linear(x64, Wqd, bqd)
+    k64 = torch.nn.functional.linear(x64, W64[D:2 * D], b64[D:2 * D])
+    outs64 = {"both": [qd64, k64], "q": [qd64], "k": [k64]}[which]
+    dx64, dW64, db64 = torch.autograd.grad(outs64, [x64, W64, b64], [g.double() for g in gs])
+    for got, want in ((qd, qd64), (k, k64), (dx, dx64), (dW, dW64), (db, db64)):
+        assert got.shape == want.shape
+        assert float((got.double() - want).abs().max()) <= 4e-6 * max(1.0, float(want.abs().max())) * (2 if got is dW or got is db else 1) * 4
+    assert float(qd[..., D + 1:].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("size,exp", [(256, 1), (64, 1), (128, 2), (100, 1)])
 def test_merged_weights_kernels(gpu, size, exp):
     """csrc/merge_weights.hip (one launch each way) against the torch formulation of fused.merged_weights in float64: the merged

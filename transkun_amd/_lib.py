@@ -65,6 +65,7 @@ _SIGS = {
     "scorer_proj_nn": (_i, [_vp, _i64, _i64, _i, _vp, _i64, _i, _vp, _i64, _vp, _vp, _vp, _i, _i, _vp]),
     "scorer_proj_tn_workspace_bytes": (_sz, [_i64, _i, _i]),
     "scorer_merge_weights_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "scorer_stage_linear": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "scorer_merge_weights_bwd_workspace_bytes": (_sz, [_i]),
     "scorer_merge_weights_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "scorer_proj_tn": (_i, [_vp, _i64, _i64, _i, _i, _i, _vp, _i64, _i, _vp, _i64, _vp, _vp, _sz, _vp]),

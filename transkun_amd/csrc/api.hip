@@ -83,6 +83,8 @@ void launch_merge_weights_fwd(const float* W, const float* bias, int D, int size
 void launch_merge_weights_bwd(const float* W, const float* bias, const float* dWm, const float* dbm, int D, int size, float* dW, float* dbias,
                               float* ws, hipStream_t stream);
 size_t merge_weights_bwd_workspace_bytes(int size);
+void launch_stage_linear(const float* W, const float* bias, int D, int size, int rows_pad, float* BT, float* Wqd, float* w2, float* b2,
+                         hipStream_t stream);
 int launch_proj_tn(const float* A, long long lda, long long M, int R, int extra_col0, int total_rows, const float* X, long long ldx, int N,
                    float* dW, long long lddw, float* db, void* ws, size_t ws_bytes, hipStream_t stream);
 size_t persist_workspace_bytes(int T, int B);
@@ -764,6 +766,16 @@ int scorer_merge_weights_fwd(const float* W, const float* bias, int D, int size,
     SEMICRF_CHECK_ARG(D >= 1 && size >= 1 && size <= 256 && rows >= size + 2, "scorer_merge_weights: D=%d size=%d (<= 256) rows=%d (>= size + 2)", D, size, rows);
     launch_merge_weights_fwd(W, bias, D, size, rows, Wm, bm, WmT, (hipStream_t)stream);
     SEMICRF_CHECK_LAUNCH("scorer_merge_weights_fwd");
+    return SEMICRF_OK;
+}
+
+int scorer_stage_linear(const float* W, const float* bias, int D, int size, int rows_pad, float* BT, float* Wqd, float* w2, float* b2,
+                        semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(W && bias && BT && Wqd && w2 && b2, "W/bias/BT/Wqd/w2/b2 must be non-NULL");
+    SEMICRF_CHECK_ARG(D >= 1 && size >= 1 && rows_pad >= D + 1 && rows_pad < (1 << 20), "scorer_stage_linear: D=%d size=%d rows_pad=%d (>= D + 1)", D, size, rows_pad);
+    launch_stage_linear(W, bias, D, size, rows_pad, BT, Wqd, w2, b2, (hipStream_t)stream);
+    SEMICRF_CHECK_LAUNCH("scorer_stage_linear");
     return SEMICRF_OK;
 }
 

@@ -131,7 +131,44 @@ __global__ __launch_bounds__(256) void merge_weights_bwd_kernel(const float* __r
     }
 }
 
+// The reference Linear's parameters in the layouts the projection kernels read (transkun_amd.scorer._ScorerLinearPacked), one launch:
+//   BT  [size][2 D]      BT[k][n] = W[n][k] for the q and k rows: scorer_proj_nn's B for q (columns 0 .. D-1, ldb = 2 D) and k (D ..)
+//   Wqd [rows_pad][size] the rows [Wq; diag row; zeros]: B of the input gradient through [q | diag | 0 ..]
+//   w2  [2][size], b2 [2] the diagonal row and a zero row (the two extra columns of the forward), their biases
+__global__ __launch_bounds__(256) void stage_linear_kernel(const float* __restrict__ W, const float* __restrict__ bias, int D, int size,
+                                                           int rows_pad, int ntx, int nty, float* __restrict__ BT, float* __restrict__ Wqd,
+                                                           float* __restrict__ w2, float* __restrict__ b2)
+{
+    __shared__ float tile[32][33];
+    const int b = blockIdx.x;
+    const int ntrans = ntx * nty;
+    if (b < ntrans) {                                     // 32 x 32 tile of the transpose
+        const int j0 = (b % ntx) * 32, i0 = (b / ntx) * 32;   // i: row of W (n), j: column of W (k)
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        for (int k = ty; k < 32; k += 8)
+            if (i0 + k < 2 * D && j0 + tx < size) tile[k][tx] = W[(size_t)(i0 + k) * size + j0 + tx];
+        __syncthreads();
+        for (int k = ty; k < 32; k += 8)
+            if (j0 + k < size && i0 + tx < 2 * D) BT[(size_t)(j0 + k) * (2 * D) + i0 + tx] = tile[tx][k];
+    } else if (b < ntrans + rows_pad) {                   // a row of Wqd
+        const int r = b - ntrans;
+        const float* src = r < D ? W + (size_t)r * size : (r == D ? W + (size_t)(2 * D) * size : nullptr);
+        for (int k = threadIdx.x; k < size; k += 256) Wqd[(size_t)r * size + k] = src ? src[k] : 0.0f;
+    } else {                                              // w2, b2
+        for (int k = threadIdx.x; k < size; k += 256) { w2[k] = W[(size_t)(2 * D) * size + k]; w2[size + k] = 0.0f; }
+        if (threadIdx.x == 0) { b2[0] = bias[2 * D]; b2[1] = 0.0f; }
+    }
+}
+
 }  // namespace
+
+void launch_stage_linear(const float* W, const float* bias, int D, int size, int rows_pad, float* BT, float* Wqd, float* w2, float* b2,
+                         hipStream_t stream)
+{
+    const int ntx = (size + 31) / 32, nty = (2 * D + 31) / 32;
+    hipLaunchKernelGGL(stage_linear_kernel, dim3(ntx * nty + rows_pad + 1), dim3(256), 0, stream, W, bias, D, size, rows_pad, ntx, nty, BT, Wqd,
+                       w2, b2);
+}
 
 void launch_merge_weights_fwd(const float* W, const float* bias, int D, int size, int rows, float* Wm, float* bm, float* WmT, hipStream_t stream)
 {

@@ -371,6 +371,14 @@ void proj_tn_op(Tensor dy, int64_t lddy, int64_t M, int64_t R, int64_t extra_col
           "scorer_proj_tn");
 }
 
+void stage_linear_op(Tensor W, Tensor bias, int64_t D, int64_t size, int64_t rows_pad, Tensor BT, Tensor Wqd, Tensor w2, Tensor b2)
+{
+    Ctx c(W); c.same(W, bias, BT, Wqd); c.same(W, w2, b2);
+    STD_TORCH_CHECK(D >= 1 && size >= 1 && rows_pad >= D + 1 && rows_pad < (1 << 20) && D < (1 << 20) && size < (1 << 20), "semicrf: bad D / size / rows_pad");
+    check(scorer_stage_linear(f32(W, (2 * D + 1) * size, "W"), f32(bias, 2 * D + 1, "bias"), (int)D, (int)size, (int)rows_pad,
+                              f32w(BT, size * 2 * D, "BT"), f32w(Wqd, rows_pad * size, "Wqd"), f32w(w2, 2 * size, "w2"), f32w(b2, 2, "b2"), c.stream),
+          "scorer_stage_linear");
+}
 void merge_weights_fwd_op(Tensor W, Tensor bias, int64_t D, int64_t size, int64_t rows, Tensor Wm, Tensor bm, Tensor WmT, bool has_t)
 {
     Ctx c(W); c.same(W, bias, Wm, bm);
@@ -469,6 +477,7 @@ STABLE_TORCH_LIBRARY(semicrf, m)
           "int lddd, int lddrc) -> ()");
     m.def("proj_nn(Tensor A, int lda, int M, int K, Tensor B, int ldb, int N, Tensor(a!) out, int ldout, Tensor bias, bool has_bias, Tensor w2, "
           "Tensor b2, bool has_w2, int zero_cols, bool accumulate) -> ()");
+    m.def("stage_linear(Tensor W, Tensor bias, int D, int size, int rows_pad, Tensor(a!) BT, Tensor(b!) Wqd, Tensor(c!) w2, Tensor(d!) b2) -> ()");
     m.def("merge_weights_fwd(Tensor W, Tensor bias, int D, int size, int rows, Tensor(a!) Wm, Tensor(b!) bm, Tensor(c!) WmT, bool has_t) -> ()");
     m.def("merge_weights_bwd(Tensor W, Tensor bias, Tensor dWm, Tensor dbm, int D, int size, int rows, Tensor(a!) dW, Tensor(b!) dbias, Tensor(c!) ws) -> ()");
     m.def("proj_tn(Tensor dy, int lddy, int M, int R, int extra_col0, int total_rows, Tensor x, int ldx, int N, Tensor(a!) dW, int lddw, "
@@ -512,6 +521,7 @@ STABLE_TORCH_LIBRARY_IMPL(semicrf, CUDA, m)
     m.impl("proj_nn", TORCH_BOX(&proj_nn_op));
     m.impl("proj_tn", TORCH_BOX(&proj_tn_op));
     m.impl("merge_weights_fwd", TORCH_BOX(&merge_weights_fwd_op));
+    m.impl("stage_linear", TORCH_BOX(&stage_linear_op));
     m.impl("merge_weights_bwd", TORCH_BOX(&merge_weights_bwd_op));
     m.impl("interval_features_gather", TORCH_BOX(&interval_features_gather_op));
     m.impl("interval_features_gather_bwd", TORCH_BOX(&interval_features_gather_bwd_op));

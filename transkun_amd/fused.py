@@ -27,7 +27,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .scorer import (BF16X3, QPAD, ScaledInnerProductIntervalScorer, _ScorerLinear, _interval_score_raw, bwd_workspace, proj_forward,
+from .scorer import (BF16X3, QPAD, ScaledInnerProductIntervalScorer, _ScorerLinear, _ScorerLinearPacked, _interval_score_raw, bwd_workspace, proj_forward,
                      proj_input_grad, proj_weight_grad, qd_weights, slot_maps, slot_pitch)
 
 _nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
@@ -273,6 +273,9 @@ def scorer_crf_logprob(scorer: ScaledInnerProductIntervalScorer, ctx: torch.Tens
     if projection == "merged" and merged_eligible(scorer.size, T):
         Wm, bm = merged_weights(W, bias, D)
         return _MergedScorerCRFLogProb.apply(x.contiguous(), Wm, bm, pairs, offsets, N, P, T, D, _lib.LEN_MODES[scorer.lengthScaling], fs)
-    Wqd, bqd = qd_weights(W, bias, D)
-    qd, k = _ScorerLinear.apply(x, Wqd, bqd, W[D:2 * D], bias[D:2 * D])
+    if _ScorerLinearPacked.eligible(x, W, bias, D):
+        qd, k = _ScorerLinearPacked.apply(x, W, bias, D)
+    else:
+        Wqd, bqd = qd_weights(W, bias, D)
+        qd, k = _ScorerLinear.apply(x, Wqd, bqd, W[D:2 * D], bias[D:2 * D])
     return _ScorerCRFLogProb.apply(qd, k, pairs, offsets, N, P, T, D, _lib.LEN_MODES[scorer.lengthScaling], fs)

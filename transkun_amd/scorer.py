@@ -299,6 +299,93 @@ class _ScorerLinear(torch.autograd.Function):
         return (dx, dW1 if need[1] else None, db1 if need[2] else None, dW2 if need[3] else None, db2 if need[4] else None)
 
 
+class _ScorerLinearPacked(torch.autograd.Function):
+    """_ScorerLinear on the Linear's OWN parameters (W [2 D + 1, size], bias), for the shapes the projection kernels take: the
+    regrouping ([q | diag | pad] and k) happens in the operand layouts of ONE staging launch (scorer_stage_linear) and the two
+    weight gradients are written straight into the rows of ONE dW / dbias -- where qd_weights + _ScorerLinear cost ~25 small torch
+    kernels per step (cats, zero fills, staging copies, fill + copy + add per slice gradient)."""
+
+    @staticmethod
+    def eligible(x, W, bias, D):
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        return (_proj_ok(x2, D + QPAD) and K in _PROJ_SIZES and D in _PROJ_SIZES and W.is_cuda and W.dtype == torch.float32
+                and bias.dtype == torch.float32 and tuple(W.shape) == (2 * D + 1, K) and tuple(bias.shape) == (2 * D + 1,))
+
+    @staticmethod
+    def forward(ctx, x, W, bias, D):
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
+        Wc, bc = W.contiguous(), bias.contiguous()
+        dev = x.device
+        rows_pad = (D + QPAD + 31) // 32 * 32
+        BT = torch.empty(K, 2 * D, dtype=torch.float32, device=dev)
+        Wqd = torch.empty(rows_pad, K, dtype=torch.float32, device=dev)
+        w2 = torch.empty(2, K, dtype=torch.float32, device=dev)
+        b2 = torch.empty(2, dtype=torch.float32, device=dev)
+        ops = _lib.ops()
+        ops.stage_linear(Wc, bc, D, K, rows_pad, BT, Wqd, w2, b2)
+        qd = torch.empty(M, D + QPAD, dtype=torch.float32, device=dev)
+        k = torch.empty(M, D, dtype=torch.float32, device=dev)
+        none = _lib_none(dev)
+        flat = BT.view(-1)
+        ops.proj_nn(x2, K, M, K, flat, 2 * D, D, qd, D + QPAD, bc[:D], True, w2, b2, True, QPAD - 2, False)
+        ops.proj_nn(x2, K, M, K, flat[D:], 2 * D, D, k, D, bc[D:2 * D], True, none, none, False, 0, False)
+        ctx.save_for_backward(x, Wc, Wqd)
+        ctx.D = D
+        return qd.view(*x.shape[:-1], D + QPAD), k.view(*x.shape[:-1], D)
+
+    @staticmethod
+    def backward(ctx, dqd, dk):
+        x, Wc, Wqd = ctx.saved_tensors
+        D = ctx.D
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
+        dev = x.device
+        ops = _lib.ops()
+        none = _lib_none(dev)
+        g1 = dqd.reshape(M, D + QPAD).contiguous() if dqd is not None else None
+        g2 = dk.reshape(M, D).contiguous() if dk is not None else None
+        need = ctx.needs_input_grad
+        dx = None
+        if need[0] and (g1 is not None or g2 is not None):
+            dx = torch.empty(M, K, dtype=torch.float32, device=dev)
+            if g1 is not None:
+                ops.proj_nn(g1, D + QPAD, M, D + QPAD, Wqd, K, K, dx, K, none, False, none, none, False, 0, False)
+            if g2 is not None:                                                 # B = the k rows of W as they lie
+                ops.proj_nn(g2, D, M, D, Wc.view(-1)[D * K:], K, K, dx, K, none, False, none, none, False, 0, g1 is not None)
+            dx = dx.view(x.shape)
+        dW = db = None
+        if need[1] or need[2]:
+            # one dW / dbias: the q call writes rows 0 .. D + QPAD - 1 (its extra row D is the diagonal row's gradient: moved to row
+            # 2 D), then the k call writes rows D .. 2 D - 1 over what the first one left there
+            rows = max(2 * D + 1, D + QPAD)
+            dW = torch.zeros(rows, K, dtype=torch.float32, device=dev) if (g1 is None or g2 is None) else torch.empty(rows, K, dtype=torch.float32, device=dev)
+            db = torch.zeros(rows, dtype=torch.float32, device=dev) if (g1 is None or g2 is None) else torch.empty(rows, dtype=torch.float32, device=dev)
+            if g1 is not None:
+                key = ("tn", M, D, K)
+                n = _BWD_WS.get(key)
+                if n is None:
+                    n = _BWD_WS[key] = int(_lib.load().scorer_proj_tn_workspace_bytes(M, D, K))
+                ws = torch.empty(n, dtype=torch.uint8, device=dev)
+                ops.proj_tn(g1, D + QPAD, M, D, D, D + QPAD, x2, K, K, dW, K, db, ws)
+                dW[2 * D].copy_(dW[D])
+                db[2 * D:2 * D + 1].copy_(db[D:D + 1])
+                if g2 is None:
+                    dW[D:2 * D].zero_(); db[D:2 * D].zero_()
+            if g2 is not None:
+                key = ("tn", M, D, K)
+                n = _BWD_WS.get(key)
+                if n is None:
+                    n = _BWD_WS[key] = int(_lib.load().scorer_proj_tn_workspace_bytes(M, D, K))
+                ws = torch.empty(n, dtype=torch.uint8, device=dev)
+                ops.proj_tn(g2, D, M, D, -1, D, x2, K, K, dW.view(-1)[D * K:], K, db[D:], ws)
+            dW, db = dW[:2 * D + 1], db[:2 * D + 1]
+        return dx, dW if need[1] else None, db if need[2] else None, None
+
+
 class _IntervalScore(torch.autograd.Function):
     """S = lenscale * (q*qscale) k^T + diag, chain-minor layout; forward and backward are HIP kernels
     (every contraction size: wider than 256 runs as column chunks, a size that is no multiple of 32 is zero-padded).
@@ -388,8 +475,11 @@ class ScaledInnerProductIntervalScorer(nn.Module):
         lin = self.map[0]
         W, bias = lin.weight, lin.bias
         x = ctx.float()
-        Wqd, bqd = qd_weights(W, bias, D)
-        qd, k = _ScorerLinear.apply(x, Wqd, bqd, W[D:2 * D], bias[D:2 * D])
+        if _ScorerLinearPacked.eligible(x, W, bias, D):
+            qd, k = _ScorerLinearPacked.apply(x, W, bias, D)
+        else:
+            Wqd, bqd = qd_weights(W, bias, D)
+            qd, k = _ScorerLinear.apply(x, Wqd, bqd, W[D:2 * D], bias[D:2 * D])
         if self.contraction not in ("fp32", "bf16x3"):
             raise ValueError(f"contraction must be 'fp32' or 'bf16x3', not {self.contraction!r}")
         fs = int(self.fullSquare) | (BF16X3 if self.contraction == "bf16x3" else 0)
