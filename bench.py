@@ -404,7 +404,7 @@ def _cpu_baseline(args, s_d, n_d, T, B, nseg):
     try:
         from transkun_amd import CRF as _CRF, synth as _synth
         iv = _synth.synthetic_intervals(T, B, seed=1234)
-        nthreads = max(1, min(avail, _physical_cores() or avail, 64))        # (its OpenMP loop has B / 8 tasks)
+        nthreads = max(1, min(avail, _physical_cores() or avail, 32))        # (its OpenMP loops have B / 16 blocks of work)
         torch.set_num_threads(nthreads)
         sc_p = sc.clone().requires_grad_(); nc_p = nc.clone().requires_grad_()
         pt = []

@@ -193,10 +193,17 @@ class _GradPool:
     def take(self, T: int, B: int, device):
         """(dscore [T,T,B] fp32, flags): a pooled buffer with flags = GRAD_UPPER_IS_ZERO, or a fresh one with flags 0."""
         nbytes = 4 * T * T * B
-        if not self.enabled or device.type != "cuda" or nbytes < self.min_bytes or torch.cuda.is_current_stream_capturing():
-            return torch.empty(T, T, B, dtype=torch.float32, device=device), 0, None
-        key = (device.index if device.index is not None else torch.cuda.current_device(),
-               torch.cuda.current_stream(device).cuda_stream, T, B)
+        if device.type == "cpu":
+            # host tensors too: the host kernels write the zeros anyway, but a fresh 1.4 GB allocation is 350 000 first-touch page
+            # faults that many threads take at once (T=1024 x 352: the backward took 1.4 s on 8 threads and 8 - 20 s on 22 - 64)
+            if not self.enabled or nbytes < self.min_bytes:
+                return torch.empty(T, T, B, dtype=torch.float32, device=device), 0, None
+            key = ("cpu", 0, T, B)
+        else:
+            if not self.enabled or device.type != "cuda" or nbytes < self.min_bytes or torch.cuda.is_current_stream_capturing():
+                return torch.empty(T, T, B, dtype=torch.float32, device=device), 0, None
+            key = (device.index if device.index is not None else torch.cuda.current_device(),
+                   torch.cuda.current_stream(device).cuda_stream, T, B)
         with self.lock:
             for i in range(len(self.entries) - 1, -1, -1):
                 k, keeper, ver = self.entries[i]
