@@ -27,9 +27,9 @@ def shard_chains(n_chains: int, world_size: int, rank: int, multiple: int = 4) -
 def fused_loss_allreduce(loss: torch.Tensor, total_len: float, n_batch: float, group=None) -> torch.Tensor:
     """SUM all-reduce of (loss, length, batch count) as ONE [3] fp32 message (train.py:215-217 issues three)."""
     import torch.distributed as dist
-    stats = torch.stack([loss.detach().float().reshape(()),
-                         torch.tensor(float(total_len), device=loss.device),
-                         torch.tensor(float(n_batch), device=loss.device)])
+    l32 = loss.detach().float().reshape(())
+    # (new_full is a fill on the device; torch.tensor(x, device=...) would be a copy from pageable memory: a host synchronisation)
+    stats = torch.stack([l32, l32.new_full((), float(total_len)), l32.new_full((), float(n_batch))])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
     return stats

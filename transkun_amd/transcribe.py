@@ -412,6 +412,15 @@ class SegmentTranscriber(nn.Module):
             if K > 0:
                 merger.add_step(s, rows, K, active)
 
+        # every step's segment begin times in ONE upload, packed by step (a per-step torch.tensor(..., device=...) is a copy from
+        # pageable memory: the host waits for the device each time -- tools/sync_audit.py)
+        bt_rows, bt_off = [], []
+        for s in range(nsteps):
+            bt_off.append(len(bt_rows))
+            bt_rows.extend(plans[f]["begins"][s] / self.fs - plans[f]["padTimeBegin"] for f in range(len(plans)) if s < len(plans[f]["begins"]))
+        bt_host = torch.tensor(bt_rows, dtype=torch.float64)
+        bt_all = bt_host.pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else bt_host
+
         for s in range(nsteps):
             active = [f for f, p in enumerate(plans) if s < len(p["begins"])]
             if active != active_prev:                                                   # recordings that ended drop out of the batch
@@ -419,8 +428,7 @@ class SegmentTranscriber(nn.Module):
                 start = start.view(len(active_prev), P)[keep].reshape(-1).contiguous()
                 active_prev = active
             ctxBatch = torch.cat([ctx_fns[f](s, T) for f in active], dim=0) if len(active) > 1 else ctx_fns[active[0]](s, T)
-            beginTime = torch.tensor([plans[f]["begins"][s] / self.fs - plans[f]["padTimeBegin"] for f in active], dtype=torch.float64,
-                                     device=dev)                                         # :766
+            beginTime = bt_all[bt_off[s]:bt_off[s] + len(active)]                        # :766
             cap = None
             if use_cap and s > 0:
                 cap = max(int(self.capFloor), (int(self.capFactor * kmax_per_file[0] * len(active)) + 1023) // 1024 * 1024)
