@@ -29,17 +29,22 @@ def _random_steps(rng, n_files, n_steps, P):
     return steps
 
 
-@pytest.mark.parametrize("merge,resolve,vel_float", [(True, True, False), (True, False, False), (False, True, True), (True, True, True)])
-def test_packed_merge_equals_python_merge(merge, resolve, vel_float):
+@pytest.mark.parametrize("merge,resolve,vel_float,eager", [(True, True, False, False), (True, False, False, False), (False, True, True, False),
+                                                           (True, True, True, False), (True, True, False, True), (True, False, True, True),
+                                                           (True, True, True, True), (False, True, False, True)])
+def test_packed_merge_equals_python_merge(merge, resolve, vel_float, eager):
+    """eager: the Notes are made inside add_step as events settle (without the merge the request is ignored: same results)."""
     rng = np.random.default_rng(7)
     P = len(PITCHES)
     n_files, n_steps = 4, 6
     steps = _random_steps(rng, n_files, n_steps, P)
-    packed = PackedEventMerger(n_files, PITCHES, merge)
+    packed = PackedEventMerger(n_files, PITCHES, merge, eager_resolve=resolve if eager else None)
+    assert packed.eager == (eager and merge)
     packed.vel_float = vel_float
     ref = [EventMerger(merge) for _ in range(n_files)]
     for s, (active, rows) in enumerate(steps):
-        packed.add_step(s, rows, rows.shape[0], active)
+        nxt = steps[s + 1][0] if s + 1 < len(steps) else []
+        packed.add_step(s, rows, rows.shape[0], active, later_events_from=[8.0 * s if f in nxt else 1e300 for f in active] if eager else None)
         # the reference's order within a segment: sorted by (start, end, pitch) (transcribeFrames :722)
         per_file = [[] for _ in active]
         for r in rows:

@@ -151,15 +151,27 @@ static PyObject* m_pack_into(PyObject* self, PyObject* args)
 #include <stdlib.h>
 #include <string.h>
 
-typedef struct { double start, end, vel; char on, off; } TmEv;
-typedef struct { TmEv* v; long n, cap; int seen; long first_step; double first_start, first_end; } TmTrack;
-typedef struct { long n_files, P; int merge; TmTrack* tracks; } TmMerger;
+typedef struct { double start, end, vel; char on, off, settled; } TmEv;
+typedef struct { double start, end; PyObject* obj; } TmFin;           /* eager mode: a finished Note and its sort key */
+typedef struct { TmEv* v; long n, cap; int seen; long first_step; double first_start, first_end;
+                 long nfin; TmFin* f; long nf, fcap; } TmTrack;        /* eager: events [0, nfin) are settled, their Notes in f[0 .. nf) */
+typedef struct { long n_files, P; int merge; TmTrack* tracks;
+                 int eager;                                           /* 0: Notes at tm_finish; 1: made as events settle, resolveOverlapping applied; 2: without */
+                 PyObject* cls; PyObject* pseq; Py_ssize_t so[6]; int vel_float; } TmMerger;
 
 static void tm_free(PyObject* cap)
 {
     TmMerger* m = (TmMerger*)PyCapsule_GetPointer(cap, "semicrf.tm");
     if (!m) return;
-    if (m->tracks) { for (long i = 0; i < m->n_files * m->P; ++i) free(m->tracks[i].v); free(m->tracks); }
+    if (m->tracks) {
+        for (long i = 0; i < m->n_files * m->P; ++i) {
+            free(m->tracks[i].v);
+            for (long k = 0; k < m->tracks[i].nf; ++k) Py_XDECREF(m->tracks[i].f[k].obj);
+            free(m->tracks[i].f);
+        }
+        free(m->tracks);
+    }
+    Py_XDECREF(m->cls); Py_XDECREF(m->pseq);
     free(m);
 }
 
@@ -188,11 +200,156 @@ static int tm_push(TmTrack* t, const TmEv* e)
     return 0;
 }
 
+static Py_ssize_t slot_offset(PyObject* cls, const char* name)
+{
+    PyObject* d = PyObject_GetAttrString(cls, name);
+    if (!d) return -1;
+    Py_ssize_t off = -1;
+    if (Py_TYPE(d) == &PyMemberDescr_Type) off = ((PyMemberDescrObject*)d)->d_member->offset;
+    Py_DECREF(d);
+    if (off < 0) PyErr_Format(PyExc_TypeError, "the Note class must define __slots__ with `%s`", name);
+    return off;
+}
+
+
+/* A Note with its slots filled directly (no __init__ call). */
+static PyObject* tm_make_note(TmMerger* m, double start, double end, long sym, double vel, int on, int off, int vel_float, PyObject* pseq,
+                              PyTypeObject* tp, const Py_ssize_t* so)
+{
+    PyObject* o = tp->tp_alloc(tp, 0);
+    if (!o) return NULL;
+    PyObject* vals[6];
+    vals[0] = PyFloat_FromDouble(start);
+    vals[1] = PyFloat_FromDouble(end);
+    vals[2] = PySequence_Fast_GET_ITEM(pseq, sym); Py_INCREF(vals[2]);
+    vals[3] = vel_float ? PyFloat_FromDouble(vel) : PyLong_FromLong((long)vel);
+    vals[4] = on ? Py_True : Py_False; Py_INCREF(vals[4]);
+    vals[5] = off ? Py_True : Py_False; Py_INCREF(vals[5]);
+    int ok = 1;
+    for (int k = 0; k < 6; ++k) {
+        if (!vals[k]) { ok = 0; continue; }
+        *(PyObject**)((char*)o + so[k]) = vals[k];
+    }
+    (void)m;
+    if (!ok) { Py_DECREF(o); return NULL; }
+    return o;
+}
+
+/* Eager mode.  An event is SETTLED once nothing can change what becomes of it; settled events become Notes at once, while the device
+ * works on the next step.
+ *   without resolveOverlapping (eager == 2): the output is in track order and only the track's LAST event can still change (the merge
+ *     rule, ModelTransformer.py:806-822, touches nothing else): every other event settles.
+ *   with it (eager == 1; Data.py:170-214: in (start, end, pitch) order an event that starts before the previous event of its pitch has
+ *     ended cuts that one short): the unsettled event i that sorts first settles when the surviving event j that sorts next is known
+ *     for good -- j is not the track's last event (whose fields and survival are open) and j.start < bound, the time below which no
+ *     event of a LATER step can start (the caller's statement: the next segment's begin time): then nothing can come to lie between
+ *     i and j or in front of i.
+ * final != 0 (tm_finish): the last event counts as carrying an offset (:831-834) and everything settles.  -1: allocation failure. */
+static int tm_emit(TmMerger* m, TmTrack* t, long sym, const TmEv* e, double end)
+{
+    if (t->nf == t->fcap) {
+        const long nc = t->fcap ? 2 * t->fcap : 16;
+        TmFin* nv = (TmFin*)realloc(t->f, (size_t)nc * sizeof(TmFin));
+        if (!nv) return -1;
+        t->f = nv; t->fcap = nc;
+    }
+    PyObject* o = tm_make_note(m, e->start, end, sym, e->vel, e->on, 1, m->vel_float, m->pseq, (PyTypeObject*)m->cls, m->so);
+    if (!o) return -1;
+    t->f[t->nf].start = e->start; t->f[t->nf].end = end; t->f[t->nf].obj = o; ++t->nf;
+    return 0;
+}
+static int tm_before(const TmEv* v, long a, long b)      /* (start, end, index) order */
+{
+    if (v[a].start != v[b].start) return v[a].start < v[b].start;
+    if (v[a].end != v[b].end) return v[a].end < v[b].end;
+    return a < b;
+}
+static int tm_settle(TmMerger* m, TmTrack* t, long sym, int final, double bound)
+{
+    if (m->eager == 2) {
+        while (t->nfin < t->n) {
+            const long i = t->nfin;
+            const int is_last = i == t->n - 1;
+            if (is_last && !final) break;
+            if ((t->v[i].off || is_last) && tm_emit(m, t, sym, &t->v[i], t->v[i].end)) return -1;
+            t->v[i].settled = 1;
+            ++t->nfin;
+        }
+        return 0;
+    }
+    /* the usual case in one pass: the unsettled tail is in sort order already (the merge rule appends behind the last event's end;
+     * only a REPLACED last event can come to lie in front of its predecessors) */
+    {
+        while (t->nfin < t->n && t->v[t->nfin].settled) ++t->nfin;
+        const long last = t->n - 1;
+        int sorted = 1;
+        for (long k = t->nfin + 1; k < t->n && sorted; ++k)
+            if (t->v[k].settled || tm_before(t->v, k, k - 1)) sorted = 0;
+        if (sorted && t->nfin < t->n && !t->v[t->nfin].settled) {
+            long i = t->nfin;
+            while (i < t->n) {
+                if (!(t->v[i].off || i == last)) { t->v[i].settled = 1; ++i; continue; }        /* dropped */
+                long j = i + 1;
+                while (j < t->n && !(t->v[j].off || j == last)) ++j;                           /* the next survivor */
+                if (!final && (i == last || j >= t->n || j == last || !(t->v[j].start < bound))) break;
+                double end = t->v[i].end;
+                if (j < t->n && end > t->v[j].start) end = t->v[j].start;
+                if (t->v[i].start < end && tm_emit(m, t, sym, &t->v[i], end)) return -1;
+                t->v[i].settled = 1;
+                for (long k = i + 1; k < j; ++k) t->v[k].settled = 1;                         /* the dropped ones in between */
+                i = j;
+            }
+            while (t->nfin < t->n && t->v[t->nfin].settled) ++t->nfin;
+            return 0;
+        }
+    }
+    while (1) {
+        while (t->nfin < t->n && t->v[t->nfin].settled) ++t->nfin;
+        if (t->nfin >= t->n) return 0;
+        const long last = t->n - 1;
+        long i = -1, j = -1;                              /* first and second unsettled SURVIVOR-or-open events in sort order */
+        for (long k = t->nfin; k < t->n; ++k) {
+            if (t->v[k].settled) continue;
+            if (!(t->v[k].off || k == last)) { t->v[k].settled = 1; continue; }      /* no offset, not the last: dropped (:837-841) */
+            if (i < 0 || tm_before(t->v, k, i)) { j = i; i = k; }
+            else if (j < 0 || tm_before(t->v, k, j)) j = k;
+        }
+        if (i < 0) continue;                              /* (only dropped ones were left) */
+        if (!final && (i == last || (j >= 0 && (j == last || !(t->v[j].start < bound))))) return 0;
+        if (!final && j < 0) return 0;                    /* (i is not the last, yet no other candidate: cannot happen, stay safe) */
+        double end = t->v[i].end;
+        if (j >= 0 && end > t->v[j].start) end = t->v[j].start;
+        if (t->v[i].start < end && tm_emit(m, t, sym, &t->v[i], end)) return -1;      /* (else: left without duration) */
+        t->v[i].settled = 1;
+    }
+}
+
+/* tm_eager(capsule, NoteClass, pitches, resolve): switch the merger to eager mode (before the first tm_add; needs merge on) */
+static PyObject* m_tm_eager(PyObject* self, PyObject* args)
+{
+    PyObject *cap, *cls, *pitches; int resolve;
+    if (!PyArg_ParseTuple(args, "OOOp", &cap, &cls, &pitches, &resolve)) return NULL;
+    TmMerger* m = (TmMerger*)PyCapsule_GetPointer(cap, "semicrf.tm");
+    if (!m) return NULL;
+    if (!m->merge) { PyErr_SetString(PyExc_ValueError, "eager mode needs the incomplete-event merge (a track's events are then in time order)"); return NULL; }
+    if (!PyType_Check(cls)) { PyErr_SetString(PyExc_TypeError, "NoteClass must be a class"); return NULL; }
+    PyObject* pseq = PySequence_Fast(pitches, "pitches must be a sequence");
+    if (!pseq) return NULL;
+    if (PySequence_Fast_GET_SIZE(pseq) != m->P) { Py_DECREF(pseq); PyErr_SetString(PyExc_ValueError, "bad pitches"); return NULL; }
+    const char* names[6] = {"start", "end", "pitch", "velocity", "hasOnset", "hasOffset"};
+    for (int i = 0; i < 6; ++i) if ((m->so[i] = slot_offset(cls, names[i])) < 0) { Py_DECREF(pseq); return NULL; }
+    Py_XDECREF(m->cls); Py_XDECREF(m->pseq);
+    Py_INCREF(cls); m->cls = cls; m->pseq = pseq;
+    m->eager = resolve ? 1 : 2;
+    Py_RETURN_NONE;
+}
+
 static PyObject* m_tm_add(PyObject* self, PyObject* args)
 {
     PyObject *cap, *active;
-    long step; unsigned long long addr; long long K;
-    if (!PyArg_ParseTuple(args, "OlKLO", &cap, &step, &addr, &K, &active)) return NULL;
+    long step; unsigned long long addr; long long K; int vel_float = 0;
+    PyObject* bounds = NULL;          /* eager mode with resolveOverlapping: per active recording, the time below which no later step's event starts */
+    if (!PyArg_ParseTuple(args, "OlKLO|pO", &cap, &step, &addr, &K, &active, &vel_float, &bounds)) return NULL;
     TmMerger* m = (TmMerger*)PyCapsule_GetPointer(cap, "semicrf.tm");
     if (!m) return NULL;
     PyObject* seq = PySequence_Fast(active, "active must be a sequence of recording indices");
@@ -212,7 +369,7 @@ static PyObject* m_tm_add(PyObject* self, PyObject* args)
         const long sg = chain / m->P;
         if (sym < 0 || sym >= m->P || sg < 0 || sg >= na) { PyErr_SetString(PyExc_IndexError, "event row out of range"); return NULL; }
         TmTrack* t = &m->tracks[files[sg] * m->P + sym];
-        TmEv e; e.start = r[0]; e.end = r[1]; e.on = r[2] != 0.0; e.off = r[3] != 0.0; e.vel = r[4];
+        TmEv e; e.start = r[0]; e.end = r[1]; e.on = r[2] != 0.0; e.off = r[3] != 0.0; e.vel = r[4]; e.settled = 0;
         if (!t->seen) { t->seen = 1; t->first_step = step; t->first_start = e.start; t->first_end = e.end; }
         if (m->merge && t->n > 0) {                                   /* ModelTransformer.py:806-822 */
             TmEv* last = &t->v[t->n - 1];
@@ -223,6 +380,22 @@ static PyObject* m_tm_add(PyObject* self, PyObject* args)
             }
         }
         if (e.on && tm_push(t, &e)) return PyErr_NoMemory();            /* :824-825 */
+    }
+    if (m->eager) {                                                     /* Notes for what has settled: the device is busy with the next step */
+        m->vel_float = vel_float;
+        PyObject* bseq = (bounds && bounds != Py_None) ? PySequence_Fast(bounds, "bounds must be a sequence of floats") : NULL;
+        if (bounds && bounds != Py_None && !bseq) return NULL;
+        if (bseq && PySequence_Fast_GET_SIZE(bseq) != na) { Py_DECREF(bseq); PyErr_SetString(PyExc_ValueError, "one bound per active recording"); return NULL; }
+        for (Py_ssize_t a = 0; a < na; ++a) {
+            double bound = -1e300;                                      /* no statement: with resolveOverlapping nothing settles before tm_finish */
+            if (bseq) {
+                bound = PyFloat_AsDouble(PySequence_Fast_GET_ITEM(bseq, a));
+                if (bound == -1.0 && PyErr_Occurred()) { Py_DECREF(bseq); return NULL; }
+            }
+            for (long sym = 0; sym < m->P; ++sym)
+                if (tm_settle(m, &m->tracks[files[a] * m->P + sym], sym, 0, bound)) { Py_XDECREF(bseq); return PyErr_Occurred() ? NULL : PyErr_NoMemory(); }
+        }
+        Py_XDECREF(bseq);
     }
     Py_RETURN_NONE;
 }
@@ -246,15 +419,77 @@ static int tm_cmp_key(const void* a, const void* b)
     return x->pitch < y->pitch ? -1 : (x->pitch > y->pitch);
 }
 
-static Py_ssize_t slot_offset(PyObject* cls, const char* name)
+/* eager mode: settle what is left, then hand out the Notes -- with resolveOverlapping in (start, end, pitch) order (a heap merge of the
+ * tracks, each already in that order), else in the reference's byType order (symbols as first seen, :837-841) */
+typedef struct { long trk; long pos; double start, end; long pitch; } TmHead;
+static int tm_head_less(const TmHead* x, const TmHead* y)
 {
-    PyObject* d = PyObject_GetAttrString(cls, name);
-    if (!d) return -1;
-    Py_ssize_t off = -1;
-    if (Py_TYPE(d) == &PyMemberDescr_Type) off = ((PyMemberDescrObject*)d)->d_member->offset;
-    Py_DECREF(d);
-    if (off < 0) PyErr_Format(PyExc_TypeError, "the Note class must define __slots__ with `%s`", name);
-    return off;
+    if (x->start != y->start) return x->start < y->start;
+    if (x->end != y->end) return x->end < y->end;
+    if (x->pitch != y->pitch) return x->pitch < y->pitch;
+    return x->trk < y->trk;
+}
+static void tm_sift(TmHead* h, long n, long i)
+{
+    while (1) {
+        long l = 2 * i + 1, r = l + 1, b = i;
+        if (l < n && tm_head_less(&h[l], &h[b])) b = l;
+        if (r < n && tm_head_less(&h[r], &h[b])) b = r;
+        if (b == i) return;
+        TmHead t = h[i]; h[i] = h[b]; h[b] = t;
+        i = b;
+    }
+}
+static PyObject* tm_finish_eager(TmMerger* m, long file, int vel_float, int resolve)
+{
+    if ((resolve ? 1 : 2) != m->eager) { PyErr_SetString(PyExc_ValueError, "tm_finish: `resolve` differs from what tm_eager was given"); return NULL; }
+    m->vel_float = vel_float;
+    TmTrack* tr = m->tracks + file * m->P;
+    long total = 0;
+    for (long s = 0; s < m->P; ++s) {
+        if (tm_settle(m, &tr[s], s, 1, 1e300)) return PyErr_Occurred() ? NULL : PyErr_NoMemory();
+        total += tr[s].nf;
+    }
+    PyObject* out = PyList_New(total);
+    if (!out) return NULL;
+    long n = 0;
+    if (m->eager == 1) {
+        TmHead* h = (TmHead*)malloc((size_t)(m->P > 0 ? m->P : 1) * sizeof(TmHead));
+        if (!h) { Py_DECREF(out); return PyErr_NoMemory(); }
+        long nh = 0;
+        for (long s = 0; s < m->P; ++s)
+            if (tr[s].nf > 0) {
+                h[nh].trk = s; h[nh].pos = 0; h[nh].start = tr[s].f[0].start; h[nh].end = tr[s].f[0].end;
+                h[nh].pitch = PyLong_AsLong(PySequence_Fast_GET_ITEM(m->pseq, s)); ++nh;
+            }
+        for (long i = nh / 2 - 1; i >= 0; --i) tm_sift(h, nh, i);
+        while (nh > 0) {
+            TmTrack* t = &tr[h[0].trk];
+            PyList_SET_ITEM(out, n++, t->f[h[0].pos].obj);
+            t->f[h[0].pos].obj = NULL;
+            if (++h[0].pos < t->nf) { h[0].start = t->f[h[0].pos].start; h[0].end = t->f[h[0].pos].end; }
+            else { h[0] = h[nh - 1]; --nh; }
+            if (nh > 0) tm_sift(h, nh, 0);
+        }
+        free(h);
+    } else {
+        TmKey* keys = (TmKey*)malloc((size_t)(m->P > 0 ? m->P : 1) * sizeof(TmKey));
+        if (!keys) { Py_DECREF(out); return PyErr_NoMemory(); }
+        long nk = 0;
+        for (long s = 0; s < m->P; ++s)
+            if (tr[s].seen) {
+                keys[nk].step = tr[s].first_step; keys[nk].start = tr[s].first_start; keys[nk].end = tr[s].first_end;
+                keys[nk].pitch = PyLong_AsLong(PySequence_Fast_GET_ITEM(m->pseq, s)); keys[nk].sym = s; ++nk;
+            }
+        qsort(keys, (size_t)nk, sizeof(TmKey), tm_cmp_key);
+        for (long k = 0; k < nk; ++k) {
+            TmTrack* t = &tr[keys[k].sym];
+            for (long i = 0; i < t->nf; ++i) { PyList_SET_ITEM(out, n++, t->f[i].obj); t->f[i].obj = NULL; }
+        }
+        free(keys);
+    }
+    for (long s = 0; s < m->P; ++s) tr[s].nf = 0;                       /* (the list owns the Notes now) */
+    return out;
 }
 
 static PyObject* m_tm_finish(PyObject* self, PyObject* args)
@@ -265,6 +500,7 @@ static PyObject* m_tm_finish(PyObject* self, PyObject* args)
     TmMerger* m = (TmMerger*)PyCapsule_GetPointer(cap, "semicrf.tm");
     if (!m) return NULL;
     if (file < 0 || file >= m->n_files) { PyErr_SetString(PyExc_IndexError, "recording index out of range"); return NULL; }
+    if (m->eager) return tm_finish_eager(m, file, vel_float, resolve);
     PyObject* pseq = PySequence_Fast(pitches, "pitches must be a sequence");
     if (!pseq) return NULL;
     if (PySequence_Fast_GET_SIZE(pseq) != m->P || !PyType_Check(cls)) { Py_DECREF(pseq); PyErr_SetString(PyExc_ValueError, "bad pitches / class"); return NULL; }
@@ -346,6 +582,7 @@ static PyMethodDef methods[] = {
     {"tm_new", m_tm_new, METH_VARARGS, "event merger for n_files recordings of P symbols"},
     {"tm_add", m_tm_add, METH_VARARGS, "merge the packed events of one step (rows of 7 doubles at a host address)"},
     {"tm_finish", m_tm_finish, METH_VARARGS, "the final Note list of one recording"},
+    {"tm_eager", m_tm_eager, METH_VARARGS, "make the Notes as events settle (merge on): tm_eager(capsule, NoteClass, pitches, resolve)"},
     {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_semicrf_marshal", "interval-list marshalling", -1, methods};

@@ -110,19 +110,40 @@ class PackedEventMerger:
     results as the Python classes above (tests/test_transcribe_merge.py); at the event density of a batched transcription the
     per-event Python walk, not the device, used to set the pace (8 ms of host work per 0.7 ms step)."""
 
-    def __init__(self, n_files: int, pitches: Sequence[int], mergeIncompleteEvent: bool = True):
+    def __init__(self, n_files: int, pitches: Sequence[int], mergeIncompleteEvent: bool = True, eager_resolve: Optional[bool] = None):
+        """eager_resolve (True / False = the `resolve` that finish() will be called with; needs the incomplete-event merge): Note
+        objects are made inside add_step, as soon as nothing can change an event any more (it is not its track's last event and,
+        with resolveOverlapping, neither is the event that may cut it short) -- i.e. while the device works on the next step --
+        and finish() only merges the tracks' lists: 10 ms of object construction after the last step of a four-recording batch
+        become < 1 ms.  None: all Notes at finish()."""
         self.pitches = [int(p) for p in pitches]
         self.n_files = n_files
         self._m = _lib.marshal()
         self._h = self._m.tm_new(n_files, len(self.pitches), bool(mergeIncompleteEvent))
         self.vel_float = False
+        self.eager = eager_resolve is not None and bool(mergeIncompleteEvent)
+        if self.eager:
+            self._m.tm_eager(self._h, Note, self.pitches, bool(eager_resolve))
 
-    def add_step(self, step_index: int, rows, K: int, active: Sequence[int]) -> None:
-        """rows: a contiguous float64 [>= K, 7] host array (numpy or a CPU torch tensor), in chain order as the device wrote them."""
+    def add_step(self, step_index: int, rows, K: int, active: Sequence[int], later_events_from: Optional[Sequence[float]] = None) -> None:
+        """rows: a contiguous float64 [>= K, 7] host array (numpy or a CPU torch tensor), in chain order as the device wrote them.
+        later_events_from (eager mode with resolve): per active recording, a time below which no event of a LATER step starts (the
+        next segment's begin time): what lets events settle before finish(); without it they all wait."""
         if K <= 0:
             return
         addr = rows.data_ptr() if hasattr(rows, "data_ptr") else rows.ctypes.data
-        self._m.tm_add(self._h, int(step_index), int(addr), int(K), list(active))
+        if not self.eager:
+            self._m.tm_add(self._h, int(step_index), int(addr), int(K), list(active))
+            return
+        import gc
+        was = gc.isenabled()
+        gc.disable()          # (fresh cycle-free objects by the thousand: see finish)
+        try:
+            self._m.tm_add(self._h, int(step_index), int(addr), int(K), list(active), bool(self.vel_float),
+                           None if later_events_from is None else [float(b) for b in later_events_from])
+        finally:
+            if was:
+                gc.enable()
 
     def finish(self, file: int, resolve: bool = True) -> List[Note]:
         import gc
@@ -359,7 +380,7 @@ class SegmentTranscriber(nn.Module):
         plans = [self.segment_plan(n, stepInSecond, segmentSizeInSecond) for n in nSamples]
         P = len(self.targetMIDIPitch)
         dev = next(self.parameters()).device
-        merger = PackedEventMerger(len(plans), self.targetMIDIPitch, mergeIncompleteEvent)
+        merger = PackedEventMerger(len(plans), self.targetMIDIPitch, mergeIncompleteEvent, eager_resolve=bool(resolve))
         nsteps = max(len(p["begins"]) for p in plans)
         T = plans[0]["nFrame"]
         stepFrames = int(plans[0]["stepSize"] / self.hopSize)                           # :791
@@ -410,7 +431,11 @@ class SegmentTranscriber(nn.Module):
                     raise _Overflow()
             kmax_per_file[0] = max(kmax_per_file[0], K / max(len(active), 1))
             if K > 0:
-                merger.add_step(s, rows, K, active)
+                # no event of step s + 1 starts before that step's segment begins (minus the refinement's half frame: one frame here)
+                frame = self.hopSize / self.fs
+                later = [plans[f]["begins"][s + 1] / self.fs - plans[f]["padTimeBegin"] - frame if s + 1 < len(plans[f]["begins"]) else 1e300
+                         for f in active]
+                merger.add_step(s, rows, K, active, later_events_from=later)
 
         # every step's segment begin times in ONE upload, packed by step (a per-step torch.tensor(..., device=...) is a copy from
         # pageable memory: the host waits for the device each time -- tools/sync_audit.py)
