@@ -1352,7 +1352,7 @@ def test_transcribe_many_equals_one_by_one(gpu):
     try:
         restarted = m.transcribe_many([fn_a, fn_b, fn_b], [n_full, n_short, n_full])
     finally:
-        m.capFactor, m.capFloor = 2.0, 4096
+        m.capFactor, m.capFloor = 1.5, 4096
     for x, y, z in zip(together, waited, restarted):
         assert [e.astuple() for e in x] == [e.astuple() for e in y] == [e.astuple() for e in z]
 

@@ -175,7 +175,7 @@ class SegmentTranscriber(nn.Module):
         self.targetMIDIPitch = list(targetMIDIPitch) if targetMIDIPitch is not None else [-64, -67] + list(range(21, 108 + 1))   # :97
         self.scorer = ScaledInnerProductIntervalScorer(size, 1)
         self.scorer.fullSquare = 2      # S goes straight into this package's decode, which never reads begin > end: no zero fill
-        self.capFactor, self.capFloor = 2.0, 4096     # transcribe_many: rows for the heads = capFactor x the largest count seen, at least capFloor
+        self.capFactor, self.capFloor = 1.5, 4096     # transcribe_many: rows for the heads = capFactor x the largest count seen, at least capFloor
         self.projection = "separate"    # "merged": the scorer's two projections as one (see decode_step); scores then differ from
                                         # the reference's by fp32 reassociation, so the default keeps its operation order
         self._merged = None
@@ -373,7 +373,7 @@ class SegmentTranscriber(nn.Module):
         """Several recordings in lock step: step s decodes segment s of every recording that still has one as ONE batch
         (NBatch = 90 x #recordings).  The forced start positions of step s+1 never leave the device.
 
-        After the first step nothing waits for the device inside a step: the attribute heads run on a CAPPED number of rows (twice
+        After the first step nothing waits for the device inside a step: the attribute heads run on a CAPPED number of rows (1.5 x
         the largest interval count seen so far per recording in the batch), the real count travels to the host with the step's rows
         and is checked one step late, when the rows are merged.  A count above the cap (the heads saw a truncated list) restarts
         the whole call with `synchronous=True`: every step then waits for its count, as in round 3.  Same Notes either way."""
