@@ -1,5 +1,6 @@
 """Activity histogram of the far-field waves (probe build, debug flag 1024): tiles taken per 4 us of the sweep, by the panel
-workgroups' waves and by the spare waves of the spine workgroups -> the streaming rate over the course of the launch."""
+workgroups' waves and by the spare waves of the spine workgroups -> the streaming rate over the course of the launch.
+(Every XCD's tiles are bucketed against the start of its own first workgroup: s_memrealtime counts per XCD.)"""
 import argparse, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()

@@ -1299,7 +1299,8 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                 // activity histogram (tools/activity_hist.py): tiles taken per 4 us bucket, panel and spare waves apart
                 u64* const hb = P.ts + (3 * T) / 2;
                 const u64 now = __builtin_amdgcn_s_memrealtime();
-                const u64 t0 = __hip_atomic_load(hb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (s_memrealtime counts per XCD: every XCD's tiles are bucketed against the start of ITS first workgroup)
+                const u64 t0 = __hip_atomic_load(hb + 129 + (__builtin_amdgcn_s_getreg(6164) & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 u64 b = now > t0 ? (now - t0) / 400 : 0;
                 if (b > 63) b = 63;
                 atomicAdd((unsigned long long*)(hb + 1 + 64 * hist_role + b), 1ull);
@@ -1649,8 +1650,11 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
     // clock probe (probe build, debug flag 128): shader cycles and 100 MHz ticks of one panel workgroup over the launch
     const bool clk = SEMICRF_PANEL_PROBES && (DBGF(P) & 128u) && ticket == nSpineWG + 3 && threadIdx.x == 0;
     if (clk) { P.ts[600] = __builtin_readcyclecounter(); P.ts[601] = __builtin_amdgcn_s_memrealtime(); }
-    if (SEMICRF_PROBE_HIST && (DBGF(P) & 1024u) && threadIdx.x == 0)          // activity histogram: t0 = the first workgroup's start
-        atomicMin((unsigned long long*)(P.ts + (3 * P.T) / 2), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    if (SEMICRF_PROBE_HIST && (DBGF(P) & 1024u) && threadIdx.x == 0) {        // activity histogram: t0 = the first workgroup's start, per XCD
+        const unsigned long long now = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+        atomicMin((unsigned long long*)(P.ts + (3 * P.T) / 2), now);
+        atomicMin((unsigned long long*)(P.ts + (3 * P.T) / 2 + 129 + (__builtin_amdgcn_s_getreg(6164) & 7)), now);     // hwreg(HW_REG_XCC_ID, 0, 4)
+    }
     if (ticket < nSpineWG) {
         // chain group = ticket: neighbouring groups read neighbouring 16-byte pieces of the same sectors, and
         // measured fetch traffic is 3x lower this way than with groups spread 8 tickets apart (0.13 vs 0.36 GB for
