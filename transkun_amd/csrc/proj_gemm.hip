@@ -425,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void proj_gemm_kernel(Args P)
 // The two extra rows of the weight gradient and the two extra entries of the bias gradient (the packed outputs' columns c / diag):
 // out[j][n] = sum_m dy[m][col0 + j] x[m][n] over this block's rows -- a dot product per column on the side of the matrix-core part
 // (memory-bound: x is read once more).  Partial sums per block, reduced with the rest in a fixed order.
-constexpr int XROWS = 256;                  // rows per block
+constexpr int XROWS = 128;                  // rows per block (two blocks per compute unit at the model's 62 190 rows)
 __global__ __launch_bounds__(256) void proj_extra_tn_kernel(const float* __restrict__ dy, long long lddy, long long M, int col0,
                                                             const float* __restrict__ x, long long ldx, int N,
                                                             float* __restrict__ part_extra, float* __restrict__ part_xbias)
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void proj_extra_tn_kernel(const float* __restr
 }
 
 // dW[r][n] = sum_s part[s][r][n] (r < rows: the matrix part), the two extra rows from part_extra, db from part_bias.  A block per
-// output row (and one for the bias gradient); its four waves take every fourth partial result each (independent loads, four columns
+// output row and 64 columns (and a block row for the bias gradient); 16 groups of lanes take every 16th partial result each (independent loads, four columns
 // per lane) and are combined in a fixed order: the result does not depend on timing.
 __global__ __launch_bounds__(256) void proj_reduce_kernel(const float* __restrict__ part, int S, int Mp, int D, int rows,
                                                           const float* __restrict__ part_extra, const float* __restrict__ part_xbias,
@@ -467,9 +467,11 @@ __global__ __launch_bounds__(256) void proj_reduce_kernel(const float* __restric
                                                           float* __restrict__ dW, long long lddw, int total_rows,
                                                           float* __restrict__ db)
 {
-    __shared__ float sh[4][256];
-    const int g = threadIdx.x >> 6, q = threadIdx.x & 63;
-    const int n0 = blockIdx.x * 256 + 4 * q;
+    // a block = one output row x 64 columns: 16 quads of columns x 16 groups that take every 16th partial result each
+    constexpr int RG = 16, RQ = 16;
+    __shared__ float sh[RG][4 * RQ];
+    const int g = threadIdx.x / RQ, q = threadIdx.x % RQ;
+    const int n0 = blockIdx.x * (4 * RQ) + 4 * q;
     const int r = blockIdx.y;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     const float* src = nullptr;          // partial result i, column n: src[i * pitch + n]
@@ -485,15 +487,15 @@ __global__ __launch_bounds__(256) void proj_reduce_kernel(const float* __restric
     if (r < total_rows) {
         if (src && n0 < ncols) {         // (D is a multiple of 64: whole quads)
             int i = g;
-            for (; i + 12 < count; i += 16) {
-                const float4 a = *(const float4*)(src + (size_t)i * pitch + n0), b = *(const float4*)(src + (size_t)(i + 4) * pitch + n0);
-                const float4 c = *(const float4*)(src + (size_t)(i + 8) * pitch + n0), d = *(const float4*)(src + (size_t)(i + 12) * pitch + n0);
+            for (; i + 3 * RG < count; i += 4 * RG) {
+                const float4 a = *(const float4*)(src + (size_t)i * pitch + n0), b = *(const float4*)(src + (size_t)(i + RG) * pitch + n0);
+                const float4 c = *(const float4*)(src + (size_t)(i + 2 * RG) * pitch + n0), d = *(const float4*)(src + (size_t)(i + 3 * RG) * pitch + n0);
                 s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
                 s[0] += b.x; s[1] += b.y; s[2] += b.z; s[3] += b.w;
                 s[0] += c.x; s[1] += c.y; s[2] += c.z; s[3] += c.w;
                 s[0] += d.x; s[1] += d.y; s[2] += d.z; s[3] += d.w;
             }
-            for (; i < count; i += 4) {
+            for (; i < count; i += RG) {
                 const float4 a = *(const float4*)(src + (size_t)i * pitch + n0);
                 s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
             }
@@ -504,9 +506,9 @@ __global__ __launch_bounds__(256) void proj_reduce_kernel(const float* __restric
             const int n = n0 + c;
             if (n >= nbias) continue;
             if (n < rows) {
-                for (int i = g; i < S; i += 4) s[c] += part_bias[(size_t)i * bias_pitch + n];
+                for (int i = g; i < S; i += RG) s[c] += part_bias[(size_t)i * bias_pitch + n];
             } else if (part_xbias && n >= extra_row0 && n < extra_row0 + 2) {
-                for (int i = g; i < SX; i += 4) s[c] += part_xbias[(size_t)i * 2 + (n - extra_row0)];
+                for (int i = g; i < SX; i += RG) s[c] += part_xbias[(size_t)i * 2 + (n - extra_row0)];
             }
         }
     }
@@ -517,7 +519,9 @@ __global__ __launch_bounds__(256) void proj_reduce_kernel(const float* __restric
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int n = n0 + c;
-            const float v = ((sh[0][4 * q + c] + sh[1][4 * q + c]) + sh[2][4 * q + c]) + sh[3][4 * q + c];
+            float v = sh[0][4 * q + c];
+#pragma unroll
+            for (int k = 1; k < RG; ++k) v += sh[k][4 * q + c];       // fixed order
             if (r < total_rows) { if (n < D) dW[(size_t)r * lddw + n] = v; }
             else if (db && n < nbias) db[n] = v;
         }
@@ -624,7 +628,7 @@ int launch_proj_tn(const float* A, long long lda, long long M, int R, int extra_
     if (extra_col0 >= 0)
         hipLaunchKernelGGL(pj::proj_extra_tn_kernel, dim3((unsigned)SX), dim3(256), 0, stream, A, lda, M, extra_col0, X, ldx, N, pextra, pxbias);
     const int nb = total_rows;
-    const dim3 grid((unsigned)(((N > nb ? N : nb) + 255) / 256), (unsigned)(total_rows + 1));
+    const dim3 grid((unsigned)(((N > nb ? N : nb) + 63) / 64), (unsigned)(total_rows + 1));
     hipLaunchKernelGGL(pj::proj_reduce_kernel, grid, dim3(256), 0, stream, part, S, Mp, N, R, extra_col0 >= 0 ? pextra : nullptr,
                        extra_col0 >= 0 ? pxbias : nullptr, SX, extra_col0, pbias, Mp + 8, nb, dW, lddw, total_rows, db);
     return 0;
