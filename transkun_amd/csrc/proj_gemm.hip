@@ -425,13 +425,15 @@ __global__ __launch_bounds__(512, 2) void proj_gemm_kernel(Args P)
 // The two extra rows of the weight gradient and the two extra entries of the bias gradient (the packed outputs' columns c / diag):
 // out[j][n] = sum_m dy[m][col0 + j] x[m][n] over this block's rows -- a dot product per column on the side of the matrix-core part
 // (memory-bound: x is read once more).  Partial sums per block, reduced with the rest in a fixed order.
-constexpr int XROWS = 128;                  // rows per block (two blocks per compute unit at the model's 62 190 rows)
+constexpr int XROWS_MIN = 128;              // rows per block: at least this many, and about 512 blocks (two per compute unit; the reduction
+                                            // walks one partial result per block)
+__host__ inline int xrows_of(long long M) { long long x = (M + 511) / 512; x = (x + 31) / 32 * 32; return (int)(x < XROWS_MIN ? XROWS_MIN : x); }
 __global__ __launch_bounds__(256) void proj_extra_tn_kernel(const float* __restrict__ dy, long long lddy, long long M, int col0,
                                                             const float* __restrict__ x, long long ldx, int N,
-                                                            float* __restrict__ part_extra, float* __restrict__ part_xbias)
+                                                            float* __restrict__ part_extra, float* __restrict__ part_xbias, int xrows)
 {
-    const long long m0 = (long long)blockIdx.x * XROWS;
-    const long long m1 = m0 + XROWS < M ? m0 + XROWS : M;
+    const long long m0 = (long long)blockIdx.x * xrows;
+    const long long m1 = m0 + xrows < M ? m0 + xrows : M;
     const int n = threadIdx.x;
     float s0 = 0.f, s1 = 0.f, b0 = 0.f, b1 = 0.f;
     if (n < N) {
@@ -595,7 +597,7 @@ size_t proj_tn_workspace_bytes(long long M, int R, int N)
 {
     int S, ks, Mp;
     proj_tn_geometry(M, R, &S, &ks, &Mp);
-    const size_t SX = (size_t)((M + pj::XROWS - 1) / pj::XROWS);
+    const size_t SX = (size_t)((M + pj::xrows_of(M) - 1) / pj::xrows_of(M));
     return ((size_t)S * Mp * N + (size_t)S * (Mp + 8) + SX * 2 * N + SX * 2) * sizeof(float) + 256;
 }
 
@@ -612,7 +614,8 @@ int launch_proj_tn(const float* A, long long lda, long long M, int R, int extra_
     float* part = (float*)ws;
     float* pbias = part + (size_t)S * Mp * N;
     float* pextra = pbias + (size_t)S * (Mp + 8);
-    const int SX = (int)((M + pj::XROWS - 1) / pj::XROWS);
+    const int xrows = pj::xrows_of(M);
+    const int SX = (int)((M + xrows - 1) / xrows);
     float* pxbias = pextra + (size_t)SX * 2 * N;
     pj::Args P{};
     P.A = A; P.lda = lda; P.Arows = (int)M; P.Acols = R;
@@ -626,7 +629,7 @@ int launch_proj_tn(const float* A, long long lda, long long M, int R, int extra_
     default: proj_launch<true, 4, false>(P, nitems, 0, stream); break;
     }
     if (extra_col0 >= 0)
-        hipLaunchKernelGGL(pj::proj_extra_tn_kernel, dim3((unsigned)SX), dim3(256), 0, stream, A, lda, M, extra_col0, X, ldx, N, pextra, pxbias);
+        hipLaunchKernelGGL(pj::proj_extra_tn_kernel, dim3((unsigned)SX), dim3(256), 0, stream, A, lda, M, extra_col0, X, ldx, N, pextra, pxbias, xrows);
     const int nb = total_rows;
     const dim3 grid((unsigned)(((N > nb ? N : nb) + 63) / 64), (unsigned)(total_rows + 1));
     hipLaunchKernelGGL(pj::proj_reduce_kernel, grid, dim3(256), 0, stream, part, S, Mp, N, R, extra_col0 >= 0 ? pextra : nullptr,
