@@ -1282,6 +1282,56 @@ def test_transcribe_end_to_end_vs_reference(gpu, name):
 
 
 @pytest.mark.gpu
+def test_hot_paths_do_not_wait_for_the_device(gpu):
+    """The training-side hot paths enqueue and return: under torch's sync debug mode ("error": any synchronising torch call raises) a
+    warm logProb step, the fused and the module scorer + CRF steps and train_step run through.  (Round 4 found four hidden waits this
+    way -- tools/sync_audit.py; decode and the transcription loop's first step synchronise by design and are not part of this.)"""
+    from transkun_amd import CRF, synth
+    from transkun_amd.fused import scorer_crf_logprob
+    from transkun_amd.scorer import ScaledInnerProductIntervalScorer
+    from transkun_amd.trainstep import SegmentModel, train_step
+    T, B = 256, 64
+    score, noise = synth.crf_inputs(T, B, 5, gpu, "randn")
+    iv = synth.synthetic_intervals(T, B, seed=5)
+    score.requires_grad_(); noise.requires_grad_()
+
+    def headline():
+        score.grad = None; noise.grad = None
+        (CRF.NeuralSemiCRFInterval(score, noise).logProb(iv).sum() * -0.25).backward()
+
+    Ts, P, D, N = 200, 90, 64, 2
+    m = ScaledInnerProductIntervalScorer(D, 1).to(gpu)
+    ctx = (synth.hash_normal(N * P * Ts * D, 11, gpu).view(N, P, Ts, D) * 0.5).requires_grad_()
+    iv2 = synth.synthetic_intervals(Ts, N * P, seed=11)
+
+    def fused():
+        m.zero_grad(); ctx.grad = None
+        (-scorer_crf_logprob(m, ctx, iv2).view(N, -1).sum(-1).mean() / 50).backward()
+
+    def module():
+        m.zero_grad(); ctx.grad = None
+        S, b = m(ctx)
+        (-CRF.NeuralSemiCRFInterval(S.flatten(-2, -1), b.flatten(-2, -1)).logProb(iv2).view(N, -1).sum(-1).mean() / 50).backward()
+
+    model = SegmentModel(D).to(gpu)
+
+    def train():
+        ctx.grad = None
+        train_step(model, ctx, iv2)
+
+    for fn in (headline, fused, module, train):
+        for _ in range(3):
+            fn()                                    # warm: pools, workspaces, the allocator
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            fn()
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("size,which", [(256, "both"), (128, "both"), (64, "q"), (256, "k")])
 def test_scorer_linear_packed(gpu, size, which):
     """_ScorerLinearPacked (the Linear's own parameters through scorer_stage_linear + the projection kernels, gradients written into
