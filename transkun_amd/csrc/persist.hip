@@ -65,6 +65,10 @@ constexpr int RING = SEMICRF_RING; // waves per ring; band = RING-1 off-diagonal
 // instead of RING.  Measured chain: 7.5 us (88 chains) to 10 us (352) against 4 x 1.4 us of ring time per band; every extra tile
 // costs the loader 4 more 64-line loads per row block (ring alone: 1.34 -> 1.64 us per block at 88 chains, 1.41 -> 1.88 at 352).
 constexpr int NNEAR = SEMICRF_NNEAR;
+#ifndef SEMICRF_BANDX
+#define SEMICRF_BANDX 0            // 1: the loader takes the band from a spine-major copy (whole 128-byte lines), see band_copy
+#endif
+constexpr int NBT = RING + NNEAR;  // band tiles per row block and spine (the ring's RING, then the near tiles)
 constexpr int FAR0 = RING + NNEAR; // first block with a far field of its own; the newest far tile of block k is k - FAR0
 constexpr int RS = 4;              // chains per ring (one per lane)
 constexpr int GS = RS;              // chains per spine workgroup
@@ -146,6 +150,9 @@ struct SweepParams {
     unsigned* ctrl;        // [1] error, [2] panel task queue head, [3] zero-fill row queue head, [64] workgroups that have left (leases)
     u64* ts;               // [2T] debug timestamps of spine 0, ring 0 (dbg & 16)
     unsigned* ug;          // [T][B] u as float bits (position-major: index p*B + c); U_EMPTY until the spine publishes it
+    unsigned* ug_other;    // leased workspaces: the u buffer of the PREVIOUS launch into this workspace (the two alternate); this launch
+                           // puts it back to U_EMPTY, at its start and off every critical path (nullptr: nothing to clean)
+    int bandWaves;         // GRAD: waves per panel workgroup that write the band's marginals (band_role); 0: the ring waves do
     u64* farg;             // [parts][T][B] granules of far-field partials (part = column range of TPT tiles)
     float* u_out;          // [T][B] by FRAME (natural-log units for LSE) or nullptr
     float* last_out;       // [B] value at the last position (logZ for DIR 0) or nullptr
@@ -158,6 +165,9 @@ struct SweepParams {
     float gscale;
     float* dScore;         // [T][T][B]: lower triangle + diagonal written here (the upper triangle by zero_upper_kernel)
     float* dNoise;         // [T-1][B]
+    const float* band;     // SEMICRF_BANDX: [K][bandSpines][NBT][16 columns][16 rows][4 chains]: the band, spine-major
+    int bandSpines;        // ... spines of the whole batch (the copy is indexed by the batch's spine number)
+    int bandK0;            // ... row blocks < bandK0 are still loaded from the score tensor itself
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -413,9 +423,21 @@ __device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* 
     constexpr int LDEPTH = 3 * NL <= 63 ? 3 : 2;
     static_assert(2 * NL <= 63, "loader pipeline");
 
+    const float* const bandp = SEMICRF_BANDX ? P.band + (size_t)(cbase / GS) * NBT * (TILE_BYTES / 4) + lane * 4 : nullptr;
+    const size_t band_kr = (size_t)P.bandSpines * NBT * (TILE_BYTES / 4);
     auto issue = [&](int kr) {
         const int slot = kr % NRBUF;
         const int prow_t = kr * PB + tr < T ? kr * PB + tr : T - 1;
+        const bool fromband = SEMICRF_BANDX && kr >= P.bandK0;
+        if (fromband) {
+            const float* const bk = bandp + (size_t)kr * band_kr;
+#pragma unroll
+            for (int i = 0; i < RING; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    __builtin_amdgcn_global_load_lds((gbl_void_t*)(bk + i * (TILE_BYTES / 4) + q * 256),
+                                                     (lds_void_t*)(lds + LDS_TILES + (slot * RING + i) * TILE_BYTES + q * 1024), 16, 0, SEMICRF_LOADER_AUX);
+        } else
 #pragma unroll
         for (int i = 0; i < RING; ++i) {
             const int kc = kr - (RING - 1) + i > 0 ? kr - (RING - 1) + i : 0;
@@ -441,6 +463,15 @@ __device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* 
         if (NNEAR > 0) {
             // the near tiles of row block kr: column blocks kr - RING - n (clamped: the first blocks have none, nobody reads them)
             char* const nb = lds + LDS_NEAR + (kr % NNSLOT) * NEAR_SLOT_BYTES;
+            if (fromband) {
+                const float* const bk = bandp + (size_t)kr * band_kr;
+#pragma unroll
+                for (int n = 0; n < NNEAR; ++n)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        __builtin_amdgcn_global_load_lds((gbl_void_t*)(bk + (RING + n) * (TILE_BYTES / 4) + q * 256),
+                                                         (lds_void_t*)(nb + n * TILE_BYTES + q * 1024), 16, 0, SEMICRF_LOADER_AUX);
+            } else
 #pragma unroll
             for (int n = 0; n < NNEAR; ++n) {
                 const int kc = kr - RING - n > 0 ? kr - RING - n : 0;
@@ -599,7 +630,7 @@ __device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds
 #pragma unroll
                     for (int u = 0; u < PB; ++u) {
                         t[u] = fmaf(ncell[n][u], LOG2E, uq[u]);
-                        if (GRAD && rvalid) {
+                        if (GRAD && rvalid && P.bandWaves == 0) {
                             const int j = b * PB + u;
                             const size_t co = DIR == 0 ? ((size_t)own0 * T + (size_t)j) * Bs : (size_t)(T - 1 - j) * T * Bs;
                             const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(dScore + co), 0, 0x7fffffff, 0x00020000);
@@ -696,7 +727,7 @@ __device__ __forceinline__ void static_for(F&& f)
     if constexpr (J < N) { f(IC<J>{}); static_for<J + 1, N>(f); }
 }
 
-template <int MODE, int DIR, bool GRAD>
+template <int MODE, int DIR, bool GRAD, bool RINGBAND>
 __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int ring_pos, char* lds)
 {
     // kernel arguments are copied into locals: lambdas that capture the struct by reference make the
@@ -726,6 +757,10 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
     const float4* const far = (const float4*)(lds + LDS_FAR);
     float gz = 0.f, lzc = 0.f;
     if (GRAD && cvalid) { gz = P.gout[(size_t)c * P.gstride] * P.gscale; lzc = P.logZ[c]; }               // the only global loads of a ring wave
+    // GRAD: who stores the marginals of the band (the cells the ring itself reads)?  The panel workgroups' band waves when the
+    // launch has them (band_role: whole lines, off the ring's critical path); the ring waves themselves otherwise (short sequences)
+    // (a template parameter: as a run-time flag it put a branch around every cell's store and cut the shadow batch into 16 pieces)
+    constexpr int ringBand = GRAD && RINGBAND ? 1 : 0;
     __builtin_amdgcn_s_setprio(1);
 
     for (int k = rw; k < K; k += RING) {
@@ -772,6 +807,9 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
             return DIR == 0 ? ((size_t)own0 * T + (size_t)j) * Bs : (size_t)(T - 1 - j) * T * Bs;
         };
         auto grad_store = [&](int j, float v) {
+#ifdef SEMICRF_NO_BAND_GSTORE
+            (void)j; asm volatile("" ::"v"(v)); return;      // timing experiment: the band's marginals are computed but not stored
+#endif
             const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(dScore + col_off(j)), 0, 0x7fffffff, 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, bvoff, 0, 0);
         };
@@ -854,7 +892,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
                         const int u = u4 + q;
                         const int j = b * PB + u;
                         float p = fmaf(X.v[u], LOG2E, uq[q]);
-                        if (GRAD && rvalid && j < prow) grad_store(j, gz * fexp2(p + arow));
+                        if (GRAD && ringBand && rvalid && j < prow) grad_store(j, gz * fexp2(p + arow));
                         if (last && u == PB - 1 && r == 0) {
                             if (GRAD && rvalid)       // noise marginal of the gap between prow-1 and prow
                                 dNoise[(size_t)gap_of<DIR>(prow, T) * Bs + c] = gz * fexp2(uq[q] + nz * LOG2E + arow);
@@ -941,13 +979,18 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
             lds_store64(ring + ch * 2 + ((own0 + r) % NPOS) * 8, mine, own0 + r + 1);
             __builtin_amdgcn_s_setprio(1);
             if (GRAD) {
-                // marginals of the block's own triangle and of its gaps (off the critical path: the block is out)
-                static_for<0, PB - 1>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    const float uj = row_bcast<j>(mine);
-                    if (rvalid && r > j) grad_store(own0 + j, gz * fexp2(fmaf(X[RING - 1].v[j], LOG2E, uj) + arow));
-                    if (rvalid && r == j + 1) dNoise[(size_t)gap_of<DIR>(prow, T) * Bs + c] = gz * fexp2(uj + nz * LOG2E + arow);
-                });
+                // marginals of the block's own triangle (unless the band waves write them) and of its gaps (off the critical path:
+                // the block is out).  The gap in front of row r needs u of row r - 1: ONE row shift and one store for the 15 gaps
+                // inside the block (until round 5: fifteen stores with four lanes each)
+                if (ringBand) {
+                    static_for<0, PB - 1>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        const float uj = row_bcast<j>(mine);
+                        if (rvalid && r > j) grad_store(own0 + j, gz * fexp2(fmaf(X[RING - 1].v[j], LOG2E, uj) + arow));
+                    });
+                }
+                const float um1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine), 0x111, 0xf, 0xf, false));   // row_shr:1
+                if (rvalid && r >= 1) dNoise[(size_t)gap_of<DIR>(prow, T) * Bs + c] = gz * fexp2(um1 + nz * LOG2E + arow);
             }
         } else {
             // (max,+): the same walk over the block's triangle on DPP row broadcasts.  Row j's value is final after step j-1 (the
@@ -984,7 +1027,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
         // ---- once per block: publish the 16 finished positions to HBM -----------------------------
         if (rvalid) {
             if (k == K - 1 && lds_flag_load(&s_abort) != 0) mine = __uint_as_float(0x7fc00000u);     // a wait timed out: poison the results
-            if (k < K - FAR0) {                                 // the far field of block k' ends at block k' - FAR0: nobody reads the last FAR0 blocks' u
+            if (k < K - FAR0 || (GRAD && ringBand == 0)) {      // the far field of block k' ends at block k' - FAR0: only the band waves (GRAD) read the last FAR0 blocks' u
                 unsigned ub = __float_as_uint(mine);
                 if (ub == U_EMPTY) ub = 0x7fc00000u;            // keep the one reserved pattern free (NaN input scores)
                 __hip_atomic_store(ug + (size_t)prow * Bs + c, ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1575,6 +1618,118 @@ __device__ __forceinline__ void zero_role(const SweepParams& P)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// BAND role (GRAD): the marginals of the band, written by spare waves of the panel workgroups
+// ---------------------------------------------------------------------------------------------
+// Until round 5 the ring waves stored the marginals of the cells they read themselves (the band: the diagonal tile and the
+// FAR0 - 1 tiles left of it) -- one 4-byte store per lane and cell, 64 store instructions per block in the middle of the
+// dependent chain, every one a 16-byte piece of 16 different lines: the ring of the gradient sweep needed 3.1 us per block where
+// the forward ring needs 1.4, and the whole head of the sweep ran at that pace (T=1024 x 352: 357 us with, 295 us without
+// those stores).  The band's marginals need nothing the ring has not published: marginal(pi, pj) = gz exp2(u[pj] + cell log2e +
+// arow[pi]) -- the same expression, bit for bit, the panels evaluate for the far field.  So they are a task of their own:
+// (column block m, row block k = m + dk, 32-chain group g, row quarter q4), ready as soon as the ring has published block m,
+// handed out in m order to `bandWaves` otherwise idle waves of every panel workgroup.  A wave reads the tile's cells once more
+// (+12 % reads: 4 rows x 16 columns x 128 bytes, register loads in 512-byte runs), its 16 x 4 u values and writes whole lines.
+// Nobody waits for these waves: the ring's only global stores are u, the diagonal and the noise gradient.
+constexpr int CTRL_BANDQ = 32;        // [32]: band task queue head (a line of its own)
+
+template <int DIR>
+__device__ __forceinline__ void band_role(const SweepParams& P)
+{
+    const int T = P.T, B = P.B, K = P.K, c0 = P.c0, c1 = P.c1;
+    const size_t Bs = (size_t)B;
+    unsigned* const ctrl = P.ctrl;
+    const float* __restrict__ score = P.score;
+    float* const dScore = P.dScore;
+    const int lane = threadIdx.x & 63;
+    const int q8 = lane & 7, pjsub = (lane >> 3) & 1, pisub = lane >> 4;
+    const int nG = P.nPanelGroups;
+    const int nTasks = K * FAR0 * nG * 4;
+    const size_t last4 = (size_t)T * T * Bs - 4;
+    const auto ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.ug, 0, (int)((size_t)T * Bs * 4), 0x00020000);
+    while (true) {
+        int task = 0;
+        if (lane == 0) task = (int)(atomicAdd(ctrl + CTRL_BANDQ, 1u) + 1u);
+        task = __builtin_amdgcn_readfirstlane(task);
+        if (task >= nTasks) break;
+        const int q4 = task & 3, t2 = task >> 2;
+        const int g = t2 % nG, t3 = t2 / nG;
+        const int dk = t3 % FAR0, m = t3 / FAR0, k = m + dk;
+        const int pbase = k * PB + q4 * 4;
+        if (k >= K || pbase >= T) continue;
+#if defined(SEMICRF_BAND_ABL) && SEMICRF_BAND_ABL == 2
+        continue;                                                    // timing ablation: the band tasks are only drawn
+#endif
+        const int pi = pbase + pisub;
+        const bool rowok = pi < T;
+        const int pic = rowok ? pi : T - 1;
+        const int c = c0 + g * GP + q8 * 4;
+        const int cl = c < c1 ? c : c0;
+        const bool v0 = c < c1, v1 = c + 1 < c1, v2 = c + 2 < c1, v3 = c + 3 < c1;
+        float gz[4], ar[4];
+        {
+            const int fr = frame_of<DIR>(pic, T);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = c + i < c1;
+                const float lz = ok ? P.logZ[c + i] : 0.f;
+                gz[i] = ok ? P.gout[(size_t)(c + i) * P.gstride] * P.gscale : 0.f;
+                ar[i] = ok ? (P.vfwd[(size_t)fr * Bs + c + i] - lz) * LOG2E : 0.f;
+            }
+        }
+        v4u x[8], uu[8];
+        size_t off[8];                                               // element offset of the cell (loads: clamped into the tensor)
+        unsigned uoff[8];
+        bool use[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int pj = m * PB + 2 * e + pjsub;
+            use[e] = rowok && pj < pi;
+            const int pjc = pj < pic ? pj : (pic > 0 ? pic - 1 : 0);       // the diagonal tile: cells at and above the diagonal are not used
+            off[e] = cell_index<DIR>(pic, pjc, T) * Bs + cl;
+            uoff[e] = (unsigned)(((size_t)pjc * Bs + cl) * 4);
+            const v4u_a4 t = *(const v4u_a4*)(score + (off[e] < last4 ? off[e] : last4));
+            x[e] = t;
+            uu[e] = __builtin_amdgcn_raw_buffer_load_b128(ursrc, uoff[e], 0, 0);
+        }
+        // u not published yet (or a stale line of the launch's start): again with device scope until the ring is there
+        {
+            int spins = 0;
+            while (true) {
+                bool ok = true;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    ok = ok && (uu[e].x != U_EMPTY || !v0) && (uu[e].y != U_EMPTY || !v1) && (uu[e].z != U_EMPTY || !v2) && (uu[e].w != U_EMPTY || !v3);
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(64);
+                if (spin_abort(ctrl, spins, SPIN_LIMIT, 14)) break;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) uu[e] = __builtin_amdgcn_raw_buffer_load_b128(ursrc, uoff[e], 0, 16);     // 16 = sc1
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (!use[e] || !v0) continue;
+            v4u gv;
+            gv.x = __float_as_uint(gz[0] * fexp2(fmaf(__uint_as_float(x[e].x), LOG2E, __uint_as_float(uu[e].x)) + ar[0]));
+            gv.y = __float_as_uint(gz[1] * fexp2(fmaf(__uint_as_float(x[e].y), LOG2E, __uint_as_float(uu[e].y)) + ar[1]));
+            gv.z = __float_as_uint(gz[2] * fexp2(fmaf(__uint_as_float(x[e].z), LOG2E, __uint_as_float(uu[e].z)) + ar[2]));
+            gv.w = __float_as_uint(gz[3] * fexp2(fmaf(__uint_as_float(x[e].w), LOG2E, __uint_as_float(uu[e].w)) + ar[3]));
+            float* const dst = dScore + off[e];
+#if defined(SEMICRF_BAND_ABL) && SEMICRF_BAND_ABL == 1
+            asm volatile("" ::"v"(gv));                              // timing ablation: computed, not stored
+            continue;
+#endif
+            if (v3) { const v4u_a4 ga = gv; __builtin_nontemporal_store(ga, (v4u_a4*)dst); }
+            else {                                                   // ragged tail of the chain range
+                dst[0] = __uint_as_float(gv.x);
+                if (v1) dst[1] = __uint_as_float(gv.y);
+                if (v2) dst[2] = __uint_as_float(gv.z);
+            }
+        }
+    }
+}
+
 // Workgroup index -> role ticket (spines: tickets < nSpine = the chain group; panel workgroups: nSpine + a dense rank).
 // The eight rings of a 32-chain panel group read the 16-byte pieces of the SAME 128-byte lines of the band, and their far
 // waves take partials from the same tasks: they belong on ONE XCD (one L2).  Block b is observed to run on XCD b % 8 (a
@@ -1647,6 +1802,17 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
     const int nSpineWG = (P.nSpine + SPH - 1) / SPH;
     const int ticket = wg_ticket(nSpineWG, (int)gridDim.x, (int)blockIdx.x);
     const int wave = (int)(threadIdx.x >> 6);
+    if (P.ug_other && wave == NT / 64 - 1) {
+        // Leased workspace: the u values of the PREVIOUS launch go back to U_EMPTY here -- the two launches use alternate
+        // buffers, so this one's own values can stay until the next launch: nobody has to know when the last reader of a u is
+        // through (rounds 2-4: the rings cleared their group's u at the end of the sweep, which ruled out any reader that may
+        // finish after the ring).  Every workgroup clears one slice with its last wave (idle in every role), in whole 16-byte pieces.
+        const size_t n = (size_t)P.T * P.B, n4 = n / 4;
+        const size_t per = (n4 + gridDim.x - 1) / gridDim.x, i0 = per * blockIdx.x, i1 = i0 + per < n4 ? i0 + per : n4;
+        const v4u e = {U_EMPTY, U_EMPTY, U_EMPTY, U_EMPTY};
+        for (size_t i = i0 + (threadIdx.x & 63); i < i1; i += 64) ((v4u*)P.ug_other)[i] = e;
+        if (blockIdx.x == 0 && (threadIdx.x & 63) < (int)(n - n4 * 4)) P.ug_other[n4 * 4 + (threadIdx.x & 63)] = U_EMPTY;
+    }
     // clock probe (probe build, debug flag 128): shader cycles and 100 MHz ticks of one panel workgroup over the launch
     const bool clk = SEMICRF_PANEL_PROBES && (DBGF(P) & 128u) && ticket == nSpineWG + 3 && threadIdx.x == 0;
     if (clk) { P.ts[600] = __builtin_readcyclecounter(); P.ts[601] = __builtin_amdgcn_s_memrealtime(); }
@@ -1682,30 +1848,9 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
         } else if (sg >= P.nSpine) {
             // (an odd number of spines: the last workgroup's second one has no chains)
         } else if (hw < RING) {
-            if (!(DBGF(P) & 8u)) spine_role<MODE, DIR, GRAD>(P, sg, hw, lds_h);
-            if (P.selfclean && hw == (P.K - 1) % RING) {
-                // Leased workspace: u goes back to U_EMPTY.  When ANY ring of a 32-chain group is through, so is every panel
-                // task of the group (a task stores its partials for all of the group's chains at once, after its last look
-                // at u, and this ring took its last partials before its last block), and every u a task reads has been
-                // published (the last FAR0 blocks' u is never stored).  So the group's u is dead, and each of its rings --
-                // through its last block's owner, the ring mates return earlier -- clears one share of the rows in whole
-                // 128-byte pieces (its own 16 bytes of every row would be 8x the line writes: measured +25 us).
-                const int lane = threadIdx.x & 63;
-                const int g = sg / (GP / GS), j = sg % (GP / GS);
-                const int spines_in_group = P.nSpine - g * (GP / GS) < GP / GS ? P.nSpine - g * (GP / GS) : GP / GS;
-                const int p0 = (int)((long long)P.T * j / spines_in_group), p1 = (int)((long long)P.T * (j + 1) / spines_in_group);
-                const int cq = P.c0 + g * GP + (lane & 7) * 4;                  // this lane's four chains
-                for (int p = p0 + (lane >> 3); p < p1; p += 8) {
-                    unsigned* const dst = P.ug + (size_t)p * P.B + cq;
-                    if (cq + 3 < P.c1) {
-                        const v4u_a4 e = {U_EMPTY, U_EMPTY, U_EMPTY, U_EMPTY};
-                        *(v4u_a4*)dst = e;
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (cq + i < P.c1) dst[i] = U_EMPTY;
-                    }
-                }
+            if (!(DBGF(P) & 8u)) {
+                if (GRAD && P.bandWaves == 0) spine_role<MODE, DIR, GRAD, GRAD>(P, sg, hw, lds_h);
+                else spine_role<MODE, DIR, GRAD, false>(P, sg, hw, lds_h);
             }
         } else if (hw < RING + NLOADER) {
             if (!(DBGF(P) & 8u)) loader_role<DIR, GRAD>(P, sg, lds_h, hw - RING);
@@ -1716,6 +1861,7 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
         if (!(DBGF(P) & 2u) && wave < P.panelWaves)
             panel_role<MODE, DIR, GRAD>(P, s_dyn, wave, 0, P.taskBase > 0 ? (ticket - nSpineWG) * P.panelWaves + wave : -1);
         else if (GRAD && wave - P.panelWaves >= 0 && wave - P.panelWaves < P.zeroWaves) zero_role(P);
+        else if (GRAD && wave - P.panelWaves - P.zeroWaves >= 0 && wave - P.panelWaves - P.zeroWaves < P.bandWaves) band_role<DIR>(P);
     }
     if (clk) { P.ts[602] = __builtin_readcyclecounter(); P.ts[603] = __builtin_amdgcn_s_memrealtime(); }
     if (P.selfclean) {
@@ -1737,6 +1883,66 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BAND COPY (SEMICRF_BANDX): the band in spine-major order
+// ---------------------------------------------------------------------------------------------
+// A spine reads its band as 16-byte pieces (its 4 chains) of 128-byte lines: 64 lines per 1 KB load, 1024 line fills per row
+// block through its compute unit's L1.  In the copy a spine's tile is 4 KB contiguous -- [column][row][4 chains], the loader's
+// LDS image -- so the same load touches 8 lines.  One copy unit = (row block kr, 32-chain group g, band tile t, column quarter
+// q): 64 cells x 128 bytes in, 1 KB to each of the group's 8 spines out; lane = (cell of 8, chain quad): 8 lanes read one whole
+// line, and the 8 lanes of a quad write 128 contiguous bytes.  Cells and clamps are exactly the loader's own (bit-identical LDS).
+template <int DIR>
+__device__ __forceinline__ void band_copy_unit(const float* __restrict__ score, float* __restrict__ band, int T, int B,
+                                               int bandSpines, int kr, int g, int t, int q, int lane)
+{
+    const int q8 = lane & 7, cs = lane >> 3;
+    const int sgG = g * (GP / GS) + q8;                      // the batch's spine number
+    const int cbase = sgG * GS;
+    if (cbase >= B) return;
+    const size_t Bs = (size_t)B;
+    const size_t last4 = (size_t)T * T * Bs - 4;
+    const int kc0 = t < RING ? kr - t : kr - t;              // tile t: column block kr - t (t < RING: the ring's tiles, newest first)
+    const int kc = kc0 > 0 ? kc0 : 0;
+    v4u_a4 v[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int ci = q * 64 + it * 8 + cs;                 // cell of the tile in LDS order: column (ci >> 4), row (ci & 15)
+        const int col = ci >> 4, tr = ci & 15;
+        const int prow_t = kr * PB + tr < T ? kr * PB + tr : T - 1;
+        int pj = kc * PB + col;
+        pj = pj < prow_t ? pj : (prow_t > 0 ? prow_t - 1 : 0);
+        size_t off = cell_index<DIR>(prow_t, pj, T) * Bs + cbase;
+        off = off < last4 ? off : last4;
+        v[it] = *(const v4u_a4*)(score + off);
+    }
+    // loader tile index i: column block kr - (RING-1) + i for the ring's tiles, RING + n for near tile n (column block kr - RING - n)
+    const int ti = t < RING ? RING - 1 - t : t;
+    float* const dst = band + (((size_t)kr * bandSpines + sgG) * NBT + ti) * (TILE_BYTES / 4) + (q * 64 + cs) * 4;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) *(v4u*)(dst + it * 32) = v[it];
+}
+
+template <int DIR>
+__global__ __launch_bounds__(256) void band_copy_kernel(const float* __restrict__ score, float* __restrict__ band, int T, int B,
+                                                        int bandSpines, int nGroups)
+{
+    const int unit = blockIdx.x;                             // (kr, t, g)
+    const int g = unit % nGroups, t = (unit / nGroups) % NBT, kr = unit / (nGroups * NBT);
+    band_copy_unit<DIR>(score, band, T, B, bandSpines, kr, g, t, threadIdx.x >> 6, threadIdx.x & 63);
+}
+
+size_t band_copy_bytes(int T, int B)
+{
+    const int K = (T + PB - 1) / PB;
+    return (size_t)K * ((B + GS - 1) / GS) * NBT * TILE_BYTES;
+}
+void launch_band_copy(int dir, const float* score, float* band, int T, int B, hipStream_t stream)
+{
+    const int K = (T + PB - 1) / PB, nG = (B + GP - 1) / GP, nS = (B + GS - 1) / GS;
+    if (dir == 0) hipLaunchKernelGGL(band_copy_kernel<0>, dim3(K * NBT * nG), dim3(256), 0, stream, score, band, T, B, nS, nG);
+    else hipLaunchKernelGGL(band_copy_kernel<1>, dim3(K * NBT * nG), dim3(256), 0, stream, score, band, T, B, nS, nG);
 }
 
 constexpr size_t CTRL_BYTES = MAX_CHUNKS * CTRL_WORDS * sizeof(unsigned);
@@ -1807,7 +2013,7 @@ static int device_cus()
 size_t persist_workspace_bytes(int T, int B)
 {
     return CTRL_BYTES + align_up((size_t)2 * T * sizeof(u64)) + (size_t)max_parts(T) * align_up((size_t)T * B * sizeof(u64)) +
-           align_up((size_t)T * B * sizeof(unsigned));
+           2 * align_up((size_t)T * B * sizeof(unsigned));          // two u buffers: consecutive launches into a leased workspace alternate
 }
 
 // Even NBatch: the loader's 16-byte global->LDS loads and the panels' 16-byte loads need 8-byte aligned
@@ -1830,14 +2036,15 @@ static unsigned next_tag()
 
 // Launch-geometry knobs of the development tools (tools/bench_sweep.py): the environment is read only by a library built
 // with -DSEMICRF_DEBUG_BUILD=1 (once, at the first launch); the release library ignores it (-1 = the built-in choice).
-struct Knobs { int hybrid_waves, hybrid_start, panel_waves, zero_waves; };
+struct Knobs { int hybrid_waves, hybrid_start, panel_waves, zero_waves, band_waves; };
 static Knobs read_knobs()
 {
 #if defined(SEMICRF_DEBUG_BUILD) && SEMICRF_DEBUG_BUILD
     auto get = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : -1; };
-    return Knobs{get("SEMICRF_HYBRID_PANEL_WAVES"), get("SEMICRF_HYBRID_START"), get("SEMICRF_PANEL_WAVES"), get("SEMICRF_ZERO_WAVES")};
+    return Knobs{get("SEMICRF_HYBRID_PANEL_WAVES"), get("SEMICRF_HYBRID_START"), get("SEMICRF_PANEL_WAVES"), get("SEMICRF_ZERO_WAVES"),
+                 get("SEMICRF_BAND_WAVES")};
 #else
-    return Knobs{-1, -1, -1, -1};
+    return Knobs{-1, -1, -1, -1, -1};
 #endif
 }
 
@@ -1874,6 +2081,28 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         P.gstride = grad->gstride; P.gscale = grad->gscale;
     }
     P.score = score; P.noise = noise; P.T = T; P.B = B; P.K = (T + PB - 1) / PB;
+    P.band = nullptr; P.bandSpines = (B + GS - 1) / GS; P.bandK0 = 0;
+#if SEMICRF_BANDX
+    {
+        // EXPERIMENT: the copy as a pre-pass into a process-wide scratch (SEMICRF_BAND_CACHE=1: only when the inputs change)
+        static float* scratch = nullptr; static size_t scratch_bytes = 0;
+        static const void* k_score = nullptr; static int k_T = 0, k_B = 0, k_dir = -1;
+        static const bool cache = getenv("SEMICRF_BAND_CACHE") && atoi(getenv("SEMICRF_BAND_CACHE")) != 0;
+        static const int k0 = getenv("SEMICRF_BAND_K0") ? atoi(getenv("SEMICRF_BAND_K0")) : 0;
+        const size_t need = band_copy_bytes(T, B);
+        if (need > scratch_bytes) {
+            if (scratch) { (void)hipDeviceSynchronize(); (void)hipFree(scratch); }
+            if (hipMalloc(&scratch, need) != hipSuccess) return 1;
+            scratch_bytes = need; k_score = nullptr;
+        }
+        const int d = grad ? 1 : dir;
+        if (!cache || k_score != score || k_T != T || k_B != B || k_dir != d) {
+            launch_band_copy(d, score, scratch, T, B, stream);
+            k_score = score; k_T = T; k_B = B; k_dir = d;
+        }
+        P.band = scratch; P.bandK0 = k0;
+    }
+#endif
     P.tag = lease_tag ? (lease_tag % 65534u) + 1u : next_tag();
     P.dbg = 0u;
     P.selfclean = 0;
@@ -1887,7 +2116,11 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
     const size_t ts_bytes = align_up((size_t)2 * T * sizeof(u64));
     P.farg = (u64*)(w + CTRL_BYTES + ts_bytes);
     const size_t ug_off = CTRL_BYTES + ts_bytes + (size_t)max_parts(T) * align_up((size_t)T * B * sizeof(u64));
-    P.ug = (unsigned*)(w + ug_off);
+    // leased workspaces: launches alternate between the two u buffers, each puts the other one back to U_EMPTY (see the kernel)
+    const size_t ug_bytes = align_up((size_t)T * B * sizeof(unsigned));
+    const unsigned upar = lease != 0 ? (lease_tag & 1u) : 0u;
+    P.ug = (unsigned*)(w + ug_off + upar * ug_bytes);
+    P.ug_other = nullptr;
     P.u_out = u_out; P.last_out = last_out; P.code = code;
     // ONE fill: every word of the workspace starts as 0xffffffff -- u reads U_EMPTY, far-field granules carry a tag no
     // launch uses, the counters return 0 after their first increment, the error word reads CTRL_INIT
@@ -1898,6 +2131,7 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
     // instantiated HIP graph -- wrong results or a memory fault -- while this kernel replays correctly)
     if (lease != 2) hipLaunchKernelGGL(fill_ff_kernel, dim3(1024), dim3(256), 0, stream, (v4u*)ws, (fill_bytes + 15) / 16);
     P.selfclean = lease != 0 && P.dbg == 0u;
+    if (P.selfclean) P.ug_other = (unsigned*)(w + ug_off + (1u - upar) * ug_bytes);
     // what ctrl[CTRL_GEN] must read when the kernel starts: the previous launch's tag (a clean lease) or the fill
     P.expect_gen = (lease == 2 && P.selfclean) ? ((lease_tag - 1u) % 65534u) + 1u : CTRL_INIT;
     static const Knobs knobs = read_knobs();
@@ -1972,6 +2206,14 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
             }
         }
         P.zeroWaves = zw;
+        // the band's marginals: two spare waves of every panel workgroup (none: the ring waves store them)
+        int bw = 0;
+        if (grad && nPanelWG > 0 && P.nTasks > 0) {
+            bw = 2;
+            if (knobs.band_waves >= 0) bw = knobs.band_waves;
+            if (bw > NT / 64 - pw - zw) bw = NT / 64 - pw - zw;
+        }
+        P.bandWaves = bw;
         if (P.nTasks == 0) nPanelWG = 0;
         const int grid = nSpineWG + nPanelWG;
         // the panel workgroups' waves know their first task (the first draws of ~700 waves all hit one counter at the start)
