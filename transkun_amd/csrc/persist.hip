@@ -311,6 +311,12 @@ constexpr int LDS_RING = LDS_FAR + NFAR * 64 * 16;                     // [NPOS]
 #ifndef SEMICRF_STAGGER
 #define SEMICRF_STAGGER 32          // s_sleep units (64 cycles) per block of distance before a panel wave starts on its known first task
 #endif
+#ifndef SEMICRF_GRAD_LAZY
+#define SEMICRF_GRAD_LAZY 127        // s_sleep units between a gradient-sweep panel wave's polls for a tile that is not its task's newest
+#endif
+#ifndef SEMICRF_GRAD_HSTART
+#define SEMICRF_GRAD_HSTART 12       // gradient sweep: the spine workgroups' spare waves stream from this row block on
+#endif
 #ifndef SEMICRF_LOADER_PACE
 #define SEMICRF_LOADER_PACE 0       // s_sleep units between the loader's 1 KB band loads (0: a burst per row block)
 #endif
@@ -1046,7 +1052,10 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
 // ---------------------------------------------------------------------------------------------
 // PANEL role (per wave)
 // ---------------------------------------------------------------------------------------------
-constexpr int GRAD_AUX = 2;                  // nt: the gradient is written once
+#ifndef SEMICRF_GRAD_AUX
+#define SEMICRF_GRAD_AUX 2
+#endif
+constexpr int GRAD_AUX = SEMICRF_GRAD_AUX;   // nt: the gradient is written once
 constexpr int CELL_AUX = 2;                  // nt: every cell is read once -- keep the stream from evicting the (re-read) u values from L2
 #ifndef SEMICRF_PNS
 #define SEMICRF_PNS 3
@@ -1374,7 +1383,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                         // (lazy: 240 us, prompt: 212 us), the bandwidth-bound gradient sweep wants the fabric quiet
                         // (prompt: 505-525 us, lazy: 465-472 us).
                         if (m == q) __builtin_amdgcn_s_sleep(2);
-                        else if (GRAD) __builtin_amdgcn_s_sleep(127);
+                        else if (GRAD) __builtin_amdgcn_s_sleep(SEMICRF_GRAD_LAZY);
                         else __builtin_amdgcn_s_sleep(16);
                         if (spin_abort(ctrl, spins, SPIN_LIMIT, 5)) break;
                         // One round trip per poll: the 2 KB tile is fetched again together with a light probe -- one word per
@@ -1482,6 +1491,10 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                                     gv.y = __float_as_uint(gz[1] * fexp2(t[h][1] + arow[rr][1]));
                                     gv.z = __float_as_uint(gz[2] * fexp2(t[h][2] + arow[rr][2]));
                                     gv.w = __float_as_uint(gz[3] * fexp2(t[h][3] + arow[rr][3]));
+#ifdef SEMICRF_NO_PANEL_GSTORE
+                                    asm volatile("" ::"v"(gv));          // timing ablation: the far field's marginals are computed, not stored
+                                    continue;
+#endif
                                     if (c + 3 < c1) __builtin_amdgcn_raw_buffer_store_b128(gv, gs, G.voff, so, GRAD_AUX);
                                     else {                                  // ragged tail of the chain range
                                         __builtin_amdgcn_raw_buffer_store_b32(gv.x, gs, G.voff, so, 0);
@@ -2178,7 +2191,7 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         if (knobs.hybrid_waves >= 0 && knobs.hybrid_waves <= HPW_MAX) hpw = knobs.hybrid_waves;
         // (round 2, after the panel math got cheaper: later is better -- T=691: 143-150 us from block 28 vs 160 from 16;
         // T=512: 89 from 20 vs 92 from 12; T=1024: 185 from 40 vs 188 from 32; T=2048: 583-598 from 32-48 vs 602-617 from 64-80)
-        int hstart = grad ? 12 : P.K * 5 / 8;
+        int hstart = grad ? SEMICRF_GRAD_HSTART : P.K * 5 / 8;
         hstart = hstart < 8 ? 8 : (hstart > 40 ? 40 : hstart);
         if (knobs.hybrid_start >= 0) hstart = knobs.hybrid_start;
         P.hybridStart = hstart;
