@@ -7,7 +7,7 @@ os.environ["SEMICRF_DEBUG_FLAGS"] = "16"
 from transkun_amd import _lib, synth
 nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
 ap = argparse.ArgumentParser()
-ap.add_argument("--T", type=int, default=1024); ap.add_argument("--B", type=int, default=352)
+ap.add_argument("--T", type=int, default=1024); ap.add_argument("--B", type=int, default=352); ap.add_argument("--fwd", type=int, default=0)
 a = ap.parse_args()
 T, B = a.T, a.B
 K = (T + 15) // 16
@@ -16,10 +16,14 @@ s, n = synth.crf_inputs(T, B, 1234, dev)
 lz, v = nsci._logz_fwd_raw(s, n, True); g = torch.ones(B, device=dev)
 ws = _lib.leased_workspace(_lib.OP_LOGZ_BWD, T, B, dev)
 dn = torch.empty_like(n); q = torch.empty(0, device=dev); ds = torch.zeros(T, T, B, device=dev)
-for _ in range(3): _lib.ops().logz_bwd(s, n, v, lz, g, ds, dn, q, False, nsci.GRAD_UPPER_IS_ZERO, ws)
+if a.fwd:
+    ws = _lib.leased_workspace(_lib.OP_LOGZ_FWD, T, B, dev)
+    for _ in range(3): _lib.ops().logz_fwd(s, n, lz, v, True, ws)
+else:
+    for _ in range(3): _lib.ops().logz_bwd(s, n, v, lz, g, ds, dn, q, False, nsci.GRAD_UPPER_IS_ZERO, ws)
 torch.cuda.synchronize()
 CT = 16 * 256 * 4
-ts = ws[CT:CT + T * 8].view(torch.int64).cpu().numpy().astype(np.float64) / 100.0
+ts = ws[CT:CT + 2 * T * 8].view(torch.int64).cpu().numpy().astype(np.float64) / 100.0
 pub, got, far = ts[0:64], ts[64:128], ts[128:192]
 t0 = pub[0]
 print(f"GRAD T={T} B={B}: publish time of block k (us):", [round(float(pub[k] - t0), 1) for k in range(0, min(K, 64), 4)])
@@ -51,3 +55,12 @@ if ts.shape[0] >= 960 and ts[640:960].any():
     st, po = ts[640:704], ts[896:960]
     ks2 = np.arange(8, min(K, 64))
     print("  far wave: start after publish(k-4): mean %.2f; partials-in: mean %.2f" % ((st[ks2] - pub[ks2 - 4]).mean(), (po[ks2] - pub[ks2 - 4]).mean()))
+if T >= 1024:
+    A, Bq, D, E, NP = ts[1536:1600], ts[1600:1664], ts[1664:1728], ts[1728:1792], ts[1792:1856] * 100.0
+    ks = np.arange(8, min(K, 64))
+    p = pub[ks - 4]
+    print("  newest tile of the traced task, us after publish(k-4): iteration start %.2f, stage in %.2f, seen %.2f, math done %.2f, drained %.2f, stored %.2f; polls %.1f" % (
+        (A[ks] - p).mean(), (Bq[ks] - p).mean(), (seen[ks] - p).mean(), (D[ks] - p).mean(), (E[ks] - p).mean(), (stored[ks] - p).mean(), NP[ks].mean()))
+    for k in list(range(8, 40, 3)):
+        p0 = pub[k - 4]
+        print(f"   {k:3d}: start {A[k]-p0:6.2f} stage {Bq[k]-p0:6.2f} seen {seen[k]-p0:6.2f} math {D[k]-p0:6.2f} drained {E[k]-p0:6.2f} stored {stored[k]-p0:6.2f} polls {NP[k]:.0f}")

@@ -152,6 +152,7 @@ struct SweepParams {
     unsigned* ug;          // [T][B] u as float bits (position-major: index p*B + c); U_EMPTY until the spine publishes it
     unsigned* ug_other;    // leased workspaces: the u buffer of the PREVIOUS launch into this workspace (the two alternate); this launch
                            // puts it back to U_EMPTY, at its start and off every critical path (nullptr: nothing to clean)
+    int gradLazyShort;     // GRAD: panel waves poll for a tile that is not their task's newest every ~0.5 us instead of every ~4
     int bandWaves;         // GRAD: waves per panel workgroup that write the band's marginals (band_role); 0: the ring waves do
     u64* farg;             // [parts][T][B] granules of far-field partials (part = column range of TPT tiles)
     float* u_out;          // [T][B] by FRAME (natural-log units for LSE) or nullptr
@@ -1345,7 +1346,11 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
         for (int m = m0, s = 0; m < m1; ++m, s = (s + 1 == PNS ? 0 : s + 1)) {
             char* const stage = stage0 + s * PSTAGE_BYTES;
             // ---- wait for the stage, move it to registers ------------------------------------------------
+            const bool tprobe = SEMICRF_PANEL_PROBES && (dbg & 16u) && g == 0 && q4 == 0 && m == q && lane == 0 && k < 64 && T >= 1024;
+            if (tprobe) P.ts[1536 + k] = __builtin_amdgcn_s_memrealtime();
             panel_wait_younger(issued - (s == 0 ? mark0 : (s == 1 ? mark1 : mark2)));
+            if (tprobe) P.ts[1600 + k] = __builtin_amdgcn_s_memrealtime();
+            int npoll = 0;
             if (tr && m == m0) tsp[1] = __builtin_amdgcn_s_memrealtime();
             if (SEMICRF_PROBE_HIST && (dbg & 1024u) && lane == 0) {
                 // activity histogram (tools/activity_hist.py): tiles taken per 4 us bucket, panel and spare waves apart
@@ -1383,9 +1388,15 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                         // (lazy: 240 us, prompt: 212 us), the bandwidth-bound gradient sweep wants the fabric quiet
                         // (prompt: 505-525 us, lazy: 465-472 us).
                         if (m == q) __builtin_amdgcn_s_sleep(2);
-                        else if (GRAD) __builtin_amdgcn_s_sleep(SEMICRF_GRAD_LAZY);
+                        else if (GRAD) {
+                            // (round 5: the lazy poll pays only where the gradient sweep is bandwidth-bound; with few chains it is
+                            // hand-off-bound like the forward sweep -- T=691 x 96: 122 -> 112 us, T=1024 x 88: 222 -> 216 with the short one)
+                            if (P.gradLazyShort) __builtin_amdgcn_s_sleep(16);
+                            else __builtin_amdgcn_s_sleep(SEMICRF_GRAD_LAZY);
+                        }
                         else __builtin_amdgcn_s_sleep(16);
                         if (spin_abort(ctrl, spins, SPIN_LIMIT, 5)) break;
+                        ++npoll;
                         // One round trip per poll: the 2 KB tile is fetched again together with a light probe -- one word per
                         // lane, the block's last position for the first of the lane's four chains (a ring publishes its
                         // 16 positions x 4 chains with one store instruction).  The LDS copy is only read back and checked
@@ -1417,14 +1428,24 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                 const float uv[2][4] = {{__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z), __uint_as_float(g0.w)},
                                         {__uint_as_float(g1.x), __uint_as_float(g1.y), __uint_as_float(g1.z), __uint_as_float(g1.w)}};
 
-                if (MODE == 0 && !GRAD) {
-                    // The same accumulation with half the vector instructions (the panels are issue- and power-bound next
+                if (MODE == 0) {
+                    // The accumulation with half the vector instructions (the panels are issue- and power-bound next
                     // to their loads): the exponent argument t - M = cell*log2e + (u - M) is ONE packed fma per two chains
                     // on top of one packed subtract, the overflow test is a max3 tree over those arguments, the sums are
                     // packed adds: 17 plain instructions + 8 exps per row of 8 cells instead of 35 + 8.
+                    // GRAD (round 5: the same packed form, and ONE exponential per cell): the marginal gz 2^(t + arow) is the
+                    // accumulator's own term p = 2^(t - M) times the per-(row, chain) factor gz 2^(M + arow) -- four exponentials
+                    // per row of eight cells instead of eight more.  (Until then the gradient sweep ran the unpacked form with
+                    // two exponentials per cell: a frontier task's tile took 1.3 us of math against 0.3 in the forward sweep,
+                    // and the ring's block period in the head of the sweep IS that task's time per tile.  M + arow <= ~97: M sits
+                    // RESC_LIFT above the largest term when it is set and 2^(term + arow) is a marginal; a cell whose term
+                    // lies 2^-30 below that one underflows -- as it does in the sum -- where the reference holds a marginal below
+                    // 1e-9.)  The beta values are bit-identical to the plain beta sweep's.
                     typedef float v2f __attribute__((ext_vector_type(2)));
                     const v2f l2e = {LOG2E, LOG2E};
                     const v2f u2[2][2] = {{{uv[0][0], uv[0][1]}, {uv[0][2], uv[0][3]}}, {{uv[1][0], uv[1][1]}, {uv[1][2], uv[1][3]}}};
+                    const auto gs = __builtin_amdgcn_make_buffer_rsrc((void*)(GRAD ? dScore + panel_tile_off<DIR>(G, m, T, Bs) : nullptr), 0,
+                                                                      0x7fffffff, 0x00020000);
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         v2f e[2][2];
@@ -1452,6 +1473,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                                 if (i & 1) { e[0][i >> 1].y = e0; e[1][i >> 1].y = e1; } else { e[0][i >> 1].x = e0; e[1][i >> 1].x = e1; }
                             }
                         }
+                        v2f mg[2][2];                                   // GRAD: the marginals of the row's two cell groups
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             v2f sj = {aS[rr][2 * j], aS[rr][2 * j + 1]};
@@ -1459,26 +1481,15 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                             const v2f p1 = {fexp2(e[1][j].x), fexp2(e[1][j].y)};
                             sj = (sj + p0) + p1;
                             aS[rr][2 * j] = sj.x; aS[rr][2 * j + 1] = sj.y;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                } else if (MODE == 0) {
-                    // t = u + cell*log2e; lazily rescaled accumulators: one exp per cell, rare rescale branch.
-                    // One row at a time (scheduling fences in between) to bound the live registers.
-                    const auto gs = __builtin_amdgcn_make_buffer_rsrc((void*)(GRAD ? dScore + panel_tile_off<DIR>(G, m, T, Bs) : nullptr), 0,
-                                                                      0x7fffffff, 0x00020000);
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        float t[2][4];
-                        float exc = 0.0f;
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const v4u xv = xo[rr * 2 + h];
-                            const float xe[4] = {__uint_as_float(xv.x), __uint_as_float(xv.y), __uint_as_float(xv.z), __uint_as_float(xv.w)};
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                t[h][i] = fmaf(xe[i], LOG2E, uv[h][i]);
-                                exc = fmaxf(exc, t[h][i] - (aM[rr][i] + RESC_HI));
+                            if (GRAD) {
+                                const v2f mj = {aM[rr][2 * j], aM[rr][2 * j + 1]};
+                                const v2f aj = {arow[rr][2 * j], arow[rr][2 * j + 1]};
+                                const v2f fa = mj + aj;
+                                const v2f gzj = {gz[2 * j], gz[2 * j + 1]};
+                                const v2f fx = {fexp2(fa.x), fexp2(fa.y)};
+                                const v2f gF = gzj * fx;
+                                mg[0][j] = gF * p0;
+                                mg[1][j] = gF * p1;
                             }
                         }
                         if (GRAD) {
@@ -1487,10 +1498,10 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                                 if (cvalid && pbase + rr < T) {
                                     const unsigned so = panel_soff<DIR>(G, rr, h, T, Bs);
                                     v4u gv;
-                                    gv.x = __float_as_uint(gz[0] * fexp2(t[h][0] + arow[rr][0]));
-                                    gv.y = __float_as_uint(gz[1] * fexp2(t[h][1] + arow[rr][1]));
-                                    gv.z = __float_as_uint(gz[2] * fexp2(t[h][2] + arow[rr][2]));
-                                    gv.w = __float_as_uint(gz[3] * fexp2(t[h][3] + arow[rr][3]));
+                                    gv.x = __float_as_uint(mg[h][0].x);
+                                    gv.y = __float_as_uint(mg[h][0].y);
+                                    gv.z = __float_as_uint(mg[h][1].x);
+                                    gv.w = __float_as_uint(mg[h][1].y);
 #ifdef SEMICRF_NO_PANEL_GSTORE
                                     asm volatile("" ::"v"(gv));          // timing ablation: the far field's marginals are computed, not stored
                                     continue;
@@ -1504,18 +1515,9 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                                 }
                             }
                         }
-                        if (__any(exc > 0.0f)) {
-                            // some accumulator's reference point is too low (always on the first tile): move it up
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) acc_lift(aM[rr][i], aS[rr][i], fmaxf(t[0][i], t[1][i]));
-                        }
-#pragma unroll
-                        for (int h = 0; h < 2; ++h)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) aS[rr][i] += fexp2(t[h][i] - aM[rr][i]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    issued += nst;
+                    if (GRAD) issued += nst;
                 } else {
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr)
@@ -1529,6 +1531,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                         }
                 }
             }
+            if (tprobe) { P.ts[1664 + k] = __builtin_amdgcn_s_memrealtime(); P.ts[1792 + k] = (u64)npoll; }
             // ---- refill the stage PNS tiles ahead ----------------------------------------------------------
             if (refill) {
                 panel_fetch_cells<DIR>(score, G, stage, m + PNS, T, Bs);
@@ -1538,8 +1541,14 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
             }
         }
         if (tr) { tsp[2] = __builtin_amdgcn_s_memrealtime(); tsp[4] = (u64)(m1 - m0) | ((u64)k << 8) | ((u64)(frontier ? 1 : 0) << 16) | ((u64)part << 20); }
-        wait_vmcnt<0>();      // nothing of this task is in flight when its stages are reused
+        // Nothing that WRITES LDS is in flight here: every stage of the task was waited for before it was read, the coherent
+        // re-fetch of a tile's u is only issued for a tile that is still to come (and waited for there), a refill only for a tile
+        // m + PNS < m1.  What may be outstanding are the gradient stores of the last tiles -- and waiting for their
+        // acknowledgements (0.7 us, measured) sat in front of the reduction of EVERY newest tile, on the ring's critical path.
+        if (!(GRAD && MODE == 0)) wait_vmcnt<0>();
         (void)frontier;
+        if (SEMICRF_PANEL_PROBES && (dbg & 16u) && g == 0 && q4 == 0 && m1 == q + 1 && lane == 0 && k < 64 && T >= 1024)
+            P.ts[1728 + k] = __builtin_amdgcn_s_memrealtime();
 
         // ---- reduce over the 8 column slots (lane bits 3..5) --------------------------------------------------------------
         // The task's last tile is the newest one: what follows sits on the ring's critical path (16 hand-off rounds per
@@ -2227,6 +2236,7 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
             if (bw > NT / 64 - pw - zw) bw = NT / 64 - pw - zw;
         }
         P.bandWaves = bw;
+        P.gradLazyShort = nb < 256 ? 1 : 0;
         if (P.nTasks == 0) nPanelWG = 0;
         const int grid = nSpineWG + nPanelWG;
         // the panel workgroups' waves know their first task (the first draws of ~700 waves all hit one counter at the start)
