@@ -38,7 +38,7 @@ void launch_segment_events(const int* pairs, const int* offsets, int B, int nSym
 void launch_eval_path(const float* score, const float* noise, int T, int B, int K, const int* pairs,
                       const int* offsets, float* out, hipStream_t stream, const float* sub = nullptr);
 void launch_eval_path_bwd(const float* gout, int T, int B, int K, const int* pairs, const int* offsets,
-                          float* dScore, float* dNoise, hipStream_t stream, int gstride = 1, float gscale = 1.0f);
+                          float* dScore, float* dNoise, hipStream_t stream, int gstride = 1, float gscale = 1.0f, int noise_term_done = 0);
 void launch_interval_score_naive(const float* q, const float* k, const float* diag, int C, int T, int D,
                                  long long ldq, long long ldk, long long ldd, float qscale, int mode, int full,
                                  float* S, hipStream_t stream);
@@ -99,7 +99,10 @@ int read_and_clear_device_status();
 
 int launch_persist_logz_bwd(const float* score, const float* noise, const float* v, const float* logZ,
                             const float* gout, int T, int B, float* dScore, float* dNoise, float* q_out, void* ws,
-                            hipStream_t stream, int lease, unsigned lease_tag, int gstride = 1, float gscale = 1.0f, int keep_upper = 0);
+                            hipStream_t stream, int lease, unsigned lease_tag, int gstride = 1, float gscale = 1.0f, int keep_upper = 0,
+                            float noise_add = 0.0f);
+int launch_persist_logprob_fwd(const float* score, const float* noise, int T, int B, float* u_out, float* logZ, const int* pairs,
+                               int K, const int* offsets, float* logProb, void* ws, hipStream_t stream, int lease, unsigned lease_tag);
 
 static bool use_persist(int T, int B) { return g_impl.load() == 0 && persist_supported(T, B); }
 
@@ -279,8 +282,11 @@ static int check_common(const float* score, const float* noise, int T, int B)
     return SEMICRF_OK;
 }
 
-int semicrf_logz_fwd(const float* score, const float* noise, int T, int B, float* logZ, float* v, void* ws,
-                     size_t ws_bytes, semicrf_stream_t stream)
+// the intervals of semicrf_logprob_fwd, when the sweep's launch can compute the path scores on the side (*folded = 1)
+struct PathFold { const int32_t* pairs; int64_t K; const int32_t* offsets; float* logProb; int folded; };
+
+static int logz_fwd_impl(const float* score, const float* noise, int T, int B, float* logZ, float* v, void* ws,
+                         size_t ws_bytes, semicrf_stream_t stream, PathFold* pf)
 {
     if (int rc = check_common(score, noise, T, B)) return rc;
     SEMICRF_CHECK_ARG(logZ != nullptr, "logZ is NULL");
@@ -297,10 +303,13 @@ int semicrf_logz_fwd(const float* score, const float* noise, int T, int B, float
     if (fast) {
         unsigned ltag = 0;
         const int lease = lease_acquire(ws, SEMICRF_OP_LOGZ_FWD, T, B, &ltag, st);
-        if (launch_persist_sweep(0, 0, score, noise, T, B, vv, logZ, nullptr, pws, st, lease, ltag)) {
+        const int rc = pf ? launch_persist_logprob_fwd(score, noise, T, B, vv, logZ, pf->pairs, (int)pf->K, pf->offsets, pf->logProb, pws, st, lease, ltag)
+                          : launch_persist_sweep(0, 0, score, noise, T, B, vv, logZ, nullptr, pws, st, lease, ltag);
+        if (rc) {
             lease_failed(ws);
             set_error("persistent sweep could not be enqueued (too many chain chunks for this device)"); return SEMICRF_ELAUNCH;
         }
+        if (pf) pf->folded = 1;
     } else {
         lease_failed(ws);
         launch_rowseq_sweep(0, 0, score, noise, T, B, vv, nullptr, logZ, st);
@@ -309,9 +318,15 @@ int semicrf_logz_fwd(const float* score, const float* noise, int T, int B, float
     return SEMICRF_OK;
 }
 
+int semicrf_logz_fwd(const float* score, const float* noise, int T, int B, float* logZ, float* v, void* ws,
+                     size_t ws_bytes, semicrf_stream_t stream)
+{
+    return logz_fwd_impl(score, noise, T, B, logZ, v, ws, ws_bytes, stream, nullptr);
+}
+
 static int logz_bwd_impl(const float* score, const float* noise, const float* v, const float* logZ,
                          const float* gout, int gstride, float gscale, int T, int B, float* dScore, float* dNoise, float* q_out,
-                         int flags, void* ws, size_t ws_bytes, semicrf_stream_t stream)
+                         int flags, void* ws, size_t ws_bytes, semicrf_stream_t stream, float noise_add = 0.0f, int* noise_folded = nullptr)
 {
     if (int rc = check_common(score, noise, T, B)) return rc;
     SEMICRF_CHECK_ARG((flags & ~SEMICRF_GRAD_UPPER_IS_ZERO) == 0, "unknown flags %d", flags);
@@ -330,10 +345,11 @@ static int logz_bwd_impl(const float* score, const float* noise, const float* v,
         // beta sweep fused with the marginals: score is read once, dScore written once
         unsigned ltag = 0;
         const int lease = lease_acquire(ws, SEMICRF_OP_LOGZ_BWD, T, B, &ltag, st);
-        if (launch_persist_logz_bwd(score, noise, v, logZ, gout, T, B, dScore, dNoise, q, pws, st, lease, ltag, gstride, gscale, keep_upper)) {
+        if (launch_persist_logz_bwd(score, noise, v, logZ, gout, T, B, dScore, dNoise, q, pws, st, lease, ltag, gstride, gscale, keep_upper, noise_add)) {
             lease_failed(ws);
             set_error("persistent sweep could not be enqueued (too many chain chunks for this device)"); return SEMICRF_ELAUNCH;
         }
+        if (noise_folded) *noise_folded = 1;        // the ring waves added noise_add * gout to every gap
     } else {
         lease_failed(ws);
         launch_rowseq_sweep(0, 1, score, noise, T, B, q, nullptr, nullptr, st);
@@ -364,8 +380,11 @@ int semicrf_logprob_fwd(const float* score, const float* noise, int T, int B, co
 {
     SEMICRF_CHECK_ARG(offsets && logProb && logZ, "offsets/logProb/logZ must be non-NULL");
     SEMICRF_CHECK_ARG(K >= 0 && K < (1ll << 31) && (K == 0 || pairs), "bad interval count");
-    if (int rc = semicrf_logz_fwd(score, noise, T, B, logZ, v, ws, ws_bytes, stream)) return rc;
-    launch_eval_path(score, noise, T, B, (int)K, pairs, offsets, logProb, (hipStream_t)stream, logZ);
+    // ONE launch where the persistent sweep runs (round 5): spare waves of the sweep's launch compute the path scores while it runs,
+    // the ring wave that finalises logZ subtracts (persist.hip: path_role); the row-sequential fallback keeps the path kernel
+    PathFold pf{pairs, K, offsets, logProb, 0};
+    if (int rc = logz_fwd_impl(score, noise, T, B, logZ, v, ws, ws_bytes, stream, &pf)) return rc;
+    if (!pf.folded) launch_eval_path(score, noise, T, B, (int)K, pairs, offsets, logProb, (hipStream_t)stream, logZ);
     SEMICRF_CHECK_LAUNCH("semicrf_logprob_fwd");
     return SEMICRF_OK;
 }
@@ -384,8 +403,12 @@ int semicrf_logprob_bwd_f(const float* score, const float* noise, const float* v
     SEMICRF_CHECK_ARG(offsets, "offsets must be non-NULL");
     SEMICRF_CHECK_ARG(K >= 0 && K < (1ll << 31) && (K == 0 || pairs), "bad interval count");
     // d logProb = d evalPath - d logZ: the marginals with -gout, then +gout on the path's cells and uncovered gaps
-    if (int rc = logz_bwd_impl(score, noise, v, logZ, gout, gout_stride, -1.0f, T, B, dScore, dNoise, nullptr, flags, ws, ws_bytes, stream)) return rc;
-    launch_eval_path_bwd(gout, T, B, (int)K, pairs, offsets, dScore, dNoise, (hipStream_t)stream, gout_stride, 1.0f);
+    // (round 5: the path score's `+ gout on every gap` is added by the gradient sweep's ring waves as they store the noise marginals;
+    // what is left for a second launch is the scatter onto the path's own cells and covered gaps)
+    int noise_folded = 0;
+    if (int rc = logz_bwd_impl(score, noise, v, logZ, gout, gout_stride, -1.0f, T, B, dScore, dNoise, nullptr, flags, ws, ws_bytes, stream,
+                               1.0f, &noise_folded)) return rc;
+    launch_eval_path_bwd(gout, T, B, (int)K, pairs, offsets, dScore, dNoise, (hipStream_t)stream, gout_stride, 1.0f, noise_folded);
     SEMICRF_CHECK_LAUNCH("semicrf_logprob_bwd");
     return SEMICRF_OK;
 }

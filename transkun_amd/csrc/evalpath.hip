@@ -8,12 +8,11 @@
 // at most T-1 values per chain.  Sums are accumulated in double (torch's CPU cumsum does the same), in an order
 // that is fixed by the thread layout: evalPath is bit-reproducible run to run.
 #include "common.h"
+#include "pathscore.h"
 
 namespace semicrf {
 
-// One 256-thread workgroup per chain: the threads stride over the chain's noise column and over its intervals (one
-// s[e,b,c] gather and the short covered-noise sum each), then a fixed-order tree reduction in double -- the result does
-// not depend on scheduling (no atomics), needs no zeroed output, and the whole call is one launch.
+// One wave per chain (four chains per 256-thread workgroup): pathscore.h -- the same function the forward sweep's path role runs.
 constexpr int EP_THREADS = 256;
 
 __global__ __launch_bounds__(EP_THREADS) void eval_path_kernel(const float* __restrict__ score,
@@ -22,24 +21,10 @@ __global__ __launch_bounds__(EP_THREADS) void eval_path_kernel(const float* __re
                                                                const int* __restrict__ offsets, float* __restrict__ out,
                                                                const float* __restrict__ sub)
 {
-    __shared__ double red[EP_THREADS];
-    const int c = blockIdx.x, tid = threadIdx.x;
-    double acc = 0.0;
-    for (int t = tid; t < T - 1; t += EP_THREADS) acc += (double)noise[(size_t)t * B + c];          // cum[T-1]
-    const int k0 = offsets[c], k1 = offsets[c + 1];
-    for (int k = k0 + tid; k < k1 && k < K; k += EP_THREADS) {
-        const int b = pairs[2 * k], e = pairs[2 * k + 1];
-        double covered = 0.0;
-        for (int t = b; t < e; ++t) covered += (double)noise[(size_t)t * B + c];
-        acc += (double)score[((size_t)e * T + b) * B + c] - covered;
-    }
-    red[tid] = acc;
-    __syncthreads();
-    for (int d = EP_THREADS / 2; d > 0; d >>= 1) {
-        if (tid < d) red[tid] += red[tid + d];
-        __syncthreads();
-    }
-    if (tid == 0) out[c] = sub ? (float)red[0] - sub[c] : (float)red[0];       // sub = logZ: logProb (reference :587-588), one fp32 subtraction
+    const int c = blockIdx.x * (EP_THREADS / 64) + (threadIdx.x >> 6);
+    if (c >= B) return;
+    const double r = path_score_wave(score, noise, T, B, K, pairs, offsets, c);
+    if ((threadIdx.x & 63) == 0) out[c] = sub ? (float)r - sub[c] : (float)r;       // sub = logZ: logProb (reference :587-588), one fp32 subtraction
 }
 
 // dNoise[t][c] += gout[c]  (d cum[T-1] / d noise): fully parallel
@@ -77,13 +62,14 @@ __global__ __launch_bounds__(256) void eval_path_bwd_pairs_kernel(const float* _
 void launch_eval_path(const float* score, const float* noise, int T, int B, int K, const int* pairs,
                       const int* offsets, float* out, hipStream_t stream, const float* sub)
 {
-    hipLaunchKernelGGL(eval_path_kernel, dim3(B), dim3(EP_THREADS), 0, stream, score, noise, T, B, K, pairs, offsets, out, sub);
+    hipLaunchKernelGGL(eval_path_kernel, dim3((B + EP_THREADS / 64 - 1) / (EP_THREADS / 64)), dim3(EP_THREADS), 0, stream, score, noise, T, B, K, pairs, offsets, out, sub);
 }
 
 void launch_eval_path_bwd(const float* gout, int T, int B, int K, const int* pairs, const int* offsets,
-                          float* dScore, float* dNoise, hipStream_t stream, int gstride, float gscale)
+                          float* dScore, float* dNoise, hipStream_t stream, int gstride, float gscale, int noise_term_done)
 {
-    if (dNoise && T > 1) {
+    // noise_term_done: the caller's gradient sweep has already added d cum[T-1] / d noise = gout to every gap (persist.hip: noiseAdd)
+    if (dNoise && T > 1 && !noise_term_done) {
         const size_t n = (size_t)(T - 1) * B;
         int g = (int)((n + 255) / 256);
         if (g > 2048) g = 2048;

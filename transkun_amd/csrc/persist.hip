@@ -32,6 +32,7 @@
 #include <atomic>
 #include <stdlib.h>
 #include "common.h"
+#include "pathscore.h"
 
 #ifndef SEMICRF_PANEL_PROBES
 #define SEMICRF_PANEL_PROBES 0      // 1: keep the panel timing probes (debug flags 4 and 32) in the hot loop
@@ -117,6 +118,7 @@ constexpr unsigned U_EMPTY = 0xffffffffu;  // not-yet-published u (a NaN pattern
 // slow every dequeue down to tens of microseconds).
 constexpr size_t CTRL_WORDS = 256;   // control words per chain chunk
 constexpr int CTRL_EXIT = 64;         // [64]: workgroups that have left (leased workspaces: the last one resets the control words)
+constexpr int CTRL_PATHQ = 160;       // [160]: path task queue head (a line of its own)
 constexpr int CTRL_GEN = 96;          // [96]: leased workspaces: the tag of the launch that last cleaned up here (CTRL_INIT after a fill);
                                       // every workgroup of the next launch compares it with what the host expects (error 13)
 
@@ -166,6 +168,16 @@ struct SweepParams {
     float gscale;
     float* dScore;         // [T][T][B]: lower triangle + diagonal written here (the upper triangle by zero_upper_kernel)
     float* dNoise;         // [T-1][B]
+    // logProb as ONE launch (round 5; LSE, DIR 0 only): a spare wave of the panel workgroups computes the path score of every chain
+    // (path_role, pathscore.h) while the sweep runs and leaves it as a {tag, value} granule; the ring wave that finalises the last
+    // position takes it and writes logProb = path - logZ (NeuralSemiCRFInterval.py:587-588)
+    const int* pathPairs;  // [K][2] (begin, end) or nullptr: no path role
+    const int* pathOffsets;// [B+1]
+    int pathK;
+    int pathSpine;         // the spine workgroups' spare wave takes path tasks too (launches without panel workgroups)
+    float* pathOut;        // [B] logProb
+    u64* pathg;            // [B] granules (workspace)
+    float noiseAdd;        // GRAD: dNoise gets noiseAdd * gout[c] on top of the marginal (d cum[T-1] / d noise of the path score), 0: nothing
     const float* band;     // SEMICRF_BANDX: [K][bandSpines][NBT][16 columns][16 rows][4 chains]: the band, spine-major
     int bandSpines;        // ... spines of the whole batch (the copy is indexed by the batch's spine number)
     int bandK0;            // ... row blocks < bandK0 are still loaded from the score tensor itself
@@ -749,6 +761,9 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
     int* const code = P.code;
     float* const dScore = P.dScore;
     float* const dNoise = P.dNoise;
+    const u64* const pathg = P.pathg;
+    float* const pathOut = P.pathOut;
+    const unsigned ptag = P.tag;
     const int rw = __builtin_amdgcn_readfirstlane(ring_pos);                // position of the wave in the ring
     const int lane = threadIdx.x & 63;
     const int r = spine_row(lane), ch = spine_chain(lane);
@@ -763,7 +778,12 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
     int* const cons = (int*)(lds + LDS_CTL) + NRBUF;
     const float4* const far = (const float4*)(lds + LDS_FAR);
     float gz = 0.f, lzc = 0.f;
-    if (GRAD && cvalid) { gz = P.gout[(size_t)c * P.gstride] * P.gscale; lzc = P.logZ[c]; }               // the only global loads of a ring wave
+    float nadd = 0.f;     // logProb's backward: + gout on every gap (the path score's cum[T-1] term; the product, then the sum: two
+                          // roundings, exactly what a separate `dNoise += gout` pass over the stored marginal gave)
+    if (GRAD && cvalid) {                                                                                 // the only global loads of a ring wave
+        const float go = P.gout[(size_t)c * P.gstride];
+        gz = go * P.gscale; lzc = P.logZ[c]; nadd = P.noiseAdd * go;
+    }
     // GRAD: who stores the marginals of the band (the cells the ring itself reads)?  The panel workgroups' band waves when the
     // launch has them (band_role: whole lines, off the ring's critical path); the ring waves themselves otherwise (short sequences)
     // (a template parameter: as a run-time flag it put a branch around every cell's store and cut the shadow batch into 16 pieces)
@@ -902,7 +922,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
                         if (GRAD && ringBand && rvalid && j < prow) grad_store(j, gz * fexp2(p + arow));
                         if (last && u == PB - 1 && r == 0) {
                             if (GRAD && rvalid)       // noise marginal of the gap between prow-1 and prow
-                                dNoise[(size_t)gap_of<DIR>(prow, T) * Bs + c] = gz * fexp2(uq[q] + nz * LOG2E + arow);
+                                dNoise[(size_t)gap_of<DIR>(prow, T) * Bs + c] = gz * fexp2(uq[q] + nz * LOG2E + arow) + nadd;
                             p = uq[q] + wl;
                         }
                         t[u] = p;
@@ -997,7 +1017,7 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
                     });
                 }
                 const float um1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine), 0x111, 0xf, 0xf, false));   // row_shr:1
-                if (rvalid && r >= 1) dNoise[(size_t)gap_of<DIR>(prow, T) * Bs + c] = gz * fexp2(um1 + nz * LOG2E + arow);
+                if (rvalid && r >= 1) dNoise[(size_t)gap_of<DIR>(prow, T) * Bs + c] = gz * fexp2(um1 + nz * LOG2E + arow) + nadd;
             }
         } else {
             // (max,+): the same walk over the block's triangle on DPP row broadcasts.  Row j's value is final after step j-1 (the
@@ -1042,6 +1062,20 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
             const float sc = MODE == 0 ? LN2 : 1.0f;
             if (u_out) u_out[(size_t)frow * Bs + c] = mine * sc;
             if (last_out && prow == T - 1) last_out[c] = mine * sc;
+            if (MODE == 0 && DIR == 0 && !GRAD && pathg && prow == T - 1) {
+                // logProb: the chain's path score was left by a path wave long ago (it needs no u); the only global LOAD of a ring
+                // wave, after its last publish
+                u64 gr;
+                int spins = 0;
+                bool ok = true;
+                while (true) {
+                    gr = load_granule(pathg + c);
+                    if ((unsigned)(gr >> 32) == ptag) break;
+                    __builtin_amdgcn_s_sleep(8);
+                    if (spin_abort(ctrl, spins, SPIN_LIMIT, 15)) { ok = false; break; }
+                }
+                pathOut[c] = ok ? __uint_as_float((unsigned)gr) - mine * sc : __uint_as_float(0x7fc00000u);
+            }
             if (GRAD)      // diagonal: gout * exp(alpha + beta - logZ + s - 2 softplus(s))
                 dScore[((size_t)frow * T + frow) * Bs + c] = gz * fexp2(arow + mine + draw - 2.0f * sp);
             if (MODE == 1) code[(size_t)c * T + frow] = (mykey + 1) | (sp > 0.0f ? 0x40000000 : 0);
@@ -1752,6 +1786,27 @@ __device__ __forceinline__ void band_role(const SweepParams& P)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// PATH role (forward sweep of logProb): the path scores, by one otherwise idle wave per workgroup
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void path_role(const SweepParams& P)
+{
+    const int nb = P.c1 - P.c0;
+    while (true) {
+        int i = 0;
+        if ((threadIdx.x & 63) == 0) i = (int)(atomicAdd(P.ctrl + CTRL_PATHQ, 1u) + 1u);
+        i = __builtin_amdgcn_readfirstlane(i);
+        if (i >= nb) break;
+        const int c = P.c0 + i;
+        const double r = path_score_wave(P.score, P.noise, P.T, P.B, P.pathK, P.pathPairs, P.pathOffsets, c);
+        // Every lane stores the (same) granule.  With `if (lane == 0) store` here the compiler threaded this branch into the next
+        // iteration's `if (lane == 0) draw` and ran the readfirstlane of the draw -- and everything behind it -- a second time with
+        // lane 0 masked off: an endless loop on chain c0 (gfx950, ROCm 7.2; found as a hang of the whole launch).
+        __builtin_amdgcn_wave_barrier();
+        store_granule(P.pathg + c, make_granule(P.tag, (float)r));
+    }
+}
+
 // Workgroup index -> role ticket (spines: tickets < nSpine = the chain group; panel workgroups: nSpine + a dense rank).
 // The eight rings of a 32-chain panel group read the 16-byte pieces of the SAME 128-byte lines of the band, and their far
 // waves take partials from the same tasks: they belong on ONE XCD (one L2).  Block b is observed to run on XCD b % 8 (a
@@ -1866,6 +1921,8 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
                     }
                 }
                 panel_role<MODE, DIR, GRAD>(P, s_dyn + LDS_HYBRID_PANEL, xw, 1);
+            } else if (MODE == 0 && DIR == 0 && !GRAD && P.pathPairs != nullptr && P.pathSpine && xw == P.hybridPanelWaves) {
+                path_role(P);
             }
         } else if (sg >= P.nSpine) {
             // (an odd number of spines: the last workgroup's second one has no chains)
@@ -1884,6 +1941,7 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
             panel_role<MODE, DIR, GRAD>(P, s_dyn, wave, 0, P.taskBase > 0 ? (ticket - nSpineWG) * P.panelWaves + wave : -1);
         else if (GRAD && wave - P.panelWaves >= 0 && wave - P.panelWaves < P.zeroWaves) zero_role(P);
         else if (GRAD && wave - P.panelWaves - P.zeroWaves >= 0 && wave - P.panelWaves - P.zeroWaves < P.bandWaves) band_role<DIR>(P);
+        else if (MODE == 0 && DIR == 0 && !GRAD && P.pathPairs != nullptr && wave == P.panelWaves) path_role(P);
     }
     if (clk) { P.ts[602] = __builtin_readcyclecounter(); P.ts[603] = __builtin_amdgcn_s_memrealtime(); }
     if (P.selfclean) {
@@ -2035,7 +2093,8 @@ static int device_cus()
 size_t persist_workspace_bytes(int T, int B)
 {
     return CTRL_BYTES + align_up((size_t)2 * T * sizeof(u64)) + (size_t)max_parts(T) * align_up((size_t)T * B * sizeof(u64)) +
-           2 * align_up((size_t)T * B * sizeof(unsigned));          // two u buffers: consecutive launches into a leased workspace alternate
+           2 * align_up((size_t)T * B * sizeof(unsigned)) +         // two u buffers: consecutive launches into a leased workspace alternate
+           align_up((size_t)B * sizeof(u64));                       // path-score granules (logProb as one launch)
 }
 
 // Even NBatch: the loader's 16-byte global->LDS loads and the panels' 16-byte loads need 8-byte aligned
@@ -2073,7 +2132,9 @@ static Knobs read_knobs()
 struct GradArgs {
     const float* vfwd; const float* logZ; const float* gout; float* dScore; float* dNoise; int gstride; float gscale;
     int keep_upper;       // the cells begin > end of dScore hold zeros already (SEMICRF_GRAD_UPPER_IS_ZERO): not written
+    float noise_add;      // dNoise += noise_add * gout on every gap (logProb's backward), 0: nothing
 };
+struct PathArgs { const int* pairs; const int* offsets; int K; float* out; };
 
 template <int MODE, int DIR, bool GRAD>
 static void launch_one(const SweepParams& P, int grid, hipStream_t stream)
@@ -2094,13 +2155,14 @@ static void launch_one(const SweepParams& P, int grid, hipStream_t stream)
 // launch count (consecutive launches in one workspace must not share a granule tag), 0 = the process-wide counter.
 static int launch_persist_sweep_impl(int mode, int dir, const float* score, const float* noise, int T, int B,
                                      float* u_out, float* last_out, int* code, void* ws, hipStream_t stream,
-                                     const GradArgs* grad, int lease, unsigned lease_tag)
+                                     const GradArgs* grad, int lease, unsigned lease_tag, const PathArgs* path = nullptr)
 {
     SweepParams P;
+    P.pathPairs = nullptr; P.pathOffsets = nullptr; P.pathK = 0; P.pathOut = nullptr; P.pathg = nullptr; P.pathSpine = 0; P.noiseAdd = 0.0f;
     P.vfwd = nullptr; P.logZ = nullptr; P.gout = nullptr; P.dScore = nullptr; P.dNoise = nullptr; P.gstride = 1; P.gscale = 1.0f;
     if (grad) {
         P.vfwd = grad->vfwd; P.logZ = grad->logZ; P.gout = grad->gout; P.dScore = grad->dScore; P.dNoise = grad->dNoise;
-        P.gstride = grad->gstride; P.gscale = grad->gscale;
+        P.gstride = grad->gstride; P.gscale = grad->gscale; P.noiseAdd = grad->noise_add;
     }
     P.score = score; P.noise = noise; P.T = T; P.B = B; P.K = (T + PB - 1) / PB;
     P.band = nullptr; P.bandSpines = (B + GS - 1) / GS; P.bandK0 = 0;
@@ -2143,6 +2205,11 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
     const unsigned upar = lease != 0 ? (lease_tag & 1u) : 0u;
     P.ug = (unsigned*)(w + ug_off + upar * ug_bytes);
     P.ug_other = nullptr;
+    if (path && mode == 0 && dir == 0 && !grad) {
+        // (offsets is never null here; pairs may be when K == 0 -- the role only looks at pairs[k] for k < K)
+        P.pathPairs = path->pairs ? path->pairs : path->offsets; P.pathOffsets = path->offsets; P.pathK = path->K; P.pathOut = path->out;
+        P.pathg = (u64*)(w + ug_off + 2 * ug_bytes);
+    }
     P.u_out = u_out; P.last_out = last_out; P.code = code;
     // ONE fill: every word of the workspace starts as 0xffffffff -- u reads U_EMPTY, far-field granules carry a tag no
     // launch uses, the counters return 0 after their first increment, the error word reads CTRL_INIT
@@ -2238,6 +2305,7 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         P.bandWaves = bw;
         P.gradLazyShort = nb < 256 ? 1 : 0;
         if (P.nTasks == 0) nPanelWG = 0;
+        P.pathSpine = nPanelWG == 0 ? 1 : 0;        // no panel workgroups (short sequences): the spine workgroups' spare wave
         const int grid = nSpineWG + nPanelWG;
         // the panel workgroups' waves know their first task (the first draws of ~700 waves all hit one counter at the start)
         P.taskBase = nPanelWG * P.panelWaves;
@@ -2257,12 +2325,20 @@ int launch_persist_sweep(int mode, int dir, const float* score, const float* noi
     return launch_persist_sweep_impl(mode, dir, score, noise, T, B, u_out, last_out, code, ws, stream, nullptr, lease, lease_tag);
 }
 
+// logZ and logProb = path - logZ in one launch (the path scores by spare waves while the sweep runs)
+int launch_persist_logprob_fwd(const float* score, const float* noise, int T, int B, float* u_out, float* logZ, const int* pairs,
+                               int K, const int* offsets, float* logProb, void* ws, hipStream_t stream, int lease, unsigned lease_tag)
+{
+    const PathArgs pa{pairs, offsets, K, logProb};
+    return launch_persist_sweep_impl(0, 0, score, noise, T, B, u_out, logZ, nullptr, ws, stream, nullptr, lease, lease_tag, &pa);
+}
+
 // Fused backward: beta sweep + marginals (dScore fully written incl. the zero upper triangle, dNoise).
 int launch_persist_logz_bwd(const float* score, const float* noise, const float* v, const float* logZ,
                             const float* gout, int T, int B, float* dScore, float* dNoise, float* q_out, void* ws,
-                            hipStream_t stream, int lease, unsigned lease_tag, int gstride, float gscale, int keep_upper)
+                            hipStream_t stream, int lease, unsigned lease_tag, int gstride, float gscale, int keep_upper, float noise_add)
 {
-    GradArgs ga{v, logZ, gout, dScore, dNoise, gstride, gscale, keep_upper};
+    GradArgs ga{v, logZ, gout, dScore, dNoise, gstride, gscale, keep_upper, noise_add};
     return launch_persist_sweep_impl(0, 1, score, noise, T, B, q_out, nullptr, nullptr, ws, stream, &ga, lease, lease_tag);
 }
 
