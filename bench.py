@@ -69,6 +69,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--cpu-sample-nbatch", type=int, default=88)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default): every rank its own [T,T,NBatch] problem; strong: the NBatch chains of ONE problem are cut "
+                         "across the ranks with transkun_amd.dist.shard_chains (352 -> 44 chains per GPU at 8), value = problems/s")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for --selftest-launch)")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="CPU-only check of the launcher: form the process group, all-reduce, print the world size seen")
@@ -144,8 +147,11 @@ def worker(args):
         if dist is not None:
             dist.all_reduce(t)
         if rank == 0:
+            from transkun_amd.dist import shard_chains
+            shards = [shard_chains(args.nbatch, seen_world, r) if args.scaling == "strong" else (0, args.nbatch) for r in range(seen_world)]
             print(json.dumps({"selftest": "launch", "n_gpus": seen_world, "allreduce_sum": float(t.item()),
-                              "backend": args.backend if dist is not None else None}), flush=True)
+                              "backend": args.backend if dist is not None else None, "scaling": args.scaling,
+                              "chains_per_rank": [e - b for b, e in shards]}), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -158,6 +164,14 @@ def worker(args):
     _lib.set_impl(args.impl)
 
     T, B = args.T, args.nbatch
+    B_total = B
+    if args.scaling == "strong" and seen_world > 1:
+        # SURVEY 8e's stand-alone form: ONE [T,T,NBatch] problem, its chains cut across the ranks (each rank holds its own shard's
+        # scores; chains are independent, so there is still no data-path collective) -- the regime where a rank's sweep is
+        # hand-off-bound (44-88 chains), which the weak curve does not show
+        from transkun_amd.dist import shard_chains
+        cb, ce = shard_chains(B, seen_world, rank)
+        B = ce - cb
     seed = 1234 + 1000 * rank
     score, noise = synth.crf_inputs(T, B, seed, dev, "randn")
     intervals = synth.synthetic_intervals(T, B, seed=seed)
@@ -189,7 +203,7 @@ def worker(args):
     sync_all()
     elapsed_local = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed_local, dev)
-    value = seen_world * args.steps / elapsed
+    value = (1 if args.scaling == "strong" else seen_world) * args.steps / elapsed
     log(f"timed region done: {elapsed / args.steps * 1e3:.3f} ms/step")
     # the same K steps four more times (each bracketed like the timed region): the spread of the headline on THIS box.  `value`
     # stays the first region's.
@@ -274,18 +288,21 @@ def worker(args):
 
     if rank == 0:
         line = {
-            "metric": "semi-CRF logProb+backward steps/sec at T=1024, NBatch=352" if (T, B) == (1024, 352)
-                      else f"semi-CRF logProb+backward steps/sec at T={T}, NBatch={B}",
+            "metric": "semi-CRF logProb+backward steps/sec at T=1024, NBatch=352" if (T, B_total) == (1024, 352)
+                      else f"semi-CRF logProb+backward steps/sec at T={T}, NBatch={B_total}",
             "value": round(value, 3), "unit": "steps/s", "n_gpus": seen_world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"NeuralSemiCRFInterval(score, noise).logProb(intervals) fwd+bwd through the public API "
-                                   f"(Python interval lists packed inside the timed region), T={T}, NBatch={B} per GPU, "
+                                   f"(Python interval lists packed inside the timed region), T={T}, NBatch={B} per GPU"
+                                   + (f" (= NBatch {B_total} cut across {seen_world} ranks)" if args.scaling == "strong" else "") + ", "
                                    f"fp32, exact-hash randn-like scores resident in HBM",
                        "T": T, "NBatch": B, "impl": args.impl,
                        "parallelism": f"chains sharded, {seen_world} rank(s) seen by the process group, no data-path collective"
                                       + ("; [3] fp32 loss all-reduce per step over RCCL" if seen_world > 1 else "")},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "extra": extra,
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            # BASELINE.json's second metric ("decode segments/sec", configs[2]: T=2048, NBatch=352, forcedStartPos set) as a named field
+            "decode": extra.pop("_decode", None), "extra": extra,
         }
         if diag is not None:
             line["multi_gpu_diagnostics"] = diag
@@ -489,6 +506,17 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
             extra[tag + "_segments_per_s_end_to_end"] = round((Bd / 88) / dt, 2)
             extra[tag + "_ms_device"] = round(dk * 1e3, 3)
             extra[tag + "_segments_per_s_device"] = round((Bd / 88) / dk, 1)
+            if kind == "randn":
+                dbytes = algorithmic_bytes_logz_fwd(Td, Bd)          # the Viterbi sweep reads the same cells as the forward sweep
+                extra["_decode"] = {
+                    "config": f"NeuralSemiCRFInterval.decode(forcedStartPos=[4]*{Bd}), T={Td}, NBatch={Bd} (= {Bd // 88} segments of 88 chains), "
+                              f"randn scores ({nint} intervals); decoded intervals bit-identical to the reference (tests)",
+                    "segments_per_s_device": round((Bd / 88) / dk, 1), "ms_device": round(dk * 1e3, 3),
+                    "segments_per_s_api": round((Bd / 88) / dt, 2), "ms_api_python_lists": round(dt * 1e3, 3),
+                    "ms_api_packed_arrays": round(dpk * 1e3, 3),
+                    "roofline": {"bound": "hbm", "kernel": "semicrf_viterbi (sweep + backtrack + pack)", "algorithmic_bytes": dbytes,
+                                 "achieved": round(dbytes / dk / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(dbytes / dk / 1e9 / HBM_PEAK_GBS, 4)}}
             del sd, nd, crf_d
         log("decode done; interval scorer next")
 

@@ -111,6 +111,13 @@ def test_bench_launcher_creates_its_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["allreduce_sum"] == 2.0
+    assert line["scaling"] == "weak" and line["chains_per_rank"] == [352, 352]
+    # --scaling strong: the 352 chains of ONE problem cut across the ranks (44 per GPU at 8)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-launch", "--backend", "gloo",
+                        "--scaling", "strong"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["chains_per_rank"] == [176, 176]
     env2 = dict(env, WORLD_SIZE="1", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-launch"],
                        capture_output=True, text=True, timeout=120, env=env2)

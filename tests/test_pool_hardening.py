@@ -1,0 +1,76 @@
+"""Host side of the gradient / score pools: CPU only, the product's own host kernels.
+  * torch.inference_mode(): inference tensors have no version counter -- the pool must step aside, not raise;
+  * a torch build without the private torch._C._storage_Use_Count: pool off, ONE warning, results unchanged;
+  * per-shape cap and held-bytes accounting."""
+import importlib
+import warnings
+
+import torch
+
+from transkun_amd import CRF, synth
+
+
+def _nsci():
+    return importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
+
+
+def test_forward_backward_under_inference_mode():
+    m = _nsci()
+    T, B = 256, 80                                   # 21 MB gradient: above the pool's 16 MB floor
+    s, n = synth.crf_inputs(T, B, 1, torch.device("cpu"), "randn")
+    m.grad_pool_clear()
+    with torch.inference_mode():
+        lz, g, gn = CRF.forward_backward(s, n)
+        assert m.grad_pool_bytes() == 0              # nothing pooled under inference_mode
+    lz2, g2, gn2 = CRF.forward_backward(s, n)
+    with torch.no_grad():
+        lz3, g3, gn3 = CRF.forward_backward(s, n)
+    assert torch.equal(g, g2) and torch.equal(g, g3) and torch.equal(gn, gn2) and torch.equal(lz, lz2)
+    assert bool((g.permute(2, 0, 1).triu(1) == 0).all())
+    m.grad_pool_clear()
+
+
+def test_pool_without_private_use_count(monkeypatch):
+    m = _nsci()
+    T, B = 256, 80
+    s, n = synth.crf_inputs(T, B, 2, torch.device("cpu"), "randn")
+    want = CRF.forward_backward(s, n)
+    monkeypatch.setattr(m, "_USE_COUNT", None)
+    m._WARNED.discard("use_count")
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        pool = m._GradPool()
+        pool2 = m._GradPool()
+    assert not pool.enabled and not pool2.enabled
+    assert sum("_storage_Use_Count" in str(w.message) for w in rec) == 1          # one warning, not one per pool
+    monkeypatch.setattr(m, "_GRAD_POOL", pool)
+    sc = s.clone().requires_grad_(); nc = n.clone().requires_grad_()
+    iv = synth.synthetic_intervals(T, B, seed=2)
+    for _ in range(2):                               # a second step would have hit the pool
+        sc.grad = None; nc.grad = None
+        (-CRF.NeuralSemiCRFInterval(sc, nc).logProb(iv).sum()).backward()
+    got = CRF.forward_backward(s, n)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    assert pool.held_bytes() == 0 and pool.hits == 0
+
+
+def test_pool_keeps_two_buffers_per_shape():
+    m = _nsci()
+    pool = m._GradPool()
+    if not pool.enabled:
+        return
+    T, B = 128, 260                                  # 17 MB
+    bufs = []
+    for _ in range(4):
+        t, flags, key = pool.take(T, B, torch.device("cpu"))
+        assert flags == 0 and key is not None
+        t.zero_()
+        bufs.append((key, t))
+    for key, t in bufs:
+        pool.give(key, t)
+    del bufs, t
+    assert pool.held_bytes() == 2 * 4 * T * T * B    # PER_KEY = 2
+    t, flags, key = pool.take(T, B, torch.device("cpu"))
+    assert flags == m.GRAD_UPPER_IS_ZERO             # untouched since the library's write: the zeros are still there
+    pool.clear()
+    assert pool.held_bytes() == 0

@@ -175,33 +175,71 @@ def _logz_fwd_raw(score, noise, want_v: bool):
 GRAD_UPPER_IS_ZERO = 1          # include/semicrf_hip.h: SEMICRF_GRAD_UPPER_IS_ZERO
 
 
+# torch._C._storage_Use_Count is a private binding (present in every torch 2.x this was run on): without it the pool cannot know
+# that nobody else holds a buffer, so it stays off -- one warning, every gradient is then written in full like before round 4.
+_USE_COUNT = getattr(torch._C, "_storage_Use_Count", None)
+_WARNED = set()
+
+
+def _warn_once(tag: str, msg: str) -> None:
+    if tag not in _WARNED:
+        _WARNED.add(tag)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
 def _storage_users(t: torch.Tensor) -> int:
     st = t.untyped_storage()
-    return torch._C._storage_Use_Count(st._cdata) - 1           # minus the temporary `st`
+    return _USE_COUNT(st._cdata) - 1           # minus the temporary `st`
+
+
+def _empty_or_trim(shape, device):
+    """torch.empty; on an out-of-memory error the pools (which hold memory outside the caching allocator's reach) are released
+    and the allocation is tried once more."""
+    try:
+        return torch.empty(shape, dtype=torch.float32, device=device)
+    except torch.OutOfMemoryError:
+        grad_pool_clear()
+        if device.type == "cuda":
+            torch.cuda.empty_cache()
+        return torch.empty(shape, dtype=torch.float32, device=device)
 
 
 class _GradPool:
+    PER_KEY = 2                      # buffers kept per (device, stream, T, B): what one training step can have in flight
+
     def __init__(self):
         import threading
         self.lock = threading.Lock()
         self.entries = []            # [key, keeper, version] -- most recently used last
         self.enabled = not os.environ.get("SEMICRF_NO_GRAD_POOL")
-        self.max_bytes = int(os.environ.get("SEMICRF_GRAD_POOL_BYTES", str(8 << 30)))
+        if self.enabled and _USE_COUNT is None:
+            self.enabled = False
+            _warn_once("use_count", "transkun_amd: torch._C._storage_Use_Count is not available in this torch build; the pool of "
+                                    "gradient / score buffers is off (every dense gradient is written in full, zeros included)")
+        # budget: SEMICRF_GRAD_POOL_BYTES, else 4 GiB (two [1024,1024,352] buffers are 2.75 GiB); never more than PER_KEY per shape
+        self.max_bytes = int(os.environ.get("SEMICRF_GRAD_POOL_BYTES", str(4 << 30)))
         self.min_bytes = 16 << 20    # smaller gradients: the zeros cost microseconds
         self.hits = self.misses = 0  # statistics (tests, bench)
+
+    def held_bytes(self) -> int:
+        """Bytes of device / host memory the pool keeps alive right now (outside the caching allocator's reach)."""
+        with self.lock:
+            return sum(e[1].numel() * 4 for e in self.entries)
 
     def take(self, T: int, B: int, device):
         """(dscore [T,T,B] fp32, flags): a pooled buffer with flags = GRAD_UPPER_IS_ZERO, or a fresh one with flags 0."""
         nbytes = 4 * T * T * B
+        # inference tensors have no version counter (and nothing computes gradients under inference_mode): never pooled
+        if not self.enabled or nbytes < self.min_bytes or torch.is_inference_mode_enabled():
+            return _empty_or_trim((T, T, B), device), 0, None
         if device.type == "cpu":
             # host tensors too: the host kernels write the zeros anyway, but a fresh 1.4 GB allocation is 350 000 first-touch page
             # faults that many threads take at once (T=1024 x 352: the backward took 1.4 s on 8 threads and 8 - 20 s on 22 - 64)
-            if not self.enabled or nbytes < self.min_bytes:
-                return torch.empty(T, T, B, dtype=torch.float32, device=device), 0, None
             key = ("cpu", 0, T, B)
         else:
-            if not self.enabled or device.type != "cuda" or nbytes < self.min_bytes or torch.cuda.is_current_stream_capturing():
-                return torch.empty(T, T, B, dtype=torch.float32, device=device), 0, None
+            if device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+                return _empty_or_trim((T, T, B), device), 0, None
             key = (device.index if device.index is not None else torch.cuda.current_device(),
                    torch.cuda.current_stream(device).cuda_stream, T, B)
         with self.lock:
@@ -215,16 +253,20 @@ class _GradPool:
                     self.misses += 1
                     return keeper, 0, key                                # written in place since: everything is written again
             self.misses += 1
-        return torch.empty(T, T, B, dtype=torch.float32, device=device), 0, key
+        return _empty_or_trim((T, T, B), device), 0, key
 
     def give(self, key, dscore: torch.Tensor) -> None:
         """After the library's last write into `dscore` (its upper triangle holds exact zeros now): remember the memory."""
-        if key is None:
+        if key is None or dscore.is_inference():
             return
         keeper = dscore.detach()
         nbytes = keeper.numel() * 4
         with self.lock:
             self.entries.append([key, keeper, keeper._version])
+            same = [i for i, e in enumerate(self.entries) if e[0] == key]
+            for i in same[:-self.PER_KEY]:                               # the oldest of this shape beyond PER_KEY
+                self.entries[i] = None
+            self.entries = [e for e in self.entries if e is not None]
             total = 0
             for i in range(len(self.entries) - 1, -1, -1):               # newest first; drop what exceeds the budget
                 total += self.entries[i][1].numel() * 4
@@ -251,23 +293,20 @@ class _GradPool:
 _GRAD_POOL = _GradPool()
 
 
+def grad_pool_bytes() -> int:
+    """Bytes the gradient pool and the scorer's score pool hold right now."""
+    from .. import scorer as _sc
+    return _GRAD_POOL.held_bytes() + (_sc._SCORE_POOL.held_bytes() if _sc._SCORE_POOL is not None else 0)
+
+
 def grad_pool_clear() -> None:
-    """Release the gradient buffers the pool holds (they are otherwise kept until the budget SEMICRF_GRAD_POOL_BYTES, 8 GiB by
-    default, is exceeded; SEMICRF_NO_GRAD_POOL=1 disables the pool) -- and the interval scorer's pool of score tensors, which
-    works the same way (transkun_amd/scorer.py)."""
+    """Release the gradient buffers the pool holds (at most two per (device, stream, T, B) and SEMICRF_GRAD_POOL_BYTES -- 4 GiB by
+    default -- in total; SEMICRF_NO_GRAD_POOL=1 disables the pool; an out-of-memory error inside the library releases them by
+    itself) -- and the interval scorer's pool of score tensors, which works the same way (transkun_amd/scorer.py)."""
     _GRAD_POOL.clear()
     from .. import scorer as _sc
     if _sc._SCORE_POOL is not None:
         _sc._SCORE_POOL.clear()
-
-
-def _raise_async_error(what: str) -> None:
-    """A hand-off wait that timed out on the device poisons its outputs with NaN and raises a pinned host word; wherever the
-    mirror has synchronised anyway it looks at the word (no synchronisation of its own) and turns it into an exception."""
-    code = _lib.async_error()
-    if code:
-        raise RuntimeError(f"{what}: a bounded hand-off wait timed out on the device (code {code}: GPU shared with work that kept "
-                           "part of the persistent kernel from running, or a CU mask?); the results are invalid")
 
 
 def _logz_bwd_raw(score, noise, v, logz, gout, want_q: bool = False):

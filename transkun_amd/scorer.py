@@ -187,6 +187,16 @@ def _proj_ok(a2: torch.Tensor, n_cols: int) -> bool:
             and _lib.get_impl() == 0 and not os.environ.get("SEMICRF_TORCH_PROJECTION"))
 
 
+def _stock_gemm_note(what: str, x: torch.Tensor) -> None:
+    """One warning per reason: a projection of this module left the library's exact-fp32 GEMMs (csrc/proj_gemm.hip: sizes 64 / 128 /
+    256, 16-byte aligned contiguous rows, < 2 GiB per operand) for torch's stock GEMM -- same result to fp32 rounding, a different
+    speed; silent until round 5."""
+    if x.is_cuda and _lib.get_impl() == 0 and not os.environ.get("SEMICRF_TORCH_PROJECTION"):
+        from .CRF.NeuralSemiCRFInterval import _warn_once
+        _warn_once("stock_gemm_" + what, f"transkun_amd.scorer: {what} runs on torch's stock GEMM (shape {tuple(x.shape)}: outside the "
+                                          "library kernels' sizes {64,128,256} / alignment / 2 GiB limits)")
+
+
 def proj_forward(x2: torch.Tensor, W: torch.Tensor, b: torch.Tensor, n_main: int, Wt: torch.Tensor = None) -> torch.Tensor:
     """y [M, Nout] = x2 W^T + b for the PACKED projection outputs of this package (LayersTransformer.py:388-397, :406-410 regrouped):
     W [Nout, K] holds n_main main rows, then -- if Nout > n_main -- two extra rows ([diag | 0] or [c | diag]) and zero rows.  On the
@@ -194,6 +204,7 @@ def proj_forward(x2: torch.Tensor, W: torch.Tensor, b: torch.Tensor, n_main: int
     M, K = x2.shape
     Nout = W.shape[0]
     if not (_proj_ok(x2, Nout) and K in _PROJ_SIZES and n_main in _PROJ_SIZES and (Nout == n_main or Nout >= n_main + 2) and Nout % 4 == 0):
+        _stock_gemm_note("the projection's forward", x2)
         return F.linear(x2, W, b)
     if Wt is None or Wt.shape != ((K + 31) // 32 * 32, n_main) or not Wt.is_contiguous():
         Wt = W.new_zeros((K + 31) // 32 * 32, n_main)        # the contraction index as row, whole chunks of 32 rows
@@ -212,6 +223,7 @@ def proj_input_grad(dy2: torch.Tensor, W: torch.Tensor, out: torch.Tensor = None
     M, Nout = dy2.shape
     K = W.shape[1]
     if not (_proj_ok(dy2, K) and K in _PROJ_SIZES and (out is None or (out.is_contiguous() and out.shape == (M, K)))):
+        _stock_gemm_note("the projection's input gradient", dy2)
         return dy2.mm(W) if out is None else out.addmm_(dy2, W)
     if Wp is None or Wp.shape != ((Nout + 31) // 32 * 32, K) or not Wp.is_contiguous():       # (W with zero rows up to whole chunks)
         Wp = W.new_zeros((Nout + 31) // 32 * 32, K)
@@ -228,10 +240,11 @@ def proj_weight_grad(dy2: torch.Tensor, x2: torch.Tensor, n_main: int):
     M, Nout = dy2.shape
     K = x2.shape[1]
     if not (_proj_ok(dy2, K) and _proj_ok(x2, Nout) and K in _PROJ_SIZES and 1 <= n_main <= Nout and (Nout == n_main or Nout >= n_main + 2)):
+        _stock_gemm_note("the projection's weight gradient", dy2)
         return _tn_splitk(dy2, x2), dy2.sum(0)
     dW = torch.empty(Nout, K, dtype=torch.float32, device=dy2.device)
     db = torch.empty(Nout, dtype=torch.float32, device=dy2.device)
-    key = ("tn", M, n_main, K)
+    key = ("tn", M, n_main, K, dy2.device.index)
     n = _BWD_WS.get(key)
     if n is None:
         n = _BWD_WS[key] = int(_lib.load().scorer_proj_tn_workspace_bytes(M, n_main, K))
@@ -269,6 +282,7 @@ class _ScorerLinear(torch.autograd.Function):
             qd = proj_forward(x2, Wqd, bqd, D).view(*x.shape[:-1], D + QPAD)
             k = proj_forward(x2, Wk, bk, D).view(*x.shape[:-1], D)
             return qd, k
+        _stock_gemm_note("the scorer's Linear", x2)
         return F.linear(x, Wqd, bqd), F.linear(x, Wk, bk)
 
     @staticmethod
@@ -348,6 +362,11 @@ class _ScorerLinearPacked(torch.autograd.Function):
         none = _lib_none(dev)
         g1 = dqd.reshape(M, D + QPAD).contiguous() if dqd is not None else None
         g2 = dk.reshape(M, D).contiguous() if dk is not None else None
+        # (a contiguous VIEW may start anywhere: the kernels want 16-byte aligned rows)
+        if g1 is not None and g1.data_ptr() % 16:
+            g1 = g1.clone()
+        if g2 is not None and g2.data_ptr() % 16:
+            g2 = g2.clone()
         need = ctx.needs_input_grad
         dx = None
         if need[0] and (g1 is not None or g2 is not None):
@@ -365,7 +384,7 @@ class _ScorerLinearPacked(torch.autograd.Function):
             dW = torch.zeros(rows, K, dtype=torch.float32, device=dev) if (g1 is None or g2 is None) else torch.empty(rows, K, dtype=torch.float32, device=dev)
             db = torch.zeros(rows, dtype=torch.float32, device=dev) if (g1 is None or g2 is None) else torch.empty(rows, dtype=torch.float32, device=dev)
             if g1 is not None:
-                key = ("tn", M, D, K)
+                key = ("tn", M, D, K, dev.index)              # (the geometry depends on that device's compute-unit count)
                 n = _BWD_WS.get(key)
                 if n is None:
                     n = _BWD_WS[key] = int(_lib.load().scorer_proj_tn_workspace_bytes(M, D, K))
@@ -376,7 +395,7 @@ class _ScorerLinearPacked(torch.autograd.Function):
                 if g2 is None:
                     dW[D:2 * D].zero_(); db[D:2 * D].zero_()
             if g2 is not None:
-                key = ("tn", M, D, K)
+                key = ("tn", M, D, K, dev.index)              # (the geometry depends on that device's compute-unit count)
                 n = _BWD_WS.get(key)
                 if n is None:
                     n = _BWD_WS[key] = int(_lib.load().scorer_proj_tn_workspace_bytes(M, D, K))

@@ -250,11 +250,14 @@ class SegmentTranscriber(nn.Module):
         if k_cap is not None:
             # no host trip: k_cap rows, the chains' ranges cut at k_cap, the (begin, end) of the unused rows made valid frame indices
             K = int(k_cap)
-            offsets = torch.clamp(offsets, max=K)
+            # (a decode whose hand-off wait timed out leaves offsets[-1] = -1: every chain is then EMPTY for the kernels below --
+            # they must not index with ranges the decode never validated; the count, checked one step late, raises)
+            offsets = torch.clamp(offsets, min=0, max=K) * (offsets[-1:] >= 0).to(offsets.dtype)
             pairs = pairs[:K].clamp(0, T - 1)
         else:
             K = int(offsets[-1])                                                         # the step's one host sync
             if K < 0:
+                _lib.async_error()               # consumed here: the next library call must not report this time-out again
                 raise RuntimeError("semicrf_viterbi: a bounded hand-off wait timed out on the device; the decode result is invalid")
         lastP = torch.empty(B, dtype=torch.int32, device=dev)
         nextStart = torch.empty(B, dtype=torch.int32, device=dev)
@@ -376,7 +379,8 @@ class SegmentTranscriber(nn.Module):
         After the first step nothing waits for the device inside a step: the attribute heads run on a CAPPED number of rows (1.5 x
         the largest interval count seen so far per recording in the batch), the real count travels to the host with the step's rows
         and is checked one step late, when the rows are merged.  A count above the cap (the heads saw a truncated list) restarts
-        the whole call with `synchronous=True`: every step then waits for its count, as in round 3.  Same Notes either way."""
+        the whole call with `synchronous=True`: every step then waits for its count, as in round 3.  Same Notes either way.
+        `ctx_fns[f](s, T)` must therefore be RE-CALLABLE (a pure function of the step): a restart asks for step 0 again."""
         plans = [self.segment_plan(n, stepInSecond, segmentSizeInSecond) for n in nSamples]
         P = len(self.targetMIDIPitch)
         dev = next(self.parameters()).device
@@ -426,6 +430,7 @@ class SegmentTranscriber(nn.Module):
             if cap is not None:
                 K = int(kpin[s & 1])
                 if K < 0:
+                    _lib.async_error()           # consumed here: the next library call must not report this time-out again
                     raise RuntimeError("semicrf_viterbi: a bounded hand-off wait timed out on the device; the decode result is invalid")
                 if K > cap:
                     raise _Overflow()
