@@ -67,7 +67,22 @@ constexpr int RING = SEMICRF_RING; // waves per ring; band = RING-1 off-diagonal
 // costs the loader 4 more 64-line loads per row block (ring alone: 1.34 -> 1.64 us per block at 88 chains, 1.41 -> 1.88 at 352).
 constexpr int NNEAR = SEMICRF_NNEAR;
 #ifndef SEMICRF_BANDX
-#define SEMICRF_BANDX 0            // 1: the loader takes the band from a spine-major copy (whole 128-byte lines), see band_copy
+#define SEMICRF_BANDX 1            // 1: launches with few chains copy the band into spine-major order while they run (copy_role) and
+#endif                              //    their loaders read whole 128-byte lines; 0: the loader always reads the score tensor itself
+#ifndef SEMICRF_BANDX_MAXB
+#define SEMICRF_BANDX_MAXB 192     // ... for at most this many chains per launch (the copy moves the band twice more: at 352 chains
+#endif                              //    that is 1.5 TB/s each way in the head of the sweep, where the hand-offs want a quiet fabric)
+#ifndef SEMICRF_BAND_LOAD_AUX
+#define SEMICRF_BAND_LOAD_AUX 16
+#endif
+#ifndef SEMICRF_BANDX_WGSTRIDE
+#define SEMICRF_BANDX_WGSTRIDE 3   // ... in every n-th panel workgroup (every one: the copy's burst delays the first hand-offs)
+#endif
+#ifndef SEMICRF_BANDX_WAVES
+#define SEMICRF_BANDX_WAVES 1      // ... copy waves per panel workgroup (1 / 2 / 4: 127 / 130 / 139 us at T=1024 x 88)
+#endif
+#ifndef SEMICRF_BANDX_K0
+#define SEMICRF_BANDX_K0 8         // ... row blocks below this one are loaded from the score tensor (the copy has not started yet)
 #endif
 constexpr int NBT = RING + NNEAR;  // band tiles per row block and spine (the ring's RING, then the near tiles)
 constexpr int FAR0 = RING + NNEAR; // first block with a far field of its own; the newest far tile of block k is k - FAR0
@@ -118,6 +133,7 @@ constexpr unsigned U_EMPTY = 0xffffffffu;  // not-yet-published u (a NaN pattern
 // slow every dequeue down to tens of microseconds).
 constexpr size_t CTRL_WORDS = 256;   // control words per chain chunk
 constexpr int CTRL_EXIT = 64;         // [64]: workgroups that have left (leased workspaces: the last one resets the control words)
+constexpr int CTRL_COPYQ = 192;       // [192]: band copy task queue head (a line of its own)
 constexpr int CTRL_PATHQ = 160;       // [160]: path task queue head (a line of its own)
 constexpr int CTRL_GEN = 96;          // [96]: leased workspaces: the tag of the launch that last cleaned up here (CTRL_INIT after a fill);
                                       // every workgroup of the next launch compares it with what the host expects (error 13)
@@ -178,9 +194,12 @@ struct SweepParams {
     float* pathOut;        // [B] logProb
     u64* pathg;            // [B] granules (workspace)
     float noiseAdd;        // GRAD: dNoise gets noiseAdd * gout[c] on top of the marginal (d cum[T-1] / d noise of the path score), 0: nothing
-    const float* band;     // SEMICRF_BANDX: [K][bandSpines][NBT][16 columns][16 rows][4 chains]: the band, spine-major
+    float* band;           // SEMICRF_BANDX: [K][bandSpines][NBT][16 columns][16 rows][4 chains]: the band, spine-major (workspace), or nullptr
+    unsigned* bandFlags;   // ... [32-chain groups][K + 2][8]: {launch tag, row block} once tile t of (row block, group) has been copied
     int bandSpines;        // ... spines of the whole batch (the copy is indexed by the batch's spine number)
-    int bandK0;            // ... row blocks < bandK0 are still loaded from the score tensor itself
+    int bandGroups;        // ... 32-chain groups of the whole batch
+    int bandK0;            // ... row blocks < bandK0 are loaded from the score tensor itself
+    int copyWaves;         // ... waves per panel workgroup that copy (copy_role)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -442,12 +461,37 @@ __device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* 
     constexpr int LDEPTH = 3 * NL <= 63 ? 3 : 2;
     static_assert(2 * NL <= 63, "loader pipeline");
 
-    const float* const bandp = SEMICRF_BANDX ? P.band + (size_t)(cbase / GS) * NBT * (TILE_BYTES / 4) + lane * 4 : nullptr;
+    const bool useband = SEMICRF_BANDX && P.band != nullptr;
+    const float* const bandp = useband ? P.band + (size_t)(cbase / GS) * NBT * (TILE_BYTES / 4) + lane * 4 : nullptr;
     const size_t band_kr = (size_t)P.bandSpines * NBT * (TILE_BYTES / 4);
+    // The copy's hand-off: NBT words per (32-chain group, row block), each {launch tag, row block} once its tile is in place.  The
+    // loader looks at them with a SCALAR load (its own counter: the vector-memory counter of this wave counts LDS-DMA pieces exactly)
+    // that takes two row blocks at once, request and wait in ONE asm statement: the compiler believes an asm's outputs are there when
+    // the statement ends -- a first version requested a row block ahead and waited later, and the compiler copied the registers in
+    // between and reused them while the load was still on its way (a memory aperture violation a microsecond later).
+    typedef unsigned v16u __attribute__((ext_vector_type(16)));
+    const int bKpad = K + 2;
+    const unsigned* const bflags = useband ? P.bandFlags + (size_t)(cbase / GP) * bKpad * 8 : nullptr;
+    const unsigned btag = P.tag;
+    int ready_upto = -1;                       // row blocks <= ready_upto are known to be copied
+    auto band_ready = [&](int kr) -> bool {
+        const uintptr_t fa = (uintptr_t)(bflags + (size_t)kr * 8);                 // wave-uniform by construction; said explicitly for the "s" operand
+        const u64 fp = (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)fa) |
+                       ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(fa >> 32)) << 32);
+        v16u f;
+        asm volatile("s_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(f) : "s"(fp) : "memory");
+        // (a flag word is {launch tag, row block}: neither the fill nor a previous launch's words can pass for this row block's)
+        const unsigned want0 = ((btag & 0xffffu) << 16) | (unsigned)kr, want1 = want0 + 1u;
+        bool ok0 = true, ok1 = true;
+#pragma unroll
+        for (int i = 0; i < NBT; ++i) { ok0 = ok0 && f[i] == want0; ok1 = ok1 && f[8 + i] == want1; }
+        if (ok0) ready_upto = ok1 ? kr + 1 : kr;
+        return ok0;
+    };
     auto issue = [&](int kr) {
         const int slot = kr % NRBUF;
         const int prow_t = kr * PB + tr < T ? kr * PB + tr : T - 1;
-        const bool fromband = SEMICRF_BANDX && kr >= P.bandK0;
+        const bool fromband = useband && kr >= P.bandK0;
         if (fromband) {
             const float* const bk = bandp + (size_t)kr * band_kr;
 #pragma unroll
@@ -455,7 +499,7 @@ __device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* 
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     __builtin_amdgcn_global_load_lds((gbl_void_t*)(bk + i * (TILE_BYTES / 4) + q * 256),
-                                                     (lds_void_t*)(lds + LDS_TILES + (slot * RING + i) * TILE_BYTES + q * 1024), 16, 0, SEMICRF_LOADER_AUX);
+                                                     (lds_void_t*)(lds + LDS_TILES + (slot * RING + i) * TILE_BYTES + q * 1024), 16, 0, SEMICRF_BAND_LOAD_AUX);   // sc1: written by another CU in this launch
         } else
 #pragma unroll
         for (int i = 0; i < RING; ++i) {
@@ -489,7 +533,7 @@ __device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* 
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         __builtin_amdgcn_global_load_lds((gbl_void_t*)(bk + (RING + n) * (TILE_BYTES / 4) + q * 256),
-                                                         (lds_void_t*)(nb + n * TILE_BYTES + q * 1024), 16, 0, SEMICRF_LOADER_AUX);
+                                                         (lds_void_t*)(nb + n * TILE_BYTES + q * 1024), 16, 0, 16);
             } else
 #pragma unroll
             for (int n = 0; n < NNEAR; ++n) {
@@ -533,6 +577,14 @@ __device__ __forceinline__ void loader_role(const SweepParams& P, int sg, char* 
             while (lds_flag_load_asm(fcons + (kr - NNSLOT - RING + NFARW * NNSLOT) % NFARW) < kr - NNSLOT + 1 && kr - NNSLOT >= RING) {
                 __builtin_amdgcn_s_sleep(2);
                 if (spin_abort(ctrl, spins, SPIN_LIMIT_LDS, 6)) return;
+            }
+        }
+        if (useband && kr >= P.bandK0 && kr > ready_upto) {
+            int spins = 0;
+            while (!band_ready(kr)) {
+                __builtin_amdgcn_s_sleep(8);
+                if (spin_abort(ctrl, spins, SPIN_LIMIT, 16)) return;
+                asm volatile("s_dcache_inv" ::: "memory");          // (a line of the scalar cache also holds the next row blocks' words: looked at too early, stale from then on)
             }
         }
         issue(kr);
@@ -1941,6 +1993,7 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
             panel_role<MODE, DIR, GRAD>(P, s_dyn, wave, 0, P.taskBase > 0 ? (ticket - nSpineWG) * P.panelWaves + wave : -1);
         else if (GRAD && wave - P.panelWaves >= 0 && wave - P.panelWaves < P.zeroWaves) zero_role(P);
         else if (GRAD && wave - P.panelWaves - P.zeroWaves >= 0 && wave - P.panelWaves - P.zeroWaves < P.bandWaves) band_role<DIR>(P);
+        else if (SEMICRF_BANDX && wave >= NT / 64 - P.copyWaves && (ticket - nSpineWG) % SEMICRF_BANDX_WGSTRIDE == 0) copy_role<DIR>(P);
         else if (MODE == 0 && DIR == 0 && !GRAD && P.pathPairs != nullptr && wave == P.panelWaves) path_role(P);
     }
     if (clk) { P.ts[602] = __builtin_readcyclecounter(); P.ts[603] = __builtin_amdgcn_s_memrealtime(); }
@@ -1974,18 +2027,14 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
 // q): 64 cells x 128 bytes in, 1 KB to each of the group's 8 spines out; lane = (cell of 8, chain quad): 8 lanes read one whole
 // line, and the 8 lanes of a quad write 128 contiguous bytes.  Cells and clamps are exactly the loader's own (bit-identical LDS).
 template <int DIR>
-__device__ __forceinline__ void band_copy_unit(const float* __restrict__ score, float* __restrict__ band, int T, int B,
-                                               int bandSpines, int kr, int g, int t, int q, int lane)
+__device__ __forceinline__ void band_copy_load(const float* __restrict__ score, int T, int B, int kr, int g, int t, int q, int lane,
+                                               v4u_a4 (&v)[8])
 {
     const int q8 = lane & 7, cs = lane >> 3;
-    const int sgG = g * (GP / GS) + q8;                      // the batch's spine number
-    const int cbase = sgG * GS;
-    if (cbase >= B) return;
+    const int cbase = (g * (GP / GS) + q8) * GS;             // the batch's spine number x 4
     const size_t Bs = (size_t)B;
     const size_t last4 = (size_t)T * T * Bs - 4;
-    const int kc0 = t < RING ? kr - t : kr - t;              // tile t: column block kr - t (t < RING: the ring's tiles, newest first)
-    const int kc = kc0 > 0 ? kc0 : 0;
-    v4u_a4 v[8];
+    const int kc = kr - t > 0 ? kr - t : 0;                  // tile t: column block kr - t (the ring's tiles, newest first, then the near tiles)
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int ci = q * 64 + it * 8 + cs;                 // cell of the tile in LDS order: column (ci >> 4), row (ci & 15)
@@ -1993,36 +2042,74 @@ __device__ __forceinline__ void band_copy_unit(const float* __restrict__ score, 
         const int prow_t = kr * PB + tr < T ? kr * PB + tr : T - 1;
         int pj = kc * PB + col;
         pj = pj < prow_t ? pj : (prow_t > 0 ? prow_t - 1 : 0);
-        size_t off = cell_index<DIR>(prow_t, pj, T) * Bs + cbase;
+        size_t off = cell_index<DIR>(prow_t, pj, T) * Bs + (cbase < B ? cbase : 0);
         off = off < last4 ? off : last4;
         v[it] = *(const v4u_a4*)(score + off);
     }
+}
+__device__ __forceinline__ void band_copy_store(float* __restrict__ band, int B, int bandSpines, int kr, int g, int t, int q, int lane,
+                                                const v4u_a4 (&v)[8])
+{
+    const int q8 = lane & 7, cs = lane >> 3;
+    const int sgG = g * (GP / GS) + q8;
+    if (sgG * GS >= B) return;
     // loader tile index i: column block kr - (RING-1) + i for the ring's tiles, RING + n for near tile n (column block kr - RING - n)
     const int ti = t < RING ? RING - 1 - t : t;
-    float* const dst = band + (((size_t)kr * bandSpines + sgG) * NBT + ti) * (TILE_BYTES / 4) + (q * 64 + cs) * 4;
+    // write-through stores (sc1): the reader is another compute unit of the same launch, possibly on another XCD
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)band, 0, 0x7fffffff, 0x00020000);
+    const unsigned voff = (unsigned)(((((size_t)kr * bandSpines + sgG) * NBT + ti) * (TILE_BYTES / 4) + (q * 64 + cs) * 4) * 4);
 #pragma unroll
-    for (int it = 0; it < 8; ++it) *(v4u*)(dst + it * 32) = v[it];
+    for (int it = 0; it < 8; ++it) __builtin_amdgcn_raw_buffer_store_b128(v[it], rs, voff + it * 128, 0, 16);
 }
 
+// COPY role: tasks (row block kr >= bandK0, band tile t, 32-chain group g) in that order from an atomic queue; a task is the tile's
+// four quarters, then -- all of its stores acknowledged -- the launch tag in the tile's flag word.
 template <int DIR>
-__global__ __launch_bounds__(256) void band_copy_kernel(const float* __restrict__ score, float* __restrict__ band, int T, int B,
-                                                        int bandSpines, int nGroups)
+__device__ __forceinline__ void copy_role(const SweepParams& P)
 {
-    const int unit = blockIdx.x;                             // (kr, t, g)
-    const int g = unit % nGroups, t = (unit / nGroups) % NBT, kr = unit / (nGroups * NBT);
-    band_copy_unit<DIR>(score, band, T, B, bandSpines, kr, g, t, threadIdx.x >> 6, threadIdx.x & 63);
+    const int K = P.K, nG = P.nPanelGroups, g0 = P.c0 / GP;
+    const int nTasks = (K - P.bandK0) * NBT * nG;
+    const int lane = threadIdx.x & 63;
+    while (true) {
+        int task = 0;
+        if (lane == 0) task = (int)(atomicAdd(P.ctrl + CTRL_COPYQ, 1u) + 1u);
+        task = __builtin_amdgcn_readfirstlane(task);
+        if (task >= nTasks) break;
+        const int g = task % nG, t = (task / nG) % NBT, kr = P.bandK0 + task / (nG * NBT);
+        // the tile's four quarters, two of them in flight (a quarter is eight 16-byte loads per lane: a wave with one quarter in flight
+        // needs 12 us per tile, and the first row blocks of the copy are wanted 6 us into the sweep)
+        v4u_a4 va[8], vb[8];
+        band_copy_load<DIR>(P.score, P.T, P.B, kr, g0 + g, t, 0, lane, va);
+        band_copy_load<DIR>(P.score, P.T, P.B, kr, g0 + g, t, 1, lane, vb);
+        band_copy_store(P.band, P.B, P.bandSpines, kr, g0 + g, t, 0, lane, va);
+        band_copy_load<DIR>(P.score, P.T, P.B, kr, g0 + g, t, 2, lane, va);
+        band_copy_store(P.band, P.B, P.bandSpines, kr, g0 + g, t, 1, lane, vb);
+        band_copy_load<DIR>(P.score, P.T, P.B, kr, g0 + g, t, 3, lane, vb);
+        band_copy_store(P.band, P.B, P.bandSpines, kr, g0 + g, t, 2, lane, va);
+        band_copy_store(P.band, P.B, P.bandSpines, kr, g0 + g, t, 3, lane, vb);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (every lane stores the same word: a lane-0 branch here would be threaded into the next draw's, see path_role)
+        __builtin_amdgcn_wave_barrier();
+        __hip_atomic_store(P.bandFlags + ((size_t)(g0 + g) * (K + 2) + kr) * 8 + t, ((P.tag & 0xffffu) << 16) | (unsigned)kr, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
-size_t band_copy_bytes(int T, int B)
+// in-sweep band copy: for which problems, and what it needs in the workspace (flags first: they are part of the launch's fill)
+static bool band_in_sweep(int T, int B)
 {
     const int K = (T + PB - 1) / PB;
-    return (size_t)K * ((B + GS - 1) / GS) * NBT * TILE_BYTES;
+    return SEMICRF_BANDX && B <= SEMICRF_BANDX_MAXB && K > SEMICRF_BANDX_K0 + FAR0;
 }
-void launch_band_copy(int dir, const float* score, float* band, int T, int B, hipStream_t stream)
+static size_t band_flag_bytes(int T, int B)
 {
-    const int K = (T + PB - 1) / PB, nG = (B + GP - 1) / GP, nS = (B + GS - 1) / GS;
-    if (dir == 0) hipLaunchKernelGGL(band_copy_kernel<0>, dim3(K * NBT * nG), dim3(256), 0, stream, score, band, T, B, nS, nG);
-    else hipLaunchKernelGGL(band_copy_kernel<1>, dim3(K * NBT * nG), dim3(256), 0, stream, score, band, T, B, nS, nG);
+    if (!band_in_sweep(T, B)) return 0;
+    return align_up((size_t)((T + PB - 1) / PB + 2) * ((B + GP - 1) / GP) * 8 * sizeof(unsigned));      // [group][K + 2 row blocks][8]
+}
+static size_t band_copy_bytes(int T, int B)
+{
+    if (!band_in_sweep(T, B)) return 0;
+    return align_up((size_t)((T + PB - 1) / PB) * ((B + GS - 1) / GS) * NBT * TILE_BYTES);
 }
 
 constexpr size_t CTRL_BYTES = MAX_CHUNKS * CTRL_WORDS * sizeof(unsigned);
@@ -2094,7 +2181,8 @@ size_t persist_workspace_bytes(int T, int B)
 {
     return CTRL_BYTES + align_up((size_t)2 * T * sizeof(u64)) + (size_t)max_parts(T) * align_up((size_t)T * B * sizeof(u64)) +
            2 * align_up((size_t)T * B * sizeof(unsigned)) +         // two u buffers: consecutive launches into a leased workspace alternate
-           align_up((size_t)B * sizeof(u64));                       // path-score granules (logProb as one launch)
+           align_up((size_t)B * sizeof(u64)) +                      // path-score granules (logProb as one launch)
+           band_flag_bytes(T, B) + band_copy_bytes(T, B);            // the spine-major band copy of launches with few chains (not filled)
 }
 
 // Even NBatch: the loader's 16-byte global->LDS loads and the panels' 16-byte loads need 8-byte aligned
@@ -2165,28 +2253,7 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         P.gstride = grad->gstride; P.gscale = grad->gscale; P.noiseAdd = grad->noise_add;
     }
     P.score = score; P.noise = noise; P.T = T; P.B = B; P.K = (T + PB - 1) / PB;
-    P.band = nullptr; P.bandSpines = (B + GS - 1) / GS; P.bandK0 = 0;
-#if SEMICRF_BANDX
-    {
-        // EXPERIMENT: the copy as a pre-pass into a process-wide scratch (SEMICRF_BAND_CACHE=1: only when the inputs change)
-        static float* scratch = nullptr; static size_t scratch_bytes = 0;
-        static const void* k_score = nullptr; static int k_T = 0, k_B = 0, k_dir = -1;
-        static const bool cache = getenv("SEMICRF_BAND_CACHE") && atoi(getenv("SEMICRF_BAND_CACHE")) != 0;
-        static const int k0 = getenv("SEMICRF_BAND_K0") ? atoi(getenv("SEMICRF_BAND_K0")) : 0;
-        const size_t need = band_copy_bytes(T, B);
-        if (need > scratch_bytes) {
-            if (scratch) { (void)hipDeviceSynchronize(); (void)hipFree(scratch); }
-            if (hipMalloc(&scratch, need) != hipSuccess) return 1;
-            scratch_bytes = need; k_score = nullptr;
-        }
-        const int d = grad ? 1 : dir;
-        if (!cache || k_score != score || k_T != T || k_B != B || k_dir != d) {
-            launch_band_copy(d, score, scratch, T, B, stream);
-            k_score = score; k_T = T; k_B = B; k_dir = d;
-        }
-        P.band = scratch; P.bandK0 = k0;
-    }
-#endif
+    P.band = nullptr; P.bandFlags = nullptr; P.bandSpines = (B + GS - 1) / GS; P.bandGroups = (B + GP - 1) / GP; P.bandK0 = 0; P.copyWaves = 0;
     P.tag = lease_tag ? (lease_tag % 65534u) + 1u : next_tag();
     P.dbg = 0u;
     P.selfclean = 0;
@@ -2205,6 +2272,8 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
     const unsigned upar = lease != 0 ? (lease_tag & 1u) : 0u;
     P.ug = (unsigned*)(w + ug_off + upar * ug_bytes);
     P.ug_other = nullptr;
+    const size_t band_off = ug_off + 2 * ug_bytes + align_up((size_t)B * sizeof(u64));
+    const bool band_ok = band_in_sweep(T, B);
     if (path && mode == 0 && dir == 0 && !grad) {
         // (offsets is never null here; pairs may be when K == 0 -- the role only looks at pairs[k] for k < K)
         P.pathPairs = path->pairs ? path->pairs : path->offsets; P.pathOffsets = path->offsets; P.pathK = path->K; P.pathOut = path->out;
@@ -2214,7 +2283,8 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
     // ONE fill: every word of the workspace starts as 0xffffffff -- u reads U_EMPTY, far-field granules carry a tag no
     // launch uses, the counters return 0 after their first increment, the error word reads CTRL_INIT
     // (probe build, flag 512: the u values of the previous launch in the same workspace stay -- panels alone on real values)
-    const size_t fill_bytes = (SEMICRF_PANEL_PROBES && (P.dbg & 512u)) ? ug_off : persist_workspace_bytes(T, B);
+    // (the band copy's scratch is not filled: its flag words, which are, say what is valid)
+    const size_t fill_bytes = (SEMICRF_PANEL_PROBES && (P.dbg & 512u)) ? ug_off : persist_workspace_bytes(T, B) - band_copy_bytes(T, B);
     if (P.dbg != 0u) lease = lease ? 1 : 0;                       // timing ablations leave anything behind
     // (a kernel of our own, not hipMemsetAsync: as fast, and a captured memset node of this size breaks the SECOND replay of an
     // instantiated HIP graph -- wrong results or a memory fault -- while this kernel replays correctly)
@@ -2306,6 +2376,14 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         P.gradLazyShort = nb < 256 ? 1 : 0;
         if (P.nTasks == 0) nPanelWG = 0;
         P.pathSpine = nPanelWG == 0 ? 1 : 0;        // no panel workgroups (short sequences): the spine workgroups' spare wave
+        // the band as a spine-major copy, made by two spare waves of every panel workgroup while the sweep runs
+        P.band = nullptr; P.copyWaves = 0;
+        if (band_ok && nchunks == 1 && nPanelWG > 0 && NT / 64 - pw - zw - bw - 1 >= SEMICRF_BANDX_WAVES) {
+            P.bandFlags = (unsigned*)(w + band_off);
+            P.band = (float*)(w + band_off + band_flag_bytes(T, B));
+            P.bandK0 = SEMICRF_BANDX_K0;
+            P.copyWaves = SEMICRF_BANDX_WAVES;
+        }
         const int grid = nSpineWG + nPanelWG;
         // the panel workgroups' waves know their first task (the first draws of ~700 waves all hit one counter at the start)
         P.taskBase = nPanelWG * P.panelWaves;
