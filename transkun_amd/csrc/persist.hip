@@ -2378,7 +2378,8 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         P.pathSpine = nPanelWG == 0 ? 1 : 0;        // no panel workgroups (short sequences): the spine workgroups' spare wave
         // the band as a spine-major copy, made by two spare waves of every panel workgroup while the sweep runs
         P.band = nullptr; P.copyWaves = 0;
-        if (band_ok && nchunks == 1 && nPanelWG > 0 && NT / 64 - pw - zw - bw - 1 >= SEMICRF_BANDX_WAVES) {
+        // (not in the gradient sweep: neutral at 88 - 96 chains, 3 % slower at 176 -- its stores leave the copy no quiet fabric)
+        if (band_ok && !grad && nchunks == 1 && nPanelWG > 0 && NT / 64 - pw - zw - bw - 1 >= SEMICRF_BANDX_WAVES) {
             P.bandFlags = (unsigned*)(w + band_off);
             P.band = (float*)(w + band_off + band_flag_bytes(T, B));
             P.bandK0 = SEMICRF_BANDX_K0;
