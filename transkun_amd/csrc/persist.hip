@@ -2365,10 +2365,11 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
             }
         }
         P.zeroWaves = zw;
-        // the band's marginals: two spare waves of every panel workgroup (none: the ring waves store them)
+        // the band's marginals: three spare waves of every panel workgroup (none: the ring waves store them).  One / two / three /
+        // four / five waves: 446 / 355 / 344 / 354 / 363 us at T=1024 x 352, 272 / 205 / 184-189 / 189 / 196 at T=691 x 384 (one box).
         int bw = 0;
         if (grad && nPanelWG > 0 && P.nTasks > 0) {
-            bw = 2;
+            bw = 3;
             if (knobs.band_waves >= 0) bw = knobs.band_waves;
             if (bw > NT / 64 - pw - zw) bw = NT / 64 - pw - zw;
         }
