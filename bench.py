@@ -540,6 +540,12 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
                                                  _lib.ptr(dq), _lib.ptr(dk2), _lib.ptr(ddg), Dq, Dq, 1, _lib.ptr(wsq), nws,
                                                  _lib.stream_of(Sq)), "interval_score_bwd_ws")
         extra["interval_score_bwd_ms"] = round(ev_time(_bwd, 5), 3)
+
+        def _bwd3():            # opt-in: the two products on the three-limb bf16 kernels (length_scaling | SEMICRF_LEN_BF16X3 = 16)
+            _lib.check(lib.interval_score_bwd_ws(_lib.ptr(Sq), _lib.ptr(qq), _lib.ptr(kk), Cq, T, Dq, Dq, Dq, 1.0 / 16, 16,
+                                                 _lib.ptr(dq), _lib.ptr(dk2), _lib.ptr(ddg), Dq, Dq, 1, _lib.ptr(wsq), nws,
+                                                 _lib.stream_of(Sq)), "interval_score_bwd_ws")
+        extra["interval_score_bwd_bf16x3_ms"] = round(ev_time(_bwd3, 5), 3)
         # the scorer is the path's matrix-bound kernel: its own roofline object (the line's `roofline` is the HBM-bound sweep)
         sflop = 2.0 * Cq * (T * (T + 1) / 2) * Dq                           # lower triangle only
         extra["scorer_roofline"] = {
@@ -550,7 +556,8 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
                     "(matrix pipe busy fraction, clock under load); cycle stamps: tools/tiled_probe.py -- bound by the CU's "
                     "vector-memory address path (DESIGN.md section 3)",
             "bf16x3_frac_fp32_equivalent": round(sflop / (extra["interval_score_fwd_bf16x3_ms"] * 1e-3) / 1e12 / 157.3, 4),
-            "backward_frac": round(2 * sflop / (extra["interval_score_bwd_ms"] * 1e-3) / 1e12 / 157.3, 4)}
+            "backward_frac": round(2 * sflop / (extra["interval_score_bwd_ms"] * 1e-3) / 1e12 / 157.3, 4),
+            "backward_bf16x3_frac_fp32_equivalent": round(2 * sflop / (extra["interval_score_bwd_bf16x3_ms"] * 1e-3) / 1e12 / 157.3, 4)}
         extra["interval_score_config"] = f"T={T}, chains={Cq}, D={Dq}, exact-fp32 MFMA, lower triangle"
         del qq, kk, dd, Sq, dq, dk2, ddg, wsq
         log("interval scorer done; segment-shaped path next")

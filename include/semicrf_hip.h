@@ -56,6 +56,12 @@ extern "C" {
  * faster.  Operands must be finite with |x| < 2^127 (the first limb rounds to nearest: larger values round to infinity);
  * limbs below the bf16 normal range (|x| < 2^-110) may be flushed to zero by the matrix instruction. */
 #define SEMICRF_SCORE_BF16X3 4
+/* The same for the backward: OR it to length_scaling of interval_score_bwd_ws* / interval_score_bwd_fused_ws* (bit 4).  The two
+ * products dq = G k, dk = G^T q run on the bf16 matrix instructions with every operand (the scaled cotangent G as well as k and q)
+ * split exactly into three limbs: |dq - dq_exact| <= 2^-21 * sum_b |G[e,b] k[b,d]| per element (likewise dk), fp32-grade, not
+ * bit-identical to the default.  Honoured where the packed path runs (workspace, D in {64,128,256}, T >= 64, aligned rows);
+ * the direct kernels ignore it (exact fp32).  ddiag and drowc are exact fp32 sums either way (drowc in a different fixed order). */
+#define SEMICRF_LEN_BF16X3 16
 
 typedef void* semicrf_stream_t;
 

@@ -791,6 +791,63 @@ def test_scorer_bf16x3(gpu, C, T, D, mode, tri):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("C,T,D,mode,rowc", [(5, 200, 64, 0, False), (9, 333, 128, 1, True), (6, 691, 256, 0, True), (3, 96, 256, 2, False),
+                                              (2, 1024, 256, 0, True), (7, 130, 256, 0, False)])
+def test_scorer_bwd_bf16x3(gpu, C, T, D, mode, rowc):
+    """The backward's two products on the bf16 matrix instructions (length_scaling | SEMICRF_LEN_BF16X3: the scaled cotangent, k and
+    q as three exact bf16 limbs each, six limb products, fp32 accumulation) against fp64.  Tolerance, stated in
+    include/semicrf_hip.h: |dq - dq64| <= 2^-21 * sum_b |G[e,b] k[b,d]| per element, likewise dk (the exact-fp32 kernels sit at the
+    same level on these inputs).  ddiag equals the exact path bit for bit, drowc to fp32 rounding (another fixed summation order);
+    the bit is honoured (some elements differ from the fp32 kernels': not a silent fallback) and ignored by the direct kernels."""
+    from transkun_amd import _lib, synth
+    from transkun_amd.scorer import LEN_BF16X3, bwd_workspace
+    _lib.set_impl(0)
+    q = synth.hash_normal(C * T * D, 271, "cpu").view(C, T, D).to(gpu)
+    k = synth.hash_normal(C * T * D, 272, "cpu").view(C, T, D).to(gpu)
+    cot = synth.hash_normal(T * T * C, 273, "cpu").view(T, T, C).to(gpu)
+    qs = 1.0 / D ** 0.5
+    ops = _lib_ops()
+    none = torch.empty(0, device=gpu)
+
+    def run(m):
+        dq = torch.full((C, T, D), float("nan"), device=gpu); dk = torch.full((C, T, D), float("nan"), device=gpu)
+        dd = torch.full((C, T), float("nan"), device=gpu)
+        dc = torch.full((C, T), float("nan"), device=gpu) if rowc else none
+        ws = bwd_workspace(C, T, D, gpu)
+        assert ws.numel() > 0
+        ops.interval_score_bwd_ws(cot, q, k, C, T, D, D, D, qs, m, C, C, dq, dk, dd, dc, D, D, 1, 1 if rowc else 0, ws)
+        return dq, dk, dd, dc
+    dq3, dk3, dd3, dc3 = run(mode | LEN_BF16X3)
+    dq1, dk1, dd1, dc1 = run(mode)
+    t = torch.arange(T, device=gpu)
+    ln = (t[:, None] - t[None, :]).double()
+    ln = ln.clamp(min=0) if mode == 0 else (ln.clamp(min=0).sqrt() if mode == 1 else torch.ones_like(ln))
+    G = cot.double() * (qs * ln * torch.ones(T, T, device=gpu).tril().double())[:, :, None]          # [e, b, c]
+    for got, other, eq in ((dq3, k, "ebc,cbd->ced"), (dk3, q, "ebc,ced->cbd")):
+        ref = torch.einsum(eq, G, other.double())
+        bound = torch.einsum(eq, G.abs(), other.double().abs()) * 2.0 ** -21 + 1e-30
+        assert float(((got.double() - ref).abs() / bound).max()) <= 1.0
+    assert torch.equal(dd3, dd1)
+    assert not torch.equal(dq3, dq1) and not torch.equal(dk3, dk1)                  # the bf16 kernels ran
+    assert float((dq3 - dq1).abs().max()) <= 4e-6 * float(dq1.abs().max())
+    assert float((dk3 - dk1).abs().max()) <= 4e-6 * float(dk1.abs().max())
+    if rowc:
+        ref = G.sum(dim=1).t()                                                      # [c, e]
+        bound = G.abs().sum(dim=1).t() * 2.0 ** -21 + 1e-30
+        assert float(((dc3.double() - ref).abs() / bound).max()) <= 1.0
+        assert float(((dc1.double() - ref).abs() / bound).max()) <= 1.0
+    # a contraction size the packed path does not take (direct kernels): the bit is accepted and changes nothing
+    if D == 64:
+        q32, k32 = q[..., :32].contiguous(), k[..., :32].contiguous()
+        outs = []
+        for m in (mode, mode | LEN_BF16X3):
+            dq = torch.empty(C, T, 32, device=gpu); dk = torch.empty(C, T, 32, device=gpu)
+            ops.interval_score_bwd_ws(cot, q32, k32, C, T, 32, 32, 32, qs, m, C, C, dq, dk, none, none, 32, 32, 1, 0, bwd_workspace(C, T, 32, gpu))
+            outs.append((dq, dk))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.gpu
 def test_scorer_bf16x3_module_vs_reference(gpu):
     """scorer.contraction = "bf16x3" at the model's real shape against the reference's own logProb and decode
     (tests/golden/segment_T691_P90.npz): same tolerances as the exact fp32 contraction."""

@@ -1,0 +1,29 @@
+"""interval_score_bwd_ws: exact fp32 against the three-limb bf16 kernels (length_scaling | 16), event-timed; run under
+rocprofv3 --kernel-trace --stats for the per-kernel split (pack / dq / dk)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from transkun_amd import _lib
+lib = _lib.load()
+dev = torch.device("cuda:0")
+shapes = ((352, 1024, 256), (360, 691, 256), (90, 691, 256), (88, 2048, 256), (352, 1024, 128))
+if len(sys.argv) > 1:
+    shapes = shapes[:int(sys.argv[1])]
+for (C, T, D) in shapes:
+    dS = torch.randn(T, T, C, device=dev); q = torch.randn(C, T, D, device=dev); k = torch.randn(C, T, D, device=dev)
+    dq = torch.empty_like(q); dk = torch.empty_like(k); dd = torch.empty(C, T, device=dev)
+    nws = int(lib.interval_score_bwd_workspace_bytes(C, T, D))
+    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)
+    res = {}
+    for name, mode in (("fp32", 0), ("bf16x3", 16)):
+        f = lambda: _lib.check(lib.interval_score_bwd_ws(_lib.ptr(dS), _lib.ptr(q), _lib.ptr(k), C, T, D, D, D, 1.0 / 16, mode, _lib.ptr(dq),
+                                                         _lib.ptr(dk), _lib.ptr(dd), D, D, 1, _lib.ptr(ws), nws, _lib.stream_of(dS)), "bwd_ws")
+        for _ in range(2): f()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(5): f()
+        e1.record(); torch.cuda.synchronize()
+        res[name] = (e0.elapsed_time(e1) / 5, dq.clone(), dk.clone())
+    fl = 2 * 2.0 * C * (T * (T + 1) / 2) * D
+    a, b = res["fp32"], res["bf16x3"]
+    print(f"C={C} T={T} D={D}: fp32 {a[0]:.3f} ms ({fl/a[0]/1e9:.1f} TF), bf16x3 {b[0]:.3f} ms ({fl/b[0]/1e9:.1f} TF fp32-eq); "
+          f"max |d dq| {float((a[1]-b[1]).abs().max()):.3e} of {float(a[1].abs().max()):.3e}, |d dk| {float((a[2]-b[2]).abs().max()):.3e} of {float(a[2].abs().max()):.3e}", flush=True)

@@ -71,7 +71,8 @@ size_t interval_score_bwd_ws_bytes(int C, int T, int D);
 bool launch_interval_score_bwd_packed(const float* dS, const float* q, const float* k, int C, int T, int D, long long ldq,
                                       long long ldk, float qscale, int mode, float* dq, float* dk, long long lddq,
                                       long long lddk, void* ws, size_t ws_bytes, hipStream_t stream,
-                                      const float* const* fused, int group, int pitch, float* drowc = nullptr, long long lddrc = 1);
+                                      const float* const* fused, int group, int pitch, float* drowc = nullptr, long long lddrc = 1,
+                                      int prec = 0);
 int launch_interval_score_mfma(const float* q, const float* k, const float* diag, int C, int T, int D,
                                 long long ldq, long long ldk, long long ldd, float qscale, int mode, int full,
                                 float* S, hipStream_t stream, int prec, int group, int pitch, const float* rowc = nullptr,
@@ -612,6 +613,8 @@ int interval_score_bwd_ws_pc(const float* dS, const float* q, const float* k, in
     SEMICRF_CHECK_ARG(dS && q && k, "dS/q/k must be non-NULL");
     SEMICRF_CHECK_ARG(ldq >= D && ldk >= D && (!dq || lddq >= D) && (!dk || lddk >= D) && (!ddiag || lddd >= 1),
                       "bad leading dimensions");
+    const int prec = (length_scaling & SEMICRF_LEN_BF16X3) ? 1 : 0;   // opt-in: the two products on the three-limb bf16 kernels (scorer_bwd_gemm.hip)
+    length_scaling &= ~SEMICRF_LEN_BF16X3;
     SEMICRF_CHECK_ARG(length_scaling >= 0 && length_scaling <= 2, "bad length_scaling %d", length_scaling);
     SEMICRF_CHECK_ARG(interval_score_bwd_supported(C, T, D), "interval_score_bwd needs D %% 32 == 0 and D <= 256 (D=%d)", D);
     if (int rc = check_slots(C, group, pitch)) return rc;
@@ -620,7 +623,7 @@ int interval_score_bwd_ws_pc(const float* dS, const float* q, const float* k, in
     hipStream_t st = (hipStream_t)stream;
     if (g_impl.load() == 0 && (dq || dk) &&
         launch_interval_score_bwd_packed(dS, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, lddq, lddk, ws, ws_bytes, st, nullptr,
-                                         group, pitch, drowc, lddrc)) {
+                                         group, pitch, drowc, lddrc, prec)) {
         if (ddiag) launch_interval_score_bwd_diag(dS, nullptr, ddiag, C, T, lddd, group, pitch, st);      // (drowc: out of the dq GEMM)
     } else {
         SEMICRF_CHECK_ARG(!slots, "a padded slot layout needs the packed path (workspace, D in {64,128,256}, T >= 64, aligned rows)");
@@ -682,6 +685,8 @@ int interval_score_bwd_fused_ws_pc(const float* S, const float* alpha, const flo
     SEMICRF_CHECK_ARG(S && alpha && beta && logZ && gout && q && k, "S/alpha/beta/logZ/gout/q/k must be non-NULL");
     SEMICRF_CHECK_ARG(ldq >= D && ldk >= D && (!dq || lddq >= D) && (!dk || lddk >= D) && (!ddiag || lddd >= 1),
                       "bad leading dimensions");
+    const int prec = (length_scaling & SEMICRF_LEN_BF16X3) ? 1 : 0;   // opt-in: the two products on the three-limb bf16 kernels (scorer_bwd_gemm.hip)
+    length_scaling &= ~SEMICRF_LEN_BF16X3;
     SEMICRF_CHECK_ARG(length_scaling >= 0 && length_scaling <= 2, "bad length_scaling %d", length_scaling);
     SEMICRF_CHECK_ARG(interval_score_bwd_supported(C, T, D), "interval_score_bwd_fused needs D %% 32 == 0 and D <= 256 (D=%d)", D);
     if (int rc = check_slots(C, group, pitch)) return rc;
@@ -691,7 +696,7 @@ int interval_score_bwd_fused_ws_pc(const float* S, const float* alpha, const flo
     const float* fused[4] = {alpha, beta, logZ, gout};
     if (g_impl.load() == 0 && (dq || dk) &&
         launch_interval_score_bwd_packed(S, q, k, C, T, D, ldq, ldk, qscale, length_scaling, dq, dk, lddq, lddk, ws, ws_bytes, st, fused,
-                                         group, pitch, drowc, lddrc)) {
+                                         group, pitch, drowc, lddrc, prec)) {
         if (ddiag) launch_interval_score_bwd_diag(S, fused, ddiag, C, T, lddd, group, pitch, st);
     } else {
         SEMICRF_CHECK_ARG(!slots, "a padded slot layout needs the packed path (workspace, D in {64,128,256}, T >= 64, aligned rows)");

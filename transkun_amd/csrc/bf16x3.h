@@ -1,0 +1,62 @@
+// bf16x3.h -- the three-limb bf16 representation of an fp32 value (internal; shared by the opt-in kernels of the interval
+// scorer: scorer_mfma.hip forward, scorer_bwd_gemm.hip backward).
+//
+// x = hi + mid + lo EXACTLY (round-to-nearest splits: 8 + 8 + 8 significant bits and the signs of the remainders).  A product
+// of two values is the sum of nine limb products, each exact in fp32 (8 x 8 bits); six of them are accumulated by
+// v_mfma_f32_32x32x16_bf16, smallest first: hi*lo, lo*hi, mid*mid, hi*mid, mid*hi, hi*hi.  What is dropped (mid*lo, lo*mid,
+// lo*lo) is below 2^-23 |x y| per term -- the size of the rounding of one fp32 fmaf of the exact-fp32 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace semicrf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Limbs3 { bf16x8 h, m, l; };
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b)
+{
+    unsigned r;                                          // {bf16(a) in bits 15:0, bf16(b) in bits 31:16}, round to nearest even
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));      // (written out: from `(__bf16)x` the compiler converts
+    return r;                                            // the first element a second time, alone, for the shift below)
+}
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l)
+{
+    const unsigned hu = cvt_pk_bf16(a, b);
+    const f32x2 x = {a, b};
+    const f32x2 hf = {__builtin_bit_cast(float, hu << 16), __builtin_bit_cast(float, hu & 0xffff0000u)};
+    const f32x2 r1 = x - hf;                                                     // exact
+    const unsigned mu = cvt_pk_bf16(r1.x, r1.y);
+    const f32x2 mf = {__builtin_bit_cast(float, mu << 16), __builtin_bit_cast(float, mu & 0xffff0000u)};
+    const f32x2 r2 = r1 - mf;                                                    // exact, and fits 8 bits
+    h = hu; m = mu; l = cvt_pk_bf16(r2.x, r2.y);
+}
+__device__ __forceinline__ Limbs3 split8(const v4f a, const v4f b)
+{
+    unsigned h[4], m[4], l[4];
+    split_pair(a.x, a.y, h[0], m[0], l[0]);
+    split_pair(a.z, a.w, h[1], m[1], l[1]);
+    split_pair(b.x, b.y, h[2], m[2], l[2]);
+    split_pair(b.z, b.w, h[3], m[3], l[3]);
+    Limbs3 r;
+    r.h = __builtin_bit_cast(bf16x8, (u32x4){h[0], h[1], h[2], h[3]});
+    r.m = __builtin_bit_cast(bf16x8, (u32x4){m[0], m[1], m[2], m[3]});
+    r.l = __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]});
+    return r;
+}
+__device__ __forceinline__ f32x16 mma6(const Limbs3& A, const Limbs3& B, f32x16 acc)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.l, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l, B.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.m, B.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.m, B.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.h, acc, 0, 0, 0);
+    return acc;
+}
+
+}  // namespace semicrf

@@ -16,13 +16,12 @@
 // consecutive lanes on consecutive b): no second copy.  The triangular structure shows up as the contraction range
 // of an output tile (dq: b < 128 (i+1); dk: e >= 128 i); items are dealt longest first.
 #include "common.h"
+#include "bf16x3.h"
 
 #include <type_traits>
 
 namespace semicrf {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 constexpr int GM = 128;            // rows of an output tile
@@ -413,6 +412,276 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same two products on the bf16 matrix instructions, every operand as three exact bf16 limbs (bf16x3.h; opt-in:
+// length_scaling | SEMICRF_LEN_BF16X3).  Six instructions of 8 passes replace eight fp32 instructions of 16 per 16
+// contraction values: 2.67x less matrix time, fp32-grade results (not bit-identical to the exact-fp32 kernel above).
+// ---------------------------------------------------------------------------------------------
+// Same items, same output tile (128 x D, wave = 32 rows x D/2 columns), same epilogue.  What differs is the operand path.
+// v_mfma_f32_32x32x16_bf16 wants EIGHT consecutive contraction values of one row (A) / one column (B) per lane, and one of the
+// two operands of either product has the contraction index as its ROW index in memory (k[b][:] for dq; Gt[e][:] and q[e][:] for
+// dk).  So nothing goes from memory to LDS directly: every lane fetches "units" of eight contraction values into registers two
+// chunks ahead -- a unit along a memory row is two 16-byte loads, a unit across rows is eight 4-byte loads of one column
+// (consecutive lanes on consecutive columns: 256-byte runs; the row is wave-uniform and sits in the scalar offset of a buffer
+// load, so a unit costs no address arithmetic in the vector unit) -- splits each value once (~5.5 vector instructions) and stores
+// the three limbs as 16-byte pieces in exactly the layout the matrix instruction reads: [limb][row][4 pieces of 8 values],
+// pieces swizzled by row as in the forward's three-limb kernel (reads conflict-free; the column units' writes two-way).
+// Two LDS stages of 3 x (8 KB + D x 64 bytes) (144 KB at D = 256), one s_barrier per chunk.
+constexpr int G3_NS = 2;
+#ifndef SEMICRF_G3_DBG
+#define SEMICRF_G3_DBG 0          // timing ablations (variant builds only; results are wrong): 1 no matrix instructions, 2 no requests,
+#endif                            // 4 no split / limb stores, 8 no operand reads
+
+template <bool AT, int NW>
+__global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __restrict__ Gt, int Tp,
+                                                                 const float* __restrict__ other, long long ldo,
+                                                                 float* __restrict__ out, long long ldout, int C, int T,
+                                                                 float* __restrict__ rsum, long long ldrs)
+{
+    constexpr int D = 64 * NW;
+    constexpr int APL = GM * 64;                       // bytes of one limb plane of the Gt part: 128 rows x 32 values x 2 bytes
+    constexpr int BPL = D * 64;                        // ... of the k/q part: D rows (columns of k/q)
+    constexpr int BOFF = 3 * APL;
+    constexpr int STAGE = 3 * (APL + BPL);
+    constexpr int NUB = (4 * D + 511) / 512;           // k/q units per lane and chunk
+    extern __shared__ __attribute__((aligned(16))) char glds[];    // [G3_NS][STAGE]: Gt limbs h | m | l | k/q limbs h | m | l
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;           // this wave: rows 32*wm.., columns 32*NW*wn.. of the tile
+    const int nm = (T + GM - 1) / GM;
+    const long long nitems = (long long)nm * C;
+    const int nkt = Tp / GK;
+    const size_t slab = gt_chain_floats(Tp);
+
+    auto item_of = [&](long long n, int& c, int& mi, int& kbeg, int& nk) -> bool {
+        if (n >= nitems) return false;
+        const int r = (int)(n / C);
+        c = __builtin_amdgcn_readfirstlane((int)(n % C));       // (64-bit division runs in the vector unit: back to scalar registers)
+        mi = __builtin_amdgcn_readfirstlane(AT ? r : nm - 1 - r);
+        if (AT) {
+            kbeg = mi * (GM / GK);
+            nk = nkt - kbeg;
+        } else {
+            kbeg = 0;
+            nk = (mi + 1) * (GM / GK) < nkt ? (mi + 1) * (GM / GK) : nkt;
+        }
+        return true;
+    };
+
+    // ---- reading lanes: lane = (row, half); the instruction of slab sl takes piece 2*half + sl of the row ----------------
+    unsigned rdA[2], rdB[2];
+    {
+        const int ra = 32 * wm + l31, rb = 32 * NW * wn + l31;          // (column block t: + 32 rows = + 2048 bytes, same swizzle)
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            rdA[sl] = (unsigned)(ra * 64 + (((2 * half + sl) ^ ((ra >> 2) & 3)) * 16));
+            rdB[sl] = (unsigned)(BOFF + rb * 64 + (((2 * half + sl) ^ ((rb >> 2) & 3)) * 16));
+        }
+    }
+    // ---- staging lanes --------------------------------------------------------------------------------------------------
+    // Gt: dq -- unit = (row tid / 4, piece tid % 4) along the row; dk -- unit = (row = b = tid % 128, piece tid / 128) across rows e
+    const int aRow = AT ? (tid & 127) : (tid >> 2);
+    const int aPiece = AT ? (wave >> 1) : (tid & 3);
+    const unsigned wA = (unsigned)(aRow * 64 + ((aPiece ^ ((aRow >> 2) & 3)) * 16));
+    // k/q: unit u = tid + 512 j = (column u % D, piece u / D), across rows; the piece is wave-uniform
+    unsigned wB[NUB], bVoff[NUB];
+    int bPiece[NUB];
+    bool bOn[NUB];
+#pragma unroll
+    for (int j = 0; j < NUB; ++j) {
+        const int u0 = wave * 64 + 512 * j;
+        bOn[j] = D >= 128 || u0 < 4 * D;                 // (D >= 128: every lane has its NUB units)
+        bPiece[j] = u0 / D;
+        const int d = (u0 % D + lane) % D;
+        wB[j] = (unsigned)(BOFF + d * 64 + ((bPiece[j] ^ ((d >> 2) & 3)) * 16));
+        bVoff[j] = (unsigned)(d * 4);
+    }
+
+    // ---- request side (identical in all waves) ---------------------------------------------------------------------------
+    long long nx_n = blockIdx.x;
+    int nx_c = 0, nx_mi = 0, nx_kbeg = 0, nx_nk = 0, nx_j = 0;
+    bool nx_valid = item_of(nx_n, nx_c, nx_mi, nx_kbeg, nx_nk);
+    if (!nx_valid) return;                             // uniform
+    unsigned aVoff = AT ? (unsigned)((tid & 127) * 4) : 0u;
+    auto set_item_offsets = [&]() {
+        if (!AT) {
+            const int rows = Tp - nx_mi * GM < GM ? Tp - nx_mi * GM : GM;      // rows of the block that exist (the others are not stored)
+            const int R = aRow < rows ? aRow : rows - 1;
+            aVoff = (unsigned)(((size_t)R * gt_row_len(nx_mi, Tp) + aPiece * 8) * 4);
+        }
+    };
+    set_item_offsets();
+
+    // (the two 16-byte loads stay whole registers quads: copied into eight scalars, the copies -- and a wait for the loads -- sit
+    // right behind the request)
+    struct Regs { v4f alo, ahi; float a[8]; float b[NUB][8]; };
+    struct Meta { bool valid, last; int c, mi; };
+    // The loads are UNCONDITIONAL (past the last chunk the last one is fetched again and never used): with a request under a
+    // branch the compiler's wait-count bookkeeping has to assume at every merge that the younger set was not requested, and
+    // waits for everything in flight where the older set is split.
+    auto fetch = [&](Regs& g, Meta& m) {
+        m.valid = nx_valid;
+        if (SEMICRF_G3_DBG & 2) return;
+        const int k0 = (nx_kbeg + nx_j) * GK;
+        const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)(Gt + (size_t)nx_c * slab), 0, (int)(slab * 4), 0x00020000);
+        const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)(other + (size_t)nx_c * T * ldo), 0, (int)(((size_t)(T - 1) * ldo + D) * 4), 0x00020000);
+        if (!AT) {
+            const unsigned sa = (unsigned)((gt_block_off(nx_mi) + (size_t)k0) * 4);
+            g.alo = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(ra, aVoff, sa, 0));
+            g.ahi = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(ra, aVoff + 16, sa, 0));
+        } else {
+            // the chunk's 32 rows (e) lie in one 128-row block; columns past the block's row length (a last block that is not
+            // 128 wide) read the next row or the workspace's slack: they only reach output rows >= T, which are not written
+            const int kblk = k0 / GM, krl = gt_row_len(kblk, Tp);
+            const size_t r0 = gt_block_off(kblk) + (size_t)(k0 - kblk * GM + 8 * aPiece) * krl + (size_t)nx_mi * GM;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                g.a[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, aVoff, (unsigned)((r0 + (size_t)i * krl) * 4), 0));
+        }
+#pragma unroll
+        for (int j = 0; j < NUB; ++j) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int row = k0 + 8 * bPiece[j] + i;       // rows past T meet Gt == 0: any finite value will do
+                row = row < T ? row : T - 1;            // (D = 64: the waves 4..7 have no unit and fetch rows of the next chunks, unused)
+                g.b[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, bVoff[j], (unsigned)((size_t)row * ldo * 4), 0));
+            }
+        }
+        m.last = nx_j + 1 == nx_nk;
+        m.c = nx_c;
+        m.mi = nx_mi;
+        if (nx_valid && ++nx_j == nx_nk) {
+            int c2, mi2, kbeg2, nk2;
+            if (item_of(nx_n + gridDim.x, c2, mi2, kbeg2, nk2)) {
+                nx_n += gridDim.x;
+                nx_c = c2; nx_mi = mi2; nx_kbeg = kbeg2; nx_nk = nk2; nx_j = 0;
+                set_item_offsets();
+            } else {
+                nx_valid = false;
+                nx_j = nx_nk - 1;
+            }
+        }
+    };
+    float rs = 0.0f;                                    // !AT && rsum: this lane's part of its row's sum
+    const bool want_rs = !AT && rsum != nullptr;
+    auto convert = [&](const Regs& g, const Meta& m, int stage) {
+        if (SEMICRF_G3_DBG & 4) return;
+        char* base = glds + stage * STAGE;
+        v4f alo, ahi;
+        if (AT) { alo = (v4f){g.a[0], g.a[1], g.a[2], g.a[3]}; ahi = (v4f){g.a[4], g.a[5], g.a[6], g.a[7]}; }
+        else { alo = g.alo; ahi = g.ahi; }
+        {
+            const Limbs3 L = split8(alo, ahi);
+            *(bf16x8*)(base + wA) = L.h;
+            *(bf16x8*)(base + APL + wA) = L.m;
+            *(bf16x8*)(base + 2 * APL + wA) = L.l;
+        }
+        if (!AT && want_rs && m.valid) {
+            rs += ((alo.x + alo.y) + (alo.z + alo.w)) + ((ahi.x + ahi.y) + (ahi.z + ahi.w));
+            if (m.last) {
+                float tot = rs + __shfl_xor(rs, 1);
+                tot += __shfl_xor(tot, 2);
+                const int mrow = m.mi * GM + aRow;
+                if ((tid & 3) == 0 && mrow < T) rsum[((size_t)m.c * T + mrow) * ldrs] = tot;
+                rs = 0.0f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NUB; ++j) {
+            if (D < 128 && !bOn[j]) continue;
+            const Limbs3 L = split8((v4f){g.b[j][0], g.b[j][1], g.b[j][2], g.b[j][3]}, (v4f){g.b[j][4], g.b[j][5], g.b[j][6], g.b[j][7]});
+            *(bf16x8*)(base + wB[j]) = L.h;
+            *(bf16x8*)(base + BPL + wB[j]) = L.m;
+            *(bf16x8*)(base + 2 * BPL + wB[j]) = L.l;
+        }
+    };
+
+    f32x16 acc[NW];
+#pragma unroll
+    for (int t = 0; t < NW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    auto multiply = [&](int stage) {
+        const char* base = glds + stage * STAGE;
+        if (SEMICRF_G3_DBG & 8) {
+            if (!(SEMICRF_G3_DBG & 1)) {
+                Limbs3 A, B;
+                A.h = A.m = A.l = B.h = B.m = B.l = __builtin_bit_cast(bf16x8, (u32x4){(unsigned)stage, 1u, 2u, 3u});
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                    for (int t = 0; t < NW; ++t) acc[t] = mma6(A, B, acc[t]);
+            }
+            return;
+        }
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            Limbs3 A;
+            A.h = *(const bf16x8*)(base + rdA[sl]);
+            A.m = *(const bf16x8*)(base + APL + rdA[sl]);
+            A.l = *(const bf16x8*)(base + 2 * APL + rdA[sl]);
+#pragma unroll
+            for (int t = 0; t < NW; ++t) {
+                Limbs3 B;
+                B.h = *(const bf16x8*)(base + rdB[sl] + t * 2048);
+                B.m = *(const bf16x8*)(base + BPL + rdB[sl] + t * 2048);
+                B.l = *(const bf16x8*)(base + 2 * BPL + rdB[sl] + t * 2048);
+                if (SEMICRF_G3_DBG & 1) acc[t][0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, A.h).x ^ __builtin_bit_cast(u32x4, B.l).y ^ __builtin_bit_cast(u32x4, A.m).z ^ __builtin_bit_cast(u32x4, B.h).w ^ __builtin_bit_cast(u32x4, A.l).x ^ __builtin_bit_cast(u32x4, B.m).x);
+                else
+                acc[t] = mma6(A, B, acc[t]);
+            }
+        }
+    };
+
+    Regs g0, g1;
+    Meta m0 = {false, false, 0, 0}, m1 = {false, false, 0, 0};
+    g0.alo = g0.ahi = g1.alo = g1.ahi = (v4f)(0.0f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        g0.a[i] = 0.0f; g1.a[i] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NUB; ++j) { g0.b[j][i] = 0.0f; g1.b[j][i] = 0.0f; }
+    }
+    fetch(g0, m0);
+    fetch(g1, m1);
+    convert(g0, m0, 0);
+    fetch(g0, m0);
+
+    long long cur_n = blockIdx.x;
+    int c = 0, mi = 0, kbeg = 0, nk = 0, j = 0;
+    (void)item_of(cur_n, c, mi, kbeg, nk);
+    // one chunk: everybody's limbs of it are in stage P, everybody is done reading the other stage; multiply, split the next
+    // chunk into the other stage, request the chunk after next
+    auto step = [&](auto PC, Regs& gn, Meta& mn) -> bool {
+        constexpr int P = decltype(PC)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        multiply(P);
+        convert(gn, mn, P ^ 1);
+        fetch(gn, mn);
+        if (++j < nk) return true;
+        // ---- the item's 128 x D block (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) ----
+        float* ob = out + (size_t)c * T * ldout;
+#pragma unroll
+        for (int t = 0; t < NW; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mi * GM + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < T) ob[(size_t)m * ldout + 32 * NW * wn + 32 * t + l31] = acc[t][r];
+                acc[t][r] = 0.0f;
+            }
+        j = 0;
+        cur_n += gridDim.x;
+        return item_of(cur_n, c, mi, kbeg, nk);
+    };
+    while (true) {
+        if (!step(std::integral_constant<int, 0>{}, g1, m1)) break;
+        if (!step(std::integral_constant<int, 1>{}, g0, m0)) break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 static int round_up32(int T) { return (T + 31) / 32 * 32; }
@@ -445,12 +714,31 @@ static void launch_gemm(const float* Gt, int Tp, const float* other, long long l
                        AT ? nullptr : rsum, ldrs);
 }
 
+template <bool AT, int NW>
+static void launch_gemm3(const float* Gt, int Tp, const float* other, long long ldo, float* out, long long ldout, int C,
+                         int T, hipStream_t stream, float* rsum = nullptr, long long ldrs = 1)
+{
+    const size_t lds = (size_t)G3_NS * 3 * (GM * 64 + 64 * NW * 64);
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
+        (void)hipFuncSetAttribute((const void*)score_bwd_gemm3_kernel<AT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    int ncu = 256, dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+        ncu = v;
+    const long long nitems = (long long)((T + GM - 1) / GM) * C;
+    const int grid = nitems < ncu ? (int)nitems : ncu;
+    hipLaunchKernelGGL((score_bwd_gemm3_kernel<AT, NW>), dim3(grid), dim3(512), lds, stream, Gt, Tp, other, ldo, out, ldout, C, T,
+                       AT ? nullptr : rsum, ldrs);
+}
+
 // true when the packed path ran (q/k rows must be 16-byte aligned for the LDS loads)
+// prec: 0 exact fp32 (v_mfma_f32_32x32x2_f32), 1 the three-limb bf16 contraction (score_bwd_gemm3_kernel)
 // fused != nullptr: {alpha, beta, logZ, gout} and dS is the score tensor itself
 bool launch_interval_score_bwd_packed(const float* dS, const float* q, const float* k, int C, int T, int D, long long ldq,
                                       long long ldk, float qscale, int mode, float* dq, float* dk, long long lddq,
                                       long long lddk, void* ws, size_t ws_bytes, hipStream_t stream,
-                                      const float* const* fused, int group, int pitch, float* drowc, long long lddrc)
+                                      const float* const* fused, int group, int pitch, float* drowc, long long lddrc, int prec)
 {
     // drowc (may be NULL): row sums of the packed cotangent, out of the dq GEMM (which then must run: dq != NULL)
     if (drowc && !dq) return false;
@@ -476,8 +764,20 @@ bool launch_interval_score_bwd_packed(const float* dS, const float* q, const flo
     case 128: launch_gemm<AT_, 2>(Gt, Tp, OTHER, LDO, OUT, LDOUT, C, T, stream, drowc, lddrc); break;                   \
     default: launch_gemm<AT_, 4>(Gt, Tp, OTHER, LDO, OUT, LDOUT, C, T, stream, drowc, lddrc); break;                    \
     }
-    if (dq) { SEMICRF_GEMM_DISPATCH(false, k, ldk, dq, lddq) }
-    if (dk) { SEMICRF_GEMM_DISPATCH(true, q, ldq, dk, lddk) }
+#define SEMICRF_GEMM3_DISPATCH(AT_, OTHER, LDO, OUT, LDOUT)                                                             \
+    switch (D) {                                                                                                        \
+    case 64: launch_gemm3<AT_, 1>(Gt, Tp, OTHER, LDO, OUT, LDOUT, C, T, stream, drowc, lddrc); break;                   \
+    case 128: launch_gemm3<AT_, 2>(Gt, Tp, OTHER, LDO, OUT, LDOUT, C, T, stream, drowc, lddrc); break;                  \
+    default: launch_gemm3<AT_, 4>(Gt, Tp, OTHER, LDO, OUT, LDOUT, C, T, stream, drowc, lddrc); break;                   \
+    }
+    if (prec == 1) {
+        if (dq) { SEMICRF_GEMM3_DISPATCH(false, k, ldk, dq, lddq) }
+        if (dk) { SEMICRF_GEMM3_DISPATCH(true, q, ldq, dk, lddk) }
+    } else {
+        if (dq) { SEMICRF_GEMM_DISPATCH(false, k, ldk, dq, lddq) }
+        if (dk) { SEMICRF_GEMM_DISPATCH(true, q, ldq, dk, lddk) }
+    }
+#undef SEMICRF_GEMM3_DISPATCH
 #undef SEMICRF_GEMM_DISPATCH
     return true;
 }

@@ -13,6 +13,7 @@
 #include <atomic>
 #include "common.h"
 #include "scorer_tiles.h"
+#include "bf16x3.h"
 
 #include <cstdlib>
 #include <map>
@@ -519,51 +520,7 @@ constexpr int XNS = SEMICRF_SCORE_XNS;     // LDS stages (4: measured no faster,
 // lo*mid, lo*lo) is below 2^-23 |q_d k_d| per term -- the size of the rounding of one fp32 fmaf of the default path.  Six
 // instructions of 8 passes replace eight fp32 instructions of 16 per 16 contraction values: 2.7x less matrix time; the
 // split costs ~5 vector instructions per operand value and is done by every wave for its own operands.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-struct Limbs3 { bf16x8 h, m, l; };
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b)
-{
-    unsigned r;                                          // {bf16(a) in bits 15:0, bf16(b) in bits 31:16}, round to nearest even
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));      // (written out: from `(__bf16)x` the compiler converts
-    return r;                                            // the first element a second time, alone, for the shift below)
-}
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l)
-{
-    const unsigned hu = cvt_pk_bf16(a, b);
-    const f32x2 x = {a, b};
-    const f32x2 hf = {__builtin_bit_cast(float, hu << 16), __builtin_bit_cast(float, hu & 0xffff0000u)};
-    const f32x2 r1 = x - hf;                                                     // exact
-    const unsigned mu = cvt_pk_bf16(r1.x, r1.y);
-    const f32x2 mf = {__builtin_bit_cast(float, mu << 16), __builtin_bit_cast(float, mu & 0xffff0000u)};
-    const f32x2 r2 = r1 - mf;                                                    // exact, and fits 8 bits
-    h = hu; m = mu; l = cvt_pk_bf16(r2.x, r2.y);
-}
-__device__ __forceinline__ Limbs3 split8(const v4f a, const v4f b)
-{
-    unsigned h[4], m[4], l[4];
-    split_pair(a.x, a.y, h[0], m[0], l[0]);
-    split_pair(a.z, a.w, h[1], m[1], l[1]);
-    split_pair(b.x, b.y, h[2], m[2], l[2]);
-    split_pair(b.z, b.w, h[3], m[3], l[3]);
-    Limbs3 r;
-    r.h = __builtin_bit_cast(bf16x8, (u32x4){h[0], h[1], h[2], h[3]});
-    r.m = __builtin_bit_cast(bf16x8, (u32x4){m[0], m[1], m[2], m[3]});
-    r.l = __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]});
-    return r;
-}
-__device__ __forceinline__ f32x16 mma6(const Limbs3& A, const Limbs3& B, f32x16 acc)
-{
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.l, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l, B.h, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.m, B.m, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.m, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.m, B.h, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.h, acc, 0, 0, 0);
-    return acc;
-}
+// (Limbs3, split8, mma6: bf16x3.h)
 
 // XTE = tile rows (end positions): 128 -> 8 waves, one workgroup per CU; 64 -> 4 waves, two (independent) workgroups
 // per CU whose barriers and operand reads fall into each other's matrix phases (24 instead of 32 flop per byte).

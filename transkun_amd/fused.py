@@ -27,7 +27,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .scorer import (BF16X3, QPAD, ScaledInnerProductIntervalScorer, _ScorerLinear, _ScorerLinearPacked, _interval_score_raw, bwd_workspace, proj_forward,
+from .scorer import (BF16X3, LEN_BF16X3, QPAD, ScaledInnerProductIntervalScorer, _ScorerLinear, _ScorerLinearPacked, _interval_score_raw, bwd_workspace, proj_forward,
                      proj_input_grad, proj_weight_grad, qd_weights, slot_maps, slot_pitch)
 
 _nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
@@ -149,14 +149,14 @@ class _MergedScorerCRFLogProb(torch.autograd.Function):
         pairs._semicrf_K = K
         path = _nsci._eval_path_raw(S, noise, pairs, offsets_s)
         ctx.save_for_backward(x3, zc, Wm, S, noise, v, logz, pairs, offsets_s)
-        ctx.meta = (N, P, T, D, mode, K, pitch)
+        ctx.meta = (N, P, T, D, mode, K, pitch, LEN_BF16X3 if int(fs) & BF16X3 else 0)
         lp = path - logz
         return lp if real is None else lp.index_select(0, real)
 
     @staticmethod
     def backward(ctx, g):
         x3, zc, Wm, S, noise, v, logz, pairs, offsets_s = ctx.saved_tensors
-        N, P, T, D, mode, K, pitch = ctx.meta
+        N, P, T, D, mode, K, pitch, x3bit = ctx.meta
         C = N * P
         size = x3.shape[-1]
         qs = 1.0 / math.sqrt(D)
@@ -173,7 +173,7 @@ class _MergedScorerCRFLogProb(torch.autograd.Function):
         dz, dc, dd = dzc[..., :size], dzc[..., size], dzc[..., size + 1]
         dx = torch.empty(C, T, size, dtype=torch.float32, device=S.device)           # the part through the second operand
         ws = bwd_workspace(C, T, size, S.device)
-        ops.interval_score_bwd_fused_ws(S, v, beta, logz, gneg, z, x3, C, T, size, z.stride(-2), size, qs, mode, P, pitch, dz, dx, dd, dc,
+        ops.interval_score_bwd_fused_ws(S, v, beta, logz, gneg, z, x3, C, T, size, z.stride(-2), size, qs, mode | x3bit, P, pitch, dz, dx, dd, dc,
                                         dz.stride(-2), size, dd.stride(-1), dc.stride(-1), ws)
         del ws
         if K > 0:
@@ -214,14 +214,14 @@ class _ScorerCRFLogProb(torch.autograd.Function):
         pairs._semicrf_K = K
         path = _nsci._eval_path_raw(S, noise, pairs, offsets_s)
         ctx.save_for_backward(qd3, k3, S, noise, v, logz, pairs, offsets_s)
-        ctx.meta = (N, P, T, D, mode, K, pitch)
+        ctx.meta = (N, P, T, D, mode, K, pitch, LEN_BF16X3 if int(fs) & BF16X3 else 0)
         lp = path - logz
         return lp if real is None else lp.index_select(0, real)
 
     @staticmethod
     def backward(ctx, g):
         qd3, k, S, noise, v, logz, pairs, offsets_s = ctx.saved_tensors
-        N, P, T, D, mode, K, pitch = ctx.meta
+        N, P, T, D, mode, K, pitch, x3bit = ctx.meta
         C = N * P
         qs = 1.0 / math.sqrt(D)
         g = g.reshape(C).to(torch.float32).contiguous()
@@ -238,7 +238,7 @@ class _ScorerCRFLogProb(torch.autograd.Function):
         dk = torch.empty(C, T, D, dtype=torch.float32, device=S.device)
         # with a workspace: marginals evaluated by the repack kernel + two tiled GEMMs (scorer_bwd_gemm.hip)
         ws = bwd_workspace(C, T, D, S.device)
-        ops.interval_score_bwd_fused_ws(S, v, beta, logz, gneg, q, k, C, T, D, q.stride(-2), k.stride(-2), qs, mode, P, pitch, dq, dk, dd,
+        ops.interval_score_bwd_fused_ws(S, v, beta, logz, gneg, q, k, C, T, D, q.stride(-2), k.stride(-2), qs, mode | x3bit, P, pitch, dq, dk, dd,
                                         dd, dq.stride(-2), D, dd.stride(-1), 0, ws)
         del ws
         if K > 0:

@@ -108,6 +108,7 @@ def bwd_workspace(C: int, T: int, D: int, device) -> torch.Tensor:
 
 
 BF16X3 = 4      # SEMICRF_SCORE_BF16X3: OR into full_square
+LEN_BF16X3 = 16 # SEMICRF_LEN_BF16X3: OR into the backward's length-scaling mode (the two products on the three-limb bf16 kernels)
 
 
 QPAD = 4        # [q | diag | 3 zero columns]: one GEMM instead of a D-wide and a 1-wide one, rows stay 16-byte aligned
@@ -419,7 +420,7 @@ class _IntervalScore(torch.autograd.Function):
         qscale = 1.0 / math.sqrt(D)
         S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qscale, mode, full_square, P, pitch)
         ctx.save_for_backward(qd3, k3)
-        ctx.meta = (N, P, T, D, mode, (int(full_square) & 3) == 1, pitch)
+        ctx.meta = (N, P, T, D, mode | (LEN_BF16X3 if int(full_square) & BF16X3 else 0), (int(full_square) & 3) == 1, pitch)
         return S.view(T, T, N, pitch), noise.view(max(T - 1, 0), N, pitch)
 
     @staticmethod
