@@ -27,3 +27,25 @@ for (C, T, D) in shapes:
     a, b = res["fp32"], res["bf16x3"]
     print(f"C={C} T={T} D={D}: fp32 {a[0]:.3f} ms ({fl/a[0]/1e9:.1f} TF), bf16x3 {b[0]:.3f} ms ({fl/b[0]/1e9:.1f} TF fp32-eq); "
           f"max |d dq| {float((a[1]-b[1]).abs().max()):.3e} of {float(a[1].abs().max()):.3e}, |d dk| {float((a[2]-b[2]).abs().max()):.3e} of {float(a[2].abs().max()):.3e}", flush=True)
+
+if "--probe" in sys.argv:
+    # a library built with -DSEMICRF_G3_PROBE=1 (SEMICRF_LIB): cycle counters of every wave of the dq kernel behind the row sums
+    import numpy as np
+    C, T, D = 352, 1024, 256
+    dS = torch.randn(T, T, C, device=dev); q = torch.randn(C, T, D, device=dev); k = torch.randn(C, T, D, device=dev)
+    dq = torch.zeros_like(q); dk = torch.zeros_like(k); dd = torch.empty(C, T, device=dev)
+    dc = torch.zeros(C * T + 256 * 64, device=dev)
+    nws = int(lib.interval_score_bwd_workspace_bytes(C, T, D)); ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)
+    for _ in range(2):
+        _lib.check(lib.interval_score_bwd_ws_pc(_lib.ptr(dS), _lib.ptr(q), _lib.ptr(k), C, T, D, D, D, 1.0 / 16, 16, C, C, _lib.ptr(dq), _lib.ptr(dk),
+                                                _lib.ptr(dd), _lib.ptr(dc), D, D, 1, 1, _lib.ptr(ws), nws, _lib.stream_of(dS)), "bwd_ws_pc")
+    torch.cuda.synchronize()
+    names = ["multiply", "epilogue", "barrier1", "wait loads", "split+stores", "requests", "barrier2", "-"]
+    pc = dc[C * T:C * T + 256 * 64].view(256, 8, 8).cpu().numpy().astype(np.float64)
+    tot = pc[:, :, :7].sum(axis=2)
+    rt = pc[:, :, 7]
+    print("dq cycles per wave: mean %.0f min %.0f max %.0f; wall (100 MHz ticks) mean %.0f = %.1f us -> clock %.2f GHz" % (
+        tot.mean(), tot.min(), tot.max(), rt.mean(), rt.mean() / 100.0, tot.mean() / (rt.mean() * 10.0)))
+    for g, sl in (("group 0", slice(0, 4)), ("group 1", slice(4, 8))):
+        m = pc[:, sl, :7].mean(axis=(0, 1))
+        print("  ", g, " ".join("%s %.1f%% (%.0f)" % (names[i], 100 * m[i] / m.sum(), m[i]) for i in range(7)))

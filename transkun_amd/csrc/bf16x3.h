@@ -5,6 +5,10 @@
 // of two values is the sum of nine limb products, each exact in fp32 (8 x 8 bits); six of them are accumulated by
 // v_mfma_f32_32x32x16_bf16, smallest first: hi*lo, lo*hi, mid*mid, hi*mid, mid*hi, hi*hi.  What is dropped (mid*lo, lo*mid,
 // lo*lo) is below 2^-23 |x y| per term -- the size of the rounding of one fp32 fmaf of the exact-fp32 kernels.
+//
+// COMPILER HAZARD (amdclang 22, ROCm 7.2): `__builtin_bit_cast(T, v[i])` of an ELEMENT of an ext_vector_type value reads element 0
+// for every i (seen on the result of __builtin_amdgcn_raw_buffer_load_b128 and on an f32x16 accumulator: stores of acc[t][r] all
+// wrote acc[t][0]).  Bit-cast the whole vector and index the result, or use __float_as_uint / __uint_as_float on the element.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -35,13 +39,30 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsign
     const f32x2 r2 = r1 - mf;                                                    // exact, and fits 8 bits
     h = hu; m = mu; l = cvt_pk_bf16(r2.x, r2.y);
 }
+// Eight values at once, level by level: the four pairs' chains (convert, widen, subtract, convert, ...) are independent, and
+// written pair after pair the compiler keeps them in that order (every instruction waits for the one in front of it: ~12 cycles
+// per instruction in the backward kernel's cycle stamps).
 __device__ __forceinline__ Limbs3 split8(const v4f a, const v4f b)
 {
+    const f32x2 x[4] = {{a.x, a.y}, {a.z, a.w}, {b.x, b.y}, {b.z, b.w}};
     unsigned h[4], m[4], l[4];
-    split_pair(a.x, a.y, h[0], m[0], l[0]);
-    split_pair(a.z, a.w, h[1], m[1], l[1]);
-    split_pair(b.x, b.y, h[2], m[2], l[2]);
-    split_pair(b.z, b.w, h[3], m[3], l[3]);
+    f32x2 r1[4], r2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = cvt_pk_bf16(x[i].x, x[i].y);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 hf = {__builtin_bit_cast(float, h[i] << 16), __builtin_bit_cast(float, h[i] & 0xffff0000u)};
+        r1[i] = x[i] - hf;                                                       // exact
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = cvt_pk_bf16(r1[i].x, r1[i].y);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 mf = {__builtin_bit_cast(float, m[i] << 16), __builtin_bit_cast(float, m[i] & 0xffff0000u)};
+        r2[i] = r1[i] - mf;                                                      // exact, and fits 8 bits
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) l[i] = cvt_pk_bf16(r2[i].x, r2[i].y);
     Limbs3 r;
     r.h = __builtin_bit_cast(bf16x8, (u32x4){h[0], h[1], h[2], h[3]});
     r.m = __builtin_bit_cast(bf16x8, (u32x4){m[0], m[1], m[2], m[3]});

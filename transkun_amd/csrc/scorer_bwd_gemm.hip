@@ -425,11 +425,28 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __r
 // load, so a unit costs no address arithmetic in the vector unit) -- splits each value once (~5.5 vector instructions) and stores
 // the three limbs as 16-byte pieces in exactly the layout the matrix instruction reads: [limb][row][4 pieces of 8 values],
 // pieces swizzled by row as in the forward's three-limb kernel (reads conflict-free; the column units' writes two-way).
-// Two LDS stages of 3 x (8 KB + D x 64 bytes) (144 KB at D = 256), one s_barrier per chunk.
+// Two LDS stages of 3 x (8 KB + D x 64 bytes) (144 KB at D = 256).
+//
+// Schedule.  Timing ablations of the first version (every wave: barrier, multiply, split the next chunk, request; T=1024 x 352,
+// both products): matrix instructions alone 0.51 ms, everything 1.32 -- the parts ADD, because a barrier per chunk keeps the two
+// waves of a SIMD in the same phase.  So the waves are two GROUPS (0-3 and 4-7: one of each per SIMD) half a chunk apart: while
+// one group multiplies chunk n, the other splits its share of chunk n+1 and requests chunk n+3, then they swap; two barriers
+// per chunk.  A multiplying wave has the SIMD's matrix pipe to itself, so its operand reads are issued one group of six
+// instructions ahead (two sets of operand registers), the order pinned by scheduling barriers.
+#ifndef SEMICRF_G3_PROBE
+#define SEMICRF_G3_PROBE 0        // 1: cycle accounting of every wave instead of results (tools/bwd3_probe.py --probe): [0] multiply, [1] epilogue,
+#endif                            // [2] first barrier, [3] wait for the set's loads, [4] split + limb stores, [5] requests, [6] second barrier
 constexpr int G3_NS = 2;
+constexpr int NXCD_G3 = 8;        // workgroup b runs on XCD b % 8
 #ifndef SEMICRF_G3_DBG
 #define SEMICRF_G3_DBG 0          // timing ablations (variant builds only; results are wrong): 1 no matrix instructions, 2 no requests,
 #endif                            // 4 no split / limb stores, 8 no operand reads
+#ifndef SEMICRF_G3_MMA_ORDER
+#define SEMICRF_G3_MMA_ORDER 1    // 1: the limb products of a slab round-robin over the accumulators (independent neighbours); 0: six in a row per accumulator, operand reads one group ahead (within 2 % of each other, like the phase shift)
+#endif
+#ifndef SEMICRF_G3_PHASED
+#define SEMICRF_G3_PHASED 1       // 0: both groups in the same phase (the first version's schedule)
+#endif
 
 template <bool AT, int NW>
 __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __restrict__ Gt, int Tp,
@@ -442,24 +459,50 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
     constexpr int BPL = D * 64;                        // ... of the k/q part: D rows (columns of k/q)
     constexpr int BOFF = 3 * APL;
     constexpr int STAGE = 3 * (APL + BPL);
-    constexpr int NUB = (4 * D + 511) / 512;           // k/q units per lane and chunk
+    constexpr int WPP = D / 128 > 0 ? D / 128 : 1;     // waves per piece (8 rows) of the k/q part: 64 column pairs per wave
     extern __shared__ __attribute__((aligned(16))) char glds[];    // [G3_NS][STAGE]: Gt limbs h | m | l | k/q limbs h | m | l
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;           // this wave: rows 32*wm.., columns 32*NW*wn.. of the tile
+    const int grp = SEMICRF_G3_PHASED ? wave >> 2 : 0; // (waves w and w + 4 share a SIMD)
     const int nm = (T + GM - 1) / GM;
     const long long nitems = (long long)nm * C;
     const int nkt = Tp / GK;
     const size_t slab = gt_chain_floats(Tp);
 
-    auto item_of = [&](long long n, int& c, int& mi, int& kbeg, int& nk) -> bool {
-        if (n >= nitems) return false;
-        const int r = (int)(n / C);
-        c = __builtin_amdgcn_readfirstlane((int)(n % C));       // (64-bit division runs in the vector unit: back to scalar registers)
-        mi = __builtin_amdgcn_readfirstlane(AT ? r : nm - 1 - r);
+    // Item order.  An output tile re-reads its chain's k (q) rows, 1 MB per chain at T=1024, and with tiles dealt chain-fastest (the
+    // fp32 kernel's order: 256 workgroups on 256 chains) nearly all of that comes from memory: 2.4 GB per product, which the fp32
+    // kernel's 1.0 ms does not notice and this kernel's matrix time (0.26 ms) does.  Here a chain's tiles run side by side on ONE
+    // XCD (its L2 serves the other seven readers of a row): workgroup b = (XCD b % 8, slot b / 8); XCD x owns the chains c = x mod 8
+    // and walks the list [chain][position] with its slots; the tile behind a position rotates from round to round, mirrored in
+    // every other round (tiles a and nm-1-a together are one chain's average), so that the slots stay within a round of each other
+    // although their tiles differ 8 : 1 in length.  All tiles of a chain start at the same end of the contraction (dk walks it
+    // backwards).  Few chains (or a grid that is no multiple of 8): the plain order.
+    // (with few items per slot the rotation cannot even out the tile lengths: T=691 x 90 chains 0.30 -> 0.38 ms in this order)
+    const bool xcd_order = (gridDim.x % NXCD_G3) == 0 && C >= 8 * NXCD_G3 && (long long)C * nm >= 4 * (long long)gridDim.x;
+    const int nslots = gridDim.x / NXCD_G3, xcd = blockIdx.x % NXCD_G3;
+    const int cpr = nslots / nm > 0 ? nslots / nm : 1;               // chains of an XCD per round
+    // the workgroup's item number `round` (32-bit arithmetic throughout: nm * C items)
+    auto item_of = [&](int round, int& c, int& mi, int& kbeg, int& nk) -> bool {
+        unsigned ti;
+        if (xcd_order) {
+            const unsigned nch = (unsigned)(C - xcd + NXCD_G3 - 1) / NXCD_G3;       // chains of this XCD
+            const unsigned u = blockIdx.x / NXCD_G3 + (unsigned)nslots * (unsigned)round;
+            if (u >= nch * (unsigned)nm) return false;
+            const unsigned lc = u / (unsigned)nm, pos = u % (unsigned)nm, rr = lc / (unsigned)cpr;
+            const unsigned base = (pos + (rr >> 1)) % (unsigned)nm;
+            ti = (rr & 1) ? nm - 1 - base : base;                    // 0 = the longest contraction range
+            c = __builtin_amdgcn_readfirstlane((int)(lc * NXCD_G3 + xcd));  // (divisions run in the vector unit: back to scalar registers)
+        } else {
+            const unsigned n = blockIdx.x + gridDim.x * (unsigned)round;
+            if (n >= (unsigned)nitems) return false;
+            ti = n / (unsigned)C;                                    // longest first
+            c = __builtin_amdgcn_readfirstlane((int)(n % (unsigned)C));
+        }
+        mi = __builtin_amdgcn_readfirstlane(AT ? (int)ti : nm - 1 - (int)ti);
         if (AT) {
-            kbeg = mi * (GM / GK);
+            kbeg = mi * (GM / GK);                                   // chunks nkt-1 down to kbeg
             nk = nkt - kbeg;
         } else {
             kbeg = 0;
@@ -483,68 +526,85 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
     const int aRow = AT ? (tid & 127) : (tid >> 2);
     const int aPiece = AT ? (wave >> 1) : (tid & 3);
     const unsigned wA = (unsigned)(aRow * 64 + ((aPiece ^ ((aRow >> 2) & 3)) * 16));
-    // k/q: unit u = tid + 512 j = (column u % D, piece u / D), across rows; the piece is wave-uniform
-    unsigned wB[NUB], bVoff[NUB];
-    int bPiece[NUB];
-    bool bOn[NUB];
+    // k/q: a lane takes TWO adjacent columns (8-byte loads: half the vector-memory instructions of 4-byte ones, and the issue of
+    // those -- 24 per wave and chunk -- was 17 % of a wave's time) of the 8 rows of one piece: units (column 2 cp + j, piece), j = 0, 1;
+    // the piece is wave-uniform.  D = 256: all 512 lanes; D = 128: waves 0-3; D = 64: their lanes 0-31 (the others fetch a valid
+    // address again and store nothing)
+    const int bPieceRaw = wave / WPP, bCpRaw = (wave % WPP) * 64 + lane;
+    const bool bOn = D >= 256 || (bPieceRaw < 4 && bCpRaw < D / 2);
+    const int bPiece = bPieceRaw < 4 ? bPieceRaw : 3, bCp = bCpRaw < D / 2 ? bCpRaw : D / 2 - 1;
+    unsigned wB[2];
 #pragma unroll
-    for (int j = 0; j < NUB; ++j) {
-        const int u0 = wave * 64 + 512 * j;
-        bOn[j] = D >= 128 || u0 < 4 * D;                 // (D >= 128: every lane has its NUB units)
-        bPiece[j] = u0 / D;
-        const int d = (u0 % D + lane) % D;
-        wB[j] = (unsigned)(BOFF + d * 64 + ((bPiece[j] ^ ((d >> 2) & 3)) * 16));
-        bVoff[j] = (unsigned)(d * 4);
+    for (int j = 0; j < 2; ++j) {
+        const int d = 2 * bCp + j;
+        wB[j] = (unsigned)(BOFF + d * 64 + ((bPiece ^ ((d >> 2) & 3)) * 16));
     }
+    const unsigned bVoff = (unsigned)(bCp * 8);
 
     // ---- request side (identical in all waves) ---------------------------------------------------------------------------
-    long long nx_n = blockIdx.x;
+    // (per item: the buffer descriptors of the chain's slabs and the block offset; per chunk the scalar unit computes 32-bit
+    // offsets by increments -- the first version's 64-bit address arithmetic was ~500 scalar instructions per wave and chunk,
+    // 4000 issue cycles of the CU's one scalar unit against 3072 matrix cycles)
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    auto make_rsrc = [](const void* p, size_t bytes) -> v4i {
+        const unsigned long long a = (unsigned long long)(uintptr_t)p;
+        return (v4i){(int)(unsigned)a, (int)((a >> 32) & 0xffffu), (int)(unsigned)bytes, 0x00020000};
+    };
+    const unsigned ldo4 = (unsigned)(ldo * 4), somax = (unsigned)(T - 1) * ldo4;
+    int nx_round = 0;
     int nx_c = 0, nx_mi = 0, nx_kbeg = 0, nx_nk = 0, nx_j = 0;
-    bool nx_valid = item_of(nx_n, nx_c, nx_mi, nx_kbeg, nx_nk);
+    bool nx_valid = item_of(nx_round, nx_c, nx_mi, nx_kbeg, nx_nk);
     if (!nx_valid) return;                             // uniform
     unsigned aVoff = AT ? (unsigned)((tid & 127) * 4) : 0u;
+    v4i nx_ra, nx_rb;
+    unsigned nx_aoff = 0;                              // dq: byte offset of the item's 128-row block of Gt
     auto set_item_offsets = [&]() {
+        nx_ra = make_rsrc(Gt + (size_t)nx_c * slab, slab * 4);
+        nx_rb = make_rsrc(other + (size_t)nx_c * T * ldo, ((size_t)(T - 1) * ldo + D) * 4);
         if (!AT) {
             const int rows = Tp - nx_mi * GM < GM ? Tp - nx_mi * GM : GM;      // rows of the block that exist (the others are not stored)
             const int R = aRow < rows ? aRow : rows - 1;
-            aVoff = (unsigned)(((size_t)R * gt_row_len(nx_mi, Tp) + aPiece * 8) * 4);
+            aVoff = (unsigned)((R * gt_row_len(nx_mi, Tp) + aPiece * 8) * 4);
+            nx_aoff = (unsigned)(gt_block_off(nx_mi) * 4);
         }
     };
     set_item_offsets();
 
-    // (the two 16-byte loads stay whole registers quads: copied into eight scalars, the copies -- and a wait for the loads -- sit
-    // right behind the request)
-    struct Regs { v4f alo, ahi; float a[8]; float b[NUB][8]; };
+    // Requests and their waits are written out (asm): the compiler's own bookkeeping of loads in flight turned the wait for
+    // the OLDER register set into a wait for everything in every other step (vmcnt 17 -> 0 where 35 -> 18 was meant, with and
+    // without the epilogue's stores in the loop), i.e. a stall of one memory latency per chunk -- timing ablations: without the
+    // requests 1.35 ms, without the split 1.34, without both 1.33, complete 1.99.  Here a set's NLD loads are issued back to
+    // back, nothing else is in flight except the other set's NLD (the epilogue drains its stores), and the wait in front of
+    // a set's split is vmcnt(NLD).  The loaded registers are tied to that wait ("+v"): no use can move above it; the loads are
+    // UNCONDITIONAL (past the last chunk the last one is fetched again and never used) so that the count is always the same.
+    constexpr int NLD = (AT ? 8 : 2) + 8;
+    struct Regs { v4f alo, ahi; float a[8]; f32x2 b[8]; };
     struct Meta { bool valid, last; int c, mi; };
-    // The loads are UNCONDITIONAL (past the last chunk the last one is fetched again and never used): with a request under a
-    // branch the compiler's wait-count bookkeeping has to assume at every merge that the younger set was not requested, and
-    // waits for everything in flight where the older set is split.
     auto fetch = [&](Regs& g, Meta& m) {
         m.valid = nx_valid;
-        if (SEMICRF_G3_DBG & 2) return;
-        const int k0 = (nx_kbeg + nx_j) * GK;
-        const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)(Gt + (size_t)nx_c * slab), 0, (int)(slab * 4), 0x00020000);
-        const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)(other + (size_t)nx_c * T * ldo), 0, (int)(((size_t)(T - 1) * ldo + D) * 4), 0x00020000);
-        if (!AT) {
-            const unsigned sa = (unsigned)((gt_block_off(nx_mi) + (size_t)k0) * 4);
-            g.alo = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(ra, aVoff, sa, 0));
-            g.ahi = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(ra, aVoff + 16, sa, 0));
-        } else {
-            // the chunk's 32 rows (e) lie in one 128-row block; columns past the block's row length (a last block that is not
-            // 128 wide) read the next row or the workspace's slack: they only reach output rows >= T, which are not written
-            const int kblk = k0 / GM, krl = gt_row_len(kblk, Tp);
-            const size_t r0 = gt_block_off(kblk) + (size_t)(k0 - kblk * GM + 8 * aPiece) * krl + (size_t)nx_mi * GM;
+        const unsigned k0 = (unsigned)(AT ? nkt - 1 - nx_j : nx_kbeg + nx_j) * GK;
+        if (!(SEMICRF_G3_DBG & 2)) {
+            if (!AT) {
+                const unsigned sa = nx_aoff + k0 * 4;
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(g.alo) : "v"(aVoff), "s"(nx_ra), "s"(sa));
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(g.ahi) : "v"(aVoff), "s"(nx_ra), "s"(sa));
+            } else {
+                // the chunk's 32 rows (e) lie in one 128-row block; columns past the block's row length (a last block that is not
+                // 128 wide) read the next row or the workspace's slack: they only reach output rows >= T, which are not written
+                const unsigned kblk = k0 / GM, krl4 = (unsigned)gt_row_len((int)kblk, Tp) * 4;
+                unsigned so = (unsigned)GM * GM * 4 * (kblk * (kblk + 1) / 2) + (k0 - kblk * GM + 8 * aPiece) * krl4 + (unsigned)nx_mi * (GM * 4);
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                g.a[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, aVoff, (unsigned)((r0 + (size_t)i * krl) * 4), 0));
-        }
-#pragma unroll
-        for (int j = 0; j < NUB; ++j) {
+                for (int i = 0; i < 8; ++i) {
+                    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(g.a[i]) : "v"(aVoff), "s"(nx_ra), "s"(so));
+                    so += krl4;
+                }
+            }
+            unsigned sr = (k0 + 8 * bPiece) * ldo4;              // rows past T meet Gt == 0: any finite value will do (the last row's)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                int row = k0 + 8 * bPiece[j] + i;       // rows past T meet Gt == 0: any finite value will do
-                row = row < T ? row : T - 1;            // (D = 64: the waves 4..7 have no unit and fetch rows of the next chunks, unused)
-                g.b[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, bVoff[j], (unsigned)((size_t)row * ldo * 4), 0));
+                const unsigned so = sr < somax ? sr : somax;
+                asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(g.b[i]) : "v"(bVoff), "s"(nx_rb), "s"(so));
+                sr += ldo4;
             }
         }
         m.last = nx_j + 1 == nx_nk;
@@ -552,8 +612,8 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
         m.mi = nx_mi;
         if (nx_valid && ++nx_j == nx_nk) {
             int c2, mi2, kbeg2, nk2;
-            if (item_of(nx_n + gridDim.x, c2, mi2, kbeg2, nk2)) {
-                nx_n += gridDim.x;
+            if (item_of(nx_round + 1, c2, mi2, kbeg2, nk2)) {
+                ++nx_round;
                 nx_c = c2; nx_mi = mi2; nx_kbeg = kbeg2; nx_nk = nk2; nx_j = 0;
                 set_item_offsets();
             } else {
@@ -562,9 +622,22 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
             }
         }
     };
+    // the set's loads have landed (the other set's NLD younger ones may be in flight)
+    auto landed = [&](Regs& g) {
+        if (SEMICRF_G3_DBG & 2) return;
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD));
+        if (!AT) {
+            asm volatile("" : "+v"(g.alo), "+v"(g.ahi));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(g.a[i]));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(g.b[i]));
+    };
     float rs = 0.0f;                                    // !AT && rsum: this lane's part of its row's sum
     const bool want_rs = !AT && rsum != nullptr;
-    auto convert = [&](const Regs& g, const Meta& m, int stage) {
+    auto convert = [&](Regs& g, const Meta& m, int stage) {
         if (SEMICRF_G3_DBG & 4) return;
         char* base = glds + stage * STAGE;
         v4f alo, ahi;
@@ -587,12 +660,13 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
             }
         }
 #pragma unroll
-        for (int j = 0; j < NUB; ++j) {
-            if (D < 128 && !bOn[j]) continue;
-            const Limbs3 L = split8((v4f){g.b[j][0], g.b[j][1], g.b[j][2], g.b[j][3]}, (v4f){g.b[j][4], g.b[j][5], g.b[j][6], g.b[j][7]});
-            *(bf16x8*)(base + wB[j]) = L.h;
-            *(bf16x8*)(base + BPL + wB[j]) = L.m;
-            *(bf16x8*)(base + 2 * BPL + wB[j]) = L.l;
+        for (int j = 0; j < 2; ++j) {
+            const Limbs3 L = split8((v4f){g.b[0][j], g.b[1][j], g.b[2][j], g.b[3][j]}, (v4f){g.b[4][j], g.b[5][j], g.b[6][j], g.b[7][j]});
+            if (D >= 256 || bOn) {
+                *(bf16x8*)(base + wB[j]) = L.h;
+                *(bf16x8*)(base + BPL + wB[j]) = L.m;
+                *(bf16x8*)(base + 2 * BPL + wB[j]) = L.l;
+            }
         }
     };
 
@@ -601,6 +675,9 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
     for (int t = 0; t < NW; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    // 2 NW groups of six matrix instructions per chunk: group i = (slab i / NW, column block i % NW).  The reads of group i + 1
+    // are issued before the instructions of group i (two operand sets, alternating); the slab's A limbs are read with the
+    // slab's first group.
     auto multiply = [&](int stage) {
         const char* base = glds + stage * STAGE;
         if (SEMICRF_G3_DBG & 8) {
@@ -614,71 +691,163 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
             }
             return;
         }
+#if SEMICRF_G3_MMA_ORDER == 0
+        Limbs3 A[2], B[2];
+        auto ldA = [&](Limbs3& L, int sl) {
+            L.h = *(const bf16x8*)(base + rdA[sl]);
+            L.m = *(const bf16x8*)(base + APL + rdA[sl]);
+            L.l = *(const bf16x8*)(base + 2 * APL + rdA[sl]);
+        };
+        auto ldB = [&](Limbs3& L, int sl, int t) {
+            L.h = *(const bf16x8*)(base + rdB[sl] + t * 2048);
+            L.m = *(const bf16x8*)(base + BPL + rdB[sl] + t * 2048);
+            L.l = *(const bf16x8*)(base + 2 * BPL + rdB[sl] + t * 2048);
+        };
+        ldA(A[0], 0);
+        ldB(B[0], 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 2 * NW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int sl = i / NW, t = i % NW;
+            if constexpr (i + 1 < 2 * NW) {
+                constexpr int sl2 = (i + 1) / NW, t2 = (i + 1) % NW;
+                if constexpr (t2 == 0) ldA(A[sl2], sl2);
+                ldB(B[(i + 1) & 1], sl2, t2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (SEMICRF_G3_DBG & 1)
+                acc[t][0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, A[sl].h).x ^ __builtin_bit_cast(u32x4, B[i & 1].l).y ^
+                                                           __builtin_bit_cast(u32x4, A[sl].m).z ^ __builtin_bit_cast(u32x4, B[i & 1].h).w ^
+                                                           __builtin_bit_cast(u32x4, A[sl].l).x ^ __builtin_bit_cast(u32x4, B[i & 1].m).x);
+            else
+                acc[t] = mma6(A[sl], B[i & 1], acc[t]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#else
+        // a slab at a time: all its operands (A and the NW column blocks' B: 12 (1 + NW) registers), then the six limb products
+        // round-robin over the NW accumulators -- consecutive matrix instructions are independent
+        Limbs3 A, B[NW];
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
-            Limbs3 A;
             A.h = *(const bf16x8*)(base + rdA[sl]);
             A.m = *(const bf16x8*)(base + APL + rdA[sl]);
             A.l = *(const bf16x8*)(base + 2 * APL + rdA[sl]);
 #pragma unroll
             for (int t = 0; t < NW; ++t) {
-                Limbs3 B;
-                B.h = *(const bf16x8*)(base + rdB[sl] + t * 2048);
-                B.m = *(const bf16x8*)(base + BPL + rdB[sl] + t * 2048);
-                B.l = *(const bf16x8*)(base + 2 * BPL + rdB[sl] + t * 2048);
-                if (SEMICRF_G3_DBG & 1) acc[t][0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, A.h).x ^ __builtin_bit_cast(u32x4, B.l).y ^ __builtin_bit_cast(u32x4, A.m).z ^ __builtin_bit_cast(u32x4, B.h).w ^ __builtin_bit_cast(u32x4, A.l).x ^ __builtin_bit_cast(u32x4, B.m).x);
-                else
-                acc[t] = mma6(A, B, acc[t]);
+                B[t].h = *(const bf16x8*)(base + rdB[sl] + t * 2048);
+                B[t].m = *(const bf16x8*)(base + BPL + rdB[sl] + t * 2048);
+                B[t].l = *(const bf16x8*)(base + 2 * BPL + rdB[sl] + t * 2048);
             }
+#pragma unroll
+            for (int t = 0; t < NW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B[t].l, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l, B[t].h, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.m, B[t].m, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B[t].m, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.m, B[t].h, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B[t].h, acc[t], 0, 0, 0);
         }
+#endif
     };
 
-    Regs g0, g1;
-    Meta m0 = {false, false, 0, 0}, m1 = {false, false, 0, 0};
-    g0.alo = g0.ahi = g1.alo = g1.ahi = (v4f)(0.0f);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        g0.a[i] = 0.0f; g1.a[i] = 0.0f;
-#pragma unroll
-        for (int j = 0; j < NUB; ++j) { g0.b[j][i] = 0.0f; g1.b[j][i] = 0.0f; }
-    }
-    fetch(g0, m0);
-    fetch(g1, m1);
-    convert(g0, m0, 0);
-    fetch(g0, m0);
-
-    long long cur_n = blockIdx.x;
-    int c = 0, mi = 0, kbeg = 0, nk = 0, j = 0;
-    (void)item_of(cur_n, c, mi, kbeg, nk);
-    // one chunk: everybody's limbs of it are in stage P, everybody is done reading the other stage; multiply, split the next
-    // chunk into the other stage, request the chunk after next
-    auto step = [&](auto PC, Regs& gn, Meta& mn) -> bool {
-        constexpr int P = decltype(PC)::value;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+    Regs gX, gY;
+    Meta mX = {false, false, 0, 0}, mY = {false, false, 0, 0};
+    auto sync = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my limb stores are in the LDS ...
+        __builtin_amdgcn_s_barrier();                            // ... and so are everybody's; everybody is done reading the other stage
         asm volatile("" ::: "memory");
-        multiply(P);
-        convert(gn, mn, P ^ 1);
-        fetch(gn, mn);
+    };
+    // Slots (one barrier each): group 0 multiplies chunk n in slot 2n and splits chunk n+1 (into the OTHER stage) in slot 2n+1;
+    // group 1 splits chunk n+1 in slot 2n and multiplies chunk n in slot 2n+1 -- i.e. it runs the same loop one slot later and two
+    // chunks ahead with its requests: in the loop it splits chunk n+2 into the stage it has just multiplied.  Chunk 0 is split by
+    // everybody in front of the first barrier.  X is the register set split in the steps with P = 0, Y with P = 1.
+    if (grp == 0) {
+        fetch(gY, mY);
+        fetch(gX, mX);
+        landed(gY);
+        convert(gY, mY, 0);
+        fetch(gY, mY);
+        sync();
+    } else {
+        fetch(gX, mX);
+        fetch(gY, mY);
+        landed(gX);
+        convert(gX, mX, 0);
+        fetch(gX, mX);
+        sync();
+        landed(gY);
+        convert(gY, mY, 1);
+        fetch(gY, mY);
+        sync();
+    }
+
+    int cur_round = 0;
+    int c = 0, mi = 0, kbeg = 0, nk = 0, j = 0;
+    (void)item_of(cur_round, c, mi, kbeg, nk);
+    // ---- the item's 128 x D block (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)); rows >= T are
+    //      dropped by the buffer's range check (the row sits in the per-lane offset): no branches.  Then ONE wait for everything
+    //      in flight: stores and loads complete out of order with respect to each other, so with a store pending the compiler
+    //      turns every later wait for a load into vmcnt(0) -- on every path through that wait, i.e. in every chunk (the first
+    //      version: 17 -> 0 where 35 -> 18 was meant).  Draining here, once per item, keeps the chunks' waits exact. ----
+    auto finish = [&]() -> bool {
         if (++j < nk) return true;
-        // ---- the item's 128 x D block (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) ----
-        float* ob = out + (size_t)c * T * ldout;
+        const auto ro = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (size_t)c * T * ldout), 0, (int)((size_t)T * ldout * 4), 0x00020000);
+        const unsigned v0 = (unsigned)(((size_t)(mi * GM + 32 * wm + 4 * half) * ldout + 32 * NW * wn + l31) * 4);
 #pragma unroll
-        for (int t = 0; t < NW; ++t)
+        for (int r = 0; r < 16; ++r) {
+            const unsigned vr = v0 + (unsigned)((size_t)((r & 3) + 8 * (r >> 2)) * ldout * 4);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mi * GM + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < T) ob[(size_t)m * ldout + 32 * NW * wn + 32 * t + l31] = acc[t][r];
+            for (int t = 0; t < NW; ++t) {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][r]), ro, vr, t * 128, 0);     // (not __builtin_bit_cast of a vector element: bf16x3.h)
                 acc[t][r] = 0.0f;
             }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
         j = 0;
-        cur_n += gridDim.x;
-        return item_of(cur_n, c, mi, kbeg, nk);
+        return item_of(++cur_round, c, mi, kbeg, nk);
+    };
+#if SEMICRF_G3_PROBE
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = __builtin_readcyclecounter();
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+#define G3_STAMP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); pc[i] += now_ - pt; pt = now_; } while (0)
+#else
+#define G3_STAMP(i) do { } while (0)
+#endif
+    // one chunk: its limbs are in stage P
+    auto step = [&](auto PC, Regs& gn, Meta& mn) -> bool {
+        constexpr int P = decltype(PC)::value;
+        multiply(P);
+        G3_STAMP(0);
+        const bool more = finish();
+        G3_STAMP(1);
+        sync();
+        G3_STAMP(2);
+        landed(gn);
+        G3_STAMP(3);
+        convert(gn, mn, P ^ 1 ^ grp);
+        G3_STAMP(4);
+        fetch(gn, mn);
+        G3_STAMP(5);
+        sync();
+        G3_STAMP(6);
+        return more;
     };
     while (true) {
-        if (!step(std::integral_constant<int, 0>{}, g1, m1)) break;
-        if (!step(std::integral_constant<int, 1>{}, g0, m0)) break;
+        if (!step(std::integral_constant<int, 0>{}, gX, mX)) break;
+        if (!step(std::integral_constant<int, 1>{}, gY, mY)) break;
     }
+    if (SEMICRF_G3_PHASED && grp == 0) sync();                   // (group 1's last slot)
+#if SEMICRF_G3_PROBE
+    pc[7] = __builtin_amdgcn_s_memrealtime() - rt0;
+    __syncthreads();
+    if (lane == 0 && rsum)        // (behind the C x T row sums: the probe script allocates 16 K floats more)
+        for (int i = 0; i < 8; ++i) rsum[(size_t)C * T * ldrs + (size_t)(blockIdx.x * 8 + wave) * 8 + i] = (float)pc[i];
+#endif
+#undef G3_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
