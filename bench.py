@@ -672,17 +672,19 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
     world = dist.get_world_size() if dist is not None else 1
     extra["train_step_ms"] = round(dt * 1e3, 3)
     extra["train_step_segments_per_s"] = round(world * N / dt, 2)
-    # the same step with scorer.contraction = "bf16x3" (opt-in: the scorer's forward contraction and its backward products on the
-    # three-limb bf16 kernels; fp32-grade, not bit-identical -- the headline and train_step_ms stay exact fp32)
-    model.scorer.contraction = "bf16x3"
-    for _ in range(2):
-        tstep()
-    sync_all()
-    t1 = time.perf_counter()
-    for _ in range(5):
-        tstep()
-    sync_all()
-    extra["train_step_ms_bf16x3"] = round(max_over_ranks((time.perf_counter() - t1) / 5, dev) * 1e3, 3)
+    # the same step with the opt-in three-limb bf16 kernels (fp32-grade, not bit-identical -- the headline and train_step_ms stay exact
+    # fp32): scorer.contraction = "bf16x3" (forward contraction and backward products) and "bf16x3-bwd" (backward products only: at
+    # this shape the exact forward kernel is the faster one)
+    for cname, key in (("bf16x3", "train_step_ms_bf16x3"), ("bf16x3-bwd", "train_step_ms_bf16x3_bwd")):
+        model.scorer.contraction = cname
+        for _ in range(2):
+            tstep()
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            tstep()
+        sync_all()
+        extra[key] = round(max_over_ranks((time.perf_counter() - t1) / 5, dev) * 1e3, 3)
     model.scorer.contraction = "fp32"
     extra["train_step_config"] = (f"per rank: 4 segments x 90 symbols x T=691, D=256: Linear + interval scorer + fused CRF log_prob, "
                                   f"(loss/50).backward(), one [3] all-reduce, gradient exchange of "

@@ -74,3 +74,16 @@ def test_pool_keeps_two_buffers_per_shape():
     assert flags == m.GRAD_UPPER_IS_ZERO             # untouched since the library's write: the zeros are still there
     pool.clear()
     assert pool.held_bytes() == 0
+
+
+def test_contraction_modes():
+    """scorer.contraction: the four modes and their flag bits; anything else is a ValueError before any kernel runs."""
+    import pytest
+    from transkun_amd.scorer import BF16X3, BWD_BF16X3, ScaledInnerProductIntervalScorer, contraction_bits
+    assert contraction_bits("fp32") == 0
+    assert contraction_bits("bf16x3") == BF16X3 | BWD_BF16X3
+    assert contraction_bits("bf16x3-fwd") == BF16X3 and contraction_bits("bf16x3-bwd") == BWD_BF16X3
+    assert BWD_BF16X3 & 7 == 0                        # never collides with the library's full_square bits (triangle mode, BF16X3)
+    with pytest.raises(ValueError):
+        contraction_bits("tf32")
+    assert ScaledInnerProductIntervalScorer(64).contraction == "fp32"

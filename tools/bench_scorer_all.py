@@ -34,7 +34,8 @@ for (N, P, pitch, T, D) in ((1, 352, 352, 1024, 256), (4, 90, 96, 691, 256))[:1 
     dq = torch.empty_like(q); dk = torch.empty_like(k); dd = torch.empty_like(dg)
     ws = bwd_workspace(C, T, D, dev)
     bw = timeit(lambda: ops.interval_score_bwd_ws(S, q, k, C, T, D, D, D, 1.0 / 16, 0, P, pitch, dq, dk, dd, dd, D, D, 1, 0, ws))
+    bw3 = timeit(lambda: ops.interval_score_bwd_ws(S, q, k, C, T, D, D, D, 1.0 / 16, 16, P, pitch, dq, dk, dd, dd, D, D, 1, 0, ws))
     print(f"T={T} chains={C} (groups of {P} at pitch {pitch}) D={D}: fwd fp32 {f32:.3f} ms = {fl / f32 / 1e9:.1f} TFLOP/s ({fl / f32 / 1e9 / 157.3:.3f} of 157.3), "
-          f"fwd bf16x3 {b3:.3f} ms = {fl / b3 / 1e9:.1f} TFLOP/s fp32-equivalent, bwd (pack + 2 GEMMs) {bw:.3f} ms = {2 * fl / bw / 1e9:.1f} TFLOP/s", flush=True)
+          f"fwd bf16x3 {b3:.3f} ms = {fl / b3 / 1e9:.1f} TFLOP/s fp32-equivalent, bwd (pack + 2 GEMMs) {bw:.3f} ms = {2 * fl / bw / 1e9:.1f} TFLOP/s, bwd bf16x3 {bw3:.3f} ms = {2 * fl / bw3 / 1e9:.1f} TFLOP/s fp32-equivalent", flush=True)
     del q, k, dg, S, dq, dk, dd, ws
     torch.cuda.empty_cache()

@@ -27,7 +27,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .scorer import (BF16X3, LEN_BF16X3, QPAD, ScaledInnerProductIntervalScorer, _ScorerLinear, _ScorerLinearPacked, _interval_score_raw, bwd_workspace, proj_forward,
+from .scorer import (BF16X3, BWD_BF16X3, LEN_BF16X3, QPAD, contraction_bits, ScaledInnerProductIntervalScorer, _ScorerLinear, _ScorerLinearPacked, _interval_score_raw, bwd_workspace, proj_forward,
                      proj_input_grad, proj_weight_grad, qd_weights, slot_maps, slot_pitch)
 
 _nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
@@ -138,7 +138,7 @@ class _MergedScorerCRFLogProb(torch.autograd.Function):
         zc = proj_forward(x3.view(-1, size), Wm, bm, size, Wt=getattr(Wm, "_semicrf_T", None)).view(C, T, size + QPAD)   # [z | c | diag | 0 0]
         ctx.Wp = getattr(Wm, "_semicrf_padded", None)      # Wm with its rows padded to whole chunks (the input gradient's B), if it came so
         qs = 1.0 / math.sqrt(D)
-        S, noise = _interval_score_raw(zc[..., :size], x3, zc[..., size + 1], T, C, size, qs, mode, fs, P, pitch, rowc=zc[..., size])
+        S, noise = _interval_score_raw(zc[..., :size], x3, zc[..., size + 1], T, C, size, qs, mode, int(fs) & ~BWD_BF16X3, P, pitch, rowc=zc[..., size])
         if pitch != P:
             real, offmap = slot_maps(N, P, pitch, S.device)
             offsets_s = offsets.index_select(0, offmap)
@@ -149,7 +149,7 @@ class _MergedScorerCRFLogProb(torch.autograd.Function):
         pairs._semicrf_K = K
         path = _nsci._eval_path_raw(S, noise, pairs, offsets_s)
         ctx.save_for_backward(x3, zc, Wm, S, noise, v, logz, pairs, offsets_s)
-        ctx.meta = (N, P, T, D, mode, K, pitch, LEN_BF16X3 if int(fs) & BF16X3 else 0)
+        ctx.meta = (N, P, T, D, mode, K, pitch, LEN_BF16X3 if int(fs) & BWD_BF16X3 else 0)
         lp = path - logz
         return lp if real is None else lp.index_select(0, real)
 
@@ -203,7 +203,7 @@ class _ScorerCRFLogProb(torch.autograd.Function):
         pitch = slot_pitch(P, T, D, N)
         qd3, k3 = qd.reshape(C, T, D + QPAD), k.reshape(C, T, D)
         qs = 1.0 / math.sqrt(D)
-        S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qs, mode, fs, P, pitch)     # fs: 2 | BF16X3
+        S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qs, mode, int(fs) & ~BWD_BF16X3, P, pitch)     # fs: 2 | BF16X3
         if pitch != P:
             real, offmap = slot_maps(N, P, pitch, S.device)
             offsets_s = offsets.index_select(0, offmap)
@@ -214,7 +214,7 @@ class _ScorerCRFLogProb(torch.autograd.Function):
         pairs._semicrf_K = K
         path = _nsci._eval_path_raw(S, noise, pairs, offsets_s)
         ctx.save_for_backward(qd3, k3, S, noise, v, logz, pairs, offsets_s)
-        ctx.meta = (N, P, T, D, mode, K, pitch, LEN_BF16X3 if int(fs) & BF16X3 else 0)
+        ctx.meta = (N, P, T, D, mode, K, pitch, LEN_BF16X3 if int(fs) & BWD_BF16X3 else 0)
         lp = path - logz
         return lp if real is None else lp.index_select(0, real)
 
@@ -267,7 +267,7 @@ def scorer_crf_logprob(scorer: ScaledInnerProductIntervalScorer, ctx: torch.Tens
     W, bias = lin.weight, lin.bias
     x = ctx.float()
     pairs, offsets = _nsci.pack_intervals(intervals, T, N * P, ctx.device)
-    fs = 2 | (BF16X3 if getattr(scorer, "contraction", "fp32") == "bf16x3" else 0)
+    fs = 2 | contraction_bits(getattr(scorer, "contraction", "fp32"))
     if projection not in ("merged", "separate"):
         raise ValueError(f"projection must be 'merged' or 'separate', not {projection!r}")
     if projection == "merged" and merged_eligible(scorer.size, T):

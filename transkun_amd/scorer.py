@@ -109,6 +109,18 @@ def bwd_workspace(C: int, T: int, D: int, device) -> torch.Tensor:
 
 BF16X3 = 4      # SEMICRF_SCORE_BF16X3: OR into full_square
 LEN_BF16X3 = 16 # SEMICRF_LEN_BF16X3: OR into the backward's length-scaling mode (the two products on the three-limb bf16 kernels)
+BWD_BF16X3 = 8  # this package's autograd nodes only (never handed to the library): "the backward of this forward uses LEN_BF16X3"
+CONTRACTIONS = {"fp32": 0, "bf16x3": BF16X3 | BWD_BF16X3, "bf16x3-fwd": BF16X3, "bf16x3-bwd": BWD_BF16X3}
+
+
+def contraction_bits(name: str) -> int:
+    """scorer.contraction -> flag bits of the autograd nodes: 'fp32' (default, exact), 'bf16x3' (forward contraction and backward
+    products on the three-limb bf16 kernels), 'bf16x3-fwd' / 'bf16x3-bwd' (one side only: at the model's training shape the
+    backward gains 0.23 ms per step and the forward loses 0.13 against the exact kernel, profiles/r05_train_step_*)."""
+    try:
+        return CONTRACTIONS[name]
+    except KeyError:
+        raise ValueError(f"contraction must be one of {sorted(CONTRACTIONS)}, not {name!r}") from None
 
 
 QPAD = 4        # [q | diag | 3 zero columns]: one GEMM instead of a D-wide and a 1-wide one, rows stay 16-byte aligned
@@ -418,9 +430,9 @@ class _IntervalScore(torch.autograd.Function):
         pitch = pitch or P
         qd3, k3 = qd.reshape(C, T, D + QPAD), k.reshape(C, T, D)
         qscale = 1.0 / math.sqrt(D)
-        S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qscale, mode, full_square, P, pitch)
+        S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qscale, mode, int(full_square) & ~BWD_BF16X3, P, pitch)
         ctx.save_for_backward(qd3, k3)
-        ctx.meta = (N, P, T, D, mode | (LEN_BF16X3 if int(full_square) & BF16X3 else 0), (int(full_square) & 3) == 1, pitch)
+        ctx.meta = (N, P, T, D, mode | (LEN_BF16X3 if int(full_square) & BWD_BF16X3 else 0), (int(full_square) & 3) == 1, pitch)
         return S.view(T, T, N, pitch), noise.view(max(T - 1, 0), N, pitch)
 
     @staticmethod
@@ -478,7 +490,7 @@ class ScaledInnerProductIntervalScorer(nn.Module):
                                   # [T-1, N, slotPitch] with zeros in the slots P.. of every segment (include/semicrf_hip.h, "SLOT
                                   # LAYOUT") -- for callers that hand flatten(-2, -1) of both straight to NeuralSemiCRFInterval and
                                   # drop the ghost chains' results; None: the reference's [T, T, N, P]
-        self.contraction = "fp32"  # "bf16x3": opt-in forward contraction on the bf16 matrix instructions -- operands split
+        self.contraction = "fp32"  # "bf16x3" (also "bf16x3-fwd" / "bf16x3-bwd", contraction_bits): opt-in contraction on the bf16 matrix instructions -- operands split
                                   # exactly into three bf16 limbs, six limb products, fp32 accumulation: fp32-grade scores
                                   # (|error| <= 2^-21 * sum_d |q_d k_d| * scale), not bit-identical to "fp32"; the
                                   # backward is the exact fp32 one either way
@@ -500,8 +512,6 @@ class ScaledInnerProductIntervalScorer(nn.Module):
         else:
             Wqd, bqd = qd_weights(W, bias, D)
             qd, k = _ScorerLinear.apply(x, Wqd, bqd, W[D:2 * D], bias[D:2 * D])
-        if self.contraction not in ("fp32", "bf16x3"):
-            raise ValueError(f"contraction must be 'fp32' or 'bf16x3', not {self.contraction!r}")
-        fs = int(self.fullSquare) | (BF16X3 if self.contraction == "bf16x3" else 0)
+        fs = int(self.fullSquare) | contraction_bits(self.contraction)
         S, b = _IntervalScore.apply(qd, k, N, P, T, D, _lib.LEN_MODES[self.lengthScaling], fs, int(self.slotPitch or 0))
         return S, b
