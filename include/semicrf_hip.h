@@ -344,6 +344,14 @@ int interval_score_path_bwd_pc(const float* gout, const int32_t* pairs, int64_t 
  */
 int scorer_proj_nn(const float* A, int64_t lda, int64_t M, int K, const float* B, int64_t ldb, int N, float* out, int64_t ldout,
                    const float* bias, const float* w2, const float* b2, int zero_cols, int accumulate, semicrf_stream_t stream);
+/* scorer_proj_nn with the three-limb bf16 contraction (csrc/proj_gemm3.hip; opt-in, fp32-grade: |out - exact| <= 2^-21 sum_k |A[m][k] B[k][n]|
+ * per element, not bit-identical): B is split once per call into `ws` (scorer_proj_nn3_workspace_bytes; 16-byte aligned), A in the loop.
+ * N == 256 only; any other shape (or ws == NULL / too small) runs scorer_proj_nn's exact kernel.  The two extra columns are fp32 dot
+ * products as before (in another fixed order). */
+size_t scorer_proj_nn3_workspace_bytes(int K, int N);
+int scorer_proj_nn3(const float* A, int64_t lda, int64_t M, int K, const float* B, int64_t ldb, int N, float* out, int64_t ldout,
+                    const float* bias, const float* w2, const float* b2, int zero_cols, int accumulate, void* ws, size_t ws_bytes,
+                    semicrf_stream_t stream);
 size_t scorer_proj_tn_workspace_bytes(int64_t M, int R, int N);
 int scorer_proj_tn(const float* dy, int64_t lddy, int64_t M, int R, int extra_col0, int total_rows, const float* x, int64_t ldx, int N,
                    float* dW, int64_t lddw, float* db, void* ws, size_t ws_bytes, semicrf_stream_t stream);

@@ -1909,6 +1909,48 @@ def test_score_pool_upper_triangle_stays_exact(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,packed", [(691, True), (1000, False), (62190, True), (128, True), (37, False)])
+def test_projection_bf16x3(gpu, M, packed):
+    """The projection's two NN forms on the three-limb bf16 kernels (csrc/proj_gemm3.hip: scorer_proj_nn3; proj_forward / proj_input_grad
+    with prec = 1) against float64: every element within 2^-21 of sum_k |a_k b_k| (+ the bias' own rounding), the two extra columns and
+    the zero columns as with the exact kernel, the accumulating form, a packed width (260) that is no whole number of chunks, row counts
+    that are no multiple of the tile; and the kernels ran (some element differs from the exact kernels' result)."""
+    from transkun_amd import _lib, synth
+    from transkun_amd.scorer import QPAD, proj_forward, proj_input_grad
+    _lib.set_impl(0)
+    K = n_main = 256
+    Nout = n_main + QPAD if packed else n_main
+    x = synth.hash_normal(M * K, 311, gpu).view(M, K)
+    W = synth.hash_normal(Nout * K, 312, gpu).view(Nout, K) / K ** 0.5
+    b = synth.hash_normal(Nout, 313, gpu)
+    if packed:
+        W[n_main + 2:] = 0; b[n_main + 2:] = 0
+    y3, y1 = proj_forward(x, W, b, n_main, prec=1), proj_forward(x, W, b, n_main)
+    ref = x.double() @ W.double().t() + b.double()
+    bound = (x.double().abs() @ W.double().abs().t() + b.double().abs()) * 2.0 ** -21 + 1e-30
+    assert y3.shape == (M, Nout)
+    assert float(((y3.double() - ref).abs() / bound).max()) <= 1.0
+    assert not torch.equal(y3[:, :n_main], y1[:, :n_main])
+    if packed:
+        assert float(y3[:, n_main + 2:].abs().max()) == 0.0
+        assert float((y3[:, n_main:n_main + 2] - y1[:, n_main:n_main + 2]).abs().max()) <= 4e-6 * float(y1[:, n_main:n_main + 2].abs().max())
+    dy = synth.hash_normal(M * Nout, 314, gpu).view(M, Nout)
+    if packed:
+        dy[:, n_main + 2:] = 0
+    dx3, dx1 = proj_input_grad(dy, W, prec=1), proj_input_grad(dy, W)
+    rdx = dy.double() @ W.double()
+    bdx = dy.double().abs() @ W.double().abs() * 2.0 ** -21 + 1e-30
+    assert float(((dx3.double() - rdx).abs() / bdx).max()) <= 1.0
+    assert not torch.equal(dx3, dx1)
+    base = synth.hash_normal(M * K, 315, gpu).view(M, K).contiguous()
+    acc = base.clone()
+    out = proj_input_grad(dy, W, out=acc, prec=1)
+    assert out.data_ptr() == acc.data_ptr()
+    assert float(((acc.double() - (base.double() + rdx)).abs() / (bdx + base.double().abs() * 2.0 ** -23)).max()) <= 1.0
+    assert _lib.device_status() == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,K,n_main,packed", [(1000, 256, 256, True), (4321, 256, 256, False), (130, 64, 64, True), (2999, 128, 128, True),
                                                 (62190, 256, 256, True), (33, 256, 256, True)])
 def test_projection_kernels(gpu, M, K, n_main, packed):

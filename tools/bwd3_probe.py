@@ -49,3 +49,22 @@ if "--probe" in sys.argv:
     for g, sl in (("group 0", slice(0, 4)), ("group 1", slice(4, 8))):
         m = pc[:, sl, :7].mean(axis=(0, 1))
         print("  ", g, " ".join("%s %.1f%% (%.0f)" % (names[i], 100 * m[i] / m.sum(), m[i]) for i in range(7)))
+
+if "--proj" in sys.argv:
+    # the projection's NN forms at the training shape: exact fp32 against the three-limb kernels
+    from transkun_amd.scorer import QPAD, proj_forward, proj_input_grad
+    M, K = 4 * 90 * 691, 256
+    x = torch.randn(M, K, device=dev); W = torch.randn(K + QPAD, K, device=dev) / 16; W[K + 2:] = 0; b = torch.randn(K + QPAD, device=dev); b[K + 2:] = 0
+    dy = torch.randn(M, K + QPAD, device=dev); dy[:, K + 2:] = 0
+    acc = torch.zeros(M, K, device=dev)
+    def t(f, n=5):
+        for _ in range(2): f()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(n): f()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    fl = 2.0 * M * K * (K + 2)
+    for name, p in (("fp32", 0), ("bf16x3", 1)):
+        tf = t(lambda: proj_forward(x, W, b, K, prec=p)); tb = t(lambda: proj_input_grad(dy, W, out=acc, prec=p))
+        print(f"projection M={M} K={K} {name}: forward {tf:.3f} ms ({fl / tf / 1e9:.1f} TF), input gradient (accumulating) {tb:.3f} ms ({fl / tb / 1e9:.1f} TF)", flush=True)

@@ -63,6 +63,8 @@ _SIGS = {
     "interval_score_path_bwd_pc": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, ctypes.c_float, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "semicrf_beta": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "scorer_proj_nn": (_i, [_vp, _i64, _i64, _i, _vp, _i64, _i, _vp, _i64, _vp, _vp, _vp, _i, _i, _vp]),
+    "scorer_proj_nn3": (_i, [_vp, _i64, _i64, _i, _vp, _i64, _i, _vp, _i64, _vp, _vp, _vp, _i, _i, _vp, ctypes.c_size_t, _vp]),
+    "scorer_proj_nn3_workspace_bytes": (ctypes.c_size_t, [_i, _i]),
     "scorer_proj_tn_workspace_bytes": (_sz, [_i64, _i, _i]),
     "scorer_merge_weights_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "scorer_stage_linear": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

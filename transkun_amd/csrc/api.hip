@@ -80,6 +80,10 @@ int launch_interval_score_mfma(const float* q, const float* k, const float* diag
 int launch_proj_nn(const float* A, long long lda, long long M, int K, const float* B, long long ldb, int N, float* out, long long ldout,
                    const float* bias, const float* w2, const float* b2, int zero_cols, int accumulate, hipStream_t stream);
 size_t proj_tn_workspace_bytes(long long M, int R, int N);
+size_t proj_nn3_workspace_bytes(int K, int N);
+int launch_proj_nn3(const float* A, long long lda, long long M, int K, const float* B, long long ldb, int N, float* out, long long ldout,
+                    const float* bias, const float* w2, const float* b2, int zero_cols, int accumulate, void* ws, size_t ws_bytes,
+                    hipStream_t stream);
 void launch_merge_weights_fwd(const float* W, const float* bias, int D, int size, int rows, float* Wm, float* bm, float* WmT, hipStream_t stream);
 void launch_merge_weights_bwd(const float* W, const float* bias, const float* dWm, const float* dbm, int D, int size, float* dW, float* dbias,
                               float* ws, hipStream_t stream);
@@ -769,6 +773,21 @@ int scorer_proj_nn(const float* A, int64_t lda, int64_t M, int K, const float* B
     SEMICRF_CHECK_ARG(launch_proj_nn(A, lda, M, K, B, ldb, N, out, ldout, bias, w2, b2, zero_cols, accumulate, (hipStream_t)stream) == 0,
                       "scorer_proj_nn: N must be 64, 128 or 256, K %% 4 == 0, rows 16-byte aligned, M * ld * 4 < 2^31 (N=%d K=%d)", N, K);
     SEMICRF_CHECK_LAUNCH("scorer_proj_nn");
+    return SEMICRF_OK;
+}
+
+size_t scorer_proj_nn3_workspace_bytes(int K, int N) { return proj_nn3_workspace_bytes(K, N); }
+
+int scorer_proj_nn3(const float* A, int64_t lda, int64_t M, int K, const float* B, int64_t ldb, int N, float* out, int64_t ldout,
+                    const float* bias, const float* w2, const float* b2, int zero_cols, int accumulate, void* ws, size_t ws_bytes,
+                    semicrf_stream_t stream)
+{
+    SEMICRF_CHECK_ARG(A && B && out, "A/B/out must be non-NULL");
+    SEMICRF_CHECK_ARG(M >= 1 && K >= 4 && lda >= K && ldb >= N && zero_cols >= 0 && (!w2 || b2), "bad sizes");
+    SEMICRF_CHECK_ARG(ldout >= N + (w2 ? 2 + zero_cols : 0), "ldout too small for the packed output");
+    if (launch_proj_nn3(A, lda, M, K, B, ldb, N, out, ldout, bias, w2, b2, zero_cols, accumulate, ws, ws_bytes, (hipStream_t)stream) != 0)
+        return scorer_proj_nn(A, lda, M, K, B, ldb, N, out, ldout, bias, w2, b2, zero_cols, accumulate, stream);      // not this kernel's shape: exact
+    SEMICRF_CHECK_LAUNCH("scorer_proj_nn3");
     return SEMICRF_OK;
 }
 

@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void proj_reduce_kernel(const float* __restric
 
 }  // namespace pj
 
-static int proj_ncu()
+int proj_ncu()
 {
     int ncu = 256, dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;

@@ -359,6 +359,20 @@ void proj_nn_op(Tensor A, int64_t lda, int64_t M, int64_t K, Tensor B, int64_t l
                          has_w2 ? f32(w2, 2 * K, "w2") : nullptr, has_w2 ? f32(b2, 2, "b2") : nullptr, (int)zero_cols, accumulate ? 1 : 0, c.stream),
           "scorer_proj_nn");
 }
+void proj_nn3_op(Tensor A, int64_t lda, int64_t M, int64_t K, Tensor B, int64_t ldb, int64_t N, Tensor out, int64_t ldout, Tensor bias,
+                 bool has_bias, Tensor w2, Tensor b2, bool has_w2, int64_t zero_cols, bool accumulate, Tensor ws)
+{
+    Ctx c(A); c.same(A, B, out, ws);
+    if (has_bias) c.same(A, bias);
+    if (has_w2) c.same(A, w2, b2);
+    STD_TORCH_CHECK(M >= 1 && K >= 4 && N >= 1 && M < (1ll << 31) && K < (1 << 20) && N <= 256, "semicrf: bad M / K / N");
+    STD_TORCH_CHECK(A.numel() >= (M - 1) * lda + K && out.numel() >= (M - 1) * ldout + N + (has_w2 ? 2 + zero_cols : 0), "semicrf: A / out too small");
+    STD_TORCH_CHECK(B.numel() >= ((K + 31) / 32 * 32 - 1) * ldb + N, "semicrf: B must hold whole chunks of 32 rows (zero beyond K)");
+    check(scorer_proj_nn3(f32s(A, "A"), lda, M, (int)K, f32s(B, "B"), ldb, (int)N, f32so(out, "out"), ldout, has_bias ? f32(bias, N, "bias") : nullptr,
+                          has_w2 ? f32(w2, 2 * K, "w2") : nullptr, has_w2 ? f32(b2, 2, "b2") : nullptr, (int)zero_cols, accumulate ? 1 : 0,
+                          ws.numel() ? ws.data_ptr() : nullptr, (size_t)ws.numel() * ws.element_size(), c.stream),
+          "scorer_proj_nn3");
+}
 void proj_tn_op(Tensor dy, int64_t lddy, int64_t M, int64_t R, int64_t extra_col0, int64_t total_rows, Tensor x, int64_t ldx, int64_t N, Tensor dW,
                 int64_t lddw, Tensor db, Tensor ws)
 {
@@ -477,6 +491,8 @@ STABLE_TORCH_LIBRARY(semicrf, m)
           "int lddd, int lddrc) -> ()");
     m.def("proj_nn(Tensor A, int lda, int M, int K, Tensor B, int ldb, int N, Tensor(a!) out, int ldout, Tensor bias, bool has_bias, Tensor w2, "
           "Tensor b2, bool has_w2, int zero_cols, bool accumulate) -> ()");
+    m.def("proj_nn3(Tensor A, int lda, int M, int K, Tensor B, int ldb, int N, Tensor(a!) out, int ldout, Tensor bias, bool has_bias, Tensor w2, "
+          "Tensor b2, bool has_w2, int zero_cols, bool accumulate, Tensor(b!) ws) -> ()");
     m.def("stage_linear(Tensor W, Tensor bias, int D, int size, int rows_pad, Tensor(a!) BT, Tensor(b!) Wqd, Tensor(c!) w2, Tensor(d!) b2) -> ()");
     m.def("merge_weights_fwd(Tensor W, Tensor bias, int D, int size, int rows, Tensor(a!) Wm, Tensor(b!) bm, Tensor(c!) WmT, bool has_t) -> ()");
     m.def("merge_weights_bwd(Tensor W, Tensor bias, Tensor dWm, Tensor dbm, int D, int size, int rows, Tensor(a!) dW, Tensor(b!) dbias, Tensor(c!) ws) -> ()");
@@ -519,6 +535,7 @@ STABLE_TORCH_LIBRARY_IMPL(semicrf, CUDA, m)
     m.impl("interval_score_bwd_fused_ws", TORCH_BOX(&interval_score_bwd_fused_ws_op));
     m.impl("interval_score_path_bwd", TORCH_BOX(&interval_score_path_bwd_op));
     m.impl("proj_nn", TORCH_BOX(&proj_nn_op));
+    m.impl("proj_nn3", TORCH_BOX(&proj_nn3_op));
     m.impl("proj_tn", TORCH_BOX(&proj_tn_op));
     m.impl("merge_weights_fwd", TORCH_BOX(&merge_weights_fwd_op));
     m.impl("stage_linear", TORCH_BOX(&stage_linear_op));

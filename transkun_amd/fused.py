@@ -27,7 +27,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .scorer import (BF16X3, BWD_BF16X3, LEN_BF16X3, QPAD, contraction_bits, ScaledInnerProductIntervalScorer, _ScorerLinear, _ScorerLinearPacked, _interval_score_raw, bwd_workspace, proj_forward,
+from .scorer import (BF16X3, BWD_BF16X3, LEN_BF16X3, PROJ_BF16X3, QPAD, contraction_bits, ScaledInnerProductIntervalScorer, _ScorerLinear, _ScorerLinearPacked, _interval_score_raw, bwd_workspace, proj_forward,
                      proj_input_grad, proj_weight_grad, qd_weights, slot_maps, slot_pitch)
 
 _nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
@@ -135,10 +135,13 @@ class _MergedScorerCRFLogProb(torch.autograd.Function):
         size = x.shape[-1]
         pitch = slot_pitch(P, T, size, N)
         x3 = x.reshape(C, T, size)
-        zc = proj_forward(x3.view(-1, size), Wm, bm, size, Wt=getattr(Wm, "_semicrf_T", None)).view(C, T, size + QPAD)   # [z | c | diag | 0 0]
+        pp = 1 if int(fs) & PROJ_BF16X3 else 0
+        zc = proj_forward(x3.view(-1, size), Wm, bm, size, Wt=getattr(Wm, "_semicrf_T", None), prec=pp).view(C, T, size + QPAD)   # [z | c | diag | 0 0]
+        ctx.pp = pp
         ctx.Wp = getattr(Wm, "_semicrf_padded", None)      # Wm with its rows padded to whole chunks (the input gradient's B), if it came so
         qs = 1.0 / math.sqrt(D)
-        S, noise = _interval_score_raw(zc[..., :size], x3, zc[..., size + 1], T, C, size, qs, mode, int(fs) & ~BWD_BF16X3, P, pitch, rowc=zc[..., size])
+        S, noise = _interval_score_raw(zc[..., :size], x3, zc[..., size + 1], T, C, size, qs, mode, int(fs) & ~(BWD_BF16X3 | PROJ_BF16X3), P, pitch,
+                                       rowc=zc[..., size])
         if pitch != P:
             real, offmap = slot_maps(N, P, pitch, S.device)
             offsets_s = offsets.index_select(0, offmap)
@@ -183,7 +186,7 @@ class _MergedScorerCRFLogProb(torch.autograd.Function):
         need = ctx.needs_input_grad
         dx2 = dx.view(-1, size)
         if need[0]:
-            proj_input_grad(g2, Wm, out=dx2, Wp=ctx.Wp)               # + the part through [z | c | diag]
+            proj_input_grad(g2, Wm, out=dx2, Wp=ctx.Wp, prec=ctx.pp)  # + the part through [z | c | diag]
         dWm = dbm = None
         if need[1] or need[2]:
             dWm, dbm = proj_weight_grad(g2, x3.view(-1, size), size)
@@ -203,7 +206,7 @@ class _ScorerCRFLogProb(torch.autograd.Function):
         pitch = slot_pitch(P, T, D, N)
         qd3, k3 = qd.reshape(C, T, D + QPAD), k.reshape(C, T, D)
         qs = 1.0 / math.sqrt(D)
-        S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qs, mode, int(fs) & ~BWD_BF16X3, P, pitch)     # fs: 2 | BF16X3
+        S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qs, mode, int(fs) & ~(BWD_BF16X3 | PROJ_BF16X3), P, pitch)     # fs: 2 | BF16X3
         if pitch != P:
             real, offmap = slot_maps(N, P, pitch, S.device)
             offsets_s = offsets.index_select(0, offmap)

@@ -110,13 +110,16 @@ def bwd_workspace(C: int, T: int, D: int, device) -> torch.Tensor:
 BF16X3 = 4      # SEMICRF_SCORE_BF16X3: OR into full_square
 LEN_BF16X3 = 16 # SEMICRF_LEN_BF16X3: OR into the backward's length-scaling mode (the two products on the three-limb bf16 kernels)
 BWD_BF16X3 = 8  # this package's autograd nodes only (never handed to the library): "the backward of this forward uses LEN_BF16X3"
-CONTRACTIONS = {"fp32": 0, "bf16x3": BF16X3 | BWD_BF16X3, "bf16x3-fwd": BF16X3, "bf16x3-bwd": BWD_BF16X3}
+PROJ_BF16X3 = 32  # this package's autograd nodes only: the projection's forward and input gradient on proj_gemm3.hip (scorer_proj_nn3)
+CONTRACTIONS = {"fp32": 0, "bf16x3": BF16X3 | BWD_BF16X3, "bf16x3-fwd": BF16X3, "bf16x3-bwd": BWD_BF16X3,
+                "bf16x3-train": BWD_BF16X3 | PROJ_BF16X3, "bf16x3-all": BF16X3 | BWD_BF16X3 | PROJ_BF16X3}
 
 
 def contraction_bits(name: str) -> int:
     """scorer.contraction -> flag bits of the autograd nodes: 'fp32' (default, exact), 'bf16x3' (forward contraction and backward
     products on the three-limb bf16 kernels), 'bf16x3-fwd' / 'bf16x3-bwd' (one side only: at the model's training shape the
-    backward gains 0.23 ms per step and the forward loses 0.13 against the exact kernel, profiles/r05_train_step_*)."""
+    backward gains 0.23 ms per step and the forward loses 0.13 against the exact kernel, profiles/r05_train_step_*), 'bf16x3-train'
+    (the backward products and the merged projection's two NN GEMMs -- the fused route's fastest setting), 'bf16x3-all' (everything)."""
     try:
         return CONTRACTIONS[name]
     except KeyError:
@@ -210,7 +213,16 @@ def _stock_gemm_note(what: str, x: torch.Tensor) -> None:
                                           "library kernels' sizes {64,128,256} / alignment / 2 GiB limits)")
 
 
-def proj_forward(x2: torch.Tensor, W: torch.Tensor, b: torch.Tensor, n_main: int, Wt: torch.Tensor = None) -> torch.Tensor:
+def _proj_nn(prec: int, K: int, N: int, dev, *args) -> None:
+    """scorer_proj_nn, or scorer_proj_nn3 (prec != 0: three-limb bf16 contraction, N == 256) with its workspace."""
+    if prec and N == 256:
+        n = int(_lib.load().scorer_proj_nn3_workspace_bytes(int(K), int(N)))
+        _lib.ops().proj_nn3(*args, torch.empty(n, dtype=torch.uint8, device=dev))
+    else:
+        _lib.ops().proj_nn(*args)
+
+
+def proj_forward(x2: torch.Tensor, W: torch.Tensor, b: torch.Tensor, n_main: int, Wt: torch.Tensor = None, prec: int = 0) -> torch.Tensor:
     """y [M, Nout] = x2 W^T + b for the PACKED projection outputs of this package (LayersTransformer.py:388-397, :406-410 regrouped):
     W [Nout, K] holds n_main main rows, then -- if Nout > n_main -- two extra rows ([diag | 0] or [c | diag]) and zero rows.  On the
     library's exact-fp32 GEMM (scorer_proj_nn) where it applies, torch's GEMM otherwise."""
@@ -226,12 +238,12 @@ def proj_forward(x2: torch.Tensor, W: torch.Tensor, b: torch.Tensor, n_main: int
     has2 = Nout > n_main
     w2 = W[n_main:n_main + 2].contiguous() if has2 else b
     b2 = b[n_main:n_main + 2].contiguous() if has2 else b
-    _lib.ops().proj_nn(x2, K, M, K, Wt, n_main, n_main, y, Nout, b[:n_main].contiguous(), True, w2, b2, has2, Nout - n_main - 2 if has2 else 0,
-                       False)
+    _proj_nn(prec, K, n_main, x2.device, x2, K, M, K, Wt, n_main, n_main, y, Nout, b[:n_main].contiguous(), True, w2, b2, has2,
+             Nout - n_main - 2 if has2 else 0, False)
     return y
 
 
-def proj_input_grad(dy2: torch.Tensor, W: torch.Tensor, out: torch.Tensor = None, Wp: torch.Tensor = None) -> torch.Tensor:
+def proj_input_grad(dy2: torch.Tensor, W: torch.Tensor, out: torch.Tensor = None, Wp: torch.Tensor = None, prec: int = 0) -> torch.Tensor:
     """dy2 [M, Nout] W [Nout, K] -> [M, K]; with `out` the product is ADDED to it (the gradient through a second use of the input)."""
     M, Nout = dy2.shape
     K = W.shape[1]
@@ -243,7 +255,7 @@ def proj_input_grad(dy2: torch.Tensor, W: torch.Tensor, out: torch.Tensor = None
         Wp[:Nout] = W
     dx = out if out is not None else torch.empty(M, K, dtype=torch.float32, device=dy2.device)
     none = _lib_none(dy2.device)
-    _lib.ops().proj_nn(dy2, Nout, M, Nout, Wp, K, K, dx, K, none, False, none, none, False, 0, out is not None)
+    _proj_nn(prec, Nout, K, dy2.device, dy2, Nout, M, Nout, Wp, K, K, dx, K, none, False, none, none, False, 0, out is not None)
     return dx
 
 
@@ -430,7 +442,7 @@ class _IntervalScore(torch.autograd.Function):
         pitch = pitch or P
         qd3, k3 = qd.reshape(C, T, D + QPAD), k.reshape(C, T, D)
         qscale = 1.0 / math.sqrt(D)
-        S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qscale, mode, int(full_square) & ~BWD_BF16X3, P, pitch)
+        S, noise = _interval_score_raw(qd3[..., :D], k3, qd3[..., D], T, C, D, qscale, mode, int(full_square) & ~(BWD_BF16X3 | PROJ_BF16X3), P, pitch)
         ctx.save_for_backward(qd3, k3)
         ctx.meta = (N, P, T, D, mode | (LEN_BF16X3 if int(full_square) & BWD_BF16X3 else 0), (int(full_square) & 3) == 1, pitch)
         return S.view(T, T, N, pitch), noise.view(max(T - 1, 0), N, pitch)
