@@ -106,6 +106,10 @@ def test_full_segment_forward_config3(gpu):
     mel = MelSpectrum(win, 30, 8000, 229, fs, nExtraWins=5, log=True, toMono=True).to(gpu)
     feat = mel(normalize_gain(frames))
     assert feat.shape == (1, 1, T, 229, 6) and feat.dtype == torch.float32 and bool(torch.isfinite(feat).all())
+    # (the stand-in backbone and the scorer are randomly initialised: from a FIXED generator state -- torch's own start value -- so that the
+    # comparison below does not depend on which test modules were imported or run before; a full-suite run of round 5 drew weights for which
+    # one of the 90 chains differed by 1.2e-4 of |logProb| between the two routes, the same tests on their own passed)
+    torch.manual_seed(67280421310721)
     backbone = synth.StandInBackbone().to(gpu).to(torch.bfloat16)
     with torch.no_grad():
         ctx_bf = backbone(feat.to(torch.bfloat16))

@@ -20,11 +20,11 @@ def short(kn):
 
 
 for sub, name in (("kt", "bench_kernel_stats"), ("kt_all", "bench_all_kernels_stats"), ("kt_scorer", "scorer_kernel_stats"),
-                  ("kt_train", "train_step_kernel_stats")):
+                  ("kt_train", "train_step_kernel_stats"), ("kt_train_bf16x3", "train_step_bf16x3_train_kernel_stats")):
     f = newest(f"{SRC}/{sub}/runc/*_kernel_stats.csv")
     if f:
         shutil.copy(f, f"{DST}/{TAG}_{name}.csv")
-for f, name in (("grid.md", "grid_table.md"), ("shapes.md", "model_shapes.md"), ("bench.json", "bench_line.json"), ("scorer.txt", "scorer_timing.txt")):
+for f, name in (("bwd3.txt", "bwd_bf16x3_timing.txt"), ("train_modes.txt", "train_step_modes.txt"), ("grid.md", "grid_table.md"), ("shapes.md", "model_shapes.md"), ("bench.json", "bench_line.json"), ("scorer.txt", "scorer_timing.txt")):
     if os.path.exists(f"{SRC}/{f}"):
         shutil.copy(f"{SRC}/{f}", f"{DST}/{TAG}_{name}")
 
@@ -89,7 +89,8 @@ out["grad_traffic_over_algorithmic"] = out["grad_traffic_bytes"] / (740358784 * 
 # ---- scorer kernels: matrix-pipe utilisation and the clock under load ------------------------------------------------------------
 sc = {}
 for kn, flop_per_inst in (("interval_score_tiled_kernel<4>", 4096), ("interval_score_tile_kernel<128>", 4096), ("interval_score_tile3_kernel<128>", 32768),
-                          ("score_bwd_gemm_kernel<false, 4>", 4096), ("score_bwd_gemm_kernel<true, 4>", 4096)):
+                          ("score_bwd_gemm_kernel<false, 4>", 4096), ("score_bwd_gemm_kernel<true, 4>", 4096),
+                          ("score_bwd_gemm3_kernel<false, 4>", 32768), ("score_bwd_gemm3_kernel<true, 4>", 32768)):
     gui, us = g("pmc_scorer_SQ_BUSY_CYCLES_GRBM_GUI_ACTIVE", kn, "GRBM_GUI_ACTIVE")
     insts = g("pmc_scorer_SQ_INSTS_MFMA_SQ_VALU_MFMA_BUSY_CYCLES", kn, "SQ_INSTS_MFMA")[0]
     busy = g("pmc_scorer_SQ_INSTS_MFMA_SQ_VALU_MFMA_BUSY_CYCLES", kn, "SQ_VALU_MFMA_BUSY_CYCLES")[0]

@@ -15,6 +15,7 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra --no-live-traffic > $OUT/kt.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_all -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-live-traffic > $OUT/kt_all.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_train -- python $GRAFT_REPO_ROOT/tools/train_step_probe.py > $OUT/kt_train.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_train_bf16x3 -- python $GRAFT_REPO_ROOT/tools/train_step_probe.py bf16x3-train > $OUT/kt_train_bf16x3.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_scorer -- python $GRAFT_REPO_ROOT/tools/bench_scorer_all.py 20 > $OUT/kt_scorer.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_fwd_$c -- python $GRAFT_REPO_ROOT/tools/bench_sweep.py --ops fwd --n 5 > $OUT/pmc_fwd_$c.log 2>&1
@@ -31,6 +32,8 @@ cd $GRAFT_REPO_ROOT
 timeout 300 python tools/bench_grid.py > $OUT/grid.md 2>/dev/null
 timeout 300 python tools/bench_shapes.py > $OUT/shapes.md 2>/dev/null
 timeout 300 python tools/bench_scorer_all.py 10 > $OUT/scorer.txt 2>/dev/null
+(timeout 300 python tools/bwd3_probe.py 5 --proj 2>/dev/null | grep -v amdgpu.ids) > $OUT/bwd3.txt
+for c in fp32 bf16x3 bf16x3-bwd bf16x3-train bf16x3-all; do echo "train step, scorer.contraction = $c: $(timeout 200 python tools/train_step_probe.py $c 2>/dev/null | grep 'ms per step')"; done > $OUT/train_modes.txt
 find $OUT -name "*.csv" -size +3M -delete
 find $OUT -name "*agent_info*" -delete
-cat $OUT/pytest.log; cut -c1-300 $OUT/bench.json; cat $OUT/scorer.txt
+cat $OUT/pytest.log; cut -c1-300 $OUT/bench.json; cat $OUT/scorer.txt $OUT/bwd3.txt $OUT/train_modes.txt
