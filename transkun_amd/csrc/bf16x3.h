@@ -69,6 +69,20 @@ __device__ __forceinline__ Limbs3 split8(const v4f a, const v4f b)
     r.l = __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]});
     return r;
 }
+// The same pair after pair (fewer values alive at once: the forward's tile kernel, which sits at the register limit, keeps this form)
+__device__ __forceinline__ Limbs3 split8_pairs(const v4f a, const v4f b)
+{
+    unsigned h[4], m[4], l[4];
+    split_pair(a.x, a.y, h[0], m[0], l[0]);
+    split_pair(a.z, a.w, h[1], m[1], l[1]);
+    split_pair(b.x, b.y, h[2], m[2], l[2]);
+    split_pair(b.z, b.w, h[3], m[3], l[3]);
+    Limbs3 r;
+    r.h = __builtin_bit_cast(bf16x8, (u32x4){h[0], h[1], h[2], h[3]});
+    r.m = __builtin_bit_cast(bf16x8, (u32x4){m[0], m[1], m[2], m[3]});
+    r.l = __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]});
+    return r;
+}
 __device__ __forceinline__ f32x16 mma6(const Limbs3& A, const Limbs3& B, f32x16 acc)
 {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.l, acc, 0, 0, 0);

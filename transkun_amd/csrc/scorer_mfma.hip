@@ -916,7 +916,8 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
     constexpr int LIMB = NR * 64;                // bytes per limb plane: 32 values x 2 bytes per row
     constexpr int STAGE = 3 * LIMB;
     constexpr int NU = NR / XTE;                 // units (one row, 8 values) per lane and chunk: unit 0 is a q row, the others k rows
-    extern __shared__ __attribute__((aligned(16))) char xlds[];    // [W3_NS][STAGE]
+    extern __shared__ __attribute__((aligned(16))) char xlds[];    // [W3_NS][STAGE] | row constants [XTE][4]
+    float* const rcl = (float*)(xlds + W3_NS * 3 * (XTE + XTB) * 64);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int row = lane & 31, half = lane >> 5;
     const int wer = wave >> 1, wh = wave & 1;                       // this wave: rows 32*wer.., columns 64*wh.. of the tile
@@ -1033,7 +1034,7 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
         char* base = xlds + stage * STAGE;
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
-            const Limbs3 L = split8(g[j][0], g[j][1]);
+            const Limbs3 L = split8_pairs(g[j][0], g[j][1]);
             *(bf16x8*)(base + wof[j]) = L.h;
             *(bf16x8*)(base + LIMB + wof[j]) = L.m;
             *(bf16x8*)(base + 2 * LIMB + wof[j]) = L.l;
@@ -1074,6 +1075,15 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
         QuadInfo qi;
         (void)item_of(cur_u, et, bt, qi);
         const int c4 = qi.c4;
+        // merged projection (rowc): the item's XTE row constants of its four chains, one per thread, requested here, parked in the LDS
+        // behind the first chain's loop and read as one 16-byte piece per row in the epilogue (as 128 scattered loads INSIDE the
+        // epilogue they cost this kernel 0.26 ms at the training shape: 843 against the exact kernel's 710 us).  Zero for ghost
+        // chains and rows past T.
+        float rcv = 0.0f;
+        if (rowc) {
+            const int ri = (int)threadIdx.x / XTE, re = et * XTE + (int)threadIdx.x % XTE;
+            if (ri < qi.nr && re < T) rcv = rowc[((size_t)(qi.ck + ri) * T + re) * ldrc];
+        }
         const int erow = et * (XTE / 32) + wer, bcol = bt * (XTB / 32) + 2 * wh;
         const bool on0 = full || bcol <= erow, on1 = full || bcol + 1 <= erow;
         // (the blocks-above-the-diagonal cases are separate instantiations: a branch inside the half iteration would end the
@@ -1200,6 +1210,7 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
             else if (on0 && on1) chain_loop(std::true_type{}, std::true_type{});
             else if (on0) chain_loop(std::true_type{}, std::false_type{});
             else chain_loop(std::false_type{}, std::false_type{});
+            if (j == 0 && rowc) rcl[((int)threadIdx.x % XTE) * 4 + (int)threadIdx.x / XTE] = rcv;     // (the previous item's epilogue is behind everybody)
             if (j < 3) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -1212,6 +1223,11 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
         //      row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) ----
         {
             const bool vec = (Cs & 3) == 0 && c4 + 3 < Cs;
+            if (rowc) {                                                  // everybody's row constants are in the LDS
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int b = bt * XTB + 64 * wh + 32 * t + row;
@@ -1222,11 +1238,11 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
                     const float sc = qscale * len_scale_mfma(len, mode);
                     const float last = t == 0 ? acc0[r] : acc1[r];
                     float v[4] = {hold[0][t][r], hold[1][t][r], hold[2][t][r], last};
-                    if (rowc && e < T) {
+                    if (rowc) {
                         // merged projection (interval_score_fwd_p, rowc): a per-(chain, end) constant joins the contraction
+                        const v4f rc4 = *(const v4f*)(rcl + (32 * wer + (r & 3) + 8 * (r >> 2) + 4 * half) * 4);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (i < qi.nr) v[i] += rowc[((size_t)(qi.ck + i) * T + e) * ldrc];
+                        for (int i = 0; i < 4; ++i) v[i] += rc4[i];
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] *= sc;
@@ -1277,7 +1293,7 @@ static int launch_score_tile3(const float* q, const float* k, const float* diag,
     else
         for (int et = 0; et < net; ++et) ntiles += (et * XTE + XTE - 1) / XTB + 1 < nbt ? (et * XTE + XTE - 1) / XTB + 1 : nbt;
     const int nquadp = (G.nrq + 7) / 8 * 8;
-    const size_t lds = (size_t)W3_NS * 3 * (XTE + XTB) * 64;
+    const size_t lds = (size_t)W3_NS * 3 * (XTE + XTB) * 64 + (size_t)XTE * 16;
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)interval_score_tile3_kernel<XTE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
