@@ -68,3 +68,20 @@ if "--proj" in sys.argv:
     for name, p in (("fp32", 0), ("bf16x3", 1)):
         tf = t(lambda: proj_forward(x, W, b, K, prec=p)); tb = t(lambda: proj_input_grad(dy, W, out=acc, prec=p))
         print(f"projection M={M} K={K} {name}: forward {tf:.3f} ms ({fl / tf / 1e9:.1f} TF), input gradient (accumulating) {tb:.3f} ms ({fl / tb / 1e9:.1f} TF)", flush=True)
+
+if "--proj-probe" in sys.argv:
+    # a library built with -DSEMICRF_P3_PROBE=1: cycle counters of proj_gemm3_kernel's waves over the first rows of the output
+    import numpy as np
+    from transkun_amd.scorer import proj_input_grad
+    M, K = 4 * 90 * 691, 256
+    dy = torch.randn(M, K, device=dev); W = torch.randn(K, K, device=dev) / 16
+    for _ in range(2):
+        out = proj_input_grad(dy, W, prec=1)
+    torch.cuda.synchronize()
+    pc = out.flatten()[:256 * 64].view(256, 8, 8).cpu().numpy().astype(np.float64)
+    names = ["multiply", "epilogue", "barrier1", "wait loads", "split+stores", "requests", "barrier2"]
+    tot = pc[:, :, :7].sum(axis=2); rt = pc[:, :, 7]
+    print("proj cycles per wave: mean %.0f; wall %.1f us -> clock %.2f GHz; chunks per workgroup ~%.1f" % (tot.mean(), rt.mean() / 100.0, tot.mean() / (rt.mean() * 10.0), M / 128 / 256 * 8))
+    for g, sl in (("group 0", slice(0, 4)), ("group 1", slice(4, 8))):
+        m = pc[:, sl, :7].mean(axis=(0, 1))
+        print("  ", g, " ".join("%s %.1f%% (%.0f)" % (names[i], 100 * m[i] / m.sum(), m[i]) for i in range(7)))

@@ -3,8 +3,8 @@
 // kernel (scorer_proj_nn3; LayersTransformer.py:388-397, :406-410 and their autograd).  fp32-grade, not bit-identical.
 //
 // Same skeleton as score_bwd_gemm3_kernel (scorer_bwd_gemm.hip): a persistent workgroup of 8 waves owns a 128 x 256 output tile, two
-// wave groups half a chunk apart, two LDS stages of 72 KB (limbs in the matrix instruction's layout), requests and their waits
-// written out.  What makes this product the better customer of the three-limb contraction: the second operand is the SAME small
+// wave groups in opposite phases (ONE barrier per chunk: group 0 multiplies and then splits, group 1 splits and then multiplies), two
+// LDS stages of 72 KB (limbs in the matrix instruction's layout), requests and their waits written out.  What makes this product the better customer of the three-limb contraction: the second operand is the SAME small
 // matrix for every tile (W: 256-288 rows x 256 columns), so it is split ONCE per call by a kernel of its own into the LDS image of
 // its chunks (proj_split_b_kernel: [chunk][limb][column][4 pieces of 8 rows], 48 KB per chunk, 0.4 MB in all: L2-resident) and a
 // chunk's share arrives as plain 16-byte copies; only the A rows (one unit of eight values per lane and chunk) are split in the
@@ -29,6 +29,15 @@ __device__ __forceinline__ void static_for(F&& f)
     }
 }
 
+#ifndef SEMICRF_P3_MMA_ORDER
+#define SEMICRF_P3_MMA_ORDER 0     // 1: a slab's limb products round-robin over the four accumulators (needs all four B operand sets)
+#endif
+#ifndef SEMICRF_P3_PHASED
+#define SEMICRF_P3_PHASED 1        // 0: all waves in the same order (multiply, then split): within 3 % of the opposite phases
+#endif
+#ifndef SEMICRF_P3_PROBE
+#define SEMICRF_P3_PROBE 0         // 1: per-wave cycle accounting in place of the first output rows (tools/bwd3_probe.py --proj-probe)
+#endif
 constexpr int GM = 128;            // rows of an output tile
 constexpr int GK = 32;             // contraction values per chunk
 constexpr int N = 256;             // output columns through the matrix cores (the only width this kernel takes)
@@ -82,7 +91,7 @@ __global__ __launch_bounds__(512, 2) void proj_gemm3_kernel(Args P_)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;           // this wave: rows 32*wm.., columns 128*wn.. of the tile
-    const int grp = wave >> 2;                         // (waves w and w + 4 share a SIMD)
+    const int grp = SEMICRF_P3_PHASED ? wave >> 2 : 0; // (waves w and w + 4 share a SIMD)
     const int nm = (a_M + GM - 1) / GM;
     const int nk = a_nchunks;
     const int Kpad = nk * GK;
@@ -221,6 +230,7 @@ __global__ __launch_bounds__(512, 2) void proj_gemm3_kernel(Args P_)
     // issued before the instructions of group i (two operand sets, alternating: the register budget has no room for a whole slab's)
     auto multiply = [&](int stage) __attribute__((always_inline)) {
         const char* base = glds + stage * STAGE;
+#if SEMICRF_P3_MMA_ORDER == 0
         Limbs3 A, B[2];
         auto ldA = [&](Limbs3& L, int sl) __attribute__((always_inline)) {
             L.h = *(const bf16x8*)(base + rdA[sl]);
@@ -251,6 +261,34 @@ __global__ __launch_bounds__(512, 2) void proj_gemm3_kernel(Args P_)
                 __builtin_amdgcn_sched_barrier(0);
             }
         });
+#else
+        // a slab at a time: all its operands, then the six limb products round-robin over the accumulators (independent neighbours)
+        Limbs3 A, B[NW];
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            A.h = *(const bf16x8*)(base + rdA[sl]);
+            A.m = *(const bf16x8*)(base + APL + rdA[sl]);
+            A.l = *(const bf16x8*)(base + 2 * APL + rdA[sl]);
+#pragma unroll
+            for (int t = 0; t < NW; ++t) {
+                B[t].h = *(const bf16x8*)(base + rdB[sl] + t * 2048);
+                B[t].m = *(const bf16x8*)(base + BPL + rdB[sl] + t * 2048);
+                B[t].l = *(const bf16x8*)(base + 2 * BPL + rdB[sl] + t * 2048);
+            }
+#pragma unroll
+            for (int t = 0; t < NW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B[t].l, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l, B[t].h, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.m, B[t].m, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B[t].m, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.m, B[t].h, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B[t].h, acc[t], 0, 0, 0);
+        }
+#endif
     };
 
     // the two extra weight rows (forward), zero-padded to whole chunks; the bias values of this lane's columns
@@ -277,26 +315,16 @@ __global__ __launch_bounds__(512, 2) void proj_gemm3_kernel(Args P_)
         __builtin_amdgcn_s_barrier();                            // ... and so are everybody's; everybody is done reading the other stage
         asm volatile("" ::: "memory");
     };
-    // (slots and register sets as in score_bwd_gemm3_kernel: group 1 runs the loop one slot later and two chunks ahead)
-    if (grp == 0) {
-        fetch(gY, mY);
-        fetch(gX, mX, false);
-        landed(gY);
-        convert(gY, mY, 0);
-        fetch(gY, mY);
-        sync();
-    } else {
-        fetch(gX, mX);
-        fetch(gY, mY, false);
-        landed(gX);
-        convert(gX, mX, 0);
-        fetch(gX, mX);
-        sync();
-        landed(gY);
-        convert(gY, mY, 1);
-        fetch(gY, mY);
-        sync();
-    }
+    // Schedule: ONE barrier per chunk.  Behind it the limbs of chunk n are complete in stage P and nobody reads the other stage any
+    // more; group 0 multiplies chunk n and then splits its share of chunk n+1 into the other stage, group 1 does the same in the
+    // opposite order -- so on every SIMD one wave's matrix instructions run next to the other wave's split, and whichever is
+    // shorter does not wait for a barrier in the middle of the chunk (score_bwd_gemm3_kernel has one there: its second group runs the
+    // loop a slot later and splits into the stage it has just read).  X is the register set split in the steps with P = 0.
+    fetch(gY, mY);
+    fetch(gX, mX, false);
+    landed(gY);
+    convert(gY, mY, 0);
+    fetch(gY, mY);
 
     int cur_round = 0, mi = (int)blockIdx.x, j = 0;
     // ---- the item's 128 x 256 block (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)); rows >= M are dropped
@@ -334,22 +362,49 @@ __global__ __launch_bounds__(512, 2) void proj_gemm3_kernel(Args P_)
         mi = (int)blockIdx.x + cur_round * (int)gridDim.x;
         return mi < nm;
     };
+#if SEMICRF_P3_PROBE
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = __builtin_readcyclecounter();
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#define P3_STAMP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); pc[i] += now_ - pt; pt = now_; } while (0)
+#else
+#define P3_STAMP(i) do { } while (0)
+#endif
     auto step = [&](auto PC, Regs& gn, Meta& mn) __attribute__((always_inline)) -> bool {
         constexpr int Pst = decltype(PC)::value;
-        multiply(Pst);
-        const bool more = finish();
+        bool more = true;
         sync();
+        P3_STAMP(2);
+        if (grp == 0) {
+            multiply(Pst);
+            P3_STAMP(0);
+            more = finish();
+            P3_STAMP(1);
+        }
         landed(gn);
-        convert(gn, mn, Pst ^ 1 ^ grp);
+        P3_STAMP(3);
+        convert(gn, mn, Pst ^ 1);
+        P3_STAMP(4);
         fetch(gn, mn);
-        sync();
+        P3_STAMP(5);
+        if (grp != 0) {
+            multiply(Pst);
+            P3_STAMP(0);
+            more = finish();
+            P3_STAMP(1);
+        }
         return more;
     };
     while (true) {
         if (!step(std::integral_constant<int, 0>{}, gX, mX)) break;
         if (!step(std::integral_constant<int, 1>{}, gY, mY)) break;
     }
-    if (grp == 0) sync();                                        // (group 1's last slot)
+#if SEMICRF_P3_PROBE
+    pc[7] = __builtin_amdgcn_s_memrealtime() - rt0;              // (cycle accounting over the first rows of `out`: probe builds only)
+    __syncthreads();
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) a_out[(size_t)(blockIdx.x * 8 + wave) * 8 + i] = (float)pc[i];
+#endif
+#undef P3_STAMP
 }
 
 }  // namespace pj3
