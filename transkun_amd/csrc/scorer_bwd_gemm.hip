@@ -70,6 +70,9 @@ __host__ __device__ __forceinline__ size_t gt_chain_floats(int Tp)
 // One block = 8 end frames x 32 begin frames x 32 chains (whole 128-byte lines in; 128-byte rows out).  Only the
 // b tiles up to the end of the row's 128-aligned diagonal block are written: the GEMMs read nothing beyond.
 constexpr int PK_CH = 32, PK_E = 8, PK_B = 32;
+#ifndef SEMICRF_PACK_ORDER
+#define SEMICRF_PACK_ORDER 1
+#endif
 constexpr int PK_ROW = PK_B + 4;                   // LDS row pitch (floats): 16-byte aligned rows
 constexpr int PK_CHS = PK_E * PK_ROW + 4;          // chain pitch
 
@@ -92,7 +95,13 @@ __global__ __launch_bounds__(256) void score_bwd_pack_kernel(const float* __rest
                                                              int T, int Tp, float qscale, int mode, PackFused F, ChainSlots SL)
 {
     __shared__ __attribute__((aligned(16))) float L[PK_CH * PK_CHS];
+    // (chain groups fastest: the blocks that run side by side read neighbouring 128-byte pieces of the SAME cells -- whole runs of the
+    // chain axis -- instead of one piece each of cells 1.4 KB apart)
+#if SEMICRF_PACK_ORDER == 1
+    const int cg = blockIdx.x * PK_CH, b0 = blockIdx.y * PK_B, e0 = blockIdx.z * PK_E;
+#else
     const int b0 = blockIdx.x * PK_B, e0 = blockIdx.y * PK_E, cg = blockIdx.z * PK_CH;
+#endif
     if (b0 >= (e0 / GM + 1) * GM) return;
     const int tid = threadIdx.x;
     const bool vec = (C % 4 == 0) && (((uintptr_t)dS & 15) == 0) &&
@@ -919,7 +928,11 @@ bool launch_interval_score_bwd_packed(const float* dS, const float* q, const flo
     if ((long long)T * ldq * 4 >= (1ll << 31) || (long long)T * ldk * 4 >= (1ll << 31)) return false;
     const int Tp = round_up32(T);
     float* Gt = (float*)ws;
+#if SEMICRF_PACK_ORDER == 1
+    const dim3 pgrid((Cs + PK_CH - 1) / PK_CH, Tp / PK_B, Tp / PK_E);
+#else
     const dim3 pgrid(Tp / PK_B, Tp / PK_E, (Cs + PK_CH - 1) / PK_CH);
+#endif
     if (fused) {
         const PackFused F{fused[0], fused[1], fused[2], fused[3]};
         hipLaunchKernelGGL(score_bwd_pack_kernel<true>, pgrid, dim3(256), 0, stream, dS, Gt, Cs, T, Tp, qscale, mode, F, SL);
