@@ -675,8 +675,9 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
     # the same step with the opt-in three-limb bf16 kernels (fp32-grade, not bit-identical -- the headline and train_step_ms stay exact
     # fp32): scorer.contraction = "bf16x3" (forward contraction and backward products) and "bf16x3-bwd" (backward products only: at
     # this shape the exact forward kernel is the faster one)
-    # ... and "bf16x3-train": the backward products and the merged projection's two NN GEMMs (csrc/proj_gemm3.hip) -- the fastest setting
-    for cname, key in (("bf16x3", "train_step_ms_bf16x3"), ("bf16x3-bwd", "train_step_ms_bf16x3_bwd"), ("bf16x3-train", "train_step_ms_bf16x3_train")):
+    # ... "bf16x3-train": the backward products and the merged projection's two NN GEMMs (csrc/proj_gemm3.hip); "bf16x3-all": everything
+    for cname, key in (("bf16x3", "train_step_ms_bf16x3"), ("bf16x3-bwd", "train_step_ms_bf16x3_bwd"), ("bf16x3-train", "train_step_ms_bf16x3_train"),
+                       ("bf16x3-all", "train_step_ms_bf16x3_all")):
         model.scorer.contraction = cname
         for _ in range(2):
             tstep()

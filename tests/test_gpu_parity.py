@@ -923,7 +923,8 @@ PERSIST_SHAPES = [(1, 4), (2, 4), (15, 8), (16, 4), (17, 12), (33, 16), (48, 20)
                   (70, 2), (97, 6), (130, 90), (200, 34), (256, 90),       # B % 4 == 2: 16-byte panel loads at 8-byte alignment
                   (70, 1100), (130, 600),                                   # more chains than one launch hosts rings for: chain chunks
                   (48, 7), (130, 45), (200, 33), (333, 91), (64, 3),       # odd NBatch: 4-byte aligned 16-byte accesses
-                  (64, 1)]                                                  # one chain: ghost chain
+                  (64, 1),                                                  # one chain: ghost chain
+                  (160, 351), (160, 360), (144, 704)]                       # the chain counts of the round-4 review: odd, the model's 4 x 90, two chain chunks of 352
 
 
 @pytest.mark.parametrize("T,B", PERSIST_SHAPES, ids=[f"T{t}_B{b}" for t, b in PERSIST_SHAPES])

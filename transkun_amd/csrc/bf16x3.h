@@ -42,6 +42,21 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsign
 // Eight values at once, level by level: the four pairs' chains (convert, widen, subtract, convert, ...) are independent, and
 // written pair after pair the compiler keeps them in that order (every instruction waits for the one in front of it: ~12 cycles
 // per instruction in the backward kernel's cycle stamps).
+#ifndef SEMICRF_SPLIT_SCALAR_SUB
+#define SEMICRF_SPLIT_SCALAR_SUB 0
+#endif
+__device__ __forceinline__ f32x2 sub2(const f32x2 a, const f32x2 b)
+{
+#if SEMICRF_SPLIT_SCALAR_SUB
+    // two v_sub_f32 instead of the v_pk_add_f32 the compiler makes of `a - b` (packed fp32 next to matrix instructions is slow)
+    f32x2 r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r.x) : "v"(a.x), "v"(b.x));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r.y) : "v"(a.y), "v"(b.y));
+    return r;
+#else
+    return a - b;
+#endif
+}
 __device__ __forceinline__ Limbs3 split8(const v4f a, const v4f b)
 {
     const f32x2 x[4] = {{a.x, a.y}, {a.z, a.w}, {b.x, b.y}, {b.z, b.w}};
@@ -52,14 +67,14 @@ __device__ __forceinline__ Limbs3 split8(const v4f a, const v4f b)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const f32x2 hf = {__builtin_bit_cast(float, h[i] << 16), __builtin_bit_cast(float, h[i] & 0xffff0000u)};
-        r1[i] = x[i] - hf;                                                       // exact
+        r1[i] = sub2(x[i], hf);                                                  // exact
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) m[i] = cvt_pk_bf16(r1[i].x, r1[i].y);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const f32x2 mf = {__builtin_bit_cast(float, m[i] << 16), __builtin_bit_cast(float, m[i] & 0xffff0000u)};
-        r2[i] = r1[i] - mf;                                                      // exact, and fits 8 bits
+        r2[i] = sub2(r1[i], mf);                                                 // exact, and fits 8 bits
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) l[i] = cvt_pk_bf16(r2[i].x, r2[i].y);
