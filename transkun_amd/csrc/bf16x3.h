@@ -28,22 +28,8 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b)
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));      // (written out: from `(__bf16)x` the compiler converts
     return r;                                            // the first element a second time, alone, for the shift below)
 }
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l)
-{
-    const unsigned hu = cvt_pk_bf16(a, b);
-    const f32x2 x = {a, b};
-    const f32x2 hf = {__builtin_bit_cast(float, hu << 16), __builtin_bit_cast(float, hu & 0xffff0000u)};
-    const f32x2 r1 = x - hf;                                                     // exact
-    const unsigned mu = cvt_pk_bf16(r1.x, r1.y);
-    const f32x2 mf = {__builtin_bit_cast(float, mu << 16), __builtin_bit_cast(float, mu & 0xffff0000u)};
-    const f32x2 r2 = r1 - mf;                                                    // exact, and fits 8 bits
-    h = hu; m = mu; l = cvt_pk_bf16(r2.x, r2.y);
-}
-// Eight values at once, level by level: the four pairs' chains (convert, widen, subtract, convert, ...) are independent, and
-// written pair after pair the compiler keeps them in that order (every instruction waits for the one in front of it: ~12 cycles
-// per instruction in the backward kernel's cycle stamps).
 #ifndef SEMICRF_SPLIT_SCALAR_SUB
-#define SEMICRF_SPLIT_SCALAR_SUB 0
+#define SEMICRF_SPLIT_SCALAR_SUB 1   // (0: `a - b`, i.e. v_pk_add_f32 -- measured 6-11 % slower kernels: backward 1.69 -> 1.58 ms, projection 0.238 -> 0.212)
 #endif
 __device__ __forceinline__ f32x2 sub2(const f32x2 a, const f32x2 b)
 {
@@ -57,6 +43,20 @@ __device__ __forceinline__ f32x2 sub2(const f32x2 a, const f32x2 b)
     return a - b;
 #endif
 }
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l)
+{
+    const unsigned hu = cvt_pk_bf16(a, b);
+    const f32x2 x = {a, b};
+    const f32x2 hf = {__builtin_bit_cast(float, hu << 16), __builtin_bit_cast(float, hu & 0xffff0000u)};
+    const f32x2 r1 = sub2(x, hf);                                                // exact
+    const unsigned mu = cvt_pk_bf16(r1.x, r1.y);
+    const f32x2 mf = {__builtin_bit_cast(float, mu << 16), __builtin_bit_cast(float, mu & 0xffff0000u)};
+    const f32x2 r2 = sub2(r1, mf);                                               // exact, and fits 8 bits
+    h = hu; m = mu; l = cvt_pk_bf16(r2.x, r2.y);
+}
+// Eight values at once, level by level: the four pairs' chains (convert, widen, subtract, convert, ...) are independent, and
+// written pair after pair the compiler keeps them in that order (every instruction waits for the one in front of it: ~12 cycles
+// per instruction in the backward kernel's cycle stamps).
 __device__ __forceinline__ Limbs3 split8(const v4f a, const v4f b)
 {
     const f32x2 x[4] = {{a.x, a.y}, {a.z, a.w}, {b.x, b.y}, {b.z, b.w}};
