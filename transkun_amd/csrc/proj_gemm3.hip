@@ -32,6 +32,9 @@ __device__ __forceinline__ void static_for(F&& f)
 #ifndef SEMICRF_P3_MMA_ORDER
 #define SEMICRF_P3_MMA_ORDER 0     // 1: a slab's limb products round-robin over the four accumulators (needs all four B operand sets)
 #endif
+#ifndef SEMICRF_MMA_PRIO
+#define SEMICRF_MMA_PRIO 0       // 1: raised wave priority while a wave issues its chunk's matrix instructions
+#endif
 #ifndef SEMICRF_P3_PHASED
 #define SEMICRF_P3_PHASED 1        // 0: all waves in the same order (multiply, then split): within 3 % of the opposite phases
 #endif
@@ -375,7 +378,9 @@ __global__ __launch_bounds__(512, 2) void proj_gemm3_kernel(Args P_)
         sync();
         P3_STAMP(2);
         if (grp == 0) {
+            if (SEMICRF_MMA_PRIO) __builtin_amdgcn_s_setprio(1);
             multiply(Pst);
+            if (SEMICRF_MMA_PRIO) __builtin_amdgcn_s_setprio(0);
             P3_STAMP(0);
             more = finish();
             P3_STAMP(1);
@@ -387,7 +392,9 @@ __global__ __launch_bounds__(512, 2) void proj_gemm3_kernel(Args P_)
         fetch(gn, mn);
         P3_STAMP(5);
         if (grp != 0) {
+            if (SEMICRF_MMA_PRIO) __builtin_amdgcn_s_setprio(1);
             multiply(Pst);
+            if (SEMICRF_MMA_PRIO) __builtin_amdgcn_s_setprio(0);
             P3_STAMP(0);
             more = finish();
             P3_STAMP(1);

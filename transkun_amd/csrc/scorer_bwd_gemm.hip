@@ -453,6 +453,9 @@ constexpr int NXCD_G3 = 8;        // workgroup b runs on XCD b % 8
 #ifndef SEMICRF_G3_MMA_ORDER
 #define SEMICRF_G3_MMA_ORDER 1    // 1: the limb products of a slab round-robin over the accumulators (independent neighbours); 0: six in a row per accumulator, operand reads one group ahead (within 2 % of each other, like the phase shift)
 #endif
+#ifndef SEMICRF_MMA_PRIO
+#define SEMICRF_MMA_PRIO 0       // 1: raised wave priority while a wave issues its chunk's matrix instructions
+#endif
 #ifndef SEMICRF_G3_PHASED
 #define SEMICRF_G3_PHASED 1       // 0: both groups in the same phase (the first version's schedule)
 #endif
@@ -829,7 +832,9 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
     // one chunk: its limbs are in stage P
     auto step = [&](auto PC, Regs& gn, Meta& mn) -> bool {
         constexpr int P = decltype(PC)::value;
+        if (SEMICRF_MMA_PRIO) __builtin_amdgcn_s_setprio(1);
         multiply(P);
+        if (SEMICRF_MMA_PRIO) __builtin_amdgcn_s_setprio(0);
         G3_STAMP(0);
         const bool more = finish();
         G3_STAMP(1);
