@@ -43,6 +43,14 @@ __device__ __forceinline__ f32x2 sub2(const f32x2 a, const f32x2 b)
     return a - b;
 #endif
 }
+// plain fp32 arithmetic of the staging lanes in the same spirit (the compiler would pair neighbouring operations into v_pk_*)
+#if SEMICRF_SPLIT_SCALAR_SUB
+__device__ __forceinline__ float fmac1(float a, float b, float c) { asm("v_fmac_f32 %0, %1, %2" : "+v"(c) : "v"(a), "v"(b)); return c; }
+__device__ __forceinline__ float add1(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#else
+__device__ __forceinline__ float fmac1(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ float add1(float a, float b) { return a + b; }
+#endif
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l)
 {
     const unsigned hu = cvt_pk_bf16(a, b);

@@ -209,9 +209,9 @@ __global__ __launch_bounds__(512, 2) void proj_gemm3_kernel(Args P_)
             const float* w0 = w2l + m.k0 + 8 * aPiece;
             const v4f x0 = *(const v4f*)w0, x1 = *(const v4f*)(w0 + 4), y0 = *(const v4f*)(w0 + Kpad), y1 = *(const v4f*)(w0 + Kpad + 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { e0 = fmaf(alo[i], x0[i], e0); e1 = fmaf(alo[i], y0[i], e1); }
+            for (int i = 0; i < 4; ++i) { e0 = fmac1(alo[i], x0[i], e0); e1 = fmac1(alo[i], y0[i], e1); }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { e0 = fmaf(ahi[i], x1[i], e0); e1 = fmaf(ahi[i], y1[i], e1); }
+            for (int i = 0; i < 4; ++i) { e0 = fmac1(ahi[i], x1[i], e0); e1 = fmac1(ahi[i], y1[i], e1); }
             if (m.last) {
                 float t0 = e0 + __shfl_xor(e0, 1), t1 = e1 + __shfl_xor(e1, 1);
                 t0 += __shfl_xor(t0, 2);

@@ -662,7 +662,7 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
             *(bf16x8*)(base + 2 * APL + wA) = L.l;
         }
         if (!AT && want_rs && m.valid) {
-            rs += ((alo.x + alo.y) + (alo.z + alo.w)) + ((ahi.x + ahi.y) + (ahi.z + ahi.w));
+            rs = add1(rs, add1(add1(add1(alo.x, alo.y), add1(alo.z, alo.w)), add1(add1(ahi.x, ahi.y), add1(ahi.z, ahi.w))));
             if (m.last) {
                 float tot = rs + __shfl_xor(rs, 1);
                 tot += __shfl_xor(tot, 2);
