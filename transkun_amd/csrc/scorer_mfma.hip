@@ -1204,24 +1204,19 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
                 SCORE_PROBE(2);
             }
         };
-        // (NOT unrolled: with the four chains' loops unrolled -- times the three diagonal variants -- the kernel was 143 KB of code, and an
-        // item walked through ~70 KB of it where the instruction cache holds 64; the finished block goes to its place by a switch)
-#pragma nounroll
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (j >= qi.nr) { }                                       // a ghost slot of the quad: nothing was requested for it
             else if (on0 && on1) chain_loop(std::true_type{}, std::true_type{});
             else if (on0) chain_loop(std::true_type{}, std::false_type{});
             else chain_loop(std::false_type{}, std::false_type{});
             if (j == 0 && rowc) rcl[((int)threadIdx.x % XTE) * 4 + (int)threadIdx.x / XTE] = rcv;     // (the previous item's epilogue is behind everybody)
-            if (j == 0) {
+            if (j < 3) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { hold[0][0][r] = acc0[r]; hold[0][1][r] = acc1[r]; acc0[r] = 0.0f; acc1[r] = 0.0f; }
-            } else if (j == 1) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { hold[1][0][r] = acc0[r]; hold[1][1][r] = acc1[r]; acc0[r] = 0.0f; acc1[r] = 0.0f; }
-            } else if (j == 2) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { hold[2][0][r] = acc0[r]; hold[2][1][r] = acc1[r]; acc0[r] = 0.0f; acc1[r] = 0.0f; }
+                for (int r = 0; r < 16; ++r) {
+                    hold[j][0][r] = acc0[r]; hold[j][1][r] = acc1[r];
+                    acc0[r] = 0.0f; acc1[r] = 0.0f;
+                }
             }
         }
         // ---- write the item's four chains: one 16-byte piece per cell (C/D layout: col = lane & 31,
