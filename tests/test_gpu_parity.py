@@ -792,7 +792,8 @@ def test_scorer_bf16x3(gpu, C, T, D, mode, tri):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("C,T,D,mode,rowc", [(5, 200, 64, 0, False), (9, 333, 128, 1, True), (6, 691, 256, 0, True), (3, 96, 256, 2, False),
-                                              (2, 1024, 256, 0, True), (7, 130, 256, 0, False)])
+                                              (2, 1024, 256, 0, True), (7, 130, 256, 0, False),
+                                              (136, 1024, 256, 0, True)])          # enough items for the XCD-aware chain-major order
 def test_scorer_bwd_bf16x3(gpu, C, T, D, mode, rowc):
     """The backward's two products on the bf16 matrix instructions (length_scaling | SEMICRF_LEN_BF16X3: the scaled cotangent, k and
     q as three exact bf16 limbs each, six limb products, fp32 accumulation) against fp64.  Tolerance, stated in
