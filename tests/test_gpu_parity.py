@@ -1391,8 +1391,8 @@ def test_hot_paths_do_not_wait_for_the_device(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size,which", [(256, "both"), (128, "both"), (64, "q"), (256, "k")])
-def test_scorer_linear_packed(gpu, size, which):
+@pytest.mark.parametrize("size,which,prec", [(256, "both", 0), (128, "both", 0), (64, "q", 0), (256, "k", 0), (256, "both", 1), (128, "both", 1)])
+def test_scorer_linear_packed(gpu, size, which, prec):
     """_ScorerLinearPacked (the Linear's own parameters through scorer_stage_linear + the projection kernels, gradients written into
     one dW / dbias) against the regrouped torch route (qd_weights + _ScorerLinear on torch's GEMMs) in float64: outputs, dx, dW, db --
     with a cotangent for both outputs, for [q | diag] alone and for k alone."""
@@ -1403,7 +1403,7 @@ def test_scorer_linear_packed(gpu, size, which):
     b = (torch.randn(2 * D + 1, device=gpu) * 0.1).requires_grad_()
     x = torch.randn(2, 5, M // 10, size, device=gpu).requires_grad_()
     assert sc._ScorerLinearPacked.eligible(x, W, b, D)
-    qd, k = sc._ScorerLinearPacked.apply(x, W, b, D)
+    qd, k = sc._ScorerLinearPacked.apply(x, W, b, D, prec)     # prec = 1: the NN GEMMs on the three-limb bf16 kernels (size 256; others: exact)
     gq, gk = torch.randn_like(qd), torch.randn_like(k)
     outs, gs = {"both": ([qd, k], [gq, gk]), "q": ([qd], [gq]), "k": ([k], [gk])}[which]
     dx, dW, db = torch.autograd.grad(outs, [x, W, b], gs)

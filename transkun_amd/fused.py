@@ -277,7 +277,7 @@ def scorer_crf_logprob(scorer: ScaledInnerProductIntervalScorer, ctx: torch.Tens
         Wm, bm = merged_weights(W, bias, D)
         return _MergedScorerCRFLogProb.apply(x.contiguous(), Wm, bm, pairs, offsets, N, P, T, D, _lib.LEN_MODES[scorer.lengthScaling], fs)
     if _ScorerLinearPacked.eligible(x, W, bias, D):
-        qd, k = _ScorerLinearPacked.apply(x, W, bias, D)
+        qd, k = _ScorerLinearPacked.apply(x, W, bias, D, 1 if fs & PROJ_BF16X3 else 0)
     else:
         Wqd, bqd = qd_weights(W, bias, D)
         qd, k = _ScorerLinear.apply(x, Wqd, bqd, W[D:2 * D], bias[D:2 * D])

@@ -352,7 +352,8 @@ class _ScorerLinearPacked(torch.autograd.Function):
                 and bias.dtype == torch.float32 and tuple(W.shape) == (2 * D + 1, K) and tuple(bias.shape) == (2 * D + 1,))
 
     @staticmethod
-    def forward(ctx, x, W, bias, D):
+    def forward(ctx, x, W, bias, D, prec=0):
+        # prec = 1: the four NN GEMMs on the three-limb bf16 kernels (csrc/proj_gemm3.hip; scorer.contraction = "bf16x3-train" / "bf16x3-all")
         K = x.shape[-1]
         x2 = x.reshape(-1, K)
         M = x2.shape[0]
@@ -369,10 +370,11 @@ class _ScorerLinearPacked(torch.autograd.Function):
         k = torch.empty(M, D, dtype=torch.float32, device=dev)
         none = _lib_none(dev)
         flat = BT.view(-1)
-        ops.proj_nn(x2, K, M, K, flat, 2 * D, D, qd, D + QPAD, bc[:D], True, w2, b2, True, QPAD - 2, False)
-        ops.proj_nn(x2, K, M, K, flat[D:], 2 * D, D, k, D, bc[D:2 * D], True, none, none, False, 0, False)
+        _proj_nn(prec, K, D, dev, x2, K, M, K, flat, 2 * D, D, qd, D + QPAD, bc[:D], True, w2, b2, True, QPAD - 2, False)
+        _proj_nn(prec, K, D, dev, x2, K, M, K, flat[D:], 2 * D, D, k, D, bc[D:2 * D], True, none, none, False, 0, False)
         ctx.save_for_backward(x, Wc, Wqd)
         ctx.D = D
+        ctx.prec = prec
         return qd.view(*x.shape[:-1], D + QPAD), k.view(*x.shape[:-1], D)
 
     @staticmethod
@@ -397,9 +399,9 @@ class _ScorerLinearPacked(torch.autograd.Function):
         if need[0] and (g1 is not None or g2 is not None):
             dx = torch.empty(M, K, dtype=torch.float32, device=dev)
             if g1 is not None:
-                ops.proj_nn(g1, D + QPAD, M, D + QPAD, Wqd, K, K, dx, K, none, False, none, none, False, 0, False)
+                _proj_nn(ctx.prec, D + QPAD, K, dev, g1, D + QPAD, M, D + QPAD, Wqd, K, K, dx, K, none, False, none, none, False, 0, False)
             if g2 is not None:                                                 # B = the k rows of W as they lie
-                ops.proj_nn(g2, D, M, D, Wc.view(-1)[D * K:], K, K, dx, K, none, False, none, none, False, 0, g1 is not None)
+                _proj_nn(ctx.prec, D, K, dev, g2, D, M, D, Wc.view(-1)[D * K:], K, K, dx, K, none, False, none, none, False, 0, g1 is not None)
             dx = dx.view(x.shape)
         dW = db = None
         if need[1] or need[2]:
@@ -427,7 +429,7 @@ class _ScorerLinearPacked(torch.autograd.Function):
                 ws = torch.empty(n, dtype=torch.uint8, device=dev)
                 ops.proj_tn(g2, D, M, D, -1, D, x2, K, K, dW.view(-1)[D * K:], K, db[D:], ws)
             dW, db = dW[:2 * D + 1], db[:2 * D + 1]
-        return dx, dW if need[1] else None, db if need[2] else None, None
+        return dx, dW if need[1] else None, db if need[2] else None, None, None
 
 
 class _IntervalScore(torch.autograd.Function):
@@ -519,11 +521,11 @@ class ScaledInnerProductIntervalScorer(nn.Module):
         lin = self.map[0]
         W, bias = lin.weight, lin.bias
         x = ctx.float()
+        fs = int(self.fullSquare) | contraction_bits(self.contraction)
         if _ScorerLinearPacked.eligible(x, W, bias, D):
-            qd, k = _ScorerLinearPacked.apply(x, W, bias, D)
+            qd, k = _ScorerLinearPacked.apply(x, W, bias, D, 1 if fs & PROJ_BF16X3 else 0)
         else:
             Wqd, bqd = qd_weights(W, bias, D)
             qd, k = _ScorerLinear.apply(x, Wqd, bqd, W[D:2 * D], bias[D:2 * D])
-        fs = int(self.fullSquare) | contraction_bits(self.contraction)
         S, b = _IntervalScore.apply(qd, k, N, P, T, D, _lib.LEN_MODES[self.lengthScaling], fs, int(self.slotPitch or 0))
         return S, b
