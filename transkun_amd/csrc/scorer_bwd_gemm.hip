@@ -957,6 +957,8 @@ bool launch_interval_score_bwd_packed(const float* dS, const float* q, const flo
     case 128: launch_gemm3<AT_, 2>(Gt, Tp, OTHER, LDO, OUT, LDOUT, C, T, stream, drowc, lddrc); break;                  \
     default: launch_gemm3<AT_, 4>(Gt, Tp, OTHER, LDO, OUT, LDOUT, C, T, stream, drowc, lddrc); break;                   \
     }
+    // (the three-limb kernels address their outputs through buffers: 32-bit offsets inside a chain's [T][ld] block)
+    if (prec == 1 && ((long long)T * lddq * 4 >= (1ll << 31) || (long long)T * lddk * 4 >= (1ll << 31))) prec = 0;
     if (prec == 1) {
         if (dq) { SEMICRF_GEMM3_DISPATCH(false, k, ldk, dq, lddq) }
         if (dk) { SEMICRF_GEMM3_DISPATCH(true, q, ldq, dk, lddk) }
