@@ -352,6 +352,9 @@ size_t scorer_proj_nn3_workspace_bytes(int K, int N);
 int scorer_proj_nn3(const float* A, int64_t lda, int64_t M, int K, const float* B, int64_t ldb, int N, float* out, int64_t ldout,
                     const float* bias, const float* w2, const float* b2, int zero_cols, int accumulate, void* ws, size_t ws_bytes,
                     semicrf_stream_t stream);
+/* scorer_proj_tn, total_rows | SEMICRF_PROJ_TN_BF16X3: the matrix part of the weight gradient on the three-limb bf16 kernel (N == 256;
+ * fp32-grade, not bit-identical; the bias gradient and the two extra rows stay exact fp32 sums).  Other widths ignore the bit. */
+#define SEMICRF_PROJ_TN_BF16X3 0x40000000
 size_t scorer_proj_tn_workspace_bytes(int64_t M, int R, int N);
 int scorer_proj_tn(const float* dy, int64_t lddy, int64_t M, int R, int extra_col0, int total_rows, const float* x, int64_t ldx, int N,
                    float* dW, int64_t lddw, float* db, void* ws, size_t ws_bytes, semicrf_stream_t stream);

@@ -1949,6 +1949,18 @@ def test_projection_bf16x3(gpu, M, packed):
     out = proj_input_grad(dy, W, out=acc, prec=1)
     assert out.data_ptr() == acc.data_ptr()
     assert float(((acc.double() - (base.double() + rdx)).abs() / (bdx + base.double().abs() * 2.0 ** -23)).max()) <= 1.0
+    # the weight gradient's matrix part (proj_tn3_kernel; the bias gradient and the two extra rows stay exact fp32 sums)
+    from transkun_amd.scorer import proj_weight_grad
+    dW3, db3 = proj_weight_grad(dy, x, n_main, prec=1)
+    dW1, db1 = proj_weight_grad(dy, x, n_main)
+    rdW = dy.double().t() @ x.double()
+    rdb = dy.double().sum(0)
+    assert dW3.shape == (Nout, K) and db3.shape == (Nout,)
+    assert float((dW3.double() - rdW).abs().max()) < 2e-5 * float(rdW.abs().max())
+    assert float((db3.double() - rdb).abs().max()) < 2e-5 * max(1.0, float(rdb.abs().max()))
+    assert not torch.equal(dW3[:n_main], dW1[:n_main])
+    if packed:
+        assert torch.equal(dW3[n_main:], dW1[n_main:])                              # the extra rows: the same side kernel
     assert _lib.device_status() == 0
 
 

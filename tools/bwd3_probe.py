@@ -66,8 +66,11 @@ if "--proj" in sys.argv:
         return e0.elapsed_time(e1) / n
     fl = 2.0 * M * K * (K + 2)
     for name, p in (("fp32", 0), ("bf16x3", 1)):
+        from transkun_amd.scorer import proj_weight_grad
         tf = t(lambda: proj_forward(x, W, b, K, prec=p)); tb = t(lambda: proj_input_grad(dy, W, out=acc, prec=p))
-        print(f"projection M={M} K={K} {name}: forward {tf:.3f} ms ({fl / tf / 1e9:.1f} TF), input gradient (accumulating) {tb:.3f} ms ({fl / tb / 1e9:.1f} TF)", flush=True)
+        tw = t(lambda: proj_weight_grad(dy, x, K, prec=p))
+        print(f"projection M={M} K={K} {name}: forward {tf:.3f} ms ({fl / tf / 1e9:.1f} TF), input gradient (accumulating) {tb:.3f} ms ({fl / tb / 1e9:.1f} TF), "
+              f"weight gradient (GEMM + extras + reduction) {tw:.3f} ms", flush=True)
 
 if "--proj-probe" in sys.argv:
     # a library built with -DSEMICRF_P3_PROBE=1: cycle counters of proj_gemm3_kernel's waves over the first rows of the output

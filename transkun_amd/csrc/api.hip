@@ -797,9 +797,11 @@ int scorer_proj_tn(const float* dy, int64_t lddy, int64_t M, int R, int extra_co
                    float* dW, int64_t lddw, float* db, void* ws, size_t ws_bytes, semicrf_stream_t stream)
 {
     SEMICRF_CHECK_ARG(dy && x && dW, "dy/x/dW must be non-NULL");
+    const int x3flag = total_rows & SEMICRF_PROJ_TN_BF16X3;       // opt-in: the matrix part on the three-limb bf16 kernel
+    total_rows &= ~SEMICRF_PROJ_TN_BF16X3;
     SEMICRF_CHECK_ARG(M >= 1 && R >= 1 && total_rows >= R && lddy >= R && ldx >= N && lddw >= N, "bad sizes");
     SEMICRF_CHECK_ARG(extra_col0 < 0 || (extra_col0 >= R && extra_col0 + 2 <= total_rows && extra_col0 + 2 <= lddy), "bad extra columns");
-    const int rc = launch_proj_tn(dy, lddy, M, R, extra_col0, total_rows, x, ldx, N, dW, lddw, db, ws, ws_bytes, (hipStream_t)stream);
+    const int rc = launch_proj_tn(dy, lddy, M, R, extra_col0, total_rows | x3flag, x, ldx, N, dW, lddw, db, ws, ws_bytes, (hipStream_t)stream);
     if (rc == 2) { set_error("scorer_proj_tn: workspace missing or too small"); return SEMICRF_EWORKSPACE; }
     SEMICRF_CHECK_ARG(rc == 0, "scorer_proj_tn: N must be 64, 128 or 256, rows 16-byte aligned, M * ld * 4 < 2^31 (N=%d)", N);
     SEMICRF_CHECK_LAUNCH("scorer_proj_tn");

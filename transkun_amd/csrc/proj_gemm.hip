@@ -603,9 +603,14 @@ size_t proj_tn_workspace_bytes(long long M, int R, int N)
 
 // dW[R (+2)][N] = A[:, :R]^T X, db = column sums of A (first R columns, + the two extra columns extra_col0, +1 when >= 0); rows
 // of dW beyond R + 2 up to total_rows are set to zero
+int launch_proj_tn3_core(const float* A, long long lda, long long M, int R, const float* X, long long ldx, int N, float* part, int Mp,
+                         float* pbias, int bias_pitch, int S, int kslice, hipStream_t stream);      // proj_gemm3.hip
+
 int launch_proj_tn(const float* A, long long lda, long long M, int R, int extra_col0, int total_rows, const float* X, long long ldx, int N,
                    float* dW, long long lddw, float* db, void* ws, size_t ws_bytes, hipStream_t stream)
 {
+    const int prec = (total_rows & SEMICRF_PROJ_TN_BF16X3) ? 1 : 0;        // opt-in: the matrix part on the three-limb bf16 kernel (N == 256)
+    total_rows &= ~SEMICRF_PROJ_TN_BF16X3;
     if (!(N == 64 || N == 128 || N == 256) || R < 1 || M < 1) return 1;
     if (((uintptr_t)A & 15) || ((uintptr_t)X & 15) || lda % 4 || ldx % 4 || M * lda * 4 >= (1ll << 31) || M * ldx * 4 >= (1ll << 31)) return 1;
     if (!ws || ws_bytes < proj_tn_workspace_bytes(M, R, N) || ((uintptr_t)ws & 15)) return 2;
@@ -623,6 +628,8 @@ int launch_proj_tn(const float* A, long long lda, long long M, int R, int extra_
     P.out = part; P.ldout = N; P.Mout = R; P.K = (int)M; P.accumulate = 0; P.bias = nullptr; P.w2 = nullptr; P.b2 = nullptr;
     P.zero_cols = 0; P.nslices = S; P.kslice = ks; P.extra_col0 = -1; P.part_bias = pbias; P.bias_pitch = Mp + 8; P.part_extra = nullptr;
     const long long nitems = (long long)(Mp / pj::GM) * S;
+    if (prec && launch_proj_tn3_core(A, lda, M, R, X, ldx, N, part, Mp, pbias, Mp + 8, S, ks, stream) == 0) {
+    } else
     switch (N) {
     case 64: proj_launch<true, 1, false>(P, nitems, 0, stream); break;
     case 128: proj_launch<true, 2, false>(P, nitems, 0, stream); break;

@@ -414,6 +414,272 @@ __global__ __launch_bounds__(512, 2) void proj_gemm3_kernel(Args P_)
 #undef P3_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------
+// The weight gradient's matrix part on the same contraction: part[sl][r][n] = sum over the slice's rows m of dy[m][r] x[m][n]
+// (launch_proj_tn's split-K partial slabs; its fixed-order reduction, the two extra rows and the bias gradient's extras stay as they
+// are).  Both operands have the contraction index as their ROW index in memory: column units for dy (one column, eight rows: 4-byte
+// loads, the row in the scalar offset) and column-pair units for x (8-byte loads), both split in the loop -- 2.75 vector
+// instructions per matrix instruction like the scorer's backward, whose skeleton this is; the bias gradient (column sums of dy) falls
+// out of the staged dy values, combined over a column's four pieces through the LDS.
+// ---------------------------------------------------------------------------------------------
+struct ArgsT {
+    const float* A; long long lda; int M, lda_cols;      // dy [M][lda] (lda_cols: columns a lane may touch, <= lda)
+    const float* X; long long ldx;                        // x [M][256]
+    float* part; int Mp;                                  // [S][Mp][256]
+    float* pbias; int bias_pitch;                         // [S][bias_pitch]
+    int nslices, kslice;                                  // row slices of the contraction (chunks per slice)
+};
+
+__global__ __launch_bounds__(512, 2) void proj_tn3_kernel(ArgsT P_)
+{
+    const float* const a_A = P_.A; const long long a_lda = P_.lda; const int a_M = P_.M, a_cols = P_.lda_cols;
+    const float* const a_X = P_.X; const long long a_ldx = P_.ldx; float* const a_part = P_.part; const int a_Mp = P_.Mp;
+    float* const a_pbias = P_.pbias; const int a_bpitch = P_.bias_pitch; const int a_S = P_.nslices, a_ks = P_.kslice;
+    extern __shared__ __attribute__((aligned(16))) char glds[];    // [2][STAGE] | column sums [2][4][128] floats
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int grp = wave >> 2;
+    const int nm = a_Mp / GM;
+    const int nkt = (a_M + GK - 1) / GK;
+    const int nitems = nm * a_S;
+    float* const csl = (float*)(glds + 2 * STAGE);
+
+    unsigned rdA[2], rdB[2];
+    {
+        const int ra = 32 * wm + l31, rb = 32 * NW * wn + l31;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            rdA[sl] = (unsigned)(ra * 64 + (((2 * half + sl) ^ ((ra >> 2) & 3)) * 16));
+            rdB[sl] = (unsigned)(BOFF + rb * 64 + (((2 * half + sl) ^ ((rb >> 2) & 3)) * 16));
+        }
+    }
+    // staging lanes: dy -- unit = (column tid % 128 of the tile, piece tid / 128) across rows; x -- units (column 2 cp + j, piece wave / 2)
+    const int aRow = tid & 127, aPiece = wave >> 1;
+    const unsigned wA = (unsigned)(aRow * 64 + ((aPiece ^ ((aRow >> 2) & 3)) * 16));
+    const int bCp = (wave & 1) * 64 + lane, bPiece = wave >> 1;
+    unsigned wB[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int d = 2 * bCp + j;
+        wB[j] = (unsigned)(BOFF + d * 64 + ((bPiece ^ ((d >> 2) & 3)) * 16));
+    }
+    const unsigned bVoff = (unsigned)(bCp * 8);
+
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    auto make_rsrc = [](const void* p, size_t bytes) -> v4i {
+        const unsigned long long a = (unsigned long long)(uintptr_t)p;
+        return (v4i){__builtin_amdgcn_readfirstlane((int)(unsigned)a), __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu)),
+                     __builtin_amdgcn_readfirstlane((int)(unsigned)bytes), 0x00020000};
+    };
+    const v4i ra = make_rsrc(a_A, ((size_t)(a_M - 1) * a_lda + a_cols) * 4);
+    const v4i rb = make_rsrc(a_X, ((size_t)(a_M - 1) * a_ldx + N) * 4);
+    const unsigned lda4 = (unsigned)(a_lda * 4), ldx4 = (unsigned)(a_ldx * 4);
+    const unsigned amax = (unsigned)(a_M - 1) * lda4, xmax = (unsigned)(a_M - 1) * ldx4;
+
+    auto item_of = [&](int n, int& mi, int& sl, int& kbeg, int& nk) __attribute__((always_inline)) -> bool {
+        if (n >= nitems) return false;
+        mi = __builtin_amdgcn_readfirstlane(n % nm);
+        sl = __builtin_amdgcn_readfirstlane(n / nm);
+        kbeg = sl * a_ks;
+        nk = nkt - kbeg < a_ks ? nkt - kbeg : a_ks;
+        return nk > 0;
+    };
+    int nx_n = (int)blockIdx.x, nx_mi = 0, nx_sl = 0, nx_kbeg = 0, nx_nk = 0, nx_j = 0;
+    bool nx_valid = item_of(nx_n, nx_mi, nx_sl, nx_kbeg, nx_nk);
+    if (!nx_valid) return;                             // uniform (slices are never empty: S = ceil(chunks / kslice))
+    unsigned aVoff = 0;
+    auto set_item_offsets = [&]() __attribute__((always_inline)) {
+        const int col = nx_mi * GM + aRow;
+        aVoff = (unsigned)((col < a_cols ? col : a_cols - 1) * 4);            // (a clamped column's output row is beyond R: never reduced)
+    };
+    set_item_offsets();
+
+    constexpr int NLD = 8 + 8;
+    struct Regs { float a[8]; f32x2 b[8]; };
+    struct Meta { bool valid, last; int mi, sl, m0; };
+    auto fetch = [&](Regs& g, Meta& m) __attribute__((always_inline)) {
+        m.valid = nx_valid;
+        const unsigned m0 = (unsigned)(nx_kbeg + nx_j) * GK;
+        {
+            unsigned sr = (m0 + 8 * aPiece) * lda4;             // rows past M: the last row's values, zeroed in the split
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned so = sr < amax ? sr : amax;
+                asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(g.a[i]) : "v"(aVoff), "s"(ra), "s"(so));
+                sr += lda4;
+            }
+        }
+        {
+            unsigned sr = (m0 + 8 * bPiece) * ldx4;             // rows past M meet dy == 0: any finite value will do
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned so = sr < xmax ? sr : xmax;
+                asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(g.b[i]) : "v"(bVoff), "s"(rb), "s"(so));
+                sr += ldx4;
+            }
+        }
+        m.last = nx_j + 1 == nx_nk;
+        m.mi = nx_mi;
+        m.sl = nx_sl;
+        m.m0 = (int)m0;
+        if (nx_valid && ++nx_j == nx_nk) {
+            int mi2, sl2, kbeg2, nk2;
+            if (item_of(nx_n + (int)gridDim.x, mi2, sl2, kbeg2, nk2)) {
+                nx_n += (int)gridDim.x;
+                nx_mi = mi2; nx_sl = sl2; nx_kbeg = kbeg2; nx_nk = nk2; nx_j = 0;
+                set_item_offsets();
+            } else {
+                nx_valid = false;
+                nx_j = nx_nk - 1;
+            }
+        }
+    };
+    auto landed = [&](Regs& g) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(g.a[i]));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(g.b[i]));
+    };
+    float cs = 0.0f;                                    // this lane's part of its column's sum over the slice (bias gradient)
+    int cpar = 0;                                       // which of the two column-sum buffers the item being split uses
+    auto convert = [&](Regs& g, const Meta& m, int stage) __attribute__((always_inline)) {
+        char* base = glds + stage * STAGE;
+        if (m.m0 + GK > a_M) {                          // the contraction's last chunk (uniform): rows past M must not meet anything
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (m.m0 + 8 * aPiece + i >= a_M) g.a[i] = 0.0f;
+        }
+        {
+            const Limbs3 L = split8((v4f){g.a[0], g.a[1], g.a[2], g.a[3]}, (v4f){g.a[4], g.a[5], g.a[6], g.a[7]});
+            *(bf16x8*)(base + wA) = L.h;
+            *(bf16x8*)(base + APL + wA) = L.m;
+            *(bf16x8*)(base + 2 * APL + wA) = L.l;
+        }
+        if (m.valid) {
+            cs = add1(cs, add1(add1(add1(g.a[0], g.a[1]), add1(g.a[2], g.a[3])), add1(add1(g.a[4], g.a[5]), add1(g.a[6], g.a[7]))));
+            if (m.last) {                               // parked for whoever stores the item's bias sums (behind the next barrier)
+                csl[cpar * 512 + aPiece * 128 + aRow] = cs;
+                cs = 0.0f;
+                cpar ^= 1;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const Limbs3 L = split8((v4f){g.b[0][j], g.b[1][j], g.b[2][j], g.b[3][j]}, (v4f){g.b[4][j], g.b[5][j], g.b[6][j], g.b[7][j]});
+            *(bf16x8*)(base + wB[j]) = L.h;
+            *(bf16x8*)(base + BPL + wB[j]) = L.m;
+            *(bf16x8*)(base + 2 * BPL + wB[j]) = L.l;
+        }
+    };
+
+    f32x16 acc[NW];
+#pragma unroll
+    for (int t = 0; t < NW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    auto multiply = [&](int stage) __attribute__((always_inline)) {
+        const char* base = glds + stage * STAGE;
+        Limbs3 A, B[2];
+        auto ldA = [&](Limbs3& L, int sl) __attribute__((always_inline)) {
+            L.h = *(const bf16x8*)(base + rdA[sl]);
+            L.m = *(const bf16x8*)(base + APL + rdA[sl]);
+            L.l = *(const bf16x8*)(base + 2 * APL + rdA[sl]);
+        };
+        auto ldB = [&](Limbs3& L, int sl, int t) __attribute__((always_inline)) {
+            L.h = *(const bf16x8*)(base + rdB[sl] + t * 2048);
+            L.m = *(const bf16x8*)(base + BPL + rdB[sl] + t * 2048);
+            L.l = *(const bf16x8*)(base + 2 * BPL + rdB[sl] + t * 2048);
+        };
+        ldA(A, 0);
+        ldB(B[0], 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 2 * NW>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int t = i % NW;
+            if constexpr (i + 1 < 2 * NW) {
+                constexpr int sl2 = (i + 1) / NW, t2 = (i + 1) % NW;
+                if constexpr (t2 != 0) ldB(B[(i + 1) & 1], sl2, t2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[t] = mma6(A, B[i & 1], acc[t]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (i + 1 < 2 * NW && (i + 1) % NW == 0) {
+                ldA(A, (i + 1) / NW);
+                ldB(B[(i + 1) & 1], (i + 1) / NW, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+    };
+
+    Regs gX, gY;
+    Meta mX = {false, false, 0, 0, 0}, mY = {false, false, 0, 0, 0};
+    auto sync = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    fetch(gY, mY);
+    fetch(gX, mX);
+    landed(gY);
+    convert(gY, mY, 0);
+    fetch(gY, mY);
+
+    int cur_n = (int)blockIdx.x, mi = 0, sl = 0, kbeg = 0, nk = 0, j = 0;
+    (void)item_of(cur_n, mi, sl, kbeg, nk);
+    int bpar = 0;                                       // the column-sum buffer of the item being multiplied
+    auto finish = [&]() __attribute__((always_inline)) -> bool {
+        if (++j < nk) return true;
+        float* ob = a_part + ((size_t)sl * a_Mp + (size_t)mi * GM) * N;
+        const auto ro = __builtin_amdgcn_make_buffer_rsrc((void*)ob, 0, (int)((size_t)GM * N * 4), 0x00020000);
+        const unsigned v0 = (unsigned)(((32 * wm + 4 * half) * N + 32 * NW * wn + l31) * 4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned vr = v0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * N * 4);
+#pragma unroll
+            for (int t = 0; t < NW; ++t) {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][r]), ro, vr, t * 128, 0);
+                acc[t][r] = 0.0f;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
+        j = 0;
+        cur_n += (int)gridDim.x;
+        return item_of(cur_n, mi, sl, kbeg, nk);
+    };
+    auto step = [&](auto PC, Regs& gn, Meta& mn) __attribute__((always_inline)) -> bool {
+        constexpr int Pst = decltype(PC)::value;
+        bool more = true;
+        sync();
+        // chunk (kbeg + j) of item (mi, sl) is complete in stage Pst; if it is the item's last one, its column sums are in the LDS as well
+        if (j + 1 == nk) {
+            if (tid < 128) {
+                const float* c4 = csl + bpar * 512 + tid;
+                a_pbias[(size_t)sl * a_bpitch + mi * GM + tid] = (c4[0] + c4[128]) + (c4[256] + c4[384]);
+            }
+            bpar ^= 1;
+        }
+        if (grp == 0) {
+            multiply(Pst);
+            more = finish();
+        }
+        landed(gn);
+        convert(gn, mn, Pst ^ 1);
+        fetch(gn, mn);
+        if (grp != 0) {
+            multiply(Pst);
+            more = finish();
+        }
+        return more;
+    };
+    while (true) {
+        if (!step(std::integral_constant<int, 0>{}, gX, mX)) break;
+        if (!step(std::integral_constant<int, 1>{}, gY, mY)) break;
+    }
+}
+
 }  // namespace pj3
 
 bool proj_gemm_supported(long long M, int K, int N, const void* A, long long lda, const void* B, long long ldb, const void* out,
@@ -454,6 +720,26 @@ int launch_proj_nn3(const float* A, long long lda, long long M, int K, const flo
             (void)hipFuncSetAttribute((const void*)pj3::proj_gemm3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         hipLaunchKernelGGL((pj3::proj_gemm3_kernel<false>), dim3(grid), dim3(512), lds, stream, P);
     }
+    return 0;
+}
+
+// the matrix part of launch_proj_tn (proj_gemm.hip) on the three-limb kernels: 0 = ran
+int launch_proj_tn3_core(const float* A, long long lda, long long M, int R, const float* X, long long ldx, int N, float* part, int Mp,
+                         float* pbias, int bias_pitch, int S, int kslice, hipStream_t stream)
+{
+    if (N != pj3::N || Mp % pj3::GM != 0 || M * lda * 4 >= (1ll << 31) || M * ldx * 4 >= (1ll << 31)) return 1;
+    pj3::ArgsT P{};
+    P.A = A; P.lda = lda; P.M = (int)M; P.lda_cols = (int)(lda < Mp ? lda : Mp);
+    P.X = X; P.ldx = ldx; P.part = part; P.Mp = Mp; P.pbias = pbias; P.bias_pitch = bias_pitch; P.nslices = S; P.kslice = kslice;
+    (void)R;
+    const size_t lds = (size_t)2 * pj3::STAGE + 4096;
+    static PerDeviceOnce attr_once;
+    if (attr_once.first())
+        (void)hipFuncSetAttribute((const void*)pj3::proj_tn3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    const long long nitems = (long long)(Mp / pj3::GM) * S;
+    const int ncu = proj_ncu();
+    const int grid = nitems < ncu ? (int)nitems : ncu;
+    hipLaunchKernelGGL(pj3::proj_tn3_kernel, dim3(grid), dim3(512), lds, stream, P);
     return 0;
 }
 

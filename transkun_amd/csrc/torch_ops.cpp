@@ -377,10 +377,12 @@ void proj_tn_op(Tensor dy, int64_t lddy, int64_t M, int64_t R, int64_t extra_col
                 int64_t lddw, Tensor db, Tensor ws)
 {
     Ctx c(dy); c.same(dy, x, dW, db, ws);
+    const int64_t x3flag = total_rows & SEMICRF_PROJ_TN_BF16X3;  // opt-in: the matrix part on the three-limb bf16 kernel
+    total_rows &= ~(int64_t)SEMICRF_PROJ_TN_BF16X3;
     STD_TORCH_CHECK(M >= 1 && R >= 1 && N >= 1 && N <= 256 && M < (1ll << 31) && total_rows >= R && total_rows < (1 << 20), "semicrf: bad sizes");
     STD_TORCH_CHECK(dy.numel() >= (M - 1) * lddy + R && x.numel() >= (M - 1) * ldx + N && dW.numel() >= (total_rows - 1) * lddw + N,
                     "semicrf: dy / x / dW too small");
-    check(scorer_proj_tn(f32s(dy, "dy"), lddy, M, (int)R, (int)extra_col0, (int)total_rows, f32s(x, "x"), ldx, (int)N, f32so(dW, "dW"), lddw,
+    check(scorer_proj_tn(f32s(dy, "dy"), lddy, M, (int)R, (int)extra_col0, (int)(total_rows | x3flag), f32s(x, "x"), ldx, (int)N, f32so(dW, "dW"), lddw,
                          f32w(db, total_rows, "db"), bytes(ws, "ws"), (size_t)ws.numel(), c.stream),
           "scorer_proj_tn");
 }

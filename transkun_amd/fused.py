@@ -189,7 +189,7 @@ class _MergedScorerCRFLogProb(torch.autograd.Function):
             proj_input_grad(g2, Wm, out=dx2, Wp=ctx.Wp, prec=ctx.pp)  # + the part through [z | c | diag]
         dWm = dbm = None
         if need[1] or need[2]:
-            dWm, dbm = proj_weight_grad(g2, x3.view(-1, size), size)
+            dWm, dbm = proj_weight_grad(g2, x3.view(-1, size), size, prec=ctx.pp)
         return (dx2.view(N, P, T, size) if need[0] else None, dWm if need[1] else None, dbm if need[2] else None, None, None, None, None, None,
                 None, None, None)
 

@@ -259,7 +259,10 @@ def proj_input_grad(dy2: torch.Tensor, W: torch.Tensor, out: torch.Tensor = None
     return dx
 
 
-def proj_weight_grad(dy2: torch.Tensor, x2: torch.Tensor, n_main: int):
+PROJ_TN_BF16X3 = 0x40000000     # SEMICRF_PROJ_TN_BF16X3: OR into proj_tn's total_rows
+
+
+def proj_weight_grad(dy2: torch.Tensor, x2: torch.Tensor, n_main: int, prec: int = 0):
     """(dW [Nout, K], db [Nout]) = (dy2^T x2, column sums of dy2) with the contraction over the M rows split into slices (partial sums
     in a workspace, fixed summation order)."""
     M, Nout = dy2.shape
@@ -274,7 +277,7 @@ def proj_weight_grad(dy2: torch.Tensor, x2: torch.Tensor, n_main: int):
     if n is None:
         n = _BWD_WS[key] = int(_lib.load().scorer_proj_tn_workspace_bytes(M, n_main, K))
     ws = torch.empty(n, dtype=torch.uint8, device=dy2.device)
-    _lib.ops().proj_tn(dy2, Nout, M, n_main, n_main if Nout > n_main else -1, Nout, x2, K, K, dW, K, db, ws)
+    _lib.ops().proj_tn(dy2, Nout, M, n_main, n_main if Nout > n_main else -1, Nout | (PROJ_TN_BF16X3 if prec else 0), x2, K, K, dW, K, db, ws)
     return dW, db
 
 
@@ -416,7 +419,7 @@ class _ScorerLinearPacked(torch.autograd.Function):
                 if n is None:
                     n = _BWD_WS[key] = int(_lib.load().scorer_proj_tn_workspace_bytes(M, D, K))
                 ws = torch.empty(n, dtype=torch.uint8, device=dev)
-                ops.proj_tn(g1, D + QPAD, M, D, D, D + QPAD, x2, K, K, dW, K, db, ws)
+                ops.proj_tn(g1, D + QPAD, M, D, D, (D + QPAD) | (PROJ_TN_BF16X3 if ctx.prec else 0), x2, K, K, dW, K, db, ws)
                 dW[2 * D].copy_(dW[D])
                 db[2 * D:2 * D + 1].copy_(db[D:D + 1])
                 if g2 is None:
@@ -427,7 +430,7 @@ class _ScorerLinearPacked(torch.autograd.Function):
                 if n is None:
                     n = _BWD_WS[key] = int(_lib.load().scorer_proj_tn_workspace_bytes(M, D, K))
                 ws = torch.empty(n, dtype=torch.uint8, device=dev)
-                ops.proj_tn(g2, D, M, D, -1, D, x2, K, K, dW.view(-1)[D * K:], K, db[D:], ws)
+                ops.proj_tn(g2, D, M, D, -1, D | (PROJ_TN_BF16X3 if ctx.prec else 0), x2, K, K, dW.view(-1)[D * K:], K, db[D:], ws)
             dW, db = dW[:2 * D + 1], db[:2 * D + 1]
         return dx, dW if need[1] else None, db if need[2] else None, None, None
 
