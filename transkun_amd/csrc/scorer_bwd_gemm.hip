@@ -456,6 +456,18 @@ constexpr int NXCD_G3 = 8;        // workgroup b runs on XCD b % 8
 #ifndef SEMICRF_MMA_PRIO
 #define SEMICRF_MMA_PRIO 0       // 1: raised wave priority while a wave issues its chunk's matrix instructions
 #endif
+#ifndef SEMICRF_G3_ABL
+#define SEMICRF_G3_ABL 0          // timing ablations of the interleaved form (variant builds only; results are wrong): 1 no split pieces,
+#endif                            // 2 the operands of a chunk's first instruction group for all of it (no LDS reads inside), 4 no requests
+#ifndef SEMICRF_G3_PRIO_FLIP
+#define SEMICRF_G3_PRIO_FLIP 24    // (interleaved form) the younger wave of a SIMD goes first for this many matrix instructions of a chunk (0: never)
+#endif
+#ifndef SEMICRF_G3_FILL_LOADS
+#define SEMICRF_G3_FILL_LOADS 1    // (interleaved form) the requests for the chunk after next between the matrix instructions, too
+#endif
+#ifndef SEMICRF_G3_INTERLEAVE
+#define SEMICRF_G3_INTERLEAVE 1   // 1: every wave splits the next chunk between its own matrix instructions, one barrier per chunk; 0: two wave groups
+#endif
 #ifndef SEMICRF_G3_PHASED
 #define SEMICRF_G3_PHASED 1       // 0: both groups in the same phase (the first version's schedule)
 #endif
@@ -592,33 +604,23 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
     constexpr int NLD = (AT ? 8 : 2) + 8;
     struct Regs { v4f alo, ahi; float a[8]; f32x2 b[8]; };
     struct Meta { bool valid, last; int c, mi; };
-    auto fetch = [&](Regs& g, Meta& m) {
+    // A request for one chunk = prepare (the chunk's scalar offsets, and the walk over the items moves on) + issue (the loads; the
+    // interleaved schedule issues them between its matrix instructions, the B loads and the A loads at different places).
+    struct Pend { v4i ra, rb; unsigned av, sa, krl4, sr; };
+    auto prepare = [&](Meta& m, Pend& q) __attribute__((always_inline)) {
         m.valid = nx_valid;
         const unsigned k0 = (unsigned)(AT ? nkt - 1 - nx_j : nx_kbeg + nx_j) * GK;
-        if (!(SEMICRF_G3_DBG & 2)) {
-            if (!AT) {
-                const unsigned sa = nx_aoff + k0 * 4;
-                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(g.alo) : "v"(aVoff), "s"(nx_ra), "s"(sa));
-                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(g.ahi) : "v"(aVoff), "s"(nx_ra), "s"(sa));
-            } else {
-                // the chunk's 32 rows (e) lie in one 128-row block; columns past the block's row length (a last block that is not
-                // 128 wide) read the next row or the workspace's slack: they only reach output rows >= T, which are not written
-                const unsigned kblk = k0 / GM, krl4 = (unsigned)gt_row_len((int)kblk, Tp) * 4;
-                unsigned so = (unsigned)GM * GM * 4 * (kblk * (kblk + 1) / 2) + (k0 - kblk * GM + 8 * aPiece) * krl4 + (unsigned)nx_mi * (GM * 4);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(g.a[i]) : "v"(aVoff), "s"(nx_ra), "s"(so));
-                    so += krl4;
-                }
-            }
-            unsigned sr = (k0 + 8 * bPiece) * ldo4;              // rows past T meet Gt == 0: any finite value will do (the last row's)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const unsigned so = sr < somax ? sr : somax;
-                asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(g.b[i]) : "v"(bVoff), "s"(nx_rb), "s"(so));
-                sr += ldo4;
-            }
+        q.ra = nx_ra; q.rb = nx_rb; q.av = aVoff; q.krl4 = 0;
+        if (!AT) {
+            q.sa = nx_aoff + k0 * 4;
+        } else {
+            // the chunk's 32 rows (e) lie in one 128-row block; columns past the block's row length (a last block that is not
+            // 128 wide) read the next row or the workspace's slack: they only reach output rows >= T, which are not written
+            const unsigned kblk = k0 / GM;
+            q.krl4 = (unsigned)gt_row_len((int)kblk, Tp) * 4;
+            q.sa = (unsigned)GM * GM * 4 * (kblk * (kblk + 1) / 2) + (k0 - kblk * GM + 8 * aPiece) * q.krl4 + (unsigned)nx_mi * (GM * 4);
         }
+        q.sr = (k0 + 8 * bPiece) * ldo4;                         // rows past T meet Gt == 0: any finite value will do (the last row's)
         m.last = nx_j + 1 == nx_nk;
         m.c = nx_c;
         m.mi = nx_mi;
@@ -633,6 +635,34 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
                 nx_j = nx_nk - 1;
             }
         }
+    };
+    auto issue_a = [&](Regs& g, const Pend& q, int i0, int n) __attribute__((always_inline)) {     // AT: loads i0 .. i0 + n - 1 of 8; else both
+        if (SEMICRF_G3_DBG & 2) return;
+        if (!AT) {
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(g.alo) : "v"(q.av), "s"(q.ra), "s"(q.sa));
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(g.ahi) : "v"(q.av), "s"(q.ra), "s"(q.sa));
+        } else {
+#pragma unroll
+            for (int i = i0; i < i0 + n; ++i) {
+                const unsigned so = q.sa + (unsigned)i * q.krl4;
+                asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(g.a[i]) : "v"(q.av), "s"(q.ra), "s"(so));
+            }
+        }
+    };
+    auto issue_b = [&](Regs& g, const Pend& q, int i0, int n) __attribute__((always_inline)) {
+        if (SEMICRF_G3_DBG & 2) return;
+#pragma unroll
+        for (int i = i0; i < i0 + n; ++i) {
+            const unsigned sr = q.sr + (unsigned)i * ldo4;
+            const unsigned so = sr < somax ? sr : somax;
+            asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(g.b[i]) : "v"(bVoff), "s"(q.rb), "s"(so));
+        }
+    };
+    auto fetch = [&](Regs& g, Meta& m) __attribute__((always_inline)) {
+        Pend q;
+        prepare(m, q);
+        issue_a(g, q, 0, 8);
+        issue_b(g, q, 0, 8);
     };
     // the set's loads have landed (the other set's NLD younger ones may be in flight)
     auto landed = [&](Regs& g) {
@@ -766,6 +796,129 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
 #endif
     };
 
+    // The interleaved form (SEMICRF_G3_INTERLEAVE): the SAME wave splits the next chunk between its own matrix instructions -- one
+    // piece (a pair of values through the three-limb split, or a unit's three limb stores) behind every third instruction, the order
+    // pinned by scheduling barriers.  Cycle stamps and priority experiments of the two-group schedule said why: a SIMD issues to its
+    // oldest wave first, so whichever group is older runs at full speed and the other one starves (multiply 1960 cycles per chunk for
+    // the waves 0-3, 2950 for 4-7; with raised priority for 4-7 it is the other way round) -- the split next to ANOTHER wave's matrix
+    // instructions does not overlap, the split between a wave's OWN matrix instructions does (a filler per instruction is nearly free).
+    auto mma1 = [&](const Limbs3& A, const Limbs3& B, f32x16& ac, int pz) __attribute__((always_inline)) {
+        switch (pz) {
+        case 0: ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.l, ac, 0, 0, 0); break;
+        case 1: ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l, B.h, ac, 0, 0, 0); break;
+        case 2: ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.m, B.m, ac, 0, 0, 0); break;
+        case 3: ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.m, ac, 0, 0, 0); break;
+        case 4: ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.m, B.h, ac, 0, 0, 0); break;
+        default: ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.h, ac, 0, 0, 0); break;
+        }
+    };
+    // SEMICRF_G3_FILL_LOADS: the chunk after next is requested from inside, too -- the k/q columns first through the split (pieces
+    // 0-9), their loads two at a time behind the instructions 30, 33, 36, 39, the Gt unit last (pieces 10-14) and its loads behind
+    // 45 and 46: the address path works while the matrix pipe does, instead of ~550 cycles per wave behind the chunk.
+    constexpr bool FL = SEMICRF_G3_FILL_LOADS && NW == 4;
+    auto multiply_fill = [&](int stage, Regs& g, Meta& mref, int wstage) __attribute__((always_inline)) {
+        const char* base = glds + stage * STAGE;
+        char* wbase = glds + wstage * STAGE;
+        const Meta m = mref;
+        Pend q;
+        if (FL) prepare(mref, q);
+        // the values to split: unit 0 = the Gt unit, units 1, 2 = the two k/q columns of the lane's pair
+        v4f alo, ahi;
+        if (AT) { alo = (v4f){g.a[0], g.a[1], g.a[2], g.a[3]}; ahi = (v4f){g.a[4], g.a[5], g.a[6], g.a[7]}; }
+        else { alo = g.alo; ahi = g.ahi; }
+        unsigned ph[4], pm[4], pl[4];
+        auto pairv = [&](int u, int pr, float& x, float& y) __attribute__((always_inline)) {
+            if (u == 0) {
+                const v4f v = pr < 2 ? alo : ahi;
+                x = (pr & 1) ? v.z : v.x; y = (pr & 1) ? v.w : v.y;
+            } else {
+                x = g.b[2 * pr][u - 1]; y = g.b[2 * pr + 1][u - 1];
+            }
+        };
+        auto piece = [&](int k) __attribute__((always_inline)) {             // k = 0 .. 14: (unit, step k % 5)
+            const int u = FL ? (k < 10 ? 1 + k / 5 : 0) : k / 5, st = k % 5;
+            if (st < 4) {
+                float x, y;
+                pairv(u, st, x, y);
+                split_pair(x, y, ph[st], pm[st], pl[st]);
+            } else {
+                const unsigned wo = u == 0 ? wA : wB[u - 1];
+                const int pitch = u == 0 ? APL : BPL;
+                if (u == 0 || D >= 256 || bOn) {
+                    *(u32x4*)(wbase + wo) = (u32x4){ph[0], ph[1], ph[2], ph[3]};
+                    *(u32x4*)(wbase + pitch + wo) = (u32x4){pm[0], pm[1], pm[2], pm[3]};
+                    *(u32x4*)(wbase + 2 * pitch + wo) = (u32x4){pl[0], pl[1], pl[2], pl[3]};
+                }
+                if (u == 0 && !AT && want_rs && m.valid) {
+                    rs = add1(rs, add1(add1(add1(alo.x, alo.y), add1(alo.z, alo.w)), add1(add1(ahi.x, ahi.y), add1(ahi.z, ahi.w))));
+                    if (m.last) {
+                        float tot = rs + __shfl_xor(rs, 1);
+                        tot += __shfl_xor(tot, 2);
+                        const int mrow = m.mi * GM + aRow;
+                        if ((tid & 3) == 0 && mrow < T) rsum[((size_t)m.c * T + mrow) * ldrs] = tot;
+                        rs = 0.0f;
+                    }
+                }
+            }
+        };
+        Limbs3 A, B[2];
+        auto ldA = [&](Limbs3& L, int sl) __attribute__((always_inline)) {
+            L.h = *(const bf16x8*)(base + rdA[sl]);
+            L.m = *(const bf16x8*)(base + APL + rdA[sl]);
+            L.l = *(const bf16x8*)(base + 2 * APL + rdA[sl]);
+        };
+        auto ldB = [&](Limbs3& L, int sl, int t) __attribute__((always_inline)) {
+            L.h = *(const bf16x8*)(base + rdB[sl] + t * 2048);
+            L.m = *(const bf16x8*)(base + BPL + rdB[sl] + t * 2048);
+            L.l = *(const bf16x8*)(base + 2 * BPL + rdB[sl] + t * 2048);
+        };
+        // A SIMD issues to its OLDER wave first: of the two waves that share it the older one would finish its chunk ~1000 cycles ahead
+        // and wait at the barrier while the younger one goes on alone (a single wave does not fill the pipe).  So the younger one
+        // goes first in the first half of a chunk and the older one in the second: they reach the barrier together.
+        if (SEMICRF_G3_PRIO_FLIP > 0 && (wave >> 2)) __builtin_amdgcn_s_setprio(1);
+        ldA(A, 0);
+        ldB(B[0], 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 2 * NW>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int t = i % NW;
+            if constexpr (i + 1 < 2 * NW && (i + 1) % NW != 0 && !(SEMICRF_G3_ABL & 2)) ldB(B[(i + 1) & 1], (i + 1) / NW, (i + 1) % NW);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, 6>([&](auto pc) __attribute__((always_inline)) {
+                constexpr int pz = decltype(pc)::value;
+                constexpr int n = 6 * i + pz;                              // 0 .. 12 NW - 1
+                if constexpr (SEMICRF_G3_PRIO_FLIP > 0 && n == SEMICRF_G3_PRIO_FLIP * NW / 4)
+                    if (wave >> 2) __builtin_amdgcn_s_setprio(0);
+                mma1(A, B[(SEMICRF_G3_ABL & 2) ? 0 : (i & 1)], acc[t], pz);
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int every = (12 * NW) / 15 > 0 ? (12 * NW) / 15 : 1;       // NW = 4: a piece behind every third instruction
+                if constexpr (n % every == every - 1 && n / every < 15 && !(SEMICRF_G3_ABL & 1)) {
+                    piece(n / every);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (FL && n >= 30 && n <= 39 && n % 3 == 0 && !(SEMICRF_G3_ABL & 4)) {
+                    issue_b(g, q, 2 * ((n - 30) / 3), 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (FL && (n == 45 || (AT && n == 46)) && !(SEMICRF_G3_ABL & 4)) {
+                    issue_a(g, q, 4 * (n - 45), 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            if constexpr (i + 1 < 2 * NW && (i + 1) % NW == 0 && !(SEMICRF_G3_ABL & 2)) {
+                ldA(A, (i + 1) / NW);
+                ldB(B[(i + 1) & 1], (i + 1) / NW, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        // (NW < 4: fewer instructions than pieces -- the rest of the split behind the last one)
+        static_for<0, 15>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int every = (12 * NW) / 15 > 0 ? (12 * NW) / 15 : 1;
+            if constexpr (k >= (12 * NW) / every) piece(k);
+        });
+    };
+
     Regs gX, gY;
     Meta mX = {false, false, 0, 0}, mY = {false, false, 0, 0};
     auto sync = [&]() {
@@ -777,6 +930,13 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
     // group 1 splits chunk n+1 in slot 2n and multiplies chunk n in slot 2n+1 -- i.e. it runs the same loop one slot later and two
     // chunks ahead with its requests: in the loop it splits chunk n+2 into the stage it has just multiplied.  Chunk 0 is split by
     // everybody in front of the first barrier.  X is the register set split in the steps with P = 0, Y with P = 1.
+#if SEMICRF_G3_INTERLEAVE
+    fetch(gY, mY);
+    fetch(gX, mX);
+    landed(gY);
+    convert(gY, mY, 0);
+    fetch(gY, mY);
+#else
     if (grp == 0) {
         fetch(gY, mY);
         fetch(gX, mX);
@@ -796,6 +956,8 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
         fetch(gY, mY);
         sync();
     }
+
+#endif
 
     int cur_round = 0;
     int c = 0, mi = 0, kbeg = 0, nk = 0, j = 0;
@@ -829,6 +991,24 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
 #else
 #define G3_STAMP(i) do { } while (0)
 #endif
+#if SEMICRF_G3_INTERLEAVE
+    // one chunk (ONE barrier): its limbs are in stage P; every wave multiplies it and splits the next chunk into the other stage between
+    // its matrix instructions
+    auto step = [&](auto PC, Regs& gn, Meta& mn) __attribute__((always_inline)) -> bool {
+        constexpr int P = decltype(PC)::value;
+        sync();
+        G3_STAMP(2);
+        landed(gn);
+        G3_STAMP(3);
+        multiply_fill(P, gn, mn, P ^ 1);
+        G3_STAMP(0);
+        const bool more = finish();
+        G3_STAMP(1);
+        if (!FL) fetch(gn, mn);
+        G3_STAMP(5);
+        return more;
+    };
+#else
     // one chunk: its limbs are in stage P
     auto step = [&](auto PC, Regs& gn, Meta& mn) -> bool {
         constexpr int P = decltype(PC)::value;
@@ -850,11 +1030,12 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
         G3_STAMP(6);
         return more;
     };
+#endif
     while (true) {
         if (!step(std::integral_constant<int, 0>{}, gX, mX)) break;
         if (!step(std::integral_constant<int, 1>{}, gY, mY)) break;
     }
-    if (SEMICRF_G3_PHASED && grp == 0) sync();                   // (group 1's last slot)
+    if (!SEMICRF_G3_INTERLEAVE && SEMICRF_G3_PHASED && grp == 0) sync();                   // (group 1's last slot)
 #if SEMICRF_G3_PROBE
     pc[7] = __builtin_amdgcn_s_memrealtime() - rt0;
     __syncthreads();
