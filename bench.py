@@ -173,8 +173,8 @@ def worker(args):
         cb, ce = shard_chains(B, seen_world, rank)
         B = ce - cb
     seed = 1234 + 1000 * rank
-    score, noise = synth.crf_inputs(T, B, seed, dev, "randn")
-    intervals = synth.synthetic_intervals(T, B, seed=seed)
+    intervals = synth.synthetic_intervals(T, B, seed=seed)               # (host work first: the device does not sit idle between
+    score, noise = synth.crf_inputs(T, B, seed, dev, "randn")            # the generation of its inputs and the warmup steps)
     score.requires_grad_(); noise.requires_grad_()
     nseg = max(B // 88, 1)
 
@@ -552,7 +552,7 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
             "bound": "mfma", "kernel": "interval_score_tiled_kernel<4> (exact fp32, v_mfma_f32_32x32x2_f32)", "unit": "TFLOP/s",
             "achieved": round(sflop / (extra["interval_score_fwd_ms"] * 1e-3) / 1e12, 2), "peak": 157.3,
             "frac": round(sflop / (extra["interval_score_fwd_ms"] * 1e-3) / 1e12 / 157.3, 4), "algorithmic_flop": sflop,
-            "note": "time includes the zero fill of the cells above the diagonal (full_square = 0); counters: profiles/r03_derived.json "
+            "note": "through the pooled score tensor: the zeros above the diagonal are written once per buffer, not in the timed calls; counters: profiles/r03_derived.json "
                     "(matrix pipe busy fraction, clock under load); cycle stamps: tools/tiled_probe.py -- bound by the CU's "
                     "vector-memory address path (DESIGN.md section 3)",
             "bf16x3_frac_fp32_equivalent": round(sflop / (extra["interval_score_fwd_bf16x3_ms"] * 1e-3) / 1e12 / 157.3, 4),
