@@ -237,6 +237,9 @@ def worker(args):
         except Exception as ex:
             diag["diag_error"] = repr(ex)[:200]
 
+    # (the shader clock climbs for tens of milliseconds once the device is busy: two warm calls + five timed ones of a 1-2 ms kernel
+    # measure the climb -- the exact scorer backward reads 2.40 ms that way and 2.12 from the tenth call on -- so the matrix-pipe
+    # kernels below are timed over 20 calls after 8)
     def ev_time(fn, n, warm=2):
         for _ in range(warm):
             fn()
@@ -528,9 +531,9 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
         kk = synth.hash_normal(Cq * T * Dq, 6, dev).view(Cq, T, Dq)
         dd = synth.hash_normal(Cq * T, 7, dev).view(Cq, T)
         Sq, _ = _interval_score_raw(qq, kk, dd, T, Cq, Dq, 1.0 / 16, 0, False)
-        extra["interval_score_fwd_ms"] = round(ev_time(lambda: _interval_score_raw(qq, kk, dd, T, Cq, Dq, 1.0 / 16, 0, False), 5), 3)
+        extra["interval_score_fwd_ms"] = round(ev_time(lambda: _interval_score_raw(qq, kk, dd, T, Cq, Dq, 1.0 / 16, 0, False), 20, warm=8), 3)
         # (opt-in: three exact bf16 limbs per operand, six limb products on the bf16 matrix instructions -- fp32-grade, not bit-identical)
-        extra["interval_score_fwd_bf16x3_ms"] = round(ev_time(lambda: _interval_score_raw(qq, kk, dd, T, Cq, Dq, 1.0 / 16, 0, 4), 5), 3)
+        extra["interval_score_fwd_bf16x3_ms"] = round(ev_time(lambda: _interval_score_raw(qq, kk, dd, T, Cq, Dq, 1.0 / 16, 0, 4), 20, warm=8), 3)
         dq = torch.empty_like(qq); dk2 = torch.empty_like(kk); ddg = torch.empty_like(dd)
         nws = int(lib.interval_score_bwd_workspace_bytes(Cq, T, Dq))
         wsq = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)
@@ -539,13 +542,13 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
             _lib.check(lib.interval_score_bwd_ws(_lib.ptr(Sq), _lib.ptr(qq), _lib.ptr(kk), Cq, T, Dq, Dq, Dq, 1.0 / 16, 0,
                                                  _lib.ptr(dq), _lib.ptr(dk2), _lib.ptr(ddg), Dq, Dq, 1, _lib.ptr(wsq), nws,
                                                  _lib.stream_of(Sq)), "interval_score_bwd_ws")
-        extra["interval_score_bwd_ms"] = round(ev_time(_bwd, 5), 3)
+        extra["interval_score_bwd_ms"] = round(ev_time(_bwd, 20, warm=8), 3)
 
         def _bwd3():            # opt-in: the two products on the three-limb bf16 kernels (length_scaling | SEMICRF_LEN_BF16X3 = 16)
             _lib.check(lib.interval_score_bwd_ws(_lib.ptr(Sq), _lib.ptr(qq), _lib.ptr(kk), Cq, T, Dq, Dq, Dq, 1.0 / 16, 16,
                                                  _lib.ptr(dq), _lib.ptr(dk2), _lib.ptr(ddg), Dq, Dq, 1, _lib.ptr(wsq), nws,
                                                  _lib.stream_of(Sq)), "interval_score_bwd_ws")
-        extra["interval_score_bwd_bf16x3_ms"] = round(ev_time(_bwd3, 5), 3)
+        extra["interval_score_bwd_bf16x3_ms"] = round(ev_time(_bwd3, 20, warm=8), 3)
         # the scorer is the path's matrix-bound kernel: its own roofline object (the line's `roofline` is the HBM-bound sweep)
         sflop = 2.0 * Cq * (T * (T + 1) / 2) * Dq                           # lower triangle only
         extra["scorer_roofline"] = {
@@ -660,15 +663,16 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(2):
+    TS_WARM, TS_N = 5, 20         # (steady state: see ev_time's note on the clock's climb)
+    for _ in range(TS_WARM):
         tstep()
     sync_all()
     t1 = time.perf_counter()
-    for _ in range(5):
+    for _ in range(TS_N):
         tstep()
     sync_all()
     from transkun_amd.dist import max_over_ranks
-    dt = max_over_ranks((time.perf_counter() - t1) / 5, dev)
+    dt = max_over_ranks((time.perf_counter() - t1) / TS_N, dev)
     world = dist.get_world_size() if dist is not None else 1
     extra["train_step_ms"] = round(dt * 1e3, 3)
     extra["train_step_segments_per_s"] = round(world * N / dt, 2)
@@ -679,14 +683,14 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
     for cname, key in (("bf16x3", "train_step_ms_bf16x3"), ("bf16x3-bwd", "train_step_ms_bf16x3_bwd"), ("bf16x3-train", "train_step_ms_bf16x3_train"),
                        ("bf16x3-all", "train_step_ms_bf16x3_all")):
         model.scorer.contraction = cname
-        for _ in range(2):
+        for _ in range(TS_WARM):
             tstep()
         sync_all()
         t1 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(TS_N):
             tstep()
         sync_all()
-        extra[key] = round(max_over_ranks((time.perf_counter() - t1) / 5, dev) * 1e3, 3)
+        extra[key] = round(max_over_ranks((time.perf_counter() - t1) / TS_N, dev) * 1e3, 3)
     model.scorer.contraction = "fp32"
     extra["train_step_config"] = (f"per rank: 4 segments x 90 symbols x T=691, D=256: Linear + interval scorer + fused CRF log_prob, "
                                   f"(loss/50).backward(), one [3] all-reduce, gradient exchange of "

@@ -17,12 +17,14 @@ for (C, T, D) in shapes:
     for name, mode in (("fp32", 0), ("bf16x3", 16)):
         f = lambda: _lib.check(lib.interval_score_bwd_ws(_lib.ptr(dS), _lib.ptr(q), _lib.ptr(k), C, T, D, D, D, 1.0 / 16, mode, _lib.ptr(dq),
                                                          _lib.ptr(dk), _lib.ptr(dd), D, D, 1, _lib.ptr(ws), nws, _lib.stream_of(dS)), "bwd_ws")
-        for _ in range(2): f()
+        # (WARM / ITERS: the shader clock climbs for tens of milliseconds under load -- 2 + 5 calls measure the ramp, 20 + 50 the plateau)
+        nwarm, niter = int(os.environ.get("WARM", "2")), int(os.environ.get("ITERS", "5"))
+        for _ in range(nwarm): f()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(); e0.record()
-        for _ in range(5): f()
+        for _ in range(niter): f()
         e1.record(); torch.cuda.synchronize()
-        res[name] = (e0.elapsed_time(e1) / 5, dq.clone(), dk.clone())
+        res[name] = (e0.elapsed_time(e1) / niter, dq.clone(), dk.clone())
     fl = 2 * 2.0 * C * (T * (T + 1) / 2) * D
     a, b = res["fp32"], res["bf16x3"]
     print(f"C={C} T={T} D={D}: fp32 {a[0]:.3f} ms ({fl/a[0]/1e9:.1f} TF), bf16x3 {b[0]:.3f} ms ({fl/b[0]/1e9:.1f} TF fp32-eq); "
@@ -36,7 +38,7 @@ if "--probe" in sys.argv:
     dq = torch.zeros_like(q); dk = torch.zeros_like(k); dd = torch.empty(C, T, device=dev)
     dc = torch.zeros(C * T + 256 * 64, device=dev)
     nws = int(lib.interval_score_bwd_workspace_bytes(C, T, D)); ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)
-    for _ in range(2):
+    for _ in range(int(os.environ.get('PROBE_CALLS', '2'))):
         _lib.check(lib.interval_score_bwd_ws_pc(_lib.ptr(dS), _lib.ptr(q), _lib.ptr(k), C, T, D, D, D, 1.0 / 16, 16, C, C, _lib.ptr(dq), _lib.ptr(dk),
                                                 _lib.ptr(dd), _lib.ptr(dc), D, D, 1, 1, _lib.ptr(ws), nws, _lib.stream_of(dS)), "bwd_ws_pc")
     torch.cuda.synchronize()

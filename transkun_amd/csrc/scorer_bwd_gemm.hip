@@ -987,7 +987,11 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
 #if SEMICRF_G3_PROBE
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = __builtin_readcyclecounter();
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+#if SEMICRF_G3_PROBE == 2         // (2: the kernel's own clock -- one stamp at each end of a wave's life, nothing in the loop)
+#define G3_STAMP(i) do { } while (0)
+#else
 #define G3_STAMP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); pc[i] += now_ - pt; pt = now_; } while (0)
+#endif
 #else
 #define G3_STAMP(i) do { } while (0)
 #endif
@@ -1037,6 +1041,7 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
     }
     if (!SEMICRF_G3_INTERLEAVE && SEMICRF_G3_PHASED && grp == 0) sync();                   // (group 1's last slot)
 #if SEMICRF_G3_PROBE
+    if (SEMICRF_G3_PROBE == 2) pc[0] = __builtin_readcyclecounter() - pt;
     pc[7] = __builtin_amdgcn_s_memrealtime() - rt0;
     __syncthreads();
     if (lane == 0 && rsum)        // (behind the C x T row sums: the probe script allocates 16 K floats more)
