@@ -456,6 +456,13 @@ constexpr int NXCD_G3 = 8;        // workgroup b runs on XCD b % 8
 #ifndef SEMICRF_MMA_PRIO
 #define SEMICRF_MMA_PRIO 0       // 1: raised wave priority while a wave issues its chunk's matrix instructions
 #endif
+#ifndef SEMICRF_G3_FINE
+#define SEMICRF_G3_FINE 1         // (interleaved form, NW = 4) a THIRD of a piece behind every matrix instruction instead of a piece behind every third
+#endif
+#ifndef SEMICRF_G3_LEAD
+#define SEMICRF_G3_LEAD 0         // (with SEMICRF_G3_FINE) this many thirds in FRONT of a chunk's first matrix instruction, in the shadow of its first LDS
+                                  // reads (measured: 3 the same, 6 one per cent slower)
+#endif
 #ifndef SEMICRF_G3_ABL
 #define SEMICRF_G3_ABL 0          // timing ablations of the interleaved form (variant builds only; results are wrong): 1 no split pieces,
 #endif                            // 2 the operands of a chunk's first instruction group for all of it (no LDS reads inside), 4 no requests
@@ -861,6 +868,51 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
                 }
             }
         };
+        // the same work in thirds (SEMICRF_G3_FINE): a split level (convert, widen, subtract: 5 instructions) or one limb plane's store
+        // behind EVERY matrix instruction -- a whole piece is 13 dependent-ish vector instructions, longer than the instruction in
+        // front of it runs, and the wave's next matrix instruction waits behind them
+        f32x2 srem = {0.0f, 0.0f};
+        float rsa = 0.0f;
+        auto subpiece = [&](int k3) __attribute__((always_inline)) {         // k3 = 0 .. 44: (piece k3 / 3, part k3 % 3)
+            const int k = k3 / 3, part = k3 % 3;
+            const int u = FL ? (k < 10 ? 1 + k / 5 : 0) : k / 5, st = k % 5;
+            if (st < 4) {
+                if (part == 0) {
+                    float x, y;
+                    pairv(u, st, x, y);
+                    const unsigned hu = cvt_pk_bf16(x, y);
+                    const f32x2 xv = {x, y}, hf = {__builtin_bit_cast(float, hu << 16), __builtin_bit_cast(float, hu & 0xffff0000u)};
+                    ph[st] = hu;
+                    srem = sub2(xv, hf);
+                } else if (part == 1) {
+                    const unsigned mu = cvt_pk_bf16(srem.x, srem.y);
+                    const f32x2 mf = {__builtin_bit_cast(float, mu << 16), __builtin_bit_cast(float, mu & 0xffff0000u)};
+                    pm[st] = mu;
+                    srem = sub2(srem, mf);
+                } else {
+                    pl[st] = cvt_pk_bf16(srem.x, srem.y);
+                }
+            } else {
+                const unsigned wo = u == 0 ? wA : wB[u - 1];
+                const int pitch = u == 0 ? APL : BPL;
+                if (u == 0 || D >= 256 || bOn) {
+                    if (part == 0) *(u32x4*)(wbase + wo) = (u32x4){ph[0], ph[1], ph[2], ph[3]};
+                    else if (part == 1) *(u32x4*)(wbase + pitch + wo) = (u32x4){pm[0], pm[1], pm[2], pm[3]};
+                    else *(u32x4*)(wbase + 2 * pitch + wo) = (u32x4){pl[0], pl[1], pl[2], pl[3]};
+                }
+                if (u == 0 && !AT && want_rs && m.valid) {
+                    if (part == 0) rsa = add1(add1(alo.x, alo.y), add1(alo.z, alo.w));              // (the same order as piece())
+                    else if (part == 1) rs = add1(rs, add1(rsa, add1(add1(ahi.x, ahi.y), add1(ahi.z, ahi.w))));
+                    else if (m.last) {
+                        float tot = rs + __shfl_xor(rs, 1);
+                        tot += __shfl_xor(tot, 2);
+                        const int mrow = m.mi * GM + aRow;
+                        if ((tid & 3) == 0 && mrow < T) rsum[((size_t)m.c * T + mrow) * ldrs] = tot;
+                        rs = 0.0f;
+                    }
+                }
+            }
+        };
         Limbs3 A, B[2];
         auto ldA = [&](Limbs3& L, int sl) __attribute__((always_inline)) {
             L.h = *(const bf16x8*)(base + rdA[sl]);
@@ -879,6 +931,11 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
         ldA(A, 0);
         ldB(B[0], 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        constexpr int LEAD = (SEMICRF_G3_FINE && NW == 4) ? SEMICRF_G3_LEAD : 0;
+        static_for<0, LEAD>([&](auto kc) __attribute__((always_inline)) {
+            if (!(SEMICRF_G3_ABL & 1)) subpiece(decltype(kc)::value);
+        });
+        __builtin_amdgcn_sched_barrier(0);
         static_for<0, 2 * NW>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
             constexpr int t = i % NW;
@@ -892,7 +949,12 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
                 mma1(A, B[(SEMICRF_G3_ABL & 2) ? 0 : (i & 1)], acc[t], pz);
                 __builtin_amdgcn_sched_barrier(0);
                 constexpr int every = (12 * NW) / 15 > 0 ? (12 * NW) / 15 : 1;       // NW = 4: a piece behind every third instruction
-                if constexpr (n % every == every - 1 && n / every < 15 && !(SEMICRF_G3_ABL & 1)) {
+                constexpr bool FINE = SEMICRF_G3_FINE && NW == 4;
+                if constexpr (FINE && n + LEAD < 45 && !(SEMICRF_G3_ABL & 1)) {
+                    subpiece(n + LEAD);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (!FINE && n % every == every - 1 && n / every < 15 && !(SEMICRF_G3_ABL & 1)) {
                     piece(n / every);
                     __builtin_amdgcn_sched_barrier(0);
                 }
