@@ -442,6 +442,11 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __r
 // one group multiplies chunk n, the other splits its share of chunk n+1 and requests chunk n+3, then they swap; two barriers
 // per chunk.  A multiplying wave has the SIMD's matrix pipe to itself, so its operand reads are issued one group of six
 // instructions ahead (two sets of operand registers), the order pinned by scheduling barriers.
+// That form is still here (SEMICRF_G3_INTERLEAVE = 0).  The DEFAULT is the interleaved form below (multiply_fill): every wave
+// multiplies the chunk in one stage and, between its own matrix instructions, splits the next chunk into the other stage (a third
+// of a piece behind every instruction) and requests the one after it; one barrier per chunk; the younger wave of a SIMD goes first
+// for the first half of a chunk (a SIMD issues to its older wave first).  1.57 -> 1.44 ms at T=1024 x 352 at the clock's plateau.
+// What the kernel is bound by, measured: DESIGN.md section 3 ("The last schedule, and what bounds it") and profiles/r05_mfma_peak.txt.
 #ifndef SEMICRF_G3_PROBE
 #define SEMICRF_G3_PROBE 0        // 1: cycle accounting of every wave instead of results (tools/bwd3_probe.py --probe): [0] multiply, [1] epilogue,
 #endif                            // [2] first barrier, [3] wait for the set's loads, [4] split + limb stores, [5] requests, [6] second barrier
