@@ -444,8 +444,8 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __r
 // instructions ahead (two sets of operand registers), the order pinned by scheduling barriers.
 // That form is still here (SEMICRF_G3_INTERLEAVE = 0).  The DEFAULT is the interleaved form below (multiply_fill): every wave
 // multiplies the chunk in one stage and, between its own matrix instructions, splits the next chunk into the other stage (a third
-// of a piece behind every instruction) and requests the one after it; one barrier per chunk; the younger wave of a SIMD goes first
-// for the first half of a chunk (a SIMD issues to its older wave first).  1.57 -> 1.44 ms at T=1024 x 352 at the clock's plateau.
+// of a piece behind every instruction) and requests the one after it; one barrier per chunk.  1.53 -> 1.45 ms at T=1024 x 352 at
+// the clock's plateau (same box: two groups 1.528, interleaved with the requests behind the chunk 1.549, whole pieces 1.493, this 1.453).
 // What the kernel is bound by, measured: DESIGN.md section 3 ("The last schedule, and what bounds it") and profiles/r05_mfma_peak.txt.
 #ifndef SEMICRF_G3_PROBE
 #define SEMICRF_G3_PROBE 0        // 1: cycle accounting of every wave instead of results (tools/bwd3_probe.py --probe): [0] multiply, [1] epilogue,
@@ -472,7 +472,8 @@ constexpr int NXCD_G3 = 8;        // workgroup b runs on XCD b % 8
 #define SEMICRF_G3_ABL 0          // timing ablations of the interleaved form (variant builds only; results are wrong): 1 no split pieces,
 #endif                            // 2 the operands of a chunk's first instruction group for all of it (no LDS reads inside), 4 no requests
 #ifndef SEMICRF_G3_PRIO_FLIP
-#define SEMICRF_G3_PRIO_FLIP 24    // (interleaved form) the younger wave of a SIMD goes first for this many matrix instructions of a chunk (0: never)
+#define SEMICRF_G3_PRIO_FLIP 0     // (interleaved form) the younger wave of a SIMD goes first for this many matrix instructions of a chunk (0: never).
+                                   // 24 evens out the two waves' arrival at the barrier (cycle stamps) and measures 0.8 % SLOWER at the clock's plateau
 #endif
 #ifndef SEMICRF_G3_FILL_LOADS
 #define SEMICRF_G3_FILL_LOADS 1    // (interleaved form) the requests for the chunk after next between the matrix instructions, too
