@@ -183,6 +183,9 @@ __global__ __launch_bounds__(256) void score_bwd_pack_kernel(const float* __rest
 // (include/semicrf_hip.h: interval_score_bwd_ws_pc) falls out of the A values this kernel reads anyway: every lane adds up the
 // contraction values of its row that pass through it (a fixed order: chunk, group, component), the two half-waves are combined at
 // the end of the item.
+#ifndef SEMICRF_GEMM_SPREAD
+#define SEMICRF_GEMM_SPREAD 1     // 1: a chunk's LDS-DMA requests between its matrix instructions, the two waves of a SIMD at different places; 0: in a block behind the barrier
+#endif
 template <bool AT, int NW>
 __global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __restrict__ Gt, int Tp,
                                                                 const float* __restrict__ other, long long ldo,
@@ -259,31 +262,29 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __r
         }
     };
     set_offsets();
-    auto issue_chunk = [&]() {
+    // A chunk's requests = prep (scalars; the walk over the items moves on) + req(0 .. NLOAD-1).  SEMICRF_GEMM_SPREAD: the requests
+    // are not issued in a block behind the barrier -- where all eight waves queue for the CU's one vector-memory path at the same
+    // time and no wave multiplies -- but one at a time between the chunk's matrix instructions, the two waves of a SIMD at different places.
+    // (the pending request as plain locals, the resource words made at the request: through a struct handed to the lambdas the HOST
+    // pass drops the kernel's instantiation without a diagnostic and the library fails to load with an undefined kernel symbol)
+    const float* rq_pa = Gt; const float* rq_pb = other; int rq_na = 0, rq_nb = 0; unsigned rq_da = 0, rq_db = 0, rq_sa = 0, rq_va0 = 0, rq_va1 = 0, rq_kb = 0;
+    auto prep = [&]() __attribute__((always_inline)) {
         const int k0 = (nx_kbeg + nx_j) * GK;
         // bounds-checked buffers over the chain's slab: rows past the end read as zero
         const size_t slab = gt_chain_floats(Tp);
-        const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)(Gt + (size_t)nx_c * slab), 0, (int)(slab * 4), 0x00020000);
-        const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)(other + (size_t)nx_c * T * ldo), 0, (int)((size_t)T * ldo * 4), 0x00020000);
-        char* da = glds + nx_stage * GSTAGE + (2 * wave) * 1024;
-        char* db = glds + nx_stage * GSTAGE + GA_BYTES + (NW * wave) * 1024;
+        rq_pa = Gt + (size_t)nx_c * slab; rq_na = (int)(slab * 4);
+        rq_pb = other + (size_t)nx_c * T * ldo; rq_nb = (int)((size_t)T * ldo * 4);
+        rq_da = (unsigned)(nx_stage * GSTAGE + (2 * wave) * 1024);
+        rq_db = (unsigned)(nx_stage * GSTAGE + GA_BYTES + (NW * wave) * 1024);
         // AT: the chunk's 32 rows (k = e) lie in one 128-row block kblk; its row length enters the per-lane offsets
         const int kblk = k0 / GM, krl = gt_row_len(kblk, Tp);
-        const unsigned sa = AT ? (unsigned)((gt_block_off(kblk) + (size_t)(k0 - kblk * GM) * krl) * 4) : (unsigned)(k0 * 4);   // inside the slab
-        const unsigned va0 = AT ? (unsigned)((voA[0] * krl + nx_mi * GM + (lane & 31) * 4) * 4) : voA[0];
-        const unsigned va1 = AT ? (unsigned)((voA[1] * krl + nx_mi * GM + (lane & 31) * 4) * 4) : voA[1];
+        rq_sa = AT ? (unsigned)((gt_block_off(kblk) + (size_t)(k0 - kblk * GM) * krl) * 4) : (unsigned)(k0 * 4);   // inside the slab
+        rq_va0 = AT ? (unsigned)((voA[0] * krl + nx_mi * GM + (lane & 31) * 4) * 4) : voA[0];
+        rq_va1 = AT ? (unsigned)((voA[1] * krl + nx_mi * GM + (lane & 31) * 4) * 4) : voA[1];
         // the k/q rows of the last chunk may lie past T: their offset goes into the per-lane part, which is what the
         // buffer's range check looks at (the scalar offset is not checked); such rows keep the stage's old contents
         // and meet Gt == 0 (the stages are cleared once at the start so that they never hold a NaN pattern)
-        const unsigned kb = (unsigned)((size_t)k0 * ldo * 4);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)da, 16, va0, sa, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(da + 1024), 16, va1, sa, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)db, 16, voB[0] + kb, 0, 0, 0);
-        if (NW >= 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(db + 1024), 16, voB[1] + kb, 0, 0, 0);
-        if (NW >= 4) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(db + 2048), 16, voB[2] + kb, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(db + 3072), 16, voB[3] + kb, 0, 0, 0);
-        }
+        rq_kb = (unsigned)((size_t)k0 * ldo * 4);
         nx_stage = nx_stage + 1 == GNS ? 0 : nx_stage + 1;
         if (++nx_j == nx_nk) {
             nx_j = 0;
@@ -291,6 +292,24 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __r
             nx_valid = item_of(nx_n, nx_c, nx_mi, nx_kbeg, nx_nk);
             if (nx_valid) set_offsets();
         }
+    };
+    auto req = [&](int i) __attribute__((always_inline)) {
+        // (the destination through a named char*: with the cast applied to `glds + ...` directly the HOST pass drops the kernel's
+        // instantiation without a diagnostic and the library fails to load with an undefined kernel symbol)
+        if (i < 2) {
+            const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)rq_pa, 0, rq_na, 0x00020000);
+            char* dst = glds + rq_da + i * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)dst, 16, i == 0 ? rq_va0 : rq_va1, rq_sa, 0, 0);
+        } else {
+            const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)rq_pb, 0, rq_nb, 0x00020000);
+            char* dst = glds + rq_db + (i - 2) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)dst, 16, voB[i - 2] + rq_kb, 0, 0, 0);
+        }
+    };
+    auto issue_chunk = [&]() __attribute__((always_inline)) {
+        prep();
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) req(i);
     };
 
     // clear the stages once (see issue_chunk)
@@ -327,7 +346,11 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __r
             // ... and so have everybody's; everybody is also done reading the previous chunk
             __builtin_amdgcn_s_barrier();
             --inflight;
-            if (nx_valid) { issue_chunk(); ++inflight; }
+            const bool doreq = nx_valid;
+            if (doreq) {
+                if (SEMICRF_GEMM_SPREAD) prep(); else issue_chunk();
+                ++inflight;
+            }
             const unsigned sb = lds0 + (unsigned)(rd_stage * GSTAGE);
             rd_stage = rd_stage + 1 == GNS ? 0 : rd_stage + 1;
             // four groups of four contraction pairs; the operands of group g+1 are read while group g multiplies
@@ -366,12 +389,24 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __r
 #pragma unroll
                     for (int t = 0; t < NW; ++t) asm volatile("" : "+v"(bv[comp][t]));
             };
-            auto mul_group = [&](const v4f& av4, const float (&av)[4], const float (&bv)[4][4]) {
-#pragma unroll
-                for (int comp = 0; comp < 4; ++comp)
+            // (grp: the chunk's group of 16 NW / 4 instructions; with SEMICRF_GEMM_SPREAD two of the wave's requests go behind the
+            // instructions of groups 0 .. NLOAD/2 - 1: waves 0-3 behind the 1st and 3rd quarter, waves 4-7 behind the 2nd and 4th)
+            auto mul_group = [&](auto gc, const v4f& av4, const float (&av)[4], const float (&bv)[4][4]) __attribute__((always_inline)) {
+                constexpr int grp = decltype(gc)::value;
+                static_for<0, 4>([&](auto cc) __attribute__((always_inline)) {
+                    constexpr int comp = decltype(cc)::value;
 #pragma unroll
                     for (int t = 0; t < NW; ++t)
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(AT ? av[comp] : av4[comp], bv[comp][t], acc[t], 0, 0, 0);
+                    if constexpr (SEMICRF_GEMM_SPREAD != 0) {
+                        constexpr int r0 = 2 * grp + (comp >> 1);            // request behind quarter comp: 2 grp (comp 0, 1) or 2 grp + 1 (comp 2, 3)
+                        if constexpr (r0 < NLOAD) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (doreq && (wave >> 2) == (comp & 1)) req(r0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                });
                 if (!AT && want_rs) rs += (av4[0] + av4[1]) + (av4[2] + av4[3]);
             };
             read_group(std::integral_constant<int, 0>{}, a4[0], a1[0], bq[0]);
@@ -379,23 +414,23 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __r
             __builtin_amdgcn_sched_barrier(0);
             read_group(std::integral_constant<int, 1>{}, a4[1], a1[1], bq[1]);
             __builtin_amdgcn_sched_barrier(0);
-            mul_group(a4[0], a1[0], bq[0]);
+            mul_group(std::integral_constant<int, 0>{}, a4[0], a1[0], bq[0]);
             __builtin_amdgcn_sched_barrier(0);
             wait_group(a4[1], a1[1], bq[1]);
             __builtin_amdgcn_sched_barrier(0);
             read_group(std::integral_constant<int, 2>{}, a4[0], a1[0], bq[0]);
             __builtin_amdgcn_sched_barrier(0);
-            mul_group(a4[1], a1[1], bq[1]);
+            mul_group(std::integral_constant<int, 1>{}, a4[1], a1[1], bq[1]);
             __builtin_amdgcn_sched_barrier(0);
             wait_group(a4[0], a1[0], bq[0]);
             __builtin_amdgcn_sched_barrier(0);
             read_group(std::integral_constant<int, 3>{}, a4[1], a1[1], bq[1]);
             __builtin_amdgcn_sched_barrier(0);
-            mul_group(a4[0], a1[0], bq[0]);
+            mul_group(std::integral_constant<int, 2>{}, a4[0], a1[0], bq[0]);
             __builtin_amdgcn_sched_barrier(0);
             wait_group(a4[1], a1[1], bq[1]);
             __builtin_amdgcn_sched_barrier(0);
-            mul_group(a4[1], a1[1], bq[1]);
+            mul_group(std::integral_constant<int, 3>{}, a4[1], a1[1], bq[1]);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- the item's 128 x D block (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) ----
