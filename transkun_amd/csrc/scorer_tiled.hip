@@ -58,6 +58,12 @@ constexpr int YRING = 4;                     // row-constant buffers: item n's i
 constexpr int YRC = 2 * 4 * YTE * 4;         // [rowc | diag][chain][row] floats = 2 KB
 constexpr int YLDS = YNS * YSTAGE + YRING * YRC;     // 152 KB
 constexpr int YXCD = 8;
+#ifndef SEMICRF_TILED_SPREAD
+#define SEMICRF_TILED_SPREAD 0       // 1: a chunk's store and requests between its matrix instructions (in-step schedule), 0: in a block behind the barrier.
+                                     // Measured (round 5): 1: 1.131-1.134 ms, 0: 1.115-1.119 at T=1024 x 352 (0.669 / 0.661 at T=691 x 360) -- what gains 1 % in
+                                     // the backward GEMMs (SEMICRF_GEMM_SPREAD) loses 1.3 % here: the store's row constants come through the LDS
+                                     // and its wait sits in the middle of the operand reads
+#endif
 #ifndef SEMICRF_TILED_PINGPONG
 #define SEMICRF_TILED_PINGPONG 0     // 1: the two halves of the workgroup run one phase apart (measured slower, see the header)
 #endif
@@ -184,23 +190,25 @@ __global__ __launch_bounds__(512, 2) void interval_score_tiled_kernel(
             set_chain();
         }
     };
-    auto issue_chunk = [&]() __attribute__((always_inline)) {
+    // A chunk's requests: req(0 .. 5) (the wave's two q pieces and four k pieces, from the CURRENT request state), req_tail() (the row
+    // constants with a chain's first chunk; then the request state moves on).  issue_chunk() = all of them in a block;
+    // SEMICRF_TILED_SPREAD issues them one at a time between the chunk's matrix instructions instead (see the loop).
+    auto req = [&](int i) __attribute__((always_inline)) {
         char* st = ylds + nx_stage * YSTAGE;
-        const auto rq = __builtin_amdgcn_make_buffer_rsrc((void*)nx_q, 0, 0x7fffffff, 0x00020000);
-        const auto rk = __builtin_amdgcn_make_buffer_rsrc((void*)nx_k, 0, 0x7fffffff, 0x00020000);
         const int so = nx_ch * 256;                                          // 64 floats per chunk
-        {
+        if (i < 2) {
+            const auto rq = __builtin_amdgcn_make_buffer_rsrc((void*)nx_q, 0, 0x7fffffff, 0x00020000);
             const int p0 = 2 * wave;                                         // both pieces lie in the same half
-            char* dq = st + (p0 >> 3) * YQH + (p0 & 7) * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void_t*)dq, 16, voq[0], so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void_t*)(dq + 1024), 16, voq[1], so, 0, 0);
+            char* dq = st + (p0 >> 3) * YQH + (p0 & 7) * 1024 + i * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void_t*)dq, 16, voq[i], so, 0, 0);
+        } else {
+            const auto rk = __builtin_amdgcn_make_buffer_rsrc((void*)nx_k, 0, 0x7fffffff, 0x00020000);
             const int p1 = 4 * wave;
-            char* dk = st + 2 * YQH + (p1 >> 4) * YKH + (p1 & 15) * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_t*)dk, 16, vok[0], so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_t*)(dk + 1024), 16, vok[1], so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_t*)(dk + 2048), 16, vok[2], so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_t*)(dk + 3072), 16, vok[3], so, 0, 0);
+            char* dk = st + 2 * YQH + (p1 >> 4) * YKH + (p1 & 15) * 1024 + (i - 2) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_t*)dk, 16, vok[i - 2], so, 0, 0);
         }
+    };
+    auto req_tail = [&]() __attribute__((always_inline)) {
         // the chain's 64 row constants and diagonal terms, one dword per lane, AFTER the wave's operand pieces (every vmcnt wait
         // below stays at least as strict as without them): wave j for chain j, with the chain's first chunk
         if (nx_ch == 0 && wave == nx_j) {
@@ -223,6 +231,11 @@ __global__ __launch_bounds__(512, 2) void interval_score_tiled_kernel(
                 set_chain();
             }
         }
+    };
+    auto issue_chunk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) req(i);
+        req_tail();
     };
 
     set_item();
@@ -379,9 +392,17 @@ __global__ __launch_bounds__(512, 2) void interval_score_tiled_kernel(
                     __builtin_amdgcn_s_barrier();
                 }
                 TILED_PROBE(0);
-                store_chunk(ci);                                            // the previous item's rows of this chunk
+                // SEMICRF_TILED_SPREAD (in-step schedule only): the store and the six requests do not go out in a block here -- where
+                // all eight waves queue for the CU's one vector-memory path at the same time and nobody multiplies -- but one behind
+                // each group of four matrix instructions, the two waves of a SIMD one group apart
+                const bool spread = SEMICRF_TILED_SPREAD && !SEMICRF_TILED_PINGPONG && on;
+                const bool doreq = nx_valid;
+                if (!spread) store_chunk(ci);                               // the previous item's rows of this chunk
                 TILED_PROBE(1);
-                if (nx_valid) { issue_chunk(); ++inflight; }               // A: chunk + 1, B: chunk + 2
+                if (doreq) {
+                    if (!spread) issue_chunk();                             // A: chunk + 1, B: chunk + 2
+                    ++inflight;
+                }
                 TILED_PROBE(2);
                 if (SEMICRF_TILED_PINGPONG) __builtin_amdgcn_s_barrier();
                 TILED_PROBE(3);
@@ -419,12 +440,24 @@ __global__ __launch_bounds__(512, 2) void interval_score_tiled_kernel(
                         }
                         mul_g(qa[g & 1], ka[g & 1]);
                         __builtin_amdgcn_sched_barrier(0);
+                        if (spread) {
+                            // slot = g (waves 0-3) or g - 1 (waves 4-7): slot 0 the store, slots 1 .. 6 the requests
+                            if (wer == 0) {
+                                if constexpr (g == 0) store_chunk(ci);
+                                if constexpr (g >= 1 && g <= 6) { if (doreq) req(g - 1); }
+                            } else {
+                                if constexpr (g == 1) store_chunk(ci);
+                                if constexpr (g >= 2) { if (doreq) req(g - 2); }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                         if constexpr (g < 7) {
                             wait_g(qa[(g + 1) & 1], ka[(g + 1) & 1]);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     });
                     asm volatile("" : "+v"(acc));                            // (the matrix instructions stay in front of the barrier)
+                    if (spread && doreq) req_tail();
                 }
                 TILED_PROBE(4);
                 // group B: its pieces of the NEXT chunk (requested one chunk ago; the requests of this chunk's phase S may stay
