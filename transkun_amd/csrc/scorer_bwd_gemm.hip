@@ -184,7 +184,10 @@ __global__ __launch_bounds__(256) void score_bwd_pack_kernel(const float* __rest
 // contraction values of its row that pass through it (a fixed order: chunk, group, component), the two half-waves are combined at
 // the end of the item.
 #ifndef SEMICRF_GEMM_SPREAD
-#define SEMICRF_GEMM_SPREAD 1     // 1: a chunk's LDS-DMA requests between its matrix instructions, the two waves of a SIMD at different places; 0: in a block behind the barrier
+#define SEMICRF_GEMM_SPREAD 0     // 1: a chunk's LDS-DMA requests between its matrix instructions, the two waves of a SIMD at different places; 0: in a block
+                                  // behind the barrier.  Measured (round 5, T=1024 x 352, plateau): with run-time tests around the requests 2.117-2.121 ms
+                                  // against 2.143-2.147 -- but the compiler then lays the groups' blocks out of order (LDS reads textually behind their
+                                  // waits: tools/check_asm_waits.py cannot vouch for that); as straight-line bodies per wave group 2.19 against 2.125: off
 #endif
 template <bool AT, int NW>
 __global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __restrict__ Gt, int Tp,
@@ -354,7 +357,12 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __r
             const unsigned sb = lds0 + (unsigned)(rd_stage * GSTAGE);
             rd_stage = rd_stage + 1 == GNS ? 0 : rd_stage + 1;
             // four groups of four contraction pairs; the operands of group g+1 are read while group g multiplies
-            // (the registers an asm read returns must not be touched before the wait that is tied to them: no copies)
+            // (the registers an asm read returns must not be touched before the wait that is tied to them: no copies).
+            // One straight-line body per (wave group, requests or not): with run-time tests around the requests the compiler lays the
+            // groups' blocks out of order (reads textually behind their waits: tools/check_asm_waits.py cannot follow that).
+            auto body = [&](auto WGC, auto RQC) __attribute__((always_inline)) {
+            constexpr int WG = decltype(WGC)::value;
+            constexpr bool RQ = decltype(RQC)::value;
             v4f a4[2];                         // !AT: four consecutive contraction values of the row
             float a1[2][4];                    // AT: one value per read
             float bq[2][4][4];
@@ -402,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __r
                         constexpr int r0 = 2 * grp + (comp >> 1);            // request behind quarter comp: 2 grp (comp 0, 1) or 2 grp + 1 (comp 2, 3)
                         if constexpr (r0 < NLOAD) {
                             __builtin_amdgcn_sched_barrier(0);
-                            if (doreq && (wave >> 2) == (comp & 1)) req(r0);
+                            if constexpr (RQ && WG == (comp & 1)) req(r0);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -432,6 +440,10 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm_kernel(const float* __r
             __builtin_amdgcn_sched_barrier(0);
             mul_group(std::integral_constant<int, 3>{}, a4[1], a1[1], bq[1]);
             __builtin_amdgcn_sched_barrier(0);
+            };
+            if (!SEMICRF_GEMM_SPREAD || !doreq) body(std::integral_constant<int, 0>{}, std::false_type{});
+            else if ((wave >> 2) == 0) body(std::integral_constant<int, 0>{}, std::true_type{});
+            else body(std::integral_constant<int, 1>{}, std::true_type{});
         }
         // ---- the item's 128 x D block (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) ----
         {
