@@ -508,6 +508,10 @@ constexpr int NXCD_G3 = 8;        // workgroup b runs on XCD b % 8
 #ifndef SEMICRF_MMA_PRIO
 #define SEMICRF_MMA_PRIO 0       // 1: raised wave priority while a wave issues its chunk's matrix instructions
 #endif
+#ifndef SEMICRF_G3_DRAIN
+#define SEMICRF_G3_DRAIN 1        // 1: vmcnt(0) behind an item's stores.  0: none -- the hand-written vmcnt(NLD) waits stay SAFE with stores in flight (loads return
+#endif                            // in order among themselves: at most NLD operations outstanding means at most NLD loads outstanding, i.e. only the younger set's)
+                                  // -- measured the same (1.434-1.439 / 1.439-1.443 ms): the next wait for a register set drains the stores anyway
 #ifndef SEMICRF_G3_FINE
 #define SEMICRF_G3_FINE 1         // (interleaved form, NW = 4) a THIRD of a piece behind every matrix instruction instead of a piece behind every third
 #endif
@@ -1095,7 +1099,9 @@ __global__ __launch_bounds__(512, 2) void score_bwd_gemm3_kernel(const float* __
                 acc[t][r] = 0.0f;
             }
         }
+#if SEMICRF_G3_DRAIN
         __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
+#endif
         j = 0;
         return item_of(++cur_round, c, mi, kbeg, nk);
     };
