@@ -29,7 +29,13 @@
 extern "C" {
 #endif
 
-#define SEMICRF_ABI_VERSION 1
+/* ABI history.  1: rounds 1-4.  2 (round 6; the changes themselves are round 5's): new entry points scorer_proj_nn3 /
+ * scorer_proj_nn3_workspace_bytes and the flag bits SEMICRF_LEN_BF16X3, SEMICRF_PROJ_TN_BF16X3; semicrf_workspace_bytes(LOGZ_FWD /
+ * LOGZ_BWD / VITERBI) grew by a second u buffer (leased workspaces alternate), B path-score granules and -- for launches of at most
+ * 192 chains -- the spine-major band copy K * ceil(B/4) * 4 * 4 KB + its flag words (tens to ~200 MB at T = 1024..2048): callers
+ * must size workspaces with semicrf_workspace_bytes of THIS library, never with a constant from an older one.  No entry point of
+ * version 1 changed its signature or meaning. */
+#define SEMICRF_ABI_VERSION 2
 
 #define SEMICRF_OK 0
 #define SEMICRF_EINVAL 1      /* bad shape / null pointer / unsupported size */

@@ -30,7 +30,7 @@ def test_library_builds_and_exports_header_symbols():
         assert hasattr(lib, name), f"{name} declared in semicrf_hip.h but not exported"
     assert set(_lib.EXPORTED) == set(declared)
     loaded = _lib.load()
-    assert loaded.semicrf_abi_version() == 1
+    assert loaded.semicrf_abi_version() == 2
     assert loaded.semicrf_workspace_bytes(_lib.OP_VITERBI, 1024, 352) > 0
 
 

@@ -1010,14 +1010,18 @@ def test_decode_to_attribute_features_on_device(gpu):
 # ---- segment-shaped goldens: scorer -> CRF -> logProb -> backward, decode -> features (BASELINE configs[3]) ----
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("route", ["fused", "fused_separate", "unfused", "two_nodes"])
+@pytest.mark.parametrize("route", ["fused", "fused_separate", "unfused", "two_nodes", "fused_bf16x3_train", "fused_bf16x3_all",
+                                   "fused_separate_bf16x3_all", "unfused_bf16x3_all"])
 @pytest.mark.parametrize("name", ["small", "T691_P90", "T691_N4"])
 def test_segment_logprob_vs_reference(gpu, name, route):
     """ctx -> ScaledInnerProductIntervalScorer -> NeuralSemiCRFInterval -> logProb -> backward at the model's real shape
     (T=691, 90 symbols, 1 and 4 segments) against what the reference's own modules produced on the glue of
     ModelTransformer.py:199-225, :256-266 (tests/golden/segment_*.npz): the fused route (transkun_amd.fused, the dense
     gradient never written), the unfused one (logProb as one node) and the reference's unchanged call pattern
-    (evalPath + computeLogZ as two nodes, :263-265)."""
+    (evalPath + computeLogZ as two nodes, :263-265).  The `*_bf16x3_*` routes are the same compositions with scorer.contraction
+    = "bf16x3-train" (backward products + projection on the three-limb bf16 kernels) / "bf16x3-all" (the forward contraction too):
+    fp32-grade, not bit-identical to the fp32 routes -- held to the SAME tolerances against the reference's goldens
+    (LayersTransformer.py:388-433 and its autograd)."""
     from segment_common import SEGMENT_CASES, check_segment_grads, segment_inputs
     from transkun_amd import CRF, _lib
     from transkun_amd.fused import scorer_crf_logprob
@@ -1030,6 +1034,9 @@ def test_segment_logprob_vs_reference(gpu, name, route):
     with torch.no_grad():
         m.map[0].weight.copy_(W); m.map[0].bias.copy_(bias)
     ctx = ctx0.clone().requires_grad_()
+    if "_bf16x3_" in route:
+        m.contraction = "bf16x3-" + route.rsplit("_", 1)[1]
+        route = route[:route.index("_bf16x3_")]
     if route == "fused":
         lp = scorer_crf_logprob(m, ctx, iv)                                  # default: the merged projection where it applies
     elif route == "fused_separate":

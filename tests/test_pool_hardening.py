@@ -77,13 +77,24 @@ def test_pool_keeps_two_buffers_per_shape():
 
 
 def test_contraction_modes():
-    """scorer.contraction: the four modes and their flag bits; anything else is a ValueError before any kernel runs."""
+    """scorer.contraction: all six modes and their flag bits; anything else is a ValueError before any kernel runs."""
     import pytest
-    from transkun_amd.scorer import BF16X3, BWD_BF16X3, ScaledInnerProductIntervalScorer, contraction_bits
+    from transkun_amd.scorer import (BF16X3, BWD_BF16X3, CONTRACTIONS, LEN_BF16X3, PROJ_BF16X3, ScaledInnerProductIntervalScorer,
+                                     contraction_bits)
+    assert sorted(CONTRACTIONS) == ["bf16x3", "bf16x3-all", "bf16x3-bwd", "bf16x3-fwd", "bf16x3-train", "fp32"]
     assert contraction_bits("fp32") == 0
     assert contraction_bits("bf16x3") == BF16X3 | BWD_BF16X3
     assert contraction_bits("bf16x3-fwd") == BF16X3 and contraction_bits("bf16x3-bwd") == BWD_BF16X3
-    assert BWD_BF16X3 & 7 == 0                        # never collides with the library's full_square bits (triangle mode, BF16X3)
+    assert contraction_bits("bf16x3-train") == BWD_BF16X3 | PROJ_BF16X3          # backward products + the projection's NN GEMMs
+    assert contraction_bits("bf16x3-all") == BF16X3 | BWD_BF16X3 | PROJ_BF16X3   # ... and the forward contraction
+    # the package-private bits never collide with what the library reads from full_square (bits 0-1: triangle mode, 4: BF16X3)
+    # or with each other; LEN_BF16X3 is a bit of the BACKWARD's length-scaling argument (modes 0..2), not of full_square
+    assert BWD_BF16X3 & 7 == 0 and PROJ_BF16X3 & 7 == 0 and BWD_BF16X3 & PROJ_BF16X3 == 0
+    assert PROJ_BF16X3 & (BF16X3 | BWD_BF16X3) == 0 and LEN_BF16X3 & 3 == 0
+    for name, bits in CONTRACTIONS.items():
+        assert bits & ~(BF16X3 | BWD_BF16X3 | PROJ_BF16X3) == 0, name
     with pytest.raises(ValueError):
         contraction_bits("tf32")
+    with pytest.raises(ValueError):
+        contraction_bits("bf16x3-proj")
     assert ScaledInnerProductIntervalScorer(64).contraction == "fp32"

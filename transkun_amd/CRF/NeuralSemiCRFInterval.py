@@ -198,7 +198,7 @@ def _empty_or_trim(shape, device):
     and the allocation is tried once more."""
     try:
         return torch.empty(shape, dtype=torch.float32, device=device)
-    except torch.OutOfMemoryError:
+    except getattr(torch, "OutOfMemoryError", torch.cuda.OutOfMemoryError):      # (older torch 2.x: only torch.cuda.OutOfMemoryError)
         grad_pool_clear()
         if device.type == "cuda":
             torch.cuda.empty_cache()
@@ -321,6 +321,24 @@ def _logz_bwd_raw(score, noise, v, logz, gout, want_q: bool = False):
     _lib.ops().logz_bwd(score, noise, v, logz, gout, dscore, dnoise, q, want_q, flags, ws)
     _GRAD_POOL.give(pkey, dscore)
     return dscore, dnoise, (q if want_q else None)
+
+
+def _logprob_fwd_raw(score, noise, pairs, offsets, want_v: bool):
+    """(logProb [B], logZ [B], alpha [T,B] or None) from ONE launch: spare waves of the forward sweep compute the path scores, the
+    ring wave that finalises logZ subtracts (semicrf_logprob_fwd; bit-identical to _eval_path_raw(...) - logZ).  `pairs` must be
+    ready on the current stream (_ready)."""
+    K = getattr(pairs, "_semicrf_K", pairs.shape[0])
+    if _odd_pad(score):
+        logz, v = _logz_fwd_raw(score, noise, want_v)
+        return _eval_path_raw(score, noise, pairs, offsets) - logz, logz, v
+    T, B = score.shape[0], score.shape[2]
+    dev = score.device
+    lp = torch.empty(B, dtype=torch.float32, device=dev)
+    logz = torch.empty(B, dtype=torch.float32, device=dev)
+    v = torch.empty((T, B) if want_v else (0,), dtype=torch.float32, device=dev)
+    ws = _lib.leased_workspace(_lib.OP_LOGZ_FWD, T, B, dev)
+    _lib.ops().logprob_fwd(score, noise, pairs, int(K), offsets, lp, logz, v, want_v, ws)
+    return lp, logz, (v if want_v else None)
 
 
 def _eval_path_raw(score, noise, pairs, offsets):
@@ -555,18 +573,8 @@ class _LogProb(torch.autograd.Function):
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         T, B = score_c.shape[0], score_c.shape[2]
         K = getattr(pairs, "_semicrf_K", pairs.shape[0])
-        if _odd_pad(score_c):
-            logz, v = _logz_fwd_raw(score_c, noise_c, want_v=need)
-            _ready(pairs)
-            lp = _eval_path_raw(score_c, noise_c, pairs, offsets) - logz
-        else:
-            dev = score_c.device
-            lp = torch.empty(B, dtype=torch.float32, device=dev)
-            logz = torch.empty(B, dtype=torch.float32, device=dev)
-            v = torch.empty((T, B) if need else (0,), dtype=torch.float32, device=dev)
-            ws = _lib.leased_workspace(_lib.OP_LOGZ_FWD, T, B, dev)
-            _ready(pairs)                               # the intervals' copy ran on a side stream
-            _lib.ops().logprob_fwd(score_c, noise_c, pairs, int(K), offsets, lp, logz, v, need, ws)
+        _ready(pairs)                                   # the intervals' copy ran on a side stream
+        lp, logz, v = _logprob_fwd_raw(score_c, noise_c, pairs, offsets, need)
         if need:
             ctx.save_for_backward(score_c, noise_c, v, logz, pairs, offsets)
             ctx.K = K

@@ -700,13 +700,13 @@ int launch_proj_nn3(const float* A, long long lda, long long M, int K, const flo
     if (!ws || ((uintptr_t)ws & 15) || ws_bytes < proj_nn3_workspace_bytes(K, N)) return 1;
     if ((long long)M * ldout * 4 >= (1ll << 31)) return 1;
     const int nchunks = (K + pj3::GK - 1) / pj3::GK;
+    const size_t lds = (size_t)2 * pj3::STAGE + (w2 ? (size_t)2 * nchunks * pj3::GK * 4 : 0);
+    if (lds > 160 * 1024 - 512) return 1;                    // (before anything is enqueued: the caller runs the exact kernel instead)
     hipLaunchKernelGGL(pj3::proj_split_b_kernel, dim3((nchunks * 4 * pj3::N + 255) / 256), dim3(256), 0, stream, B, ldb, nchunks * pj3::GK,
                        (char*)ws, nchunks);
     pj3::Args P{};
     P.A = A; P.lda = lda; P.M = (int)M; P.K = K; P.Bl = (const char*)ws; P.nchunks = nchunks; P.out = out; P.ldout = ldout;
     P.accumulate = accumulate; P.bias = bias; P.w2 = w2; P.b2 = b2; P.zero_cols = zero_cols;
-    const size_t lds = (size_t)2 * pj3::STAGE + (w2 ? (size_t)2 * nchunks * pj3::GK * 4 : 0);
-    if (lds > 160 * 1024 - 512) return 1;
     static PerDeviceOnce attr_once[2];
     const long long nitems = (M + pj3::GM - 1) / pj3::GM;
     const int ncu = proj_ncu();

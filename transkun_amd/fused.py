@@ -27,7 +27,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .scorer import (BF16X3, BWD_BF16X3, LEN_BF16X3, PROJ_BF16X3, QPAD, contraction_bits, ScaledInnerProductIntervalScorer, _ScorerLinear, _ScorerLinearPacked, _interval_score_raw, bwd_workspace, proj_forward,
+from .scorer import (_bf16x3_selfcheck, BF16X3, BWD_BF16X3, LEN_BF16X3, PROJ_BF16X3, QPAD, contraction_bits, ScaledInnerProductIntervalScorer, _ScorerLinear, _ScorerLinearPacked, _interval_score_raw, bwd_workspace, proj_forward,
                      proj_input_grad, proj_weight_grad, qd_weights, slot_maps, slot_pitch)
 
 _nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
@@ -147,13 +147,14 @@ class _MergedScorerCRFLogProb(torch.autograd.Function):
             offsets_s = offsets.index_select(0, offmap)
         else:
             real, offsets_s = None, offsets
-        logz, v = _nsci._logz_fwd_raw(S, noise, True)
         K = getattr(pairs, "_semicrf_K", pairs.shape[0])
         pairs._semicrf_K = K
-        path = _nsci._eval_path_raw(S, noise, pairs, offsets_s)
+        _nsci._ready(pairs)
+        # logProb = path - logZ from ONE launch (spare waves of the forward sweep compute the path scores: no eval_path kernel, no
+        # dependent boundary behind the sweep) -- the same call the unfused _LogProb node makes
+        lp, logz, v = _nsci._logprob_fwd_raw(S, noise, pairs, offsets_s, True)
         ctx.save_for_backward(x3, zc, Wm, S, noise, v, logz, pairs, offsets_s)
         ctx.meta = (N, P, T, D, mode, K, pitch, LEN_BF16X3 if int(fs) & BWD_BF16X3 else 0)
-        lp = path - logz
         return lp if real is None else lp.index_select(0, real)
 
     @staticmethod
@@ -212,13 +213,14 @@ class _ScorerCRFLogProb(torch.autograd.Function):
             offsets_s = offsets.index_select(0, offmap)
         else:
             real, offsets_s = None, offsets
-        logz, v = _nsci._logz_fwd_raw(S, noise, True)
         K = getattr(pairs, "_semicrf_K", pairs.shape[0])
         pairs._semicrf_K = K
-        path = _nsci._eval_path_raw(S, noise, pairs, offsets_s)
+        _nsci._ready(pairs)
+        # logProb = path - logZ from ONE launch (spare waves of the forward sweep compute the path scores: no eval_path kernel, no
+        # dependent boundary behind the sweep) -- the same call the unfused _LogProb node makes
+        lp, logz, v = _nsci._logprob_fwd_raw(S, noise, pairs, offsets_s, True)
         ctx.save_for_backward(qd3, k3, S, noise, v, logz, pairs, offsets_s)
         ctx.meta = (N, P, T, D, mode, K, pitch, LEN_BF16X3 if int(fs) & BWD_BF16X3 else 0)
-        lp = path - logz
         return lp if real is None else lp.index_select(0, real)
 
     @staticmethod
@@ -271,6 +273,8 @@ def scorer_crf_logprob(scorer: ScaledInnerProductIntervalScorer, ctx: torch.Tens
     x = ctx.float()
     pairs, offsets = _nsci.pack_intervals(intervals, T, N * P, ctx.device)
     fs = 2 | contraction_bits(getattr(scorer, "contraction", "fp32"))
+    if fs & (BF16X3 | BWD_BF16X3 | PROJ_BF16X3):
+        _bf16x3_selfcheck(x.device)
     if projection not in ("merged", "separate"):
         raise ValueError(f"projection must be 'merged' or 'separate', not {projection!r}")
     if projection == "merged" and merged_eligible(scorer.size, T):

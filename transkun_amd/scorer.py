@@ -126,6 +126,44 @@ def contraction_bits(name: str) -> int:
         raise ValueError(f"contraction must be one of {sorted(CONTRACTIONS)}, not {name!r}") from None
 
 
+_BF16X3_CHECKED = {}
+
+
+def _bf16x3_selfcheck(device) -> None:
+    """First use of a three-limb contraction on `device`: one small problem (1 x 4 chains x T = 256 x size 256) through
+    "bf16x3-all" and through the exact fp32 kernels, scores and all three gradients compared at 1e-4 of their largest value (the
+    three-limb error bound is ~1e-6 there; a stale or torn operand is O(1)).  Why: the three-limb kernels issue their operand
+    loads and wait for them in separate asm statements (csrc/proj_gemm3.hip, scorer_bwd_gemm.hip `landed()`), which is only
+    correct while the compiler keeps the loaded registers untouched in between -- true for the build this was measured on, not a
+    property a toolchain bump must preserve.  A mismatch raises instead of training on garbage; the exact default never runs this."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if _BF16X3_CHECKED.get(key) or device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+        return
+    _BF16X3_CHECKED[key] = True              # (set first: the check itself goes through forward())
+    from . import synth
+    size, P, T = 256, 4, 256
+    res = {}
+    with torch.enable_grad():
+        for mode in ("fp32", "bf16x3-all"):
+            m = ScaledInnerProductIntervalScorer(size).to(device)
+            with torch.no_grad():
+                m.map[0].weight.copy_(synth.hash_normal(m.map[0].weight.numel(), 901, device).view_as(m.map[0].weight) / 16.0)
+                m.map[0].bias.copy_(synth.hash_normal(m.map[0].bias.numel(), 902, device) / 4.0)
+            m.contraction = mode
+            x = synth.hash_normal(P * T * size, 903, device).view(1, P, T, size).requires_grad_()
+            S, _ = m(x)
+            w = synth.hash_normal(S.numel(), 904, device).view_as(S)
+            (torch.tril(S.permute(2, 3, 0, 1)) * torch.tril(w.permute(2, 3, 0, 1))).sum().backward()
+            res[mode] = (S.detach(), x.grad, m.map[0].weight.grad, m.map[0].bias.grad)
+    for name, a, b in zip(("scores", "d ctx", "d weight", "d bias"), res["fp32"], res["bf16x3-all"]):
+        a, b = torch.tril(a.permute(2, 3, 0, 1)) if name == "scores" else a, torch.tril(b.permute(2, 3, 0, 1)) if name == "scores" else b
+        err, ref = float((a - b).abs().max()), float(a.abs().max())
+        if not err <= 1e-4 * ref:
+            _BF16X3_CHECKED[key] = False
+            raise RuntimeError(f"transkun_amd.scorer: the three-limb bf16 kernels disagree with the exact fp32 kernels on this device "
+                               f"({name}: max |difference| {err:.3e} against max |value| {ref:.3e}); use scorer.contraction = 'fp32'")
+
+
 QPAD = 4        # [q | diag | 3 zero columns]: one GEMM instead of a D-wide and a 1-wide one, rows stay 16-byte aligned
 
 
@@ -507,10 +545,15 @@ class ScaledInnerProductIntervalScorer(nn.Module):
                                   # [T-1, N, slotPitch] with zeros in the slots P.. of every segment (include/semicrf_hip.h, "SLOT
                                   # LAYOUT") -- for callers that hand flatten(-2, -1) of both straight to NeuralSemiCRFInterval and
                                   # drop the ghost chains' results; None: the reference's [T, T, N, P]
-        self.contraction = "fp32"  # "bf16x3" (also "bf16x3-fwd" / "bf16x3-bwd", contraction_bits): opt-in contraction on the bf16 matrix instructions -- operands split
-                                  # exactly into three bf16 limbs, six limb products, fp32 accumulation: fp32-grade scores
-                                  # (|error| <= 2^-21 * sum_d |q_d k_d| * scale), not bit-identical to "fp32"; the
-                                  # backward is the exact fp32 one either way
+        self.contraction = "fp32"  # opt-in contraction on the bf16 matrix instructions (contraction_bits): operands split exactly into
+                                  # three bf16 limbs, six limb products, fp32 accumulation -- fp32-grade (|error| <= 2^-21 *
+                                  # sum_d |q_d k_d| * scale), NOT bit-identical to "fp32".  "bf16x3-fwd": the forward contraction
+                                  # only (the backward stays the exact fp32 one); "bf16x3-bwd": the backward's two products only;
+                                  # "bf16x3": both (since round 5 -- until then this name meant the forward only: gradients under
+                                  # "bf16x3" are fp32-grade now, no longer bit-identical to "fp32"; use "bf16x3-fwd" for the old
+                                  # meaning); "bf16x3-train": backward + the projection's NN GEMMs; "bf16x3-all": everything.
+                                  # The first use of any of them on a device runs a self-check against the exact kernels
+                                  # (_bf16x3_selfcheck).
 
     def forward(self, ctx):
         # ctx: [N, P, T, size]
@@ -525,6 +568,8 @@ class ScaledInnerProductIntervalScorer(nn.Module):
         W, bias = lin.weight, lin.bias
         x = ctx.float()
         fs = int(self.fullSquare) | contraction_bits(self.contraction)
+        if fs & (BF16X3 | BWD_BF16X3 | PROJ_BF16X3):
+            _bf16x3_selfcheck(x.device)
         if _ScorerLinearPacked.eligible(x, W, bias, D):
             qd, k = _ScorerLinearPacked.apply(x, W, bias, D, 1 if fs & PROJ_BF16X3 else 0)
         else:
