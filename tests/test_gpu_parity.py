@@ -1694,6 +1694,40 @@ def test_fused_scorer_crf_expansion_factor(gpu, proj):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,P,T", [(1, 90, 691), (2, 10, 300), (1, 29, 256)])
+def test_scorer_bf16x3_row_constant_with_padding_quads(gpu, N, P, T):
+    """interval_score_tile3_kernel with a row constant (the merged projection) in a slot layout that has PADDING quads (a 90-symbol
+    segment in 96 slots: quad 23 holds no real chain).  Round 5's kernel let a padding item overwrite the row-constant buffer under
+    the waves that were still reading the previous item's -- quads 7 and 15 wrong by up to 176 at the model's shape, found by
+    test_segment_logprob_vs_reference[*-fused_bf16x3_all].  Every cell of every real slot within the three-limb bound of the exact
+    kernel's, ghost slots exactly zero."""
+    import math
+    from transkun_amd import _lib, synth
+    from transkun_amd.scorer import BF16X3, _interval_score_raw, slot_pitch
+    _lib.set_impl(0)
+    D = 256
+    C = N * P
+    pitch = slot_pitch(P, T, D, N)
+    assert pitch > P and ((pitch - P) >= 4 or N > 1)
+    z = synth.hash_normal(C * T * (D + 4), 811, gpu).view(C, T, D + 4)
+    x = synth.hash_normal(C * T * D, 812, gpu).view(C, T, D)
+    qs = 1.0 / math.sqrt(D)
+    out = {}
+    for tag, fs in (("exact", 2), ("bf16x3", 2 | BF16X3)):
+        S, _ = _interval_score_raw(z[..., :D], x, z[..., D + 1], T, C, D, qs, 0, fs, P, pitch, rowc=z[..., D] * 8.0)
+        out[tag] = S.clone()
+    tri = torch.tril(torch.ones(T, T, dtype=torch.bool, device=gpu)).unsqueeze(-1)
+    d = ((out["exact"] - out["bf16x3"]).abs() * tri).amax(dim=(0, 1))
+    scale = float((out["exact"].abs() * tri).max())
+    real = torch.zeros(N * pitch, dtype=torch.bool, device=gpu)
+    for n in range(N):
+        real[n * pitch:n * pitch + P] = True
+    assert float(d[real].max()) <= 2e-5 * scale, (float(d[real].max()), scale, d.tolist())
+    assert float((out["bf16x3"].abs() * tri)[:, :, ~real].max()) == 0.0
+    assert _lib.device_status() == 0
+
+
+@pytest.mark.gpu
 def test_fused_merged_projection_with_bf16x3_contraction(gpu):
     """The merged projection together with the opt-in three-limb bf16 contraction (the row constant then goes through
     interval_score_tile3_kernel's epilogue): logProb and gradients against the unfused exact-fp32 route."""

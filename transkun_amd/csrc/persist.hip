@@ -131,7 +131,11 @@ constexpr unsigned U_EMPTY = 0xffffffffu;  // not-yet-published u (a NaN pattern
 // control words of a launch (all start at 0xffffffff).  Separate 128-byte lines: counters that take atomics must
 // not share a line with words that are polled (hundreds of idle waves reading a line that others update atomically
 // slow every dequeue down to tens of microseconds).
-constexpr size_t CTRL_WORDS = 256;   // control words per chain chunk
+#ifndef SEMICRF_XQ
+#define SEMICRF_XQ 0               // 1: per-XCD panel task queues (experiment, see panel_next_task)
+#endif
+constexpr size_t CTRL_WORDS = 512;   // control words per chain chunk
+constexpr int CTRL_XQ0 = 256;         // [256 + 32 x]: panel task queue head of XCD x (SEMICRF_XQ; a line each)
 constexpr int CTRL_EXIT = 64;         // [64]: workgroups that have left (leased workspaces: the last one resets the control words)
 constexpr int CTRL_COPYQ = 192;       // [192]: band copy task queue head (a line of its own)
 constexpr int CTRL_PATHQ = 160;       // [160]: path task queue head (a line of its own)
@@ -1143,7 +1147,10 @@ __device__ __forceinline__ void spine_role(const SweepParams& P, int sg, int rin
 #define SEMICRF_GRAD_AUX 2
 #endif
 constexpr int GRAD_AUX = SEMICRF_GRAD_AUX;   // nt: the gradient is written once
-constexpr int CELL_AUX = 2;                  // nt: every cell is read once -- keep the stream from evicting the (re-read) u values from L2
+#ifndef SEMICRF_CELL_AUX
+#define SEMICRF_CELL_AUX 2
+#endif
+constexpr int CELL_AUX = SEMICRF_CELL_AUX;   // nt: every cell is read once -- keep the stream from evicting the (re-read) u values from L2
 #ifndef SEMICRF_PNS
 #define SEMICRF_PNS 3
 #endif
@@ -1278,13 +1285,9 @@ __device__ __forceinline__ void panel_wait_younger(int y)
 // prefetch and "recent-tile" waves on the spine CUs were all measured slower, DESIGN.md section 3 "Round 2".)
 struct PanelTask { int k, part, g, q4; };
 
-// queue position -> task
-__device__ __forceinline__ void panel_task_decode(const SweepParams& P, int task, PanelTask& t)
+// (block, part) number tt -> block k and column part
+__device__ __forceinline__ void panel_tt_decode(int tt, PanelTask& t)
 {
-    t.q4 = task & 3;
-    const int t2 = task >> 2;
-    t.g = t2 % P.nPanelGroups;
-    int tt = t2 / P.nPanelGroups;
     if (tt < LEADT - 1) { t.part = 0; t.k = FAR0 + tt; return; }      // the first LEADT - 1 blocks: one part
     tt -= LEADT - 1;
     int a = 0;
@@ -1294,15 +1297,45 @@ __device__ __forceinline__ void panel_task_decode(const SweepParams& P, int task
     t.part = tt % (a + 1);
     t.k = FAR0 + q;
 }
+// queue position -> task
+__device__ __forceinline__ void panel_task_decode(const SweepParams& P, int task, PanelTask& t)
+{
+    t.q4 = task & 3;
+    const int t2 = task >> 2;
+    t.g = t2 % P.nPanelGroups;
+    panel_tt_decode(t2 / P.nPanelGroups, t);
+}
 
 __device__ __forceinline__ bool panel_next_task(const SweepParams& P, PanelTask& t)
 {
+#if SEMICRF_XQ
+    // Per-XCD queues: XCD x (= workgroup index % 8, as wg_ticket assumes) hands out the (block, part, row quarter) combinations
+    // number x, x + 8, ... -- each with ALL of its chain groups, one after the other.  The tasks of neighbouring chain groups then
+    // run at the same time behind ONE L2: when 4 NBatch is no multiple of 128 bytes every 128-byte piece straddles two lines, and
+    // the neighbour group's task fetches the same two.  An empty queue: take from the next XCD's.
+    const int x0 = (int)(blockIdx.x & 7);
+    const int ncombo = P.nTasks / P.nPanelGroups;            // (block, part) x 4 row quarters
+    for (int xs = 0; xs < 8; ++xs) {
+        const int x = (x0 + xs) & 7;
+        int i = 0;
+        if ((threadIdx.x & 63) == 0) i = (int)(atomicAdd(P.ctrl + CTRL_XQ0 + 32 * x, 1u) + 1u);
+        i = __builtin_amdgcn_readfirstlane(i);
+        const int combo = (i / P.nPanelGroups) * 8 + x;
+        if (combo >= ncombo) continue;
+        t.g = i % P.nPanelGroups;
+        t.q4 = combo & 3;
+        panel_tt_decode(combo >> 2, t);
+        return true;
+    }
+    return false;
+#else
     int task = 0;
     if ((threadIdx.x & 63) == 0) task = (int)(atomicAdd(P.ctrl + 2, 1u) + 1u);        // counters start at 0xffffffff (one 0xff fill)
     task = __builtin_amdgcn_readfirstlane(task) + P.taskBase;
     if (task >= P.nTasks) return false;
     panel_task_decode(P, task, t);
     return true;
+#endif
 }
 
 template <int MODE, int DIR, bool GRAD>
@@ -2388,7 +2421,7 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         }
         const int grid = nSpineWG + nPanelWG;
         // the panel workgroups' waves know their first task (the first draws of ~700 waves all hit one counter at the start)
-        P.taskBase = nPanelWG * P.panelWaves;
+        P.taskBase = SEMICRF_XQ ? 0 : nPanelWG * P.panelWaves;
         if (P.taskBase > P.nTasks) P.taskBase = P.nTasks;
         if (grad) launch_one<0, 1, true>(P, grid, stream);
         else if (mode == 0 && dir == 0) launch_one<0, 0, false>(P, grid, stream);

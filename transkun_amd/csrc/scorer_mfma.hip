@@ -1210,7 +1210,11 @@ __global__ __launch_bounds__(512, 2) void interval_score_tile3_kernel(
             else if (on0 && on1) chain_loop(std::true_type{}, std::true_type{});
             else if (on0) chain_loop(std::true_type{}, std::false_type{});
             else chain_loop(std::false_type{}, std::false_type{});
-            if (j == 0 && rowc) rcl[((int)threadIdx.x % XTE) * 4 + (int)threadIdx.x / XTE] = rcv;     // (the previous item's epilogue is behind everybody)
+            // (the previous item's epilogue is behind everybody: chain 0's loop has barriers.  A PADDING item -- a quad without a real chain,
+            // e.g. slots 92..95 of a 96-slot segment -- runs no loop, i.e. passes no barrier: it must not touch the buffer, or its zeros
+            // land under the waves that are still reading the previous item's constants.  Found by the round-6 parity test of the
+            // "bf16x3-all" route against the reference's segment goldens: quads 7 and 15 of a 90-symbol segment wrong by up to 176.)
+            if (j == 0 && rowc && qi.nr > 0) rcl[((int)threadIdx.x % XTE) * 4 + (int)threadIdx.x / XTE] = rcv;
             if (j < 3) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
