@@ -1694,7 +1694,7 @@ def test_fused_scorer_crf_expansion_factor(gpu, proj):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,P,T", [(1, 90, 691), (2, 10, 300), (1, 29, 256)])
+@pytest.mark.parametrize("N,P,T", [(1, 90, 691), (2, 10, 300), (1, 26, 256)])
 def test_scorer_bf16x3_row_constant_with_padding_quads(gpu, N, P, T):
     """interval_score_tile3_kernel with a row constant (the merged projection) in a slot layout that has PADDING quads (a 90-symbol
     segment in 96 slots: quad 23 holds no real chain).  Round 5's kernel let a padding item overwrite the row-constant buffer under
@@ -1717,13 +1717,17 @@ def test_scorer_bf16x3_row_constant_with_padding_quads(gpu, N, P, T):
         S, _ = _interval_score_raw(z[..., :D], x, z[..., D + 1], T, C, D, qs, 0, fs, P, pitch, rowc=z[..., D] * 8.0)
         out[tag] = S.clone()
     tri = torch.tril(torch.ones(T, T, dtype=torch.bool, device=gpu)).unsqueeze(-1)
-    d = ((out["exact"] - out["bf16x3"]).abs() * tri).amax(dim=(0, 1))
-    scale = float((out["exact"].abs() * tri).max())
+    zero = torch.zeros((), device=gpu)
+    for tag in out:                                   # (full_square 2: the cells above the diagonal are uninitialised)
+        out[tag] = torch.where(tri, out[tag], zero)
+        assert bool(torch.isfinite(out[tag]).all()), tag
+    d = (out["exact"] - out["bf16x3"]).abs().amax(dim=(0, 1))
+    scale = float(out["exact"].abs().max())
     real = torch.zeros(N * pitch, dtype=torch.bool, device=gpu)
     for n in range(N):
         real[n * pitch:n * pitch + P] = True
     assert float(d[real].max()) <= 2e-5 * scale, (float(d[real].max()), scale, d.tolist())
-    assert float((out["bf16x3"].abs() * tri)[:, :, ~real].max()) == 0.0
+    assert float(out["bf16x3"][:, :, ~real].abs().max()) == 0.0
     assert _lib.device_status() == 0
 
 

@@ -204,6 +204,8 @@ struct SweepParams {
     int bandGroups;        // ... 32-chain groups of the whole batch
     int bandK0;            // ... row blocks < bandK0 are loaded from the score tensor itself
     int copyWaves;         // ... waves per panel workgroup that copy (copy_role)
+    int cellNT;            // 1: the panels stream their cells non-temporal (large problems); 0: ordinary loads (see cell_policy_nt)
+    int gradNT;            // GRAD: likewise for the marginals' stores
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1231,8 +1233,8 @@ __device__ __forceinline__ void panel_fetch_gran(__amdgpu_buffer_rsrc_t ursrc, c
 //   DIR 1: instruction e fetches columns pj = 16m + 2e + pjsub for the 4 rows pi (4 x 128 B contiguous per pj):
 //          lane = (pisub, pjsub, q8), same tile base, lane part ((1-pjsub)*T + (pi_3 - pi_pisub))*B, soffset (14-2e)*T*B.
 //          The processing lane reads its cells back from ((slot>>1) + 4h)*1024 + rr*256 + (slot&1)*128 + q8*16.
-template <int DIR>
-__device__ __forceinline__ void panel_fetch_cells(const float* score, const PanelGeom& G, char* stage, int m, int T, size_t Bs)
+template <int DIR, int AUX>
+__device__ __forceinline__ void panel_fetch_cells_aux(const float* score, const PanelGeom& G, char* stage, int m, int T, size_t Bs)
 {
     // The tile base and the piece offsets are wave-uniform by construction; said explicitly, because a load whose descriptor
     // or offset the compiler takes for divergent (task state that passed a lane-dependent loop exit) is wrapped in a
@@ -1245,8 +1247,15 @@ __device__ __forceinline__ void panel_fetch_cells(const float* score, const Pane
     for (int e = 0; e < 8; ++e) {
         const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(
             (int)(DIR == 0 ? panel_soff<DIR>(G, e >> 1, e & 1, T, Bs) : (unsigned)(((size_t)(14 - 2 * e) * T * Bs) * 4)));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(stage + e * 1024), 16, G.fvoff, so, 0, CELL_AUX);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(stage + e * 1024), 16, G.fvoff, so, 0, AUX);
     }
+}
+// nt (wave-uniform run-time choice; the cache policy is an immediate of the instruction): see cell_policy_nt
+template <int DIR>
+__device__ __forceinline__ void panel_fetch_cells(const float* score, const PanelGeom& G, char* stage, int m, int T, size_t Bs, bool nt)
+{
+    if (nt) panel_fetch_cells_aux<DIR, CELL_AUX>(score, G, stage, m, T, Bs);
+    else panel_fetch_cells_aux<DIR, 0>(score, G, stage, m, T, Bs);
 }
 __device__ __forceinline__ void panel_read_gran(unsigned addr, v4u& g0, v4u& g1)
 {
@@ -1356,6 +1365,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
     const float* __restrict__ score = P.score;
     const unsigned tag = P.tag;
     const auto ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.ug, 0, (int)((size_t)T * Bs * 4), 0x00020000);
+    const bool cell_nt = __builtin_amdgcn_readfirstlane(P.cellNT) != 0, grad_nt = __builtin_amdgcn_readfirstlane(P.gradNT) != 0;
 
     // geometry of a task's tiles (see "addressing" below)
     auto geom_of = [&](const PanelTask& t, PanelGeom& G) {
@@ -1456,7 +1466,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
 #pragma unroll
         for (int i = 0; i < PNS; ++i)
             if (m0 + i < m1) {
-                panel_fetch_cells<DIR>(score, G, stage0 + i * PSTAGE_BYTES, m0 + i, T, Bs);
+                panel_fetch_cells<DIR>(score, G, stage0 + i * PSTAGE_BYTES, m0 + i, T, Bs, cell_nt);
                 if (!probe_stream && !probe_nou) panel_fetch_gran<false>(ursrc, stage0 + i * PSTAGE_BYTES, G.gvoff, m0 + i, B);
                 issued += 10;
                 if (i == 0) mark0 = issued; else if (i == 1) mark1 = issued; else mark2 = issued;
@@ -1625,7 +1635,10 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
                                     asm volatile("" ::"v"(gv));          // timing ablation: the far field's marginals are computed, not stored
                                     continue;
 #endif
-                                    if (c + 3 < c1) __builtin_amdgcn_raw_buffer_store_b128(gv, gs, G.voff, so, GRAD_AUX);
+                                    if (c + 3 < c1) {
+                                        if (grad_nt) __builtin_amdgcn_raw_buffer_store_b128(gv, gs, G.voff, so, GRAD_AUX);
+                                        else __builtin_amdgcn_raw_buffer_store_b128(gv, gs, G.voff, so, 0);
+                                    }
                                     else {                                  // ragged tail of the chain range
                                         __builtin_amdgcn_raw_buffer_store_b32(gv.x, gs, G.voff, so, 0);
                                         if (c + 1 < c1) __builtin_amdgcn_raw_buffer_store_b32(gv.y, gs, G.voff + 4, so, 0);
@@ -1653,7 +1666,7 @@ __device__ __forceinline__ void panel_role(const SweepParams& P, char* lds, int 
             if (tprobe) { P.ts[1664 + k] = __builtin_amdgcn_s_memrealtime(); P.ts[1792 + k] = (u64)npoll; }
             // ---- refill the stage PNS tiles ahead ----------------------------------------------------------
             if (refill) {
-                panel_fetch_cells<DIR>(score, G, stage, m + PNS, T, Bs);
+                panel_fetch_cells<DIR>(score, G, stage, m + PNS, T, Bs, cell_nt);
                 if (!probe_stream && !probe_nou) panel_fetch_gran<false>(ursrc, stage, G.gvoff, m + PNS, B);
                 issued += 10;
                 if (s == 0) mark0 = issued; else if (s == 1) mark1 = issued; else mark2 = issued;
@@ -1788,6 +1801,7 @@ __device__ __forceinline__ void band_role(const SweepParams& P)
     const int nTasks = K * FAR0 * nG * 4;
     const size_t last4 = (size_t)T * T * Bs - 4;
     const auto ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.ug, 0, (int)((size_t)T * Bs * 4), 0x00020000);
+    const bool grad_nt = __builtin_amdgcn_readfirstlane(P.gradNT) != 0;
     while (true) {
         int task = 0;
         if (lane == 0) task = (int)(atomicAdd(ctrl + CTRL_BANDQ, 1u) + 1u);
@@ -1861,7 +1875,11 @@ __device__ __forceinline__ void band_role(const SweepParams& P)
             asm volatile("" ::"v"(gv));                              // timing ablation: computed, not stored
             continue;
 #endif
-            if (v3) { const v4u_a4 ga = gv; __builtin_nontemporal_store(ga, (v4u_a4*)dst); }
+            if (v3) {
+                const v4u_a4 ga = gv;
+                if (grad_nt) __builtin_nontemporal_store(ga, (v4u_a4*)dst);
+                else *(v4u_a4*)dst = ga;
+            }
             else {                                                   // ragged tail of the chain range
                 dst[0] = __uint_as_float(gv.x);
                 if (v1) dst[1] = __uint_as_float(gv.y);
@@ -2147,6 +2165,40 @@ static size_t band_copy_bytes(int T, int B)
 
 constexpr size_t CTRL_BYTES = MAX_CHUNKS * CTRL_WORDS * sizeof(unsigned);
 
+// Cache policy of the panels' cell stream (round 6).  Every cell is read once per sweep, so the stream was non-temporal from
+// round 1 on (it must not evict the re-read u values from the L2s) -- right for the headline shape (0.74 GB per sweep), wrong in two
+// cases, both measured with the sweeps in the order a step runs them (tools/nt_probe.py: forward, gradient sweep, decode on one
+// tensor; profiles/r06_nt_policy.md):
+//   * the score tensor fits the 256 MB memory-side cache next to what else the step touches (lower triangle <= SEMICRF_NT_MIN_MB):
+//     the cells were just written by the scorer or read by the previous sweep of the step, and a non-temporal line is not kept
+//     there.  Gradient sweep T=1024 x 88 244 -> 190 us, 691 x 180 210 -> 168, 691 x 192 147 -> 137, 1024 x 96 183 -> 168, 512 x 352 119 ->
+//     114; forward 142 -> 132 / 116 -> 105 / 97 -> 96 / 128 -> 123 / 85 -> 85; decode level.  (With 1 GiB of unrelated traffic in front
+//     of every step the forward sweep -- then the first reader of cold cells -- loses 5 - 10 us of it again; the gradient sweep keeps
+//     its gain.)  Above ~250 MB ordinary loads lose everywhere an aligned tensor was tried (T=691 x 384: forward 129 -> 138,
+//     gradient sweep 200 -> 239; T=1024 x 352: 194 -> 216, 331 -> 357).
+//   * 4 NBatch is no multiple of 128 bytes (the reference's own chain counts: 88, 90, 360): every 32-chain piece straddles two lines
+//     and the neighbour group's task fetches the same two -- rocprofv3 FETCH_SIZE at T=691: 635 MB for 360 chains (1.84 x the
+//     algorithmic 345 MB) against 388 MB for 384 (1.05 x).  An ordinary line waits in the L2 / the memory-side cache for its
+//     second reader: gradient sweep T=691 x 360 325 -> 269 us (278 -> 255 in a loop of gradient sweeps alone), T=2048 x 88 665 -> 583.
+//     Only the gradient sweep: a loop of forward sweeps at T=691 x 360 -- the first reader of a tensor that does not fit the cache --
+//     takes 132 us non-temporal and 145 with ordinary loads, the decode sweep 167 and 184.
+// The marginals' stores stay non-temporal always (ordinary stores push the score tensor out from under the next sweep: decode
+// 159 -> 168 at T=1024 x 88, 98 -> 112 at 512 x 352).
+#ifndef SEMICRF_NT_MIN_MB
+#define SEMICRF_NT_MIN_MB 240
+#endif
+#ifndef SEMICRF_GRAD_NT_MIN_MB
+#define SEMICRF_GRAD_NT_MIN_MB 0
+#endif
+#ifndef SEMICRF_NT_MISALIGNED
+#define SEMICRF_NT_MISALIGNED 0     // 1: non-temporal also for the gradient sweep of tensors whose chain axis is no multiple of 32 (rounds 1-5)
+#endif
+static bool cell_policy_nt(int T, int nb, int min_mb)
+{
+    const double mb = 4.0 * nb * ((double)T * (T + 1) / 2) / 1e6;       // the lower triangle this launch streams
+    return mb >= (double)min_mb;
+}
+
 static int max_parts(int T)
 {
     const int K = (T + PB - 1) / PB;
@@ -2408,6 +2460,9 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         }
         P.bandWaves = bw;
         P.gradLazyShort = nb < 256 ? 1 : 0;
+        P.cellNT = cell_policy_nt(T, B, SEMICRF_NT_MIN_MB) ? 1 : 0;          // (by the whole batch: chain chunks stream the same tensor)
+        if (!SEMICRF_NT_MISALIGNED && grad && B % 32 != 0) P.cellNT = 0;      // straddling pieces: the line waits for its second reader
+        P.gradNT = cell_policy_nt(T, B, SEMICRF_GRAD_NT_MIN_MB) ? 1 : 0;
         if (P.nTasks == 0) nPanelWG = 0;
         P.pathSpine = nPanelWG == 0 ? 1 : 0;        // no panel workgroups (short sequences): the spine workgroups' spare wave
         // the band as a spine-major copy, made by two spare waves of every panel workgroup while the sweep runs
