@@ -555,12 +555,20 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
             "bound": "mfma", "kernel": "interval_score_tiled_kernel<4> (exact fp32, v_mfma_f32_32x32x2_f32)", "unit": "TFLOP/s",
             "achieved": round(sflop / (extra["interval_score_fwd_ms"] * 1e-3) / 1e12, 2), "peak": 157.3,
             "frac": round(sflop / (extra["interval_score_fwd_ms"] * 1e-3) / 1e12 / 157.3, 4), "algorithmic_flop": sflop,
-            "note": "through the pooled score tensor: the zeros above the diagonal are written once per buffer, not in the timed calls; counters: profiles/r03_derived.json "
-                    "(matrix pipe busy fraction, clock under load); cycle stamps: tools/tiled_probe.py -- bound by the CU's "
+            "note": "through the pooled score tensor: the zeros above the diagonal are written once per buffer, not in the timed calls; counters: profiles/r06_derived.json "
+                    "(matrix pipe busy fraction, clock under load; r05_derived.json when this round's pass is missing); cycle stamps: tools/tiled_probe.py -- bound by the CU's "
                     "vector-memory address path (DESIGN.md section 3)",
-            "bf16x3_frac_fp32_equivalent": round(sflop / (extra["interval_score_fwd_bf16x3_ms"] * 1e-3) / 1e12 / 157.3, 4),
             "backward_frac": round(2 * sflop / (extra["interval_score_bwd_ms"] * 1e-3) / 1e12 / 157.3, 4),
-            "backward_bf16x3_frac_fp32_equivalent": round(2 * sflop / (extra["interval_score_bwd_bf16x3_ms"] * 1e-3) / 1e12 / 157.3, 4)}
+            # the opt-in three-limb kernels run on the BF16 pipe: six bf16 limb products per fp32 product, priced against the dense bf16
+            # peak (2.5 PFLOP/s), algorithmic flops only (the forward also multiplies the part of its diagonal tiles above the diagonal)
+            "bf16x3": {"bound": "mfma", "unit": "TFLOP/s (bf16, executed = 6 x algorithmic)", "peak": 2500.0,
+                       "forward_achieved": round(6 * sflop / (extra["interval_score_fwd_bf16x3_ms"] * 1e-3) / 1e12, 1),
+                       "forward_frac": round(6 * sflop / (extra["interval_score_fwd_bf16x3_ms"] * 1e-3) / 1e12 / 2500.0, 4),
+                       "backward_achieved": round(12 * sflop / (extra["interval_score_bwd_bf16x3_ms"] * 1e-3) / 1e12, 1),
+                       "backward_frac": round(12 * sflop / (extra["interval_score_bwd_bf16x3_ms"] * 1e-3) / 1e12 / 2500.0, 4),
+                       "forward_speedup_vs_exact_fp32": round(extra["interval_score_fwd_ms"] / extra["interval_score_fwd_bf16x3_ms"], 3),
+                       "backward_speedup_vs_exact_fp32": round(extra["interval_score_bwd_ms"] / extra["interval_score_bwd_bf16x3_ms"], 3),
+                       "note": "backward = the repack kernel + both products; the pipe alone sustains 2.0-2.2 PFLOP/s on these boxes (profiles/r05_mfma_peak.txt)"}}
         extra["interval_score_config"] = f"T={T}, chains={Cq}, D={Dq}, exact-fp32 MFMA, lower triangle"
         del qq, kk, dd, Sq, dq, dk2, ddg, wsq
         log("interval scorer done; segment-shaped path next")

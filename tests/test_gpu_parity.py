@@ -954,6 +954,41 @@ def test_persist_vs_oracle(gpu, oracle, T, B, kind):
     assert _lib.device_status() == 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,B", [(691, 351), (691, 360), (691, 704), (1024, 360)], ids=lambda v: str(v))
+@pytest.mark.parametrize("kind", ["randn", "model"])
+def test_persist_model_chain_counts_full_length(gpu, oracle, T, B, kind):
+    """The chain counts a contiguous [T,T,N*90] from the reference's own glue brings (ModelTransformer.py:213-222, train.py:372: 4 x 90
+    = 360), an odd one and two chain chunks -- at the model's sequence length, where the sweeps have panels, chain chunks and band
+    waves (test_persist_vs_oracle runs these counts at T = 144..160).  The whole batch on the GPU; the C oracle on 72 of the chains
+    (the first and last 32 and 8 in the middle: both chunks of 704, the ragged last quad of 351 / 360): logZ, the dense gradient, the
+    noise gradient and the decode in both directions of exactly those chains."""
+    from transkun_amd import CRF, _lib, synth
+    _lib.set_impl(0)
+    _lib.device_status()
+    score, noise = synth.crf_inputs(T, B, 100 + T, gpu, kind)
+    idx = sorted(set(list(range(32)) + list(range(B - 32, B)) + [B // 2 + i for i in range(8)]))
+    ix = torch.tensor(idx, device=gpu)
+    sc = score.index_select(2, ix).cpu().numpy()
+    nc = noise.index_select(1, ix).cpu().numpy()
+    lz64, grad64, gn64, v64, q64 = oracle.forward_backward_f64(sc, nc)
+    lz, grad, gn = CRF.forward_backward(score, noise)
+    gt = grad_tol(lz64)
+    assert rel_err(lz.index_select(0, ix).cpu().numpy(), lz64) < LOGZ_TOL
+    assert rel_err(grad.index_select(2, ix).cpu().numpy(), grad64) < gt
+    assert rel_err(gn.index_select(1, ix).cpu().numpy(), gn64) < gt
+    up = torch.triu(torch.ones(T, T, dtype=torch.bool, device=gpu), diagonal=1)
+    assert float(grad[up].abs().max()) == 0.0                           # begin > end: exact zeros for every chain
+    del grad, gn
+    crf = CRF.NeuralSemiCRFInterval(score, noise)
+    st = [(c * 7 + 3) % T for c in range(B)]
+    sts = [st[c] for c in idx]
+    dec, decf = crf.decode(forcedStartPos=st), crf.decode(forcedStartPos=st, forward=True)
+    assert [dec[c] for c in idx] == oracle.viterbi(sc, nc, sts)
+    assert [decf[c] for c in idx] == oracle.viterbi(sc, nc, sts, forward=True)
+    assert _lib.device_status() == 0
+
+
 # ---- attribute-head interval features (SURVEY 8f rank 2) --------------------------------------------------------
 
 @pytest.mark.gpu

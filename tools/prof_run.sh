@@ -6,7 +6,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed" | tee $OUT/pytest.log
