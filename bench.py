@@ -478,6 +478,26 @@ def _extras(extra, args, dev, rank, dist, score, noise, intervals, nseg, ev_time
             nsci.pack_intervals(intervals, T, B, dev)
         torch.cuda.synchronize(dev)
         extra["pack_intervals_ms"] = round((time.perf_counter() - t1) / 20 * 1e3, 3)
+        # BASELINE configs[1]: "NeuralSemiCRFInterval logProb fwd+bwd, T=1024, NBatch=88 (one segment x 88 pitches)" -- the same public call at
+        # that shape (a parity-test case, not the headline; here for its time and the roofline fraction of its forward sweep)
+        if (T, B) == (1024, 352):
+            s2, n2 = synth.crf_inputs(1024, 88, 4321, dev, "randn")
+            s2.requires_grad_(); n2.requires_grad_()
+            iv2 = synth.synthetic_intervals(1024, 88, seed=4321)
+
+            def config2():
+                s2.grad = None; n2.grad = None
+                lp = CRF.NeuralSemiCRFInterval(s2, n2).logProb(iv2)
+                (lp.sum() * -1.0).backward()
+            c2_ms = ev_time(config2, 20, warm=3)
+            s2d, n2d = s2.detach(), n2.detach()
+            c2_fwd = ev_time(lambda: nsci._logz_fwd_raw(s2d, n2d, want_v=True), 20)
+            extra["config2_T1024_B88"] = {"logprob_fwd_bwd_ms": round(c2_ms, 4), "steps_per_s": round(1e3 / c2_ms, 1),
+                                          "logz_fwd_us": round(c2_fwd * 1e3, 1),
+                                          "logz_fwd_frac_of_8TBs": round(algorithmic_bytes_logz_fwd(1024, 88) / (c2_fwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                          "note": "hand-off-bound (64 dependent blocks; the ring alone needs 86 us); cells loaded with the ordinary cache "
+                                                  "policy at this size (csrc/persist.hip: cell_policy_nt)"}
+            del s2, n2, s2d, n2d
         log("api-level variants done; decode next")
 
         # ---- decode (BASELINE configs[2]): T=2048, NBatch=352, forcedStartPos=[4]*NBatch ---------------------------
