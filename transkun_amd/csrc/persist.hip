@@ -131,11 +131,7 @@ constexpr unsigned U_EMPTY = 0xffffffffu;  // not-yet-published u (a NaN pattern
 // control words of a launch (all start at 0xffffffff).  Separate 128-byte lines: counters that take atomics must
 // not share a line with words that are polled (hundreds of idle waves reading a line that others update atomically
 // slow every dequeue down to tens of microseconds).
-#ifndef SEMICRF_XQ
-#define SEMICRF_XQ 0               // 1: per-XCD panel task queues (experiment, see panel_next_task)
-#endif
-constexpr size_t CTRL_WORDS = 512;   // control words per chain chunk
-constexpr int CTRL_XQ0 = 256;         // [256 + 32 x]: panel task queue head of XCD x (SEMICRF_XQ; a line each)
+constexpr size_t CTRL_WORDS = 256;   // control words per chain chunk
 constexpr int CTRL_EXIT = 64;         // [64]: workgroups that have left (leased workspaces: the last one resets the control words)
 constexpr int CTRL_COPYQ = 192;       // [192]: band copy task queue head (a line of its own)
 constexpr int CTRL_PATHQ = 160;       // [160]: path task queue head (a line of its own)
@@ -1317,34 +1313,12 @@ __device__ __forceinline__ void panel_task_decode(const SweepParams& P, int task
 
 __device__ __forceinline__ bool panel_next_task(const SweepParams& P, PanelTask& t)
 {
-#if SEMICRF_XQ
-    // Per-XCD queues: XCD x (= workgroup index % 8, as wg_ticket assumes) hands out the (block, part, row quarter) combinations
-    // number x, x + 8, ... -- each with ALL of its chain groups, one after the other.  The tasks of neighbouring chain groups then
-    // run at the same time behind ONE L2: when 4 NBatch is no multiple of 128 bytes every 128-byte piece straddles two lines, and
-    // the neighbour group's task fetches the same two.  An empty queue: take from the next XCD's.
-    const int x0 = (int)(blockIdx.x & 7);
-    const int ncombo = P.nTasks / P.nPanelGroups;            // (block, part) x 4 row quarters
-    for (int xs = 0; xs < 8; ++xs) {
-        const int x = (x0 + xs) & 7;
-        int i = 0;
-        if ((threadIdx.x & 63) == 0) i = (int)(atomicAdd(P.ctrl + CTRL_XQ0 + 32 * x, 1u) + 1u);
-        i = __builtin_amdgcn_readfirstlane(i);
-        const int combo = (i / P.nPanelGroups) * 8 + x;
-        if (combo >= ncombo) continue;
-        t.g = i % P.nPanelGroups;
-        t.q4 = combo & 3;
-        panel_tt_decode(combo >> 2, t);
-        return true;
-    }
-    return false;
-#else
     int task = 0;
     if ((threadIdx.x & 63) == 0) task = (int)(atomicAdd(P.ctrl + 2, 1u) + 1u);        // counters start at 0xffffffff (one 0xff fill)
     task = __builtin_amdgcn_readfirstlane(task) + P.taskBase;
     if (task >= P.nTasks) return false;
     panel_task_decode(P, task, t);
     return true;
-#endif
 }
 
 template <int MODE, int DIR, bool GRAD>
@@ -2476,7 +2450,7 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         }
         const int grid = nSpineWG + nPanelWG;
         // the panel workgroups' waves know their first task (the first draws of ~700 waves all hit one counter at the start)
-        P.taskBase = SEMICRF_XQ ? 0 : nPanelWG * P.panelWaves;
+        P.taskBase = nPanelWG * P.panelWaves;
         if (P.taskBase > P.nTasks) P.taskBase = P.nTasks;
         if (grad) launch_one<0, 1, true>(P, grid, stream);
         else if (mode == 0 && dir == 0) launch_one<0, 0, false>(P, grid, stream);

@@ -137,7 +137,8 @@ def _bf16x3_selfcheck(device) -> None:
     correct while the compiler keeps the loaded registers untouched in between -- true for the build this was measured on, not a
     property a toolchain bump must preserve.  A mismatch raises instead of training on garbage; the exact default never runs this."""
     key = device.index if device.index is not None else torch.cuda.current_device()
-    if _BF16X3_CHECKED.get(key) or device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+    if (_BF16X3_CHECKED.get(key) or device.type != "cuda" or torch.cuda.is_current_stream_capturing()
+            or torch.is_inference_mode_enabled()):        # (inference tensors cannot require gradients: checked at the first ordinary use)
         return
     _BF16X3_CHECKED[key] = True              # (set first: the check itself goes through forward())
     from . import synth
