@@ -1767,6 +1767,19 @@ def test_scorer_bf16x3_row_constant_with_padding_quads(gpu, N, P, T):
 
 
 @pytest.mark.gpu
+def test_scorer_bf16x3_random_shapes_soak(gpu, monkeypatch):
+    """tools/soak_tile3.py, 40 random cases: the three-limb forward against the exact kernel over random T / segments / symbols / slot
+    pitches (with padding quads) / D / length scaling / triangle modes / row constant -- within the three-limb bound, ghost slots exactly
+    zero, two runs bit-identical (what a race like round 5's would break)."""
+    import os
+    import runpy
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak_tile3.py")
+    monkeypatch.setattr(sys, "argv", [tool, "11", "40"])
+    runpy.run_path(tool, run_name="__main__")
+
+
+@pytest.mark.gpu
 def test_fused_merged_projection_with_bf16x3_contraction(gpu):
     """The merged projection together with the opt-in three-limb bf16 contraction (the row constant then goes through
     interval_score_tile3_kernel's epilogue): logProb and gradients against the unfused exact-fp32 route."""
