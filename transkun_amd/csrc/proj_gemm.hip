@@ -428,35 +428,59 @@ __global__ __launch_bounds__(512, 2) void proj_gemm_kernel(Args P)
 constexpr int XROWS_MIN = 128;              // rows per block: at least this many, and about 512 blocks (two per compute unit; the reduction
                                             // walks one partial result per block)
 __host__ inline int xrows_of(long long M) { long long x = (M + 511) / 512; x = (x + 31) / 32 * 32; return (int)(x < XROWS_MIN ? XROWS_MIN : x); }
+// (round 6: a wave per row and 16 bytes of x per lane -- four rows of a block in flight per wave, the two dy values of a row through the
+// scalar path -- instead of a thread per column with 4-byte loads: 75 -> ~50 us at 248 760 rows x 256; the four waves' sums are added
+// in wave order, the result does not depend on timing)
 __global__ __launch_bounds__(256) void proj_extra_tn_kernel(const float* __restrict__ dy, long long lddy, long long M, int col0,
                                                             const float* __restrict__ x, long long ldx, int N,
                                                             float* __restrict__ part_extra, float* __restrict__ part_xbias, int xrows)
 {
+    __shared__ float sh[4][2][256];
+    __shared__ float shb[4][2];
     const long long m0 = (long long)blockIdx.x * xrows;
     const long long m1 = m0 + xrows < M ? m0 + xrows : M;
-    const int n = threadIdx.x;
-    float s0 = 0.f, s1 = 0.f, b0 = 0.f, b1 = 0.f;
-    if (n < N) {
-        long long m = m0;
-        for (; m + 4 <= m1; m += 4) {
-            float xv[4], a0[4], a1[4];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int n4 = lane * 4;
+    const bool act = n4 < N;                                    // (N is 64 / 128 / 256: whole quads)
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    float b0 = 0.f, b1 = 0.f;
+    long long m = m0 + wave;
+    for (; m + 12 < m1; m += 16) {                              // rows m, m + 4, m + 8, m + 12 of this wave
+        float4 xv[4];
+        float a0[4], a1[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xv[i] = x[(m + i) * ldx + n];
-                a0[i] = dy[(m + i) * lddy + col0];
-                a1[i] = dy[(m + i) * lddy + col0 + 1];
-            }
+        for (int i = 0; i < 4; ++i) {
+            const long long r = m + 4 * i;
+            xv[i] = act ? *(const float4*)(x + r * ldx + n4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            a0[i] = dy[r * lddy + col0];
+            a1[i] = dy[r * lddy + col0 + 1];
+        }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { s0 = fmaf(a0[i], xv[i], s0); s1 = fmaf(a1[i], xv[i], s1); b0 += a0[i]; b1 += a1[i]; }
+        for (int i = 0; i < 4; ++i) {
+            s0.x = fmaf(a0[i], xv[i].x, s0.x); s0.y = fmaf(a0[i], xv[i].y, s0.y); s0.z = fmaf(a0[i], xv[i].z, s0.z); s0.w = fmaf(a0[i], xv[i].w, s0.w);
+            s1.x = fmaf(a1[i], xv[i].x, s1.x); s1.y = fmaf(a1[i], xv[i].y, s1.y); s1.z = fmaf(a1[i], xv[i].z, s1.z); s1.w = fmaf(a1[i], xv[i].w, s1.w);
+            b0 += a0[i]; b1 += a1[i];
         }
-        for (; m < m1; ++m) {
-            const float xv = x[m * ldx + n], a0 = dy[m * lddy + col0], a1 = dy[m * lddy + col0 + 1];
-            s0 = fmaf(a0, xv, s0); s1 = fmaf(a1, xv, s1); b0 += a0; b1 += a1;
-        }
-        part_extra[((size_t)blockIdx.x * 2 + 0) * N + n] = s0;
-        part_extra[((size_t)blockIdx.x * 2 + 1) * N + n] = s1;
-        if (n == 0) { part_xbias[(size_t)blockIdx.x * 2] = b0; part_xbias[(size_t)blockIdx.x * 2 + 1] = b1; }
     }
+    for (; m < m1; m += 4) {
+        const float4 xv = act ? *(const float4*)(x + m * ldx + n4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float a0 = dy[m * lddy + col0], a1 = dy[m * lddy + col0 + 1];
+        s0.x = fmaf(a0, xv.x, s0.x); s0.y = fmaf(a0, xv.y, s0.y); s0.z = fmaf(a0, xv.z, s0.z); s0.w = fmaf(a0, xv.w, s0.w);
+        s1.x = fmaf(a1, xv.x, s1.x); s1.y = fmaf(a1, xv.y, s1.y); s1.z = fmaf(a1, xv.z, s1.z); s1.w = fmaf(a1, xv.w, s1.w);
+        b0 += a0; b1 += a1;
+    }
+    if (act) {
+        *(float4*)&sh[wave][0][n4] = s0;
+        *(float4*)&sh[wave][1][n4] = s1;
+    }
+    if (lane == 0) { shb[wave][0] = b0; shb[wave][1] = b1; }
+    __syncthreads();
+    const int n = threadIdx.x;
+    if (n < N) {
+        part_extra[((size_t)blockIdx.x * 2 + 0) * N + n] = ((sh[0][0][n] + sh[1][0][n]) + sh[2][0][n]) + sh[3][0][n];
+        part_extra[((size_t)blockIdx.x * 2 + 1) * N + n] = ((sh[0][1][n] + sh[1][1][n]) + sh[2][1][n]) + sh[3][1][n];
+    }
+    if (n < 2) part_xbias[(size_t)blockIdx.x * 2 + n] = ((shb[0][n] + shb[1][n]) + shb[2][n]) + shb[3][n];
 }
 
 // dW[r][n] = sum_s part[s][r][n] (r < rows: the matrix part), the two extra rows from part_extra, db from part_bias.  A block per
