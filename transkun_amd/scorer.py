@@ -144,7 +144,7 @@ def _bf16x3_selfcheck(device) -> None:
     from . import synth
     size, P, T = 256, 4, 256
     res = {}
-    with torch.enable_grad():
+    with torch.enable_grad(), torch.random.fork_rng(devices=[]):      # (nn.Linear's initialisation draws from the global CPU generator: not ours to advance)
         for mode in ("fp32", "bf16x3-all"):
             m = ScaledInnerProductIntervalScorer(size).to(device)
             with torch.no_grad():
