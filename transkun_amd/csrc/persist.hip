@@ -202,6 +202,7 @@ struct SweepParams {
     int copyWaves;         // ... waves per panel workgroup that copy (copy_role)
     int cellNT;            // 1: the panels stream their cells non-temporal (large problems); 0: ordinary loads (see cell_policy_nt)
     int gradNT;            // GRAD: likewise for the marginals' stores
+    int nfarw;             // far waves of a spine that take turns on the blocks (1 .. NFARW; near tiles: always NFARW)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -367,7 +368,7 @@ constexpr int LDS_RING = LDS_FAR + NFAR * 64 * 16;                     // [NPOS]
 #define SEMICRF_FAR_PRIO 0          // s_setprio of the far wave(s) (2: above the ring's shadow phase; measured: neutral)
 #endif
 #ifndef SEMICRF_NFARW
-#define SEMICRF_NFARW 1
+#define SEMICRF_NFARW 2
 #endif
 // Far waves per spine workgroup: far wave f takes the blocks k = RING + f, RING + f + NFARW, ...  One far wave needs a device-scope
 // round trip per block even when the partial has long been stored (issue the poll, wait for it: ~2 us behind the loader's
@@ -638,7 +639,10 @@ __device__ __forceinline__ void far_role(const SweepParams& P, int sg, char* lds
     if (GRAD && NNEAR > 0 && cvalid) { gz = P.gout[(size_t)c * P.gstride] * P.gscale; lzc = P.logZ[c]; }
     __builtin_amdgcn_s_setprio(SEMICRF_FAR_PRIO);     // above the ring's shadow phase (1), below its diagonal phase (3)
     const bool fprobe = SEMICRF_PANEL_PROBES && (DBGF(P) & 16u) && cbase_is_first && lane == 0;
-    for (int k = RING + fw; k < K; k += NFARW) {
+    // (NFARW far waves exist; a launch uses the first P.nfarw of them: SweepParams::nfarw)
+    const int nfar = NNEAR > 0 ? NFARW : __builtin_amdgcn_readfirstlane(P.nfarw);
+    if (fw >= nfar) return;
+    for (int k = RING + fw; k < K; k += nfar) {
         if (fprobe && k < 64) P.ts[640 + k] = __builtin_amdgcn_s_memrealtime();
         const int prow = k * PB + r;
         const bool rvalid = cvalid && prow < T;
@@ -1164,7 +1168,10 @@ constexpr int LDS_PANEL_BYTES = PW_MAX * PNS * PSTAGE_BYTES;
 // streaming rate, ~26 GB/s per compute unit that is NOT a spine, and with one spine per unit 88 of the 256 were spines at
 // NBatch = 352 (the panels alone, fed without any dependency, need 147 us there; the whole sweep took 175).
 constexpr int SPH = SEMICRF_SPH;
-constexpr int HWAVES = RING + NLOADER + NFARW;                                  // waves of one spine
+// waves of one spine.  With one spine per workgroup only the FIRST far wave sits behind the loader; the others are the workgroup's
+// LAST waves: as wave 6 a second far wave pushed the two streaming waves from SIMDs 2 and 3 to SIMDs 3 and 0 -- next to ring wave 0
+// and the loader -- and the gradient sweep, whose spare waves stream from block 12 on, lost 2 - 7 % although it uses one far wave
+constexpr int HWAVES = SPH == 1 ? RING + NLOADER + 1 : RING + NLOADER + NFARW;
 constexpr int LDS_HALF = (LDS_SPINE_BYTES + 1023) / 1024 * 1024;              // LDS of one spine
 constexpr int LDS_HYBRID_PANEL = SPH * LDS_HALF;                              // stages of a spine workgroup's panel waves
 constexpr int HPW_MAX = (160 * 1024 - 512 - LDS_HYBRID_PANEL) / (PNS * PSTAGE_BYTES) < NT / 64 - SPH * HWAVES
@@ -1984,7 +1991,10 @@ __global__ __launch_bounds__(NT) void persist_sweep_kernel(SweepParams P)
         char* const lds_h = s_dyn + half * LDS_HALF;
         if (half >= SPH) {
             const int xw = wave - SPH * HWAVES;
-            if (!(DBGF(P) & 2u) && xw < P.hybridPanelWaves) {
+            if (SPH == 1 && NFARW > 1 && wave >= NT / 64 - (NFARW - 1)) {
+                // far waves 1 .. NFARW - 1 of the (one) spine (they leave at once in launches that use fewer: far_role)
+                if (ticket < P.nSpine && !(DBGF(P) & 9u)) far_role<MODE, DIR, GRAD>(P, ticket, s_dyn, 1 + wave - (NT / 64 - (NFARW - 1)));
+            } else if (!(DBGF(P) & 2u) && xw < P.hybridPanelWaves) {
                 // Spare waves stream tiles like the panel workgroups do (their stages lie behind the spines' LDS) -- but only
                 // once the sweep is bound by the far field: during the first blocks the ring sets the pace and a streaming
                 // wave on its CU only slows it down.  They wait until the (first) ring has taken row block hybridStart.
@@ -2164,6 +2174,12 @@ constexpr size_t CTRL_BYTES = MAX_CHUNKS * CTRL_WORDS * sizeof(unsigned);
 #ifndef SEMICRF_GRAD_NT_MIN_MB
 #define SEMICRF_GRAD_NT_MIN_MB 0
 #endif
+#ifndef SEMICRF_NFARW2_MAXB
+#define SEMICRF_NFARW2_MAXB 192     // forward / decode launches of at most this many chains ...
+#endif
+#ifndef SEMICRF_NFARW2_MINT
+#define SEMICRF_NFARW2_MINT 1024    // ... and at least this many frames use two far waves per spine
+#endif
 #ifndef SEMICRF_NT_MISALIGNED
 #define SEMICRF_NT_MISALIGNED 0     // 1: non-temporal also for the gradient sweep of tensors whose chain axis is no multiple of 32 (rounds 1-5)
 #endif
@@ -2264,15 +2280,15 @@ static unsigned next_tag()
 
 // Launch-geometry knobs of the development tools (tools/bench_sweep.py): the environment is read only by a library built
 // with -DSEMICRF_DEBUG_BUILD=1 (once, at the first launch); the release library ignores it (-1 = the built-in choice).
-struct Knobs { int hybrid_waves, hybrid_start, panel_waves, zero_waves, band_waves; };
+struct Knobs { int hybrid_waves, hybrid_start, panel_waves, zero_waves, band_waves, nfarw; };
 static Knobs read_knobs()
 {
 #if defined(SEMICRF_DEBUG_BUILD) && SEMICRF_DEBUG_BUILD
     auto get = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : -1; };
     return Knobs{get("SEMICRF_HYBRID_PANEL_WAVES"), get("SEMICRF_HYBRID_START"), get("SEMICRF_PANEL_WAVES"), get("SEMICRF_ZERO_WAVES"),
-                 get("SEMICRF_BAND_WAVES")};
+                 get("SEMICRF_BAND_WAVES"), get("SEMICRF_NFARW_RT")};
 #else
-    return Knobs{-1, -1, -1, -1, -1};
+    return Knobs{-1, -1, -1, -1, -1, -1};
 #endif
 }
 
@@ -2434,6 +2450,11 @@ static int launch_persist_sweep_impl(int mode, int dir, const float* score, cons
         }
         P.bandWaves = bw;
         P.gradLazyShort = nb < 256 ? 1 : 0;
+        // Two far waves taking turns halve the far wave's share of a block's period (one device-scope round trip per block and wave):
+        // worth 3 - 4 % where the forward / decode sweeps are hand-off-bound, i.e. with few chains; with many chains, and in the gradient
+        // sweep, the second poller costs the fabric more than it returns (T=1024 x 352: 178 vs 176 us, gradient sweep 347 vs 337)
+        P.nfarw = (!grad && nb <= SEMICRF_NFARW2_MAXB && T >= SEMICRF_NFARW2_MINT && NFARW >= 2) ? 2 : 1;
+        if (knobs.nfarw >= 1 && knobs.nfarw <= NFARW) P.nfarw = knobs.nfarw;
         P.cellNT = cell_policy_nt(T, B, SEMICRF_NT_MIN_MB) ? 1 : 0;          // (by the whole batch: chain chunks stream the same tensor)
         if (!SEMICRF_NT_MISALIGNED && grad && B % 32 != 0) P.cellNT = 0;      // straddling pieces: the line waits for its second reader
         P.gradNT = cell_policy_nt(T, B, SEMICRF_GRAD_NT_MIN_MB) ? 1 : 0;
