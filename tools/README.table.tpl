@@ -2,7 +2,7 @@
 |---|---|
 | **headline**: `NeuralSemiCRFInterval(score, noise).logProb(intervals)` forward + backward through the public API, T=1024 × 352 | **__HEADLINE__ steps/s** (__MS__ ms per step; five repetitions __REPS__) |
 | log-partition forward sweep, T=1024 × 352 (the roofline kernel) | __FWDUS__ µs = __ACH__ GB/s algorithmic = **__FRAC__ of the 8 TB/s HBM roofline**; HBM traffic 1.07 × the algorithmic bytes |
-| gradient sweep, T=1024 × 352 | 320 µs minimum, 330 average over 23 launches (other boxes of the round: 339–351) (0.74 GB read + 0.74 GB written; the dense gradient's zeros are written once per pooled buffer) |
+| gradient sweep, T=1024 × 352 | 340 µs minimum, 353 average over 23 launches (the boxes of the round: 320–340 minimum) (0.74 GB read + 0.74 GB written; the dense gradient's zeros are written once per pooled buffer) |
 | BASELINE config #2, T=1024 × 88: forward sweep / gradient sweep / `logProb` forward + backward | __C2FWD__ µs (__C2FRAC__) / 185 µs / __C2MS__ ms |
 | decode T=2048 × 352, `forcedStartPos` set: "decode segments/s" on the device / as packed arrays / as the reference's Python lists | __DECDEV__ (__DECMS__ ms) / __DECPK__ ms / __DECAPI__ segments/s (__DECLIST__ ms: 657 k tuples at the CPython floor) |
 | interval scorer T=1024 × 352 × D=256, exact fp32: forward / backward | __SF__ ms (__SFR__ of the fp32 matrix pipe) / __SB__ ms |
