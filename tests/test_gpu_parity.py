@@ -955,12 +955,13 @@ def test_persist_vs_oracle(gpu, oracle, T, B, kind):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("T,B", [(691, 351), (691, 360), (691, 704), (1024, 360)], ids=lambda v: str(v))
+@pytest.mark.parametrize("T,B", [(691, 351), (691, 360), (691, 704), (1024, 360), (1024, 88), (1100, 190)], ids=lambda v: str(v))
 @pytest.mark.parametrize("kind", ["randn", "model"])
 def test_persist_model_chain_counts_full_length(gpu, oracle, T, B, kind):
     """The chain counts a contiguous [T,T,N*90] from the reference's own glue brings (ModelTransformer.py:213-222, train.py:372: 4 x 90
     = 360), an odd one and two chain chunks -- at the model's sequence length, where the sweeps have panels, chain chunks and band
-    waves (test_persist_vs_oracle runs these counts at T = 144..160).  The whole batch on the GPU; the C oracle on 72 of the chains
+    waves (test_persist_vs_oracle runs these counts at T = 144..160); T >= 1024 with at most 192 chains are the launches that use TWO far
+    waves per spine (round 6).  The whole batch on the GPU; the C oracle on 72 of the chains
     (the first and last 32 and 8 in the middle: both chunks of 704, the ragged last quad of 351 / 360): logZ, the dense gradient, the
     noise gradient and the decode in both directions of exactly those chains."""
     from transkun_amd import CRF, _lib, synth

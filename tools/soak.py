@@ -8,7 +8,8 @@ nsci = importlib.import_module("transkun_amd.CRF.NeuralSemiCRFInterval")
 dev = torch.device("cuda:0")
 def dig(t): return hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16]
 bad = 0
-for (T, B, n) in ((1024, 352, 60), (691, 90, 150), (691, 360, 60), (2048, 352, 10), (333, 46, 300), (130, 600, 60), (200, 33, 200), (512, 88, 100), (1024, 351, 20)):
+for (T, B, n) in ((1024, 352, 60), (691, 90, 150), (691, 360, 60), (2048, 352, 10), (333, 46, 300), (130, 600, 60), (200, 33, 200), (512, 88, 100), (1024, 351, 20),
+                  (1024, 88, 60), (2048, 88, 15), (1100, 190, 30)):        # two far waves per spine (forward / decode of few chains, T >= 1024)
     s, nz = synth.crf_inputs(T, B, 77, dev)
     g = synth.hash_normal(B, 5, dev)
     ref = None
